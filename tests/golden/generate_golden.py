@@ -1,0 +1,521 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (the reference lives at /root/reference and never travels to the
+GPU box):
+
+    python tests/golden/generate_golden.py
+
+What is committed is data (inputs + the outputs the reference produced for them), never reference
+source.  The reference's absent third-party imports (pymia, SimpleITK, h5py, tensorboardX,
+matplotlib) are replaced by inert stub modules: none of the code paths exercised here touches
+them.  Fixture names follow SURVEY.md section 8(c), G1..G11.
+"""
+import hashlib
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REFERENCE_ROOT = os.environ.get('RCU_REFERENCE_ROOT', '/root/reference')
+OUT_DIR = os.path.dirname(os.path.abspath(__file__))
+
+_STUBBED_ROOTS = ('pymia', 'SimpleITK', 'h5py', 'tensorboardX', 'matplotlib')
+
+
+class _StubModule(types.ModuleType):
+    """Module whose every attribute is a fresh empty class (good enough for `class X(stub.Base)`)."""
+    __path__ = []
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        cls = type(name, (object,), {})
+        setattr(self, name, cls)
+        return cls
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split('.')[0] in _STUBBED_ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        return _StubModule(spec.name)
+
+    def exec_module(self, module):
+        if module.__name__ == 'pymia.config.configuration':
+            _fill_pymia_configuration(module)
+
+
+def _fill_pymia_configuration(module):
+    """`from pymia.config.configuration import *` needs real base classes (call sites:
+    common/configuration/config.py:1, common/trainloop/config.py:7-190)."""
+
+    class Dictable:
+        def to_dict(self, **kwargs):
+            return dict(vars(self))
+
+        def from_dict(self, d, **kwargs):
+            for k, v in d.items():
+                setattr(self, k, v)
+
+    class ConfigurationBase(Dictable):
+        pass
+
+    def member_to_dict(obj):
+        return {k: (v.to_dict() if isinstance(v, Dictable) else v) for k, v in vars(obj).items()}
+
+    def dict_to_member(obj, d):
+        for k, v in d.items():
+            cur = getattr(obj, k, None)
+            if isinstance(cur, Dictable) and isinstance(v, dict):
+                cur.from_dict(v)
+            else:
+                setattr(obj, k, v)
+
+    module.Dictable = Dictable
+    module.ConfigurationBase = ConfigurationBase
+    module.member_to_dict = member_to_dict
+    module.dict_to_member = dict_to_member
+    module.__all__ = ['Dictable', 'ConfigurationBase', 'member_to_dict', 'dict_to_member']
+
+
+def install_reference():
+    sys.meta_path.insert(0, _StubFinder())
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    if not hasattr(np, 'bool'):  # reference uses np.bool (eval.py:159)
+        np.bool = bool
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT_DIR, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('wrote {} ({:.1f} KiB)'.format(path, os.path.getsize(path) / 1024))
+
+
+def randomise_bn(model, gen):
+    """Non-trivial BN running stats / affine so that eval-mode BN is not the identity."""
+    import torch.nn as nn
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.2)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=gen) * 0.2)
+            # a few negative gammas: the folded scale may be negative
+            m.weight.data[::5] *= -1.0
+
+
+def state_to_npz(model, prefix='sd::'):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+
+def dropout_modules(model):
+    import torch.nn as nn
+    return [(n, m) for n, m in model.named_modules() if isinstance(m, nn.Dropout2d)]
+
+
+def capture_masks(model, fn):
+    """Run fn() with forward hooks on every Dropout2d; returns per-call list of (site name, mask[N,C])
+    where mask holds the multiplicative factor {0, 1/(1-p)} the module applied."""
+    records = []
+    handles = []
+
+    def make_hook(name, p):
+        def hook(mod, inp, out):
+            x = inp[0]
+            if not mod.training:
+                mask = torch.ones(x.shape[:2])
+            else:
+                kept = (out.abs().sum(dim=(2, 3)) > 0) | (x.abs().sum(dim=(2, 3)) == 0)
+                mask = kept.float() / (1.0 - p)
+            records.append((name, mask.numpy().copy()))
+        return hook
+
+    for name, m in dropout_modules(model):
+        handles.append(m.register_forward_hook(make_hook(name, m.p)))
+    try:
+        result = fn()
+    finally:
+        for h in handles:
+            h.remove()
+    return result, records
+
+
+def make_unet(seed, **params):
+    import common.model.unet as ref_unet
+    torch.manual_seed(seed)
+    model = ref_unet.UNet(**params)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        randomise_bn(model, gen)
+    model.eval()
+    return model
+
+
+def g1_unet_eval():
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=4, dropout=0.05)
+    model = make_unet(1, **params)
+    gen = torch.Generator().manual_seed(11)
+    xa = torch.randn(2, 4, 32, 32, generator=gen)
+    xb = torch.randn(1, 4, 48, 32, generator=gen)
+    with torch.no_grad():
+        ya = model(xa)
+        yb = model(xb)
+    save('g1_unet_eval', params=np.array(repr(params)), x_a=xa.numpy(), logits_a=ya.numpy(),
+         x_b=xb.numpy(), logits_b=yb.numpy(), **state_to_npz(model))
+    # a wider model (start_filters=8 -> channels 8..128) on a 16-divisible non-square input
+    params8 = dict(nb_classes=2, in_channels=4, depth=4, start_filters=8, dropout=0.05)
+    model8 = make_unet(2, **params8)
+    xc = torch.randn(1, 4, 32, 48, generator=gen)
+    with torch.no_grad():
+        yc = model8(xc)
+    save('g1_unet_eval_sf8', params=np.array(repr(params8)), x=xc.numpy(), logits=yc.numpy(),
+         **state_to_npz(model8))
+
+
+def g2_unet_mc():
+    import common.utils.torchhelper as ref_th
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=4, dropout=0.3)
+    model = make_unet(3, **params)
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 4, 32, 32, generator=gen)
+    torch.manual_seed(20)
+    ref_th.set_dropout_mode(model, True)
+    T = 3
+    arrays = {}
+    site_names = [n for n, _ in dropout_modules(model)]
+    with torch.no_grad():
+        for t in range(T):
+            y, recs = capture_masks(model, lambda: model(x))
+            assert [r[0] for r in recs] == site_names
+            arrays['logits_{}'.format(t)] = y.numpy()
+            for s, (_, mask) in enumerate(recs):
+                arrays['mask_{}_{}'.format(t, s)] = mask
+    ref_th.set_dropout_mode(model, False)
+    save('g2_unet_mc', params=np.array(repr(params)), x=x.numpy(), T=np.array(T),
+         sites=np.array(site_names), **arrays, **state_to_npz(model))
+
+
+def g3_unet_center():
+    import common.utils.torchhelper as ref_th
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=4, dropout=0.5, dropout_center=4)
+    model = make_unet(4, **params)
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 4, 32, 32, generator=gen)
+    site_names = [n for n, _ in dropout_modules(model)]
+    torch.manual_seed(21)
+    ref_th.set_dropout_mode(model, True)
+    with torch.no_grad():
+        y, recs = capture_masks(model, lambda: model(x))
+    ref_th.set_dropout_mode(model, False)
+    with torch.no_grad():
+        y_eval = model(x)
+    arrays = {'mask_{}'.format(s): m for s, (_, m) in enumerate(recs)}
+    save('g3_unet_center', params=np.array(repr(params)), x=x.numpy(), logits=y.numpy(),
+         logits_eval=y_eval.numpy(), sites=np.array(site_names), **arrays, **state_to_npz(model))
+    # second placement: dropout_center=2 (only the two deepest levels carry dropout)
+    params2 = dict(nb_classes=2, in_channels=4, depth=4, start_filters=4, dropout=0.5, dropout_center=2)
+    model2 = make_unet(5, **params2)
+    site_names2 = [n for n, _ in dropout_modules(model2)]
+    save('g3_unet_center2_sites', params=np.array(repr(params2)), sites=np.array(site_names2))
+
+
+def g4_unet_sigma():
+    import common.utils.labelhelper as ref_lh
+    import torch.nn.functional as F
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=4, dropout=0.05, sigma_out=True)
+    model = make_unet(6, **params)
+    gen = torch.Generator().manual_seed(14)
+    x = torch.randn(2, 4, 32, 32, generator=gen)
+    with torch.no_grad():
+        logits, sigma = model(x)
+        # AleatoricPredictStep semantics (bin-dl/brats_test_aleatoric.py:63-73)
+        sigma_abs = sigma.abs()
+        sigma_exp = sigma.exp()
+        probs = F.softmax(logits, 1)
+    # writer-side selection (bin-dl/brats_test_aleatoric.py:95-97) on channel-last numpy arrays
+    probs_np = probs.permute(0, 2, 3, 1).numpy()
+    sig_np = sigma_abs.permute(0, 2, 3, 1).numpy()
+    prediction = np.argmax(probs_np, axis=-1)
+    sigma_pred = sig_np[ref_lh.to_one_hot(prediction, 2).astype(bool)].reshape(prediction.shape)
+    save('g4_unet_sigma', params=np.array(repr(params)), x=x.numpy(), logits=logits.numpy(),
+         sigma_raw=sigma.numpy(), sigma_abs=sigma_abs.numpy(), sigma_exp=sigma_exp.numpy(),
+         probabilities=probs.numpy(), prediction=prediction.astype(np.uint8), sigma_pred=sigma_pred,
+         **state_to_npz(model))
+
+
+def g5_unet_isic():
+    params = dict(nb_classes=2, in_channels=3, depth=4, start_filters=4, dropout=0.05)
+    model = make_unet(7, **params)
+    gen = torch.Generator().manual_seed(15)
+    x = torch.rand(1, 3, 32, 48, generator=gen)
+    with torch.no_grad():
+        y = model(x)
+    save('g5_unet_isic', params=np.array(repr(params)), x=x.numpy(), logits=y.numpy(), **state_to_npz(model))
+
+
+def _summary_via_reference(multi, do_mi, do_var):
+    import common.trainloop.context as ref_ctx
+    import rechun.dl.customsteps as ref_steps
+    bc = ref_ctx.BatchContext({}, 0)
+    bc.output['multi_probabilities'] = multi.clone()
+    ref_steps.MultiPredictionSummary(do_mi=do_mi, do_var=do_var)(bc, None, None)
+    return {k: v.numpy() for k, v in bc.output.items()}
+
+
+def g6_mc_summary():
+    gen = torch.Generator().manual_seed(16)
+    arrays = {}
+    for case, (T, N, C, H, W) in enumerate([(3, 2, 2, 8, 8), (5, 2, 2, 8, 8), (4, 1, 3, 4, 8)]):
+        logits = torch.randn(T, N, C, H, W, generator=gen) * 3
+        multi = torch.softmax(logits, 2)
+        if C == 2:
+            # exact 0/1 probabilities (where(p>0) branch) and an all-equal voxel (zero variance)
+            multi[:, 0, 0, 0, 0] = 0.0
+            multi[:, 0, 1, 0, 0] = 1.0
+            multi[:, 0, 0, 0, 1] = 0.25
+            multi[:, 0, 1, 0, 1] = 0.75
+            multi[0, 0, 0, 0, 2] = 0.0
+            multi[0, 0, 1, 0, 2] = 1.0
+        out = _summary_via_reference(multi, True, True)
+        arrays['multi_{}'.format(case)] = multi.numpy()
+        for k, v in out.items():
+            arrays['{}_{}'.format(k, case)] = v
+    # KATs from SURVEY 8(c)
+    import common.utils.torchhelper as ref_th
+    kat = ref_th.entropy(torch.tensor([[.5, .5], [1., 0.], [.9, .1]]), dim=1).numpy()
+    arrays['kat_entropy_in'] = np.array([[.5, .5], [1., 0.], [.9, .1]], dtype=np.float32)
+    arrays['kat_entropy_out'] = kat
+    save('g6_mc_summary', **arrays)
+
+
+def g7_mc_step_end2end():
+    import common.trainloop.context as ref_ctx
+    import rechun.dl.customsteps as ref_steps
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=4, dropout=0.3)
+    model = make_unet(8, **params)
+    gen = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 4, 32, 32, generator=gen).double()  # step casts with .float()
+    context = ref_ctx.TorchTestContext('cpu')
+    context.model = model
+    torch.set_grad_enabled(False)
+    T = 4
+    bc = ref_ctx.BatchContext({'images': x.clone()}, 0)
+    torch.manual_seed(20)
+    site_names = [n for n, _ in dropout_modules(model)]
+    _, recs = capture_masks(model, lambda: ref_steps.McPredictStep(T)(bc, None, context))
+    assert len(recs) == (T + 1) * len(site_names)
+    multi = bc.output['multi_probabilities'].numpy().copy()
+    ref_steps.MultiPredictionSummary(do_mi=True, do_var=True)(bc, None, context)
+    arrays = {'out::' + k: v.numpy() for k, v in bc.output.items()}
+    arrays['out_keys'] = np.array(list(bc.output.keys()))
+    S = len(site_names)
+    for t in range(T):  # records [0:S] belong to the weight-scaling pass (all ones)
+        for s in range(S):
+            arrays['mask_{}_{}'.format(t, s)] = recs[(t + 1) * S + s][1]
+    # default flags: only mean + entropy
+    bc2 = ref_ctx.BatchContext({}, 0)
+    bc2.output['multi_probabilities'] = torch.from_numpy(multi)
+    ref_steps.MultiPredictionSummary()(bc2, None, context)
+    arrays['default_out_keys'] = np.array(list(bc2.output.keys()))
+    # wrong context type: the step means to raise ValueError (customsteps.py:17-18); record what the
+    # reference really raises (its message helper fails on the tuple argument, common/utils/messages.py:5)
+    try:
+        ref_steps.McPredictStep(1)(ref_ctx.BatchContext({'images': x}, 0), None, object())
+        raised = 'none'
+    except Exception as e:  # noqa: BLE001 - recording the type is the point
+        raised = type(e).__name__
+    arrays['wrong_context_exception'] = np.array(raised)
+    save('g7_mc_step', params=np.array(repr(params)), x=x.numpy(), T=np.array(T), sites=np.array(site_names),
+         multi_probabilities=multi, **arrays, **state_to_npz(model))
+
+
+def g8_ece():
+    import common.evalutation.numpyfunctions as ref_np
+    import common.evalutation.eval as ref_ev
+    rng = np.random.RandomState(18)
+    arrays = {}
+    # (a) random volume with mask
+    p = rng.rand(6, 16, 16).astype(np.float32)
+    p[0, 0, :4] = [0.0, 1.0, 0.5, 0.1]
+    target = (rng.rand(6, 16, 16) < p * 0.8 + 0.1).astype(np.uint8)
+    mask = rng.rand(6, 16, 16) > 0.3
+    probs2 = np.stack([1 - p, p], axis=-1)
+    for tag, m in (('masked', mask), ('nomask', None)):
+        bins = {}
+        ece = ref_np.ece_binary(probs2, target, mask=m, out_bins=bins)
+        arrays['a_ece_' + tag] = np.array(ece)
+        for k, v in bins.items():
+            arrays['a_{}_{}'.format(k, tag)] = np.asarray(v)
+    arrays.update(a_p=p, a_target=target, a_mask=mask)
+    # raw bin ids exactly as _binary_calibration derives them (numpyfunctions.py:53-54)
+    edges = np.linspace(0., 1. + 1e-8, 11)
+    arrays['a_binids'] = (np.digitize(p.flatten(), edges) - 1).astype(np.int64)
+    # (b) boundary vector: every float32 threshold, its predecessor and successor, 0 and 1
+    cands = [np.float32(0.0), np.float32(1.0), np.nextafter(np.float32(1.0), np.float32(0.0))]
+    for k in range(1, 10):
+        e = edges[k]
+        c = np.float32(e)
+        for _ in range(3):
+            c = np.nextafter(c, np.float32(0.0))
+        for _ in range(7):
+            cands.append(c)
+            c = np.nextafter(c, np.float32(2.0))
+    b = np.array(cands, dtype=np.float32)
+    arrays['b_p'] = b
+    arrays['b_binids'] = (np.digitize(b, edges) - 1).astype(np.int64)
+    bt = (np.arange(b.size) % 3 == 0).astype(np.uint8)
+    bins = {}
+    arrays['b_ece'] = np.array(ref_np.ece_binary(np.stack([1 - b, b], -1), bt, out_bins=bins))
+    arrays['b_target'] = bt
+    for k, v in bins.items():
+        arrays['b_' + k] = np.asarray(v)
+    # (c) the known-answer test quoted in SURVEY 8(c)
+    kp = np.array([.05, .15, .15, .95, .65, .5, 1, 0], dtype=np.float32)
+    kt = np.array([0, 0, 1, 1, 1, 0, 1, 0], dtype=np.uint8)
+    bins = {}
+    arrays['c_ece'] = np.array(ref_np.ece_binary(np.stack([1 - kp, kp], -1), kt, out_bins=bins))
+    arrays.update(c_p=kp, c_target=kt)
+    for k, v in bins.items():
+        arrays['c_' + k] = np.asarray(v)
+    # (d) EvaluationStrategy wrapper (eval.py:118-142) incl. return_bins and other bin weightings
+    res = {}
+    ref_ev.EceBinaryNumpy(with_mask=True, return_bins=True)({'target': target, 'probabilities': probs2,
+                                                             'mask': mask}, res)
+    arrays['d_keys'] = np.array(sorted(res.keys()))
+    arrays['d_ece'] = np.array(res['ece'])
+    for w in ('log_proportion', 'power_proportion', 'mean_proportion'):
+        arrays['d_ece_' + w] = np.array(ref_np.ece_binary(probs2, target, mask=mask, bin_weighting=w))
+    arrays['d_ece_thresrange'] = np.array(ref_np.ece_binary(probs2, target, threshold_range=(0.2, 0.9)))
+    # (e) 5-bin variant
+    arrays['e_ece_5bins'] = np.array(ref_np.ece_binary(probs2, target, n_bins=5))
+    # (f) degenerate: all-masked-out -> empty input
+    save('g8_ece', **arrays)
+
+
+def g9_uncertainty():
+    import common.evalutation.numpyfunctions as ref_np
+    import rechun.eval.analysis as ref_an
+    rng = np.random.RandomState(19)
+    p = rng.rand(4, 12, 12).astype(np.float32)
+    p[0, 0, :6] = [0.0, 1.0, 0.5, 1e-7, 0.999999, 0.25]
+    target = (rng.rand(4, 12, 12) < 0.3).astype(np.uint8)
+    prediction = (p > 0.5).astype(np.uint8)
+    to_eval = {'probabilities': p.copy(), 'prediction': prediction, 'target': target}
+    to_eval = ref_an.AddBackgroundProbabilities()(to_eval)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        to_eval = ref_an.ToEntropy()(to_eval)
+    unc = to_eval['uncertainty']
+    assert unc.dtype == np.float64
+    thresholds = [0.05, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95]
+    counts = np.zeros((len(thresholds), 8), dtype=np.int64)
+    derived = np.zeros((len(thresholds), 3), dtype=np.float64)
+    for i, thr in enumerate(thresholds):
+        c = ref_np.uncertainty(prediction.astype(bool), target.astype(bool), unc > thr)
+        counts[i] = c
+        tp, tn, fp, fn, tpu, tnu, fpu, fnu = c
+        derived[i] = [ref_np.error_dice(fp, fn, tpu, tnu, fpu, fnu), ref_np.error_recall(fp, fn, fpu, fnu),
+                      ref_np.error_precision(tpu, tnu, fpu, fnu)]
+    # masked variant (numpyfunctions.py:87-90)
+    mask = rng.rand(4, 12, 12) > 0.5
+    masked = np.array(ref_np.uncertainty(prediction.astype(bool), target.astype(bool), unc > 0.5, mask=mask))
+    # numpy entropy (numpyfunctions.py:166-168)
+    ent = ref_np.entropy(np.stack([1 - p, p], -1))
+    save('g9_uncertainty', p=p, target=target, prediction=prediction, probabilities2=to_eval['probabilities'],
+         uncertainty=unc, thresholds=np.array(thresholds), counts=counts, derived=derived, mask=mask,
+         masked_counts_thr05=masked, entropy_nat=ent,
+         undefined_error_metrics=np.array([ref_np.error_dice(0, 0, 0, 0, 0, 0), ref_np.error_recall(0, 0, 0, 0),
+                                           ref_np.error_precision(0, 0, 0, 0)]))
+
+
+def g10_prep():
+    import rechun.eval.helper as ref_h
+    import rechun.eval.analysis as ref_an
+    import rechun.eval.evaldata as ref_ed
+    rng = np.random.RandomState(20)
+    u = (rng.rand(3, 8, 8).astype(np.float32) * 3.0 + 0.2)
+    pred = (rng.rand(3, 8, 8) > 0.6).astype(np.uint8)
+    arrays = dict(u=u, prediction=pred)
+    mn, mx = float(u.min()), float(u.max())
+    r = ref_h.rescale_uncertainties(u, u.min(), u.max())
+    arrays['rescaled_subject'] = r
+    arrays['rescaled_global'] = ref_h.rescale_uncertainties(u, 0.1, 3.5)
+    fg = ref_h.uncertainty_to_foreground_probabilities(r, pred)
+    arrays['foreground'] = fg
+    arrays['with_background'] = ref_h.add_background_probability(fg)
+    # composed recipes per confidence entry (analysis.py:218-274)
+    for entry in ('probabilities', 'confidence', 'sigma'):
+        ed = types.SimpleNamespace(confidence_entry=entry, id_='run')
+        prep, id_ = ref_an.get_probability_preparation(ed, rescale_confidence='subject', rescale_sigma='subject')
+        src = rng.rand(3, 8, 8).astype(np.float32) if entry == 'probabilities' else u.copy()
+        to_eval = {entry: src.copy(), 'prediction': pred.copy()}
+        out = prep(to_eval)
+        arrays['prob_prep_in_' + entry] = src
+        arrays['prob_prep_out_' + entry] = out['probabilities']
+        arrays['prob_prep_id_' + entry] = np.array(id_)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            prep_u, id_u = ref_an.get_uncertainty_preparation(ed, rescale_confidence='subject',
+                                                              rescale_sigma='subject')
+            out_u = prep_u({entry: src.copy(), 'prediction': pred.copy()})
+        arrays['unc_prep_out_' + entry] = out_u['uncertainty']
+        arrays['unc_prep_id_' + entry] = np.array(id_u)
+    # guards
+    def raises(fn):
+        try:
+            fn()
+            return False
+        except ValueError:
+            return True
+    arrays['raises_range'] = np.array(raises(lambda: ref_h.add_background_probability(np.array([0.5, 1.5]))))
+    arrays['raises_shape'] = np.array(raises(
+        lambda: ref_h.uncertainty_to_foreground_probabilities(np.zeros((2, 2)), np.zeros((2, 3)))))
+    arrays['raises_nonbinary'] = np.array(raises(
+        lambda: ref_h.uncertainty_to_foreground_probabilities(np.zeros((2, 2)), np.full((2, 2), 2))))
+    arrays['raises_entropy_classes'] = np.array(raises(
+        lambda: ref_an.ToEntropy()({'probabilities': np.zeros((2, 2, 3))})))
+    arrays['minmax'] = np.array([mn, mx])
+    save('g10_prep', **arrays)
+
+
+def g11_fullsize_digest():
+    """Full-width model (start_filters=32, 8.6M parameters) on one small slice: only a strided
+    sub-sample of the reference logits is committed; the weights are regenerated from the seed."""
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
+    model = make_unet(20, **params)
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 4, 48, 32, generator=gen)
+    with torch.no_grad():
+        y = model(x)
+    flat = y.numpy().reshape(-1)
+    n_params = sum(p.numel() for p in model.parameters())
+    keys = list(model.state_dict().keys())
+    sha = hashlib.sha256(y.numpy().tobytes()).hexdigest()
+    save('g11_fullsize_digest', params=np.array(repr(params)), seed=np.array(20), x=x.numpy(),
+         logits_strided=flat[::37].copy(), stride=np.array(37), logits_mean=np.array(flat.mean()),
+         logits_absmax=np.array(np.abs(flat).max()), n_params=np.array(n_params), n_state_tensors=np.array(len(keys)),
+         state_keys=np.array(keys), sha256_here=np.array(sha))
+
+
+def main():
+    install_reference()
+    torch.set_num_threads(4)
+    torch.set_grad_enabled(False)
+    for fn in (g1_unet_eval, g2_unet_mc, g3_unet_center, g4_unet_sigma, g5_unet_isic, g6_mc_summary,
+               g7_mc_step_end2end, g8_ece, g9_uncertainty, g10_prep, g11_fullsize_digest):
+        fn()
+
+
+if __name__ == '__main__':
+    main()

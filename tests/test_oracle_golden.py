@@ -1,0 +1,231 @@
+"""The oracle is only trusted once it reproduces every golden vector the reference produced
+(tests/golden/*.npz, made by tests/golden/generate_golden.py).  CPU-only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_params, golden_state
+from oracle import calib_oracle as co
+from oracle import c_oracle
+from oracle import summary_oracle as so
+from oracle import unet_oracle as uo
+
+
+def _close(a, b, tol=2e-6):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape
+    assert np.max(np.abs(a - b)) <= tol, np.max(np.abs(a - b))
+
+
+def test_g1_unet_eval(golden):
+    g = golden('g1_unet_eval')
+    p, st = golden_params(g), golden_state(g)
+    for tag in ('a', 'b'):
+        y = uo.unet_forward(st, g['x_' + tag], None, **p)
+        _close(y.numpy(), g['logits_' + tag])
+    g8 = golden('g1_unet_eval_sf8')
+    _close(uo.unet_forward(golden_state(g8), g8['x'], None, **golden_params(g8)).numpy(), g8['logits'])
+
+
+def test_g2_unet_mc_masks(golden):
+    g = golden('g2_unet_mc')
+    p, st = golden_params(g), golden_state(g)
+    plan, sites = uo.unet_plan(**p)
+    assert [s[0] for s in sites] == list(g['sites'])
+    for t in range(int(g['T'])):
+        masks = [g['mask_{}_{}'.format(t, s)] for s in range(len(sites))]
+        assert any((m == 0).any() for m in masks)  # dropout really active
+        _close(uo.unet_forward(st, g['x'], masks, **p).numpy(), g['logits_{}'.format(t)], 5e-6)
+
+
+def test_g3_dropout_center_sites(golden):
+    g = golden('g3_unet_center')
+    p, st = golden_params(g), golden_state(g)
+    _, sites = uo.unet_plan(**p)
+    assert [s[0] for s in sites] == list(g['sites'])
+    assert len(sites) == 9
+    masks = [g['mask_{}'.format(s)] for s in range(len(sites))]
+    _close(uo.unet_forward(st, g['x'], masks, **p).numpy(), g['logits'], 5e-6)
+    _close(uo.unet_forward(st, g['x'], None, **p).numpy(), g['logits_eval'], 5e-6)
+    g2 = golden('g3_unet_center2_sites')
+    _, sites2 = uo.unet_plan(**golden_params(g2))
+    assert [s[0] for s in sites2] == list(g2['sites'])
+
+
+def test_g4_sigma_head(golden):
+    g = golden('g4_unet_sigma')
+    p, st = golden_params(g), golden_state(g)
+    logits, sigma = uo.unet_forward(st, g['x'], None, **p)
+    _close(logits.numpy(), g['logits'])
+    _close(sigma.numpy(), g['sigma_raw'])
+    out = so.aleatoric_outputs(logits, sigma)
+    _close(out['sigma'].numpy(), g['sigma_abs'])
+    _close(out['probabilities'].numpy(), g['probabilities'])
+    _close(so.aleatoric_outputs(logits, sigma, True)['sigma'].numpy(), g['sigma_exp'], 1e-5)
+    pred = out['probabilities'].argmax(1).numpy()
+    assert np.array_equal(pred.astype(np.uint8), g['prediction'])
+    sel = np.take_along_axis(out['sigma'].numpy(), pred[:, None], axis=1)[:, 0]
+    _close(sel, g['sigma_pred'])
+
+
+def test_g5_isic_shape(golden):
+    g = golden('g5_unet_isic')
+    _close(uo.unet_forward(golden_state(g), g['x'], None, **golden_params(g)).numpy(), g['logits'])
+
+
+def test_g6_mc_summary(golden):
+    g = golden('g6_mc_summary')
+    for case in range(3):
+        out = so.multi_prediction_summary(torch.from_numpy(g['multi_{}'.format(case)]), True, True)
+        for k in ('probabilities', 'entropy', 'mutual_info', 'variance'):
+            _close(out[k].numpy(), g['{}_{}'.format(k, case)], 1e-7)
+    _close(so.torch_entropy(torch.from_numpy(g['kat_entropy_in']), dim=1).numpy(), g['kat_entropy_out'], 0)
+    # KAT: p1 in {.1,.4,.7} -> mean .4, class-mean unbiased variance .09
+    multi = torch.tensor([.1, .4, .7]).view(3, 1, 1, 1, 1)
+    multi = torch.cat([1 - multi, multi], 2)
+    o = so.multi_prediction_summary(multi, do_var=True)
+    assert abs(o['probabilities'][0, 1, 0, 0].item() - 0.4) < 1e-6
+    assert abs(o['variance'].item() - 0.09) < 1e-6
+
+
+def test_g7_mc_step_end_to_end(golden):
+    g = golden('g7_mc_step')
+    p, st = golden_params(g), golden_state(g)
+    _, sites = uo.unet_plan(**p)
+    T = int(g['T'])
+    mask_sets = [[g['mask_{}_{}'.format(t, s)] for s in range(len(sites))] for t in range(T)]
+    x = torch.from_numpy(g['x']).float()
+    ws, multi = so.mc_probabilities(lambda xx, m: uo.unet_forward(st, xx, m, **p), x, mask_sets)
+    _close(ws.numpy(), g['out::ws_probabilities'], 5e-6)
+    _close(multi.numpy(), g['multi_probabilities'], 5e-6)
+    out = so.multi_prediction_summary(multi, True, True)
+    for k in ('probabilities', 'entropy', 'mutual_info', 'variance'):
+        _close(out[k].numpy(), g['out::' + k], 5e-6)
+    assert set(g['out_keys']) == {'ws_probabilities', 'probabilities', 'entropy', 'mutual_info', 'variance'}
+    assert set(g['default_out_keys']) == {'probabilities', 'entropy'}
+
+
+def test_g8_ece(golden):
+    g = golden('g8_ece')
+    thr = co.float32_thresholds(10)
+    assert [hex(v) for v in thr.view(np.uint32)] == ['0x3dcccccd', '0x3e4ccccd', '0x3e99999a', '0x3ecccccd',
+                                                     '0x3f000001', '0x3f19999a', '0x3f333334', '0x3f4ccccd',
+                                                     '0x3f666667']
+    # raw bin ids: numpy restatement and the float32-threshold C restatement, incl. the boundary vector
+    for tag in ('a', 'b'):
+        p = g[tag + '_p'].reshape(-1)
+        assert np.array_equal(co.bin_ids(p), g[tag + '_binids'])
+        assert np.array_equal(c_oracle.bin_ids(p, thr).astype(np.int64), g[tag + '_binids'])
+    p2 = np.stack([1 - g['a_p'], g['a_p']], -1)
+    for tag, m in (('masked', g['a_mask']), ('nomask', None)):
+        bins = {}
+        ece = co.ece_binary(p2, g['a_target'], mask=m, out_bins=bins)
+        assert ece == g['a_ece_' + tag]
+        for k in ('bins_count', 'bins_avg_confidence', 'bins_positive_fraction', 'bins_non_zero'):
+            assert np.array_equal(bins[k], g['a_{}_{}'.format(k, tag)])
+        # C oracle: identical histogram -> identical ECE
+        cnt, sc, sp = c_oracle.ece_hist(g['a_p'], g['a_target'], m, thr)
+        assert co.ece_from_histogram(cnt.astype(np.int64), sc, sp.astype(np.float64)) == g['a_ece_' + tag]
+    for tag in ('b', 'c'):
+        p = g[tag + '_p']
+        bins = {}
+        assert co.ece_binary(np.stack([1 - p, p], -1), g[tag + '_target'], out_bins=bins) == g[tag + '_ece']
+        assert np.array_equal(bins['bins_count'], g[tag + '_bins_count'])
+    assert float(g['c_ece']) == pytest.approx(0.2062500030733645, abs=1e-15)  # KAT, SURVEY 8c
+    assert list(g['c_bins_count']) == [2, 2, 1, 1, 2]
+    for w in ('log_proportion', 'power_proportion', 'mean_proportion'):
+        assert co.ece_binary(p2, g['a_target'], mask=g['a_mask'], bin_weighting=w) == g['d_ece_' + w]
+    assert co.ece_binary(p2, g['a_target'], threshold_range=(0.2, 0.9)) == g['d_ece_thresrange']
+    assert co.ece_binary(p2, g['a_target'], n_bins=5) == g['e_ece_5bins']
+    assert co.ece_binary(p2, g['a_target'], mask=g['a_mask']) == g['d_ece']
+
+
+def test_g9_uncertainty_counts(golden):
+    g = golden('g9_uncertainty')
+    p = g['p']
+    p2 = co.add_background_probability(p)
+    assert np.array_equal(p2, g['probabilities2'])
+    unc = co.normalised_entropy(p2)
+    assert unc.dtype == np.float64
+    assert np.array_equal(unc, g['uncertainty'])
+    assert np.array_equal(co.numpy_entropy(p2), g['entropy_nat'])
+    pred, tgt = g['prediction'].astype(bool), g['target'].astype(bool)
+    for i, thr in enumerate(g['thresholds']):
+        c = co.uncertainty_counts(pred, tgt, unc > thr)
+        assert list(c) == list(g['counts'][i])
+        tp, tn, fp, fn, tpu, tnu, fpu, fnu = c
+        d = [co.error_dice(fp, fn, tpu, tnu, fpu, fnu), co.error_recall(fp, fn, fpu, fnu),
+             co.error_precision(tpu, tnu, fpu, fnu)]
+        assert np.array_equal(np.array(d), g['derived'][i])
+    assert list(co.uncertainty_counts(pred, tgt, unc > 0.5, mask=g['mask'])) == list(g['masked_counts_thr05'])
+    cc = c_oracle.unc_counts(unc, g['prediction'], g['target'], None, g['thresholds'])
+    assert np.array_equal(cc.astype(np.int64), g['counts'])
+    cm = c_oracle.unc_counts(unc, g['prediction'], g['target'], g['mask'], [0.5])
+    assert list(cm[0].astype(np.int64)) == list(g['masked_counts_thr05'])
+    assert list(g['undefined_error_metrics']) == [co.error_dice(0, 0, 0, 0, 0, 0), co.error_recall(0, 0, 0, 0),
+                                                  co.error_precision(0, 0, 0, 0)]
+
+
+def test_g9_correction_metrics_from_counts(golden):
+    """The derived correction metrics only need the eight counts: check against a brute-force
+    evaluation that really edits the prediction (eval.py:205-226), with the unpinned pymia restatement."""
+    g = golden('g9_uncertainty')
+    pred, tgt, unc = g['prediction'], g['target'], g['uncertainty']
+    for thr in (0.2, 0.5, 0.9):
+        u = unc > thr
+        r = co.correction_metrics(co.uncertainty_counts(pred.astype(bool), tgt.astype(bool), u))
+        for key, val in (('corrected', 0), ('corrected_add', 1)):
+            cp = pred.copy()
+            cp[u] = val
+            tp, tn, fp, fn, n = co.confusion_counts(cp, tgt)
+            assert r[key + '_dice'] == pytest.approx(co.dice_from_counts(tp, fp, fn), abs=1e-15)
+            assert r[key + '_accuracy'] == pytest.approx(co.accuracy_from_counts(tp, tn, n), abs=1e-15)
+
+
+def test_g10_preparation(golden):
+    g = golden('g10_prep')
+    u, pred = g['u'], g['prediction']
+    r = co.rescale_uncertainties(u, u.min(), u.max())
+    assert np.array_equal(r, g['rescaled_subject'])
+    assert np.array_equal(co.rescale_uncertainties(u, 0.1, 3.5), g['rescaled_global'])
+    fg = co.uncertainty_to_foreground_probabilities(r, pred)
+    assert np.array_equal(fg, g['foreground'])
+    assert np.array_equal(co.add_background_probability(fg), g['with_background'])
+    for entry, idp, idu in (('probabilities', 'run', 'run'), ('confidence', 'run_rescale', 'run_rescale'),
+                            ('sigma', 'run_rescale', 'run_rescale')):
+        src = g['prob_prep_in_' + entry]
+        out = co.probability_preparation(entry, {entry: src.copy(), 'prediction': pred.copy()})
+        assert np.array_equal(out, g['prob_prep_out_' + entry])
+        assert str(g['prob_prep_id_' + entry]) == idp
+        out_u = co.uncertainty_preparation(entry, {entry: src.copy(), 'prediction': pred.copy()})
+        assert np.array_equal(out_u, g['unc_prep_out_' + entry])
+        assert str(g['unc_prep_id_' + entry]) == idu
+    assert bool(g['raises_range']) and bool(g['raises_shape']) and bool(g['raises_nonbinary'])
+    assert bool(g['raises_entropy_classes'])
+    with pytest.raises(ValueError):
+        co.add_background_probability(np.array([0.5, 1.5]))
+    with pytest.raises(ValueError):
+        co.uncertainty_to_foreground_probabilities(np.zeros((2, 2)), np.zeros((2, 3)))
+    with pytest.raises(ValueError):
+        co.uncertainty_to_foreground_probabilities(np.zeros((2, 2)), np.full((2, 2), 2))
+    with pytest.raises(ValueError):
+        co.normalised_entropy(np.zeros((2, 2, 3)))
+
+
+def test_g11_fullsize_digest(golden):
+    """Full-width model (start_filters=32, 8.6M parameters).  The fixture holds only a strided
+    sub-sample of the reference's logits; the weights are rebuilt here by replaying the reference's
+    constructor draws (oracle.unet_oracle.reference_init_state), so a match also proves that replay."""
+    g = golden('g11_fullsize_digest')
+    p = golden_params(g)
+    st = uo.reference_init_state(int(g['seed']), bn_seed=int(g['seed']) + 1000, **p)
+    assert sorted(st.keys()) == sorted(str(k) for k in g['state_keys'])
+    assert int(g['n_state_tensors']) == 143
+    n_params = sum(v.numel() for k, v in st.items() if 'running' not in k and 'num_batches' not in k)
+    assert n_params == int(g['n_params']) == 8646018
+    y = uo.unet_forward(st, g['x'], None, **p).numpy().reshape(-1)
+    _close(y[::int(g['stride'])], g['logits_strided'], 2e-5)
+    assert abs(float(y.mean()) - float(g['logits_mean'])) < 1e-5
+    st2 = uo.synthetic_state(20, **p)
+    assert sorted(st2.keys()) == sorted(st.keys())
+    assert all(tuple(st2[k].shape) == tuple(st[k].shape) for k in st)
