@@ -1,0 +1,194 @@
+/* rcu.h -- C ABI of librcu_hip.so: the MI355X (gfx950) implementation of the repeated-stochastic-
+ * inference uncertainty path of alainjungo/reliability-challenges-uncertainty.
+ *
+ * The reference is pure Python and has no FFI of its own; the path sits behind three Python call
+ * protocols.  Each group of entry points below names the reference
+ * interface it stands behind (paths relative to the reference root):
+ *
+ *   model seam   context.model(images) -> logits | (logits, sigma)
+ *                common/model/unet.py:123-186, called from rechun/dl/customsteps.py:23,32,
+ *                common/trainloop/steps.py:84, bin-dl/brats_test_ensemble.py:85,89,
+ *                bin-dl/brats_test_aleatoric.py:63
+ *   step seam    BatchStep.__call__(batch_context, task_context, context)
+ *                common/trainloop/steps.py:14-17; McPredictStep / MultiPredictionSummary
+ *                rechun/dl/customsteps.py:10-71
+ *   metric seam  EvaluationStrategy.__call__(to_evaluate, results)
+ *                common/evalutation/eval.py:9-16; numpy kernels common/evalutation/numpyfunctions.py:6-107
+ *
+ * Conventions: every function returns 0 on success and a negative rcu_status otherwise and never
+ * throws; rcu_last_error() gives the message of the calling thread's last failure.  Pointers
+ * named *_dev are device pointers (e.g. torch tensor.data_ptr()), *_host are host pointers.
+ * `stream` is a hipStream_t passed as void* (0 = the null stream); all device work is enqueued on
+ * it and no call synchronises unless documented.  A handle is not thread-safe; distinct handles
+ * are independent.  Tensors at the boundary use the reference's layout: float32, NCHW, contiguous.
+ */
+#ifndef RCU_H
+#define RCU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rcu_status {
+    RCU_OK = 0,
+    RCU_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+    RCU_ERR_HIP = -2,       /* a HIP runtime call failed */
+    RCU_ERR_WEIGHTS = -3,   /* missing / mis-sized weight tensor */
+    RCU_ERR_STATE = -4      /* call order violated (e.g. forward before finalize_weights) */
+} rcu_status;
+
+const char* rcu_last_error(void);
+/* "librcu_hip <version> gfx950" */
+const char* rcu_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Model seam: UNet(nb_classes, in_channels, depth, start_filters, dropout, dropout_center,
+ *                  residual=False, sigma_out, provide_features=False, bn)   (unet.py:128-130)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rcu_unet rcu_unet;
+
+typedef struct rcu_unet_desc {
+    int32_t nb_classes;      /* 1..8 */
+    int32_t in_channels;
+    int32_t depth;           /* number of down / up levels */
+    int32_t start_filters;
+    int32_t has_dropout;     /* 0 <=> dropout=None: the model has no Dropout2d modules at all */
+    int32_t dropout_center;  /* -1 <=> None (dropout in every conv unit), else unet.py:74-82 */
+    int32_t sigma_out;       /* 1: twin head, forward returns (logits, sigma) */
+    int32_t bn;              /* 1: BatchNorm2d in every conv unit (folded, eval mode) */
+    int32_t height, width;   /* per-slice size; both divisible by 2^depth */
+    int32_t max_batch;       /* largest N a forward call may pass; sizes the workspace */
+} rcu_unet_desc;
+
+int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out);
+int rcu_unet_destroy(rcu_unet* h);
+/* bytes of device workspace (activations + packed weights) the handle owns */
+int64_t rcu_unet_workspace_bytes(const rcu_unet* h);
+
+/* Dropout sites in execution order (= torch named_modules order of the Dropout2d modules). */
+int rcu_unet_num_dropout_sites(const rcu_unet* h);
+int rcu_unet_dropout_site_channels(const rcu_unet* h, int site);
+/* state_dict-style name of the site, e.g. "down_convs.0.block.block.0.conv2d_batch_relu.dropout" */
+const char* rcu_unet_dropout_site_name(const rcu_unet* h, int site);
+/* sum of the sites' channel counts = floats of mask per sample and pass */
+int rcu_unet_mask_floats_per_sample(const rcu_unet* h);
+
+/* Weights: one call per state_dict tensor (torch.load(checkpoint)['state_dict'],
+ * common/model/management.py:56-64), by its key (a leading "module." is ignored,
+ * common/trainloop/context.py:167).  float32 host data in torch layout (conv: [Cout][Cin][kh][kw]).
+ * Keys the path does not need (num_batches_tracked) are accepted and ignored. */
+int rcu_unet_load_weight(rcu_unet* h, const char* name, const float* data_host, size_t count);
+/* Folds BatchNorm (A = gamma / sqrt(var + 1e-5), B = beta - A * mean), repacks every conv into the
+ * kernel layout and uploads.  Synchronous.  Fails with RCU_ERR_WEIGHTS naming the first missing key. */
+int rcu_unet_finalize_weights(rcu_unet* h);
+
+/* One forward pass of n <= max_batch slices.
+ *   x_dev       [n][in_channels][H][W]
+ *   masks_dev   NULL = eval mode (set_dropout_mode(model, False), common/utils/torchhelper.py:44-50);
+ *               else the Dropout2d factors {0, 1/(1-p)} of this pass, sites concatenated:
+ *               [site 0: n x C_0][site 1: n x C_1]...  (n * mask_floats_per_sample floats)
+ *   logits_dev  [n][nb_classes][H][W] or NULL
+ *   sigma_dev   [n][nb_classes][H][W] raw sigma head output, or NULL (must be NULL without sigma_out)
+ */
+int rcu_unet_forward(rcu_unet* h, const float* x_dev, int n, const float* masks_dev, float* logits_dev,
+                     float* sigma_dev, void* stream);
+
+/* Forward + softmax + accumulation into MC statistics, fused so that neither logits nor the
+ * probability volume reach HBM (one pass of McPredictStep's loop body, customsteps.py:30-34, or one
+ * ensemble member, brats_test_ensemble.py:85-92).  stats_dev / flags as for rcu_mc_accumulate. */
+int rcu_unet_forward_accumulate(rcu_unet* h, const float* x_dev, int n, const float* masks_dev, void* stats_dev,
+                                int flags, void* stream);
+
+/* Per-layer introspection for benchmarks: canonical FLOPs (2*Cin*Cout*9*H*W per slice, real
+ * channel counts) and the kernel configuration chosen. */
+typedef struct rcu_layer_info {
+    char name[96];
+    char kernel[64];
+    int32_t cin, cout, height, width;
+    int32_t upsample, pooled, dual_source;
+    double flops_per_slice;
+} rcu_layer_info;
+int rcu_unet_num_layers(const rcu_unet* h);
+int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info* out);
+/* Runs only conv layer `layer` on the handle's current workspace contents (benchmark aid). */
+int rcu_unet_run_layer(rcu_unet* h, int layer, int n, const float* masks_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Step seam: per-voxel sufficient statistics over T passes / K members
+ *   (McPredictStep + MultiPredictionSummary, customsteps.py:16-71; torchhelper.py:53-54)
+ * ------------------------------------------------------------------------------------------ */
+#define RCU_MC_MI 1           /* also track sum_t H(p_t)  -> mutual_info available */
+#define RCU_MC_VAR 2          /* statistics in float64 incl. sum p^2 -> variance available */
+#define RCU_MC_INPUT_PROBS 4  /* rcu_mc_accumulate input is already softmax-ed */
+
+/* Size of the statistics blob for n*hw voxels.  Layout: planes over voxel v = n_idx*hw + pix;
+ * without RCU_MC_VAR float32 planes [sum p_c (C)] [sum H (if MI)]; with RCU_MC_VAR float64 planes
+ * [sum p_c (C)] [sum p_c^2 (C)] [sum H (if MI)].  The blob is plain additive: partial blobs of
+ * disjoint pass subsets are merged by element-wise addition (one RCCL sum-reduce). */
+size_t rcu_mc_stats_bytes(size_t n, size_t hw, int nb_classes, int flags);
+int rcu_mc_begin(void* stats_dev, size_t n, size_t hw, int nb_classes, int flags, void* stream);
+/* in_dev: [n][C][hw] logits (softmax applied here) or probabilities (RCU_MC_INPUT_PROBS). */
+int rcu_mc_accumulate(const float* in_dev, void* stats_dev, size_t n, size_t hw, int nb_classes, int flags,
+                      void* stream);
+/* T = number of accumulated passes.  Outputs (any may be NULL): mean [n][C][hw]; entropy, mutual_info,
+ * variance [n][1][hw].  mutual_info needs RCU_MC_MI, variance needs RCU_MC_VAR. */
+int rcu_mc_finalize(const void* stats_dev, size_t n, size_t hw, int nb_classes, int T, int flags, float* mean_dev,
+                    float* entropy_dev, float* mutual_info_dev, float* variance_dev, void* stream);
+
+/* F.softmax(logits, 1) (customsteps.py:24; steps.py:88) */
+int rcu_softmax(const float* logits_dev, float* probs_dev, size_t n, size_t hw, int nb_classes, void* stream);
+/* AleatoricPredictStep (bin-dl/brats_test_aleatoric.py:63-73) plus the writer's selection of the
+ * predicted class' sigma (same file :95-97).  Outputs may be NULL. */
+int rcu_aleatoric(const float* logits_dev, const float* sigma_raw_dev, size_t n, size_t hw, int nb_classes,
+                  int is_log_sigma, float* probs_dev, float* sigma_dev, uint8_t* prediction_dev,
+                  float* sigma_pred_dev, void* stream);
+/* argmax over classes (first maximum) and the foreground-class probability map, as written to
+ * *_prediction / *_probabilities.nii.gz (bin-dl/brats_test_default.py:96-99). */
+int rcu_prediction_and_foreground(const float* probs_dev, size_t n, size_t hw, int nb_classes,
+                                  uint8_t* prediction_dev, float* p_foreground_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Metric seam: calibration histograms (numpyfunctions.py:6-107)
+ * ------------------------------------------------------------------------------------------ */
+#define RCU_MAX_BINS 32
+#define RCU_MAX_THRESHOLDS 16
+
+typedef struct rcu_ece_result {           /* raw histogram of one volume, all RCU_MAX_BINS slots */
+    uint64_t count[RCU_MAX_BINS];
+    double sum_conf[RCU_MAX_BINS];
+    uint64_t sum_pos[RCU_MAX_BINS];
+} rcu_ece_result;
+
+/* float32 thresholds t_k (k = 1..n_bins-1) with  sum_k [p >= t_k] == np.digitize(p, linspace(0,
+ * 1+1e-8, n_bins+1)) - 1  for every float32 p in [0, 1]  (numpyfunctions.py:53-54). */
+int rcu_ece_thresholds(int n_bins, float* thr_host);
+size_t rcu_ece_workspace_bytes(size_t n_per_volume, int n_volumes);
+/* Reliability histogram of n_volumes independent volumes of n_per_volume voxels each (volume v at
+ * offset v * n_per_volume in every array).  mask_dev NULL = all voxels (ISIC), else voxels with
+ * mask != 0 (BraTS brain mask, rechun/eval/analysis.py:118-125).  result_dev: n_volumes results. */
+int rcu_ece_hist(const float* p_dev, const uint8_t* target_dev, const uint8_t* mask_dev, size_t n_per_volume,
+                 int n_volumes, const float* thr_host, int n_bins, rcu_ece_result* result_dev, void* workspace_dev,
+                 void* stream);
+/* raw bin index per voxel (test aid: pins the binning bit-for-bit) */
+int rcu_ece_bin_ids(const float* p_dev, size_t n, const float* thr_host, int n_bins, uint8_t* ids_dev, void* stream);
+
+size_t rcu_unc_workspace_bytes(size_t n_per_volume, int n_volumes);
+/* counts_dev: [n_volumes][n_thr][8] uint64 = tp, tn, fp, fn, tpu, tnu, fpu, fnu with
+ * "uncertain" := uncertainty > thr (compared in float64), numpyfunctions.py:86-107 for every
+ * threshold of bin-eval/eval_uncertainty.py:239 in one pass.  unc_dev is float64 (unc_is_f64=1, what
+ * ToEntropy yields) or float32. */
+int rcu_unc_counts(const void* unc_dev, int unc_is_f64, const uint8_t* prediction_dev, const uint8_t* target_dev,
+                   const uint8_t* mask_dev, size_t n_per_volume, int n_volumes, const double* thr_host, int n_thr,
+                   uint64_t* counts_dev, void* workspace_dev, void* stream);
+/* ToEntropy (rechun/eval/analysis.py:196-203) on a foreground-probability map: float32 products,
+ * float64 sum, / log 2.  Either output may be NULL. */
+int rcu_normalised_entropy(const float* p_foreground_dev, size_t n, double* out_f64_dev, float* out_f32_dev,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCU_H */

@@ -1,0 +1,614 @@
+// C ABI of librcu_hip.so (see include/rcu.h): U-Net handle (layer plan, BN folding, weight
+// packing, workspace) and thin wrappers around the kernel launchers.
+#include "../../include/rcu.h"
+#include "rcu_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace rcu;
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+static int hip_fail(hipError_t e, const char* what)
+{
+    return fail(RCU_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define RCU_HIP(call)                                      \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);  \
+    } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+struct ConvLayer {
+    std::string name;        // state_dict prefix of the conv ("....conv" for units, "...upconv.1" for up convs)
+    std::string bn;          // prefix of the BatchNorm2d, empty when the conv has none
+    std::string name2, bn2;  // fused twin (conv_sigma.0) stacked on the output channels, or empty
+    int cin1 = 0, cin2 = 0;  // real channels per source
+    int c1p = 0, c2p = 0;    // padded channels per source
+    int cout = 0;            // real output channels (per twin)
+    int coutp = 0;           // padded output channels (both twins)
+    int csplit = 0;          // first channel of the twin
+    int H = 0, W = 0;
+    int upsample = 0, relu = 0;
+    int site = -1, site2 = -1;
+    int cfg = 0, NT = 0;
+    int t_src1 = -1, t_src2 = -1, t_out = -1, t_pool = -1;
+    float *wpack = nullptr, *alpha = nullptr, *betab = nullptr, *beta = nullptr;
+    size_t wpack_floats = 0;
+};
+
+struct Tensor {
+    size_t floats_per_slice = 0;
+    float* dev = nullptr;
+};
+
+struct rcu_unet {
+    rcu_unet_desc d{};
+    std::vector<ConvLayer> layers;
+    std::vector<Tensor> tensors;
+    std::vector<std::pair<std::string, int>> sites;   // (name, channels)
+    std::vector<int> site_offset;                     // prefix sums of channels
+    int mask_floats = 0;
+    int in_cp = 0, head_cp = 0, head_cph = 0;
+    int t_input = -1, t_head = -1;
+    std::map<std::string, std::vector<float>> host_weights;
+    float *w_cls = nullptr, *b_cls = nullptr, *w_sig = nullptr, *b_sig = nullptr;
+    bool finalized = false;
+    int64_t workspace_bytes = 0;
+    std::vector<void*> allocs;
+};
+
+static int new_tensor(rcu_unet* h, int H, int W, int cp)
+{
+    Tensor t;
+    t.floats_per_slice = (size_t)H * W * cp;
+    h->tensors.push_back(t);
+    return (int)h->tensors.size() - 1;
+}
+
+static bool unit_has_dropout(const rcu_unet_desc& d, int level, bool is_down, int i)
+{
+    // common/model/unet.py:63-82
+    if (!d.has_dropout) return false;
+    if (d.dropout_center < 0) return true;                 // 'all'
+    if (level == d.depth) return false;                    // 'no'
+    if (level + d.dropout_center >= d.depth) return is_down ? (i == 1) : (i == 0);   // 'last' / 'first'
+    return false;
+}
+
+static int pick_config(const ConvLayer& L)
+{
+    if (L.c1p + L.c2p == 8) return CONV_CFG_T8x16_N32_K8;
+    if (L.coutp > 32) {
+        if (L.H == 12 && L.W == 8) return CONV_CFG_S2T12x8_N64_K16;
+        return CONV_CFG_T8x16_N64_K16;
+    }
+    return CONV_CFG_T8x16_N32_K32;
+}
+
+static void add_unit(rcu_unet* h, const std::string& prefix, int cin1, int c1p, int cin2, int c2p, int cout, int H, int W,
+                     bool dropout, int t_src1, int t_src2, int t_out, int t_pool)
+{
+    ConvLayer L;
+    L.name = prefix + ".conv2d_batch_relu.conv";
+    if (h->d.bn) L.bn = prefix + ".conv2d_batch_relu.bn";
+    L.cin1 = cin1; L.c1p = c1p; L.cin2 = cin2; L.c2p = c2p;
+    L.cout = cout; L.coutp = round_up(cout, 32); L.csplit = L.coutp;
+    L.H = H; L.W = W; L.relu = 1;
+    if (dropout) {
+        L.site = (int)h->sites.size();
+        h->sites.push_back({prefix + ".conv2d_batch_relu.dropout", cout});
+    }
+    L.t_src1 = t_src1; L.t_src2 = t_src2; L.t_out = t_out; L.t_pool = t_pool;
+    h->layers.push_back(L);
+}
+
+static int build_plan(rcu_unet* h)
+{
+    const rcu_unet_desc& d = h->d;
+    const int depth = d.depth;
+    h->in_cp = round_up(d.in_channels, 8);
+    h->t_input = new_tensor(h, d.height, d.width, h->in_cp);
+    std::vector<int> skip(depth), skip_c(depth);
+    int cur = h->t_input, cur_c = d.in_channels, cur_cp = h->in_cp;
+    int c = d.start_filters;
+    char buf[128];
+    for (int l = 0; l < depth; ++l) {
+        const int H = d.height >> l, W = d.width >> l, cp = round_up(c, 32);
+        const int t_tmp = new_tensor(h, H, W, cp), t_skip = new_tensor(h, H, W, cp);
+        const int t_pool = new_tensor(h, H / 2, W / 2, cp);
+        snprintf(buf, sizeof buf, "down_convs.%d.block.block.0", l);
+        add_unit(h, buf, cur_c, cur_cp, 0, 0, c, H, W, unit_has_dropout(d, l, true, 0), cur, -1, t_tmp, -1);
+        snprintf(buf, sizeof buf, "down_convs.%d.block.block.1", l);
+        add_unit(h, buf, c, cp, 0, 0, c, H, W, unit_has_dropout(d, l, true, 1), t_tmp, -1, t_skip, t_pool);
+        skip[l] = t_skip; skip_c[l] = c;
+        cur = t_pool; cur_c = c; cur_cp = cp;
+        c *= 2;
+    }
+    {
+        const int H = d.height >> depth, W = d.width >> depth, cp = round_up(c, 32);
+        const int t_tmp = new_tensor(h, H, W, cp), t_out = new_tensor(h, H, W, cp);
+        add_unit(h, "bottom_convs.block.0", cur_c, cur_cp, 0, 0, c, H, W, unit_has_dropout(d, depth, true, 0), cur, -1,
+                 t_tmp, -1);
+        add_unit(h, "bottom_convs.block.1", c, cp, 0, 0, c, H, W, unit_has_dropout(d, depth, true, 1), t_tmp, -1, t_out,
+                 -1);
+        cur = t_out; cur_c = c; cur_cp = cp;
+    }
+    for (int j = 0; j < depth; ++j) {
+        const int l = depth - 1 - j;
+        const int H = d.height >> l, W = d.width >> l;
+        const int co = cur_c / 2, cop = round_up(co, 32);
+        const int t_up = new_tensor(h, H, W, cop), t_tmp = new_tensor(h, H, W, cop), t_out = new_tensor(h, H, W, cop);
+        ConvLayer U;   // nearest x2 + conv3x3 + bias, no BN / ReLU / dropout (unet.py:105)
+        snprintf(buf, sizeof buf, "up_convs.%d.upconv.1", j);
+        U.name = buf;
+        U.cin1 = cur_c; U.c1p = cur_cp; U.cout = co; U.coutp = cop; U.csplit = cop;
+        U.H = H; U.W = W; U.upsample = 1; U.relu = 0;
+        U.t_src1 = cur; U.t_out = t_up;
+        h->layers.push_back(U);
+        // cat((up, skip), 1) -> block: K split over the two tensors (unet.py:118-119)
+        snprintf(buf, sizeof buf, "up_convs.%d.block.block.0", j);
+        add_unit(h, buf, co, cop, skip_c[l], round_up(skip_c[l], 32), co, H, W, unit_has_dropout(d, l, false, 0), t_up,
+                 skip[l], t_tmp, -1);
+        snprintf(buf, sizeof buf, "up_convs.%d.block.block.1", j);
+        add_unit(h, buf, co, cop, 0, 0, co, H, W, unit_has_dropout(d, l, false, 1), t_tmp, -1, t_out, -1);
+        cur = t_out; cur_c = co; cur_cp = cop;
+    }
+    {   // head unit(s): conv_cls.0 [+ conv_sigma.0 stacked on the output channels] (unet.py:161-164)
+        const int cp = round_up(cur_c, 32);
+        h->head_cph = cp;
+        h->head_cp = d.sigma_out ? 2 * cp : cp;
+        h->t_head = new_tensor(h, d.height, d.width, h->head_cp);
+        add_unit(h, "conv_cls.0", cur_c, cur_cp, 0, 0, cur_c, d.height, d.width, d.has_dropout != 0, cur, -1, h->t_head,
+                 -1);
+        ConvLayer& L = h->layers.back();
+        if (d.sigma_out) {
+            L.name2 = "conv_sigma.0.conv2d_batch_relu.conv";
+            if (d.bn) L.bn2 = "conv_sigma.0.conv2d_batch_relu.bn";
+            L.csplit = cp;
+            L.coutp = 2 * cp;
+            if (d.has_dropout) {
+                L.site2 = (int)h->sites.size();
+                h->sites.push_back({"conv_sigma.0.conv2d_batch_relu.dropout", cur_c});
+            }
+        }
+    }
+    h->site_offset.assign(h->sites.size() + 1, 0);
+    for (size_t s = 0; s < h->sites.size(); ++s) h->site_offset[s + 1] = h->site_offset[s] + h->sites[s].second;
+    h->mask_floats = h->site_offset.back();
+    for (ConvLayer& L : h->layers) {
+        L.cfg = pick_config(L);
+        const ConvConfigInfo& ci = conv_config_info(L.cfg);
+        if ((L.c1p % ci.KC) != 0 || (L.c2p % ci.KC) != 0)
+            return fail(RCU_ERR_INVALID, "internal: channel chunking does not divide for layer " + L.name);
+        L.NT = (L.coutp + ci.BN - 1) / ci.BN;
+    }
+    return RCU_OK;
+}
+
+extern "C" const char* rcu_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* rcu_version(void) { return "librcu_hip 0.1.0 gfx950"; }
+
+extern "C" int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out)
+{
+    if (!desc || !out) return fail(RCU_ERR_INVALID, "rcu_unet_create: null argument");
+    const rcu_unet_desc& d = *desc;
+    if (d.nb_classes < 1 || d.nb_classes > MAX_CLASSES) return fail(RCU_ERR_INVALID, "nb_classes must be in 1..8");
+    if (d.in_channels < 1 || d.depth < 1 || d.depth > 8 || d.start_filters < 1 || d.max_batch < 1)
+        return fail(RCU_ERR_INVALID, "rcu_unet_create: bad in_channels / depth / start_filters / max_batch");
+    if (d.in_channels > 8 && d.in_channels % 32 != 0)
+        return fail(RCU_ERR_INVALID, "in_channels must be <= 8 or a multiple of 32");
+    const int div = 1 << d.depth;
+    if (d.height < div || d.width < div || d.height % div != 0 || d.width % div != 0)
+        return fail(RCU_ERR_INVALID, "height and width must be positive multiples of 2^depth (the reference's centre-pad "
+                                     "branch, unet.py:110-116, is not implemented)");
+    rcu_unet* h = new rcu_unet();
+    h->d = d;
+    int rc = build_plan(h);
+    if (rc != RCU_OK) {
+        delete h;
+        return rc;
+    }
+    // 32-bit element offsets inside the conv kernel
+    for (const Tensor& t : h->tensors)
+        if (t.floats_per_slice * (size_t)d.max_batch >= (size_t)1 << 31) {
+            delete h;
+            return fail(RCU_ERR_INVALID, "max_batch too large: an activation tensor would exceed 2^31 elements");
+        }
+    for (Tensor& t : h->tensors) {
+        const size_t bytes = t.floats_per_slice * (size_t)d.max_batch * sizeof(float);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&t.dev), bytes);
+        if (e != hipSuccess) {
+            rcu_unet_destroy(h);
+            return hip_fail(e, "hipMalloc(activation workspace)");
+        }
+        h->allocs.push_back(t.dev);
+        h->workspace_bytes += (int64_t)bytes;
+    }
+    *out = h;
+    return RCU_OK;
+}
+
+extern "C" int rcu_unet_destroy(rcu_unet* h)
+{
+    if (!h) return RCU_OK;
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+    return RCU_OK;
+}
+
+extern "C" int64_t rcu_unet_workspace_bytes(const rcu_unet* h) { return h ? h->workspace_bytes : 0; }
+extern "C" int rcu_unet_num_dropout_sites(const rcu_unet* h) { return h ? (int)h->sites.size() : 0; }
+extern "C" int rcu_unet_dropout_site_channels(const rcu_unet* h, int site)
+{
+    if (!h || site < 0 || site >= (int)h->sites.size()) return fail(RCU_ERR_INVALID, "bad dropout site index");
+    return h->sites[site].second;
+}
+extern "C" const char* rcu_unet_dropout_site_name(const rcu_unet* h, int site)
+{
+    if (!h || site < 0 || site >= (int)h->sites.size()) return "";
+    return h->sites[site].first.c_str();
+}
+extern "C" int rcu_unet_mask_floats_per_sample(const rcu_unet* h) { return h ? h->mask_floats : 0; }
+
+extern "C" int rcu_unet_load_weight(rcu_unet* h, const char* name, const float* data, size_t count)
+{
+    if (!h || !name || (!data && count)) return fail(RCU_ERR_INVALID, "rcu_unet_load_weight: null argument");
+    std::string key(name);
+    if (key.rfind("module.", 0) == 0) key = key.substr(7);
+    h->host_weights[key].assign(data, data + count);
+    h->finalized = false;
+    return RCU_OK;
+}
+
+static int get_weight(rcu_unet* h, const std::string& key, size_t count, const std::vector<float>** out)
+{
+    auto it = h->host_weights.find(key);
+    if (it == h->host_weights.end()) return fail(RCU_ERR_WEIGHTS, "missing weight tensor '" + key + "'");
+    if (it->second.size() != count)
+        return fail(RCU_ERR_WEIGHTS, "weight tensor '" + key + "' has " + std::to_string(it->second.size()) +
+                                         " elements, expected " + std::to_string(count));
+    *out = &it->second;
+    return RCU_OK;
+}
+
+template <typename T>
+static int upload(rcu_unet* h, const std::vector<T>& host, T** dev)
+{
+    RCU_HIP(hipMalloc(reinterpret_cast<void**>(dev), host.size() * sizeof(T)));
+    h->allocs.push_back(*dev);
+    h->workspace_bytes += (int64_t)(host.size() * sizeof(T));
+    RCU_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RCU_OK;
+}
+
+// Fold one conv (+ optional BN) into (packed weights, alpha, betab, beta) at output-channel offset co0.
+static int fold_conv(rcu_unet* h, const ConvLayer& L, const std::string& conv, const std::string& bn, int co0,
+                     std::vector<float>& wpack, std::vector<float>& alpha, std::vector<float>& betab,
+                     std::vector<float>& beta)
+{
+    const ConvConfigInfo& ci = conv_config_info(L.cfg);
+    const int KC = ci.KC, KCP = KC + 4, BN = ci.BN;
+    const int cin = L.cin1 + L.cin2;
+    const std::vector<float>*w, *b;
+    int rc = get_weight(h, conv + ".weight", (size_t)L.cout * cin * 9, &w);
+    if (rc) return rc;
+    rc = get_weight(h, conv + ".bias", (size_t)L.cout, &b);
+    if (rc) return rc;
+    const std::vector<float>*g = nullptr, *bt = nullptr, *mu = nullptr, *var = nullptr;
+    if (!bn.empty()) {
+        if ((rc = get_weight(h, bn + ".weight", L.cout, &g))) return rc;
+        if ((rc = get_weight(h, bn + ".bias", L.cout, &bt))) return rc;
+        if ((rc = get_weight(h, bn + ".running_mean", L.cout, &mu))) return rc;
+        if ((rc = get_weight(h, bn + ".running_var", L.cout, &var))) return rc;
+    }
+    for (int co = 0; co < L.cout; ++co) {
+        float A = 1.f, B = 0.f;
+        if (g) {
+            A = (*g)[co] / std::sqrt((*var)[co] + 1e-5f);
+            B = (*bt)[co] - A * (*mu)[co];
+        }
+        alpha[co0 + co] = A;
+        betab[co0 + co] = A * (*b)[co];
+        beta[co0 + co] = B;
+    }
+    const size_t tile_floats = (size_t)9 * BN * KCP;
+    for (int co = 0; co < L.cout; ++co) {
+        const int cop = co0 + co;
+        const int ntile = cop / BN, nn = cop % BN;
+        for (int ci_ = 0; ci_ < cin; ++ci_) {
+            const int kp = ci_ < L.cin1 ? ci_ : L.c1p + (ci_ - L.cin1);   // position in the padded K range
+            const int chunk = kp / KC, kq = kp % KC;
+            for (int tap = 0; tap < 9; ++tap) {
+                const size_t dst = ((size_t)chunk * L.NT + ntile) * tile_floats + ((size_t)tap * BN + nn) * KCP + kq;
+                wpack[dst] = (*w)[((size_t)co * cin + ci_) * 9 + tap];
+            }
+        }
+    }
+    return RCU_OK;
+}
+
+extern "C" int rcu_unet_finalize_weights(rcu_unet* h)
+{
+    if (!h) return fail(RCU_ERR_INVALID, "null handle");
+    if (h->finalized) return RCU_OK;
+    for (ConvLayer& L : h->layers) {
+        const ConvConfigInfo& ci = conv_config_info(L.cfg);
+        const int KCP = ci.KC + 4;
+        const int nchunks = (L.c1p + L.c2p) / ci.KC;
+        L.wpack_floats = (size_t)nchunks * L.NT * 9 * ci.BN * KCP;
+        std::vector<float> wpack(L.wpack_floats, 0.f);
+        const int cpad = L.NT * ci.BN;
+        std::vector<float> alpha(cpad, 0.f), betab(cpad, 0.f), beta(cpad, 0.f);
+        int rc = fold_conv(h, L, L.name, L.bn, 0, wpack, alpha, betab, beta);
+        if (rc) return rc;
+        if (!L.name2.empty()) {
+            rc = fold_conv(h, L, L.name2, L.bn2, L.csplit, wpack, alpha, betab, beta);
+            if (rc) return rc;
+        }
+        if ((rc = upload(h, wpack, &L.wpack))) return rc;
+        if ((rc = upload(h, alpha, &L.alpha))) return rc;
+        if ((rc = upload(h, betab, &L.betab))) return rc;
+        if ((rc = upload(h, beta, &L.beta))) return rc;
+    }
+    // 1x1 heads (unet.py:161, 164): [C][CPh] zero padded
+    const int C = h->d.nb_classes, cph = h->head_cph, creal = h->layers.back().cout;
+    auto head = [&](const std::string& key, float** w_dev, float** b_dev) -> int {
+        const std::vector<float>*w, *b;
+        int rc = get_weight(h, key + ".weight", (size_t)C * creal, &w);
+        if (rc) return rc;
+        if ((rc = get_weight(h, key + ".bias", (size_t)C, &b))) return rc;
+        std::vector<float> wp((size_t)C * cph, 0.f);
+        for (int c = 0; c < C; ++c)
+            for (int k = 0; k < creal; ++k) wp[(size_t)c * cph + k] = (*w)[(size_t)c * creal + k];
+        if ((rc = upload(h, wp, w_dev))) return rc;
+        return upload(h, *b, b_dev);
+    };
+    int rc = head("conv_cls.1", &h->w_cls, &h->b_cls);
+    if (rc) return rc;
+    if (h->d.sigma_out && (rc = head("conv_sigma.1", &h->w_sig, &h->b_sig))) return rc;
+    h->host_weights.clear();
+    h->finalized = true;
+    return RCU_OK;
+}
+
+static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks, hipStream_t stream)
+{
+    const ConvConfigInfo& ci = conv_config_info(L.cfg);
+    ConvArgs a{};
+    a.src1 = h->tensors[L.t_src1].dev;
+    a.src2 = L.t_src2 >= 0 ? h->tensors[L.t_src2].dev : nullptr;
+    a.wpack = L.wpack; a.alpha = L.alpha; a.betab = L.betab; a.beta = L.beta;
+    a.mask = (masks && L.site >= 0) ? masks + (size_t)n * h->site_offset[L.site] : nullptr;
+    a.mask2 = (masks && L.site2 >= 0) ? masks + (size_t)n * h->site_offset[L.site2] : nullptr;
+    a.out = h->tensors[L.t_out].dev;
+    a.pooled = L.t_pool >= 0 ? h->tensors[L.t_pool].dev : nullptr;
+    a.N = n; a.H = L.H; a.W = L.W;
+    a.C1 = L.c1p; a.C2 = L.c2p; a.CoutP = L.coutp;
+    a.Cmask = L.cout; a.Csplit = L.csplit; a.Cmask2 = L.cout;
+    a.upsample = L.upsample; a.relu = L.relu;
+    a.tiles_y = (L.H + ci.TH - 1) / ci.TH;
+    a.tiles_x = (L.W + ci.TW - 1) / ci.TW;
+    a.slice_groups = (n + ci.TS - 1) / ci.TS;
+    a.NT = L.NT;
+    RCU_HIP(launch_conv3x3(L.cfg, a, stream));
+    return RCU_OK;
+}
+
+static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, float* logits, float* sigma, void* stats,
+                        int flags, hipStream_t stream)
+{
+    if (!h || !x) return fail(RCU_ERR_INVALID, "rcu_unet_forward: null argument");
+    if (!h->finalized) return fail(RCU_ERR_STATE, "rcu_unet_forward before rcu_unet_finalize_weights");
+    if (n < 1 || n > h->d.max_batch) return fail(RCU_ERR_INVALID, "batch size outside 1..max_batch");
+    if (sigma && !h->d.sigma_out) return fail(RCU_ERR_INVALID, "sigma output requested from a model without sigma_out");
+    RCU_HIP(launch_pack_input(x, h->tensors[h->t_input].dev, n, h->d.in_channels, h->in_cp, h->d.height, h->d.width,
+                              stream));
+    for (const ConvLayer& L : h->layers) {
+        int rc = run_layer(h, L, n, masks, stream);
+        if (rc) return rc;
+    }
+    HeadArgs a{};
+    a.act = h->tensors[h->t_head].dev;
+    a.w_cls = h->w_cls; a.b_cls = h->b_cls; a.w_sig = h->w_sig; a.b_sig = h->b_sig;
+    a.logits = logits; a.sigma = sigma; a.stats = stats;
+    a.C = h->d.nb_classes; a.CP = h->head_cp; a.CPh = h->head_cph; a.stats_flags = flags;
+    a.HW = (size_t)h->d.height * h->d.width;
+    a.V = a.HW * n;
+    RCU_HIP(launch_head(a, stream));
+    return RCU_OK;
+}
+
+extern "C" int rcu_unet_forward(rcu_unet* h, const float* x_dev, int n, const float* masks_dev, float* logits_dev,
+                                float* sigma_dev, void* stream)
+{
+    return forward_impl(h, x_dev, n, masks_dev, logits_dev, sigma_dev, nullptr, 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rcu_unet_forward_accumulate(rcu_unet* h, const float* x_dev, int n, const float* masks_dev, void* stats_dev,
+                                           int flags, void* stream)
+{
+    if (!stats_dev) return fail(RCU_ERR_INVALID, "rcu_unet_forward_accumulate: null stats");
+    return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR),
+                        static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rcu_unet_num_layers(const rcu_unet* h) { return h ? (int)h->layers.size() : 0; }
+
+extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info* out)
+{
+    if (!h || !out || layer < 0 || layer >= (int)h->layers.size()) return fail(RCU_ERR_INVALID, "bad layer index");
+    const ConvLayer& L = h->layers[layer];
+    std::memset(out, 0, sizeof *out);
+    std::snprintf(out->name, sizeof out->name, "%s", L.name.c_str());
+    std::snprintf(out->kernel, sizeof out->kernel, "%s", conv_config_info(L.cfg).kernel_name);
+    out->cin = L.cin1 + L.cin2;
+    out->cout = L.name2.empty() ? L.cout : 2 * L.cout;
+    out->height = L.H; out->width = L.W;
+    out->upsample = L.upsample; out->pooled = L.t_pool >= 0; out->dual_source = L.t_src2 >= 0;
+    out->flops_per_slice = 2.0 * out->cin * out->cout * 9.0 * L.H * L.W;
+    return RCU_OK;
+}
+
+extern "C" int rcu_unet_run_layer(rcu_unet* h, int layer, int n, const float* masks_dev, void* stream)
+{
+    if (!h || layer < 0 || layer >= (int)h->layers.size()) return fail(RCU_ERR_INVALID, "bad layer index");
+    if (!h->finalized) return fail(RCU_ERR_STATE, "rcu_unet_run_layer before rcu_unet_finalize_weights");
+    if (n < 1 || n > h->d.max_batch) return fail(RCU_ERR_INVALID, "batch size outside 1..max_batch");
+    return run_layer(h, h->layers[layer], n, masks_dev, static_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// step seam
+// ------------------------------------------------------------------------------------------------
+static int check_classes(int c)
+{
+    if (c < 1 || c > MAX_CLASSES) return fail(RCU_ERR_INVALID, "nb_classes must be in 1..8");
+    return RCU_OK;
+}
+
+extern "C" size_t rcu_mc_stats_bytes(size_t n, size_t hw, int C, int flags)
+{
+    const size_t V = n * hw;
+    const size_t mi = (flags & RCU_MC_MI) ? 1 : 0;
+    if (flags & RCU_MC_VAR) return V * (2 * (size_t)C + mi) * sizeof(double);
+    return V * ((size_t)C + mi) * sizeof(float);
+}
+
+extern "C" int rcu_mc_begin(void* stats, size_t n, size_t hw, int C, int flags, void* stream)
+{
+    if (!stats) return fail(RCU_ERR_INVALID, "rcu_mc_begin: null stats");
+    if (check_classes(C)) return RCU_ERR_INVALID;
+    RCU_HIP(hipMemsetAsync(stats, 0, rcu_mc_stats_bytes(n, hw, C, flags), static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}
+
+extern "C" int rcu_mc_accumulate(const float* in, void* stats, size_t n, size_t hw, int C, int flags, void* stream)
+{
+    if (!in || !stats) return fail(RCU_ERR_INVALID, "rcu_mc_accumulate: null argument");
+    if (check_classes(C)) return RCU_ERR_INVALID;
+    if (n * hw == 0) return RCU_OK;
+    RCU_HIP(launch_mc_accumulate(in, stats, C, n, hw, flags, static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}
+
+extern "C" int rcu_mc_finalize(const void* stats, size_t n, size_t hw, int C, int T, int flags, float* mean, float* entropy,
+                               float* mi, float* var, void* stream)
+{
+    if (!stats) return fail(RCU_ERR_INVALID, "rcu_mc_finalize: null stats");
+    if (check_classes(C)) return RCU_ERR_INVALID;
+    if (T < 1) return fail(RCU_ERR_INVALID, "rcu_mc_finalize: T must be >= 1");
+    if (mi && !(flags & RCU_MC_MI)) return fail(RCU_ERR_INVALID, "mutual_info requested without RCU_MC_MI statistics");
+    if (var && !(flags & RCU_MC_VAR)) return fail(RCU_ERR_INVALID, "variance requested without RCU_MC_VAR statistics");
+    if (n * hw == 0) return RCU_OK;
+    RCU_HIP(launch_mc_finalize(stats, C, n, hw, T, flags, mean, entropy, mi, var, static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}
+
+extern "C" int rcu_softmax(const float* logits, float* probs, size_t n, size_t hw, int C, void* stream)
+{
+    if (!logits || !probs) return fail(RCU_ERR_INVALID, "rcu_softmax: null argument");
+    if (check_classes(C)) return RCU_ERR_INVALID;
+    if (n * hw == 0) return RCU_OK;
+    RCU_HIP(launch_softmax_nchw(logits, probs, C, n, hw, static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}
+
+extern "C" int rcu_aleatoric(const float* logits, const float* sigma_raw, size_t n, size_t hw, int C, int is_log_sigma,
+                             float* probs, float* sigma, uint8_t* prediction, float* sigma_pred, void* stream)
+{
+    if (!logits || !sigma_raw) return fail(RCU_ERR_INVALID, "rcu_aleatoric: null argument");
+    if (check_classes(C)) return RCU_ERR_INVALID;
+    if (n * hw == 0) return RCU_OK;
+    RCU_HIP(launch_aleatoric(logits, sigma_raw, C, n, hw, is_log_sigma, probs, sigma, prediction, sigma_pred,
+                             static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}
+
+extern "C" int rcu_prediction_and_foreground(const float* probs, size_t n, size_t hw, int C, uint8_t* prediction,
+                                             float* p_fg, void* stream)
+{
+    if (!probs) return fail(RCU_ERR_INVALID, "rcu_prediction_and_foreground: null argument");
+    if (check_classes(C)) return RCU_ERR_INVALID;
+    if (n * hw == 0) return RCU_OK;
+    RCU_HIP(launch_argmax_fg(probs, C, n, hw, prediction, p_fg, static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// metric seam
+// ------------------------------------------------------------------------------------------------
+static_assert(sizeof(rcu_ece_result) == sizeof(EceResult), "ABI struct mismatch");
+static_assert(RCU_MAX_BINS == MAX_BINS && RCU_MAX_THRESHOLDS == MAX_THR, "ABI constant mismatch");
+
+extern "C" int rcu_ece_thresholds(int n_bins, float* thr)
+{
+    if (n_bins < 1 || n_bins > MAX_BINS || !thr) return fail(RCU_ERR_INVALID, "n_bins must be in 1..32");
+    // edges = np.linspace(0, 1 + 1e-8, n_bins + 1): start + k * step with step = (stop - start) / n_bins
+    const double stop = 1.0 + 1e-8, step = stop / n_bins;
+    for (int k = 1; k < n_bins; ++k) {
+        const double edge = k * step;
+        float t = (float)edge;
+        if ((double)t < edge) t = std::nextafterf(t, INFINITY);
+        thr[k - 1] = t;
+    }
+    return RCU_OK;
+}
+
+extern "C" size_t rcu_ece_workspace_bytes(size_t n, int nv) { return ece_workspace_bytes(n, nv < 1 ? 1 : nv); }
+
+extern "C" int rcu_ece_hist(const float* p, const uint8_t* target, const uint8_t* mask, size_t n, int n_volumes,
+                            const float* thr, int n_bins, rcu_ece_result* result, void* workspace, void* stream)
+{
+    if (!result || !thr || (n && (!p || !target || !workspace)))
+        return fail(RCU_ERR_INVALID, "rcu_ece_hist: null argument");
+    if (n_bins < 1 || n_bins > MAX_BINS || n_volumes < 1) return fail(RCU_ERR_INVALID, "rcu_ece_hist: bad n_bins / n_volumes");
+    RCU_HIP(launch_ece_hist(p, target, mask, n, n_volumes, thr, n_bins, reinterpret_cast<EceResult*>(result), workspace,
+                            static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}
+
+extern "C" int rcu_ece_bin_ids(const float* p, size_t n, const float* thr, int n_bins, uint8_t* ids, void* stream)
+{
+    if ((n && (!p || !ids)) || !thr) return fail(RCU_ERR_INVALID, "rcu_ece_bin_ids: null argument");
+    if (n_bins < 1 || n_bins > MAX_BINS) return fail(RCU_ERR_INVALID, "n_bins must be in 1..32");
+    RCU_HIP(launch_bin_ids(p, n, thr, n_bins, ids, static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}
+
+extern "C" size_t rcu_unc_workspace_bytes(size_t n, int nv) { return unc_workspace_bytes(n, nv < 1 ? 1 : nv); }
+
+extern "C" int rcu_unc_counts(const void* unc, int unc_is_f64, const uint8_t* prediction, const uint8_t* target,
+                              const uint8_t* mask, size_t n, int n_volumes, const double* thr, int n_thr, uint64_t* counts,
+                              void* workspace, void* stream)
+{
+    if (!counts || !thr || (n && (!unc || !prediction || !target || !workspace)))
+        return fail(RCU_ERR_INVALID, "rcu_unc_counts: null argument");
+    if (n_thr < 1 || n_thr > MAX_THR || n_volumes < 1)
+        return fail(RCU_ERR_INVALID, "rcu_unc_counts: n_thr must be in 1..16 and n_volumes >= 1");
+    RCU_HIP(launch_unc_counts(unc, unc_is_f64, prediction, target, mask, n, n_volumes, thr, n_thr,
+                              reinterpret_cast<unsigned long long*>(counts), workspace, static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}
+
+extern "C" int rcu_normalised_entropy(const float* p_fg, size_t n, double* out64, float* out32, void* stream)
+{
+    if (n && !p_fg) return fail(RCU_ERR_INVALID, "rcu_normalised_entropy: null argument");
+    RCU_HIP(launch_norm_entropy(p_fg, n, out64, out32, static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}

@@ -1,0 +1,273 @@
+// conv3x3 (pad 1) as an implicit GEMM on the fp32 matrix cores of gfx950 (CDNA4), with the
+// reference's whole conv unit fused into one kernel:
+//
+//     out = relu( alpha_c * m_{n,c} * (W * x) + (alpha_c * b_c * m_{n,c} + beta_c) )
+//
+// which is Conv2d(3x3, pad 1)+bias -> Dropout2d -> BatchNorm2d(eval) -> ReLU of the reference
+// (common/model/unet.py:8-23) with BN folded to (alpha, beta) and the Dropout2d factor m_{n,c}
+// in {0, 1/(1-p)} supplied per (slice, channel).  Optional extras, all fused into the same pass:
+//   * second output = 2x2 max-pool of the result                  (DownConv, unet.py:85-95)
+//   * nearest x2 up-sampling folded into the input addressing     (UpConv,   unet.py:105; helpers.py:15)
+//   * K split over two source tensors instead of torch.cat        (UpConv,   unet.py:118)
+//
+// GEMM view: M = pixels (N*H*W), N = output channels, K = 9 taps x Cin.  v_mfma_f32_32x32x2_f32:
+// A operand = 32 pixels (one 4-row x 8-column patch), B operand = 32 output channels.  With that
+// pixel->row map every lane ends up owning a 4x4 pixel patch of one output channel, so the 2x2
+// max-pool needs no cross-lane traffic and every store instruction writes 2 x 128 contiguous bytes.
+//
+// Per workgroup (256 threads = 4 waves, 2 workgroups per CU): an input tile with a 1-pixel halo and
+// the weight slice of one Cin chunk are staged through LDS (register-staged: the global loads of
+// chunk k+1 are in flight while chunk k is multiplied); rows are padded by 4 floats so the
+// ds_read_b128 fragment reads are bank-conflict free.  Exact fp32 (MFMA f32 == fmaf chain).
+#include "rcu_kernels.h"
+
+namespace rcu {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int TS_, int TH_, int TW_, int BN_, int KC_, int WM_, int WN_>
+struct ConvTile {
+    static constexpr int TS = TS_, TH = TH_, TW = TW_, BN = BN_, KC = KC_, WM = WM_, WN = WN_;
+    static constexpr int THREADS = 256;
+    static constexpr int KCP = KC + 4;                      // padded row length (floats)
+    static constexpr int HW_ = (TH + 2) * (TW + 2);         // halo pixels per slice tile
+    static constexpr int HPIX = TS * HW_;
+    static constexpr int A_FLOATS = HPIX * KCP;
+    static constexpr int W_FLOATS = 9 * BN * KCP;
+    static constexpr int BPS = (TH / 4) * (TW / 8);         // 32-pixel blocks per slice tile
+    static constexpr int NBLK = TS * BPS;
+    static constexpr int MT = NBLK / WM;                    // pixel blocks per wave
+    static constexpr int NTW = BN / 32 / WN;                // channel blocks per wave
+    static constexpr int A_UNITS = HPIX * (KC / 4);         // float4 units of the input tile
+    static constexpr int NA = (A_UNITS + THREADS - 1) / THREADS;
+    static constexpr int W_UNITS = W_FLOATS / 4;
+    static constexpr int NW = (W_UNITS + THREADS - 1) / THREADS;
+    static constexpr int LDS_BYTES = (A_FLOATS + W_FLOATS) * 4;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(NBLK % WM == 0 && (BN / 32) % WN == 0, "wave tiling");
+    static_assert(TH % 4 == 0 && TW % 8 == 0 && KC % 8 == 0, "block geometry");
+};
+
+template <class T>
+__global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;
+    float* const Ws = smem + T::A_FLOATS;
+    constexpr int KC = T::KC, KCP = T::KCP, MT = T::MT, NTW = T::NTW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wn = wave % T::WN;
+    const int wm = wave / T::WN;
+
+    // ---- workgroup -> (channel tile, pixel tile).  Channel tile fastest: with the round-robin
+    // workgroup->XCD dispatch an XCD then keeps seeing the same few weight slices in its L2.
+    const int bid = blockIdx.x;
+    const int ntile = bid % a.NT;
+    int mtile = bid / a.NT;
+    const int tx = mtile % a.tiles_x;
+    mtile /= a.tiles_x;
+    const int ty = mtile % a.tiles_y;
+    const int sg = mtile / a.tiles_y;
+    const int n0 = sg * T::TS, y0 = ty * T::TH, x0 = tx * T::TW;
+
+    // ---- per-thread staging plan for the input tile (fixed over the K loop)
+    const int Hs = a.upsample ? (a.H >> 1) : a.H;
+    const int Ws_ = a.upsample ? (a.W >> 1) : a.W;
+    uint32_t pix1[T::NA], pix2[T::NA];
+    int adst[T::NA];
+    bool aval[T::NA];
+#pragma unroll
+    for (int j = 0; j < T::NA; ++j) {
+        const int u = tid + j * T::THREADS;
+        const int q = u / (KC / 4);
+        const int sub = u % (KC / 4);
+        const int s = q / T::HW_;
+        const int rem = q % T::HW_;
+        const int yy = rem / (T::TW + 2), xx = rem % (T::TW + 2);
+        const int n = n0 + s, gy = y0 + yy - 1, gx = x0 + xx - 1;
+        const bool in_tile = u < T::A_UNITS;
+        aval[j] = in_tile && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        adst[j] = in_tile ? q * KCP + sub * 4 : -1;
+        const int sy = a.upsample ? (gy >> 1) : gy, sx = a.upsample ? (gx >> 1) : gx;
+        pix1[j] = aval[j] ? (uint32_t)((n * Hs + sy) * Ws_ + sx) : 0u;
+        pix2[j] = aval[j] ? (uint32_t)((n * a.H + gy) * a.W + gx) : 0u;
+        pix1[j] = pix1[j] * (uint32_t)a.C1 + sub * 4;
+        pix2[j] = pix2[j] * (uint32_t)a.C2 + sub * 4;
+    }
+
+    const int nchunks = (a.C1 + a.C2) / KC;
+    const float4* wbase = reinterpret_cast<const float4*>(a.wpack) + (size_t)ntile * T::W_UNITS;
+    const size_t wchunk_stride = (size_t)a.NT * T::W_UNITS;   // float4 units per Cin chunk
+
+    float4 ra[T::NA], rw[T::NW];
+    auto prefetch = [&](int kc) {
+        const int c0 = kc * KC;
+        const bool first = c0 < a.C1;
+        const float* sp = first ? a.src1 + c0 : a.src2 + (c0 - a.C1);
+#pragma unroll
+        for (int j = 0; j < T::NA; ++j) {
+            const uint32_t off = first ? pix1[j] : pix2[j];
+            ra[j] = aval[j] ? *reinterpret_cast<const float4*>(sp + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float4* wp = wbase + (size_t)kc * wchunk_stride;
+#pragma unroll
+        for (int j = 0; j < T::NW; ++j) {
+            const int u = tid + j * T::THREADS;
+            if (T::W_UNITS % T::THREADS == 0 || u < T::W_UNITS) rw[j] = wp[u];
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < T::NA; ++j)
+            if (T::A_UNITS % T::THREADS == 0 || adst[j] >= 0) *reinterpret_cast<float4*>(As + adst[j]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < T::NW; ++j) {
+            const int u = tid + j * T::THREADS;
+            if (T::W_UNITS % T::THREADS == 0 || u < T::W_UNITS) reinterpret_cast<float4*>(Ws)[u] = rw[j];
+        }
+    };
+
+    // ---- fragment addresses (float offsets into As / Ws)
+    const int m = lane & 31, half = lane >> 5;
+    int a_addr[MT], b_addr[NTW];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int blk = wm * MT + mi;
+        const int s = blk / T::BPS, rb = blk % T::BPS;
+        const int by = rb / (T::TW / 8), bx = rb % (T::TW / 8);
+        const int pixel = (s * (T::TH + 2) + 4 * by + (m >> 3)) * (T::TW + 2) + 8 * bx + (m & 7);
+        a_addr[mi] = pixel * KCP + half * 4;
+    }
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) b_addr[ni] = ((wn * NTW + ni) * 32 + m) * KCP + half * 4;
+
+    f32x16 acc[MT][NTW];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+    prefetch(0);
+    for (int kc = 0; kc < nchunks; ++kc) {
+        __syncthreads();   // previous chunk fully consumed
+        stage();
+        __syncthreads();
+        if (kc + 1 < nchunks) prefetch(kc + 1);   // lands while this chunk is multiplied
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int tapA = ((tap / 3) * (T::TW + 2) + (tap % 3)) * KCP;
+            const int tapB = tap * T::BN * KCP;
+#pragma unroll
+            for (int k8 = 0; k8 < KC / 8; ++k8) {
+                float4 av[MT], bv[NTW];
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+                    av[mi] = *reinterpret_cast<const float4*>(As + a_addr[mi] + tapA + k8 * 8);
+#pragma unroll
+                for (int ni = 0; ni < NTW; ++ni)
+                    bv[ni] = *reinterpret_cast<const float4*>(Ws + b_addr[ni] + tapB + k8 * 8);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NTW; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].x, bv[ni].x, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].y, bv[ni].y, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].z, bv[ni].z, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].w, bv[ni].w, acc[mi][ni], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    // ---- epilogue: lane = output channel (lane & 31), 4x4 pixel patch per lane
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) {
+        const int co = ntile * T::BN + (wn * NTW + ni) * 32 + m;
+        if (co >= a.CoutP) continue;
+        const float al = a.alpha[co], bb = a.betab[co], be = a.beta[co];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int blk = wm * MT + mi;
+            const int s = blk / T::BPS, rb = blk % T::BPS;
+            const int by = rb / (T::TW / 8), bx = rb % (T::TW / 8);
+            const int n = n0 + s;
+            if (n >= a.N) continue;
+            float mk = 1.f;
+            if (a.mask != nullptr && co < a.Cmask) mk = a.mask[(size_t)n * a.Cmask + co];
+            if (a.mask2 != nullptr && co >= a.Csplit && co - a.Csplit < a.Cmask2)
+                mk = a.mask2[(size_t)n * a.Cmask2 + (co - a.Csplit)];
+            const float scale = al * mk, shift = bb * mk + be;
+            const int yb = y0 + 4 * by, xb = x0 + 8 * bx + 4 * half;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float t = acc[mi][ni][i] * scale + shift;
+                v[i] = a.relu ? fmaxf(t, 0.f) : t;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int y = yb + (i >> 2), x = xb + (i & 3);
+                if (y < a.H && x < a.W) a.out[((size_t)(n * a.H + y) * a.W + x) * a.CoutP + co] = v[i];
+            }
+            if (a.pooled != nullptr) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const int i0 = (2 * pr) * 4 + 2 * pc;
+                        const float mx = fmaxf(fmaxf(v[i0], v[i0 + 1]), fmaxf(v[i0 + 4], v[i0 + 5]));
+                        const int py = (yb >> 1) + pr, px = (xb >> 1) + pc;
+                        if (py < Hp && px < Wp) a.pooled[((size_t)(n * Hp + py) * Wp + px) * a.CoutP + co] = mx;
+                    }
+            }
+        }
+    }
+}
+
+using Cfg0 = ConvTile<1, 8, 16, 64, 16, 2, 2>;
+using Cfg1 = ConvTile<1, 8, 16, 32, 32, 4, 1>;
+using Cfg2 = ConvTile<1, 8, 16, 32, 8, 4, 1>;
+using Cfg3 = ConvTile<2, 12, 8, 64, 16, 2, 2>;
+
+static const ConvConfigInfo kInfo[CONV_CFG_COUNT] = {
+    {Cfg0::TS, Cfg0::TH, Cfg0::TW, Cfg0::BN, Cfg0::KC, "conv3x3_igemm<T8x16,N64,K16>"},
+    {Cfg1::TS, Cfg1::TH, Cfg1::TW, Cfg1::BN, Cfg1::KC, "conv3x3_igemm<T8x16,N32,K32>"},
+    {Cfg2::TS, Cfg2::TH, Cfg2::TW, Cfg2::BN, Cfg2::KC, "conv3x3_igemm<T8x16,N32,K8>"},
+    {Cfg3::TS, Cfg3::TH, Cfg3::TW, Cfg3::BN, Cfg3::KC, "conv3x3_igemm<S2T12x8,N64,K16>"},
+};
+
+const ConvConfigInfo& conv_config_info(int cfg) { return kInfo[cfg]; }
+
+template <class T>
+static hipError_t launch_cfg(const ConvArgs& a, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)a.NT * a.tiles_x * a.tiles_y * a.slice_groups;
+    hipLaunchKernelGGL(conv3x3_igemm<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream)
+{
+    switch (cfg) {
+        case CONV_CFG_T8x16_N64_K16: return launch_cfg<Cfg0>(a, stream);
+        case CONV_CFG_T8x16_N32_K32: return launch_cfg<Cfg1>(a, stream);
+        case CONV_CFG_T8x16_N32_K8: return launch_cfg<Cfg2>(a, stream);
+        case CONV_CFG_S2T12x8_N64_K16: return launch_cfg<Cfg3>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace rcu

@@ -1,0 +1,112 @@
+// Internal declarations shared by the HIP translation units of librcu_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace rcu {
+
+// ---------------------------------------------------------------------------------------------
+// conv3x3 implicit GEMM (rcu_conv.hip)
+// ---------------------------------------------------------------------------------------------
+// Activations are NHWC fp32 with the channel count padded to a multiple of 32 (the network input to
+// a multiple of 8); padded channels hold zeros.  One launch covers every slice of the batch.
+struct ConvArgs {
+    const float* src1;   // [N][Hs][Ws][C1]   first  K-range (channels [0, C1))
+    const float* src2;   // [N][H ][W ][C2]   second K-range (cat-free decoder), may be null (C2 = 0)
+    const float* wpack;  // [Cin/KC][NT][9][BN][KC+4]  (see pack_conv_weights in rcu_api.hip)
+    const float* alpha;  // [CoutP]  folded BN scale               (1 for bias-only convs)
+    const float* betab;  // [CoutP]  alpha * conv bias
+    const float* beta;   // [CoutP]  folded BN shift               (0 for bias-only convs)
+    const float* mask;   // [N][Cmask] dropout factors {0, 1/(1-p)} of this site, or null (eval / no site)
+    const float* mask2;  // second site for output channels >= Csplit (fused cls+sigma head unit), or null
+    float* out;          // [N][H][W][CoutP]
+    float* pooled;       // [N][H/2][W/2][CoutP] or null
+    int N, H, W;         // output grid (= input grid; for upsample: src1 grid is H/2 x W/2)
+    int C1, C2;          // padded channel counts of the two sources
+    int CoutP;           // padded output channels (multiple of 32)
+    int Cmask;           // real channel count of the dropout site (mask row length)
+    int Csplit, Cmask2;  // mask2 row = [N][Cmask2], applies to channel co - Csplit
+    int upsample;        // 1: src1 is read at (y>>1, x>>1)  (nearest x2 fused into the load)
+    int relu;            // 1: max(0, .) epilogue
+    int tiles_y, tiles_x, slice_groups, NT;
+};
+
+enum ConvConfig {
+    CONV_CFG_T8x16_N64_K16 = 0,   // 8x16-pixel tile, 64 couts, Cin chunks of 16   (workhorse)
+    CONV_CFG_T8x16_N32_K32 = 1,   // 8x16-pixel tile, 32 couts, Cin chunks of 32   (32-channel layers)
+    CONV_CFG_T8x16_N32_K8 = 2,    // first layer: Cin padded to 8
+    CONV_CFG_S2T12x8_N64_K16 = 3, // two whole 12x8 slices per workgroup           (BraTS bottom level)
+    CONV_CFG_COUNT
+};
+
+struct ConvConfigInfo {
+    int TS, TH, TW, BN, KC;
+    const char* kernel_name;
+};
+const ConvConfigInfo& conv_config_info(int cfg);
+hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// layout / head / aggregation kernels (rcu_pointwise.hip)
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_pack_input(const float* x_nchw, float* out_nhwc, int N, int C, int CP, int H, int W,
+                             hipStream_t stream);
+
+// MC statistics blob: planes over the voxel index v = n*HW + hw.
+//   flags & RCU_MC_VAR == 0 : float planes  [sum_p[0..C-1]] [sum_H if MI]
+//   flags & RCU_MC_VAR != 0 : double planes [sum_p[0..C-1]] [sum_p^2[0..C-1]] [sum_H if MI]
+constexpr int MC_MI = 1;
+constexpr int MC_VAR = 2;
+constexpr int MC_INPUT_PROBS = 4;   // accumulate: input already holds probabilities (ensemble seam)
+constexpr int MAX_CLASSES = 8;
+
+struct HeadArgs {
+    const float* act;     // [V][CP] NHWC activations of the (fused) head conv unit
+    const float* w_cls;   // [C][CPh]  1x1 weights (zero padded), bias b_cls[C]
+    const float* b_cls;
+    const float* w_sig;   // optional twin (reads channels [CPh, 2*CPh) of act)
+    const float* b_sig;
+    float* logits;        // NCHW [N][C][HW] or null
+    float* sigma;         // NCHW or null
+    void* stats;          // MC stats blob or null
+    int C, CP, CPh, stats_flags;
+    size_t V, HW;
+};
+hipError_t launch_head(const HeadArgs& a, hipStream_t stream);
+
+hipError_t launch_mc_accumulate(const float* in_nchw, void* stats, int C, size_t N, size_t HW, int flags,
+                                hipStream_t stream);
+hipError_t launch_mc_finalize(const void* stats, int C, size_t N, size_t HW, int T, int flags, float* mean,
+                              float* entropy, float* mi, float* var, hipStream_t stream);
+hipError_t launch_softmax_nchw(const float* logits, float* probs, int C, size_t N, size_t HW, hipStream_t stream);
+hipError_t launch_aleatoric(const float* logits, const float* sigma_raw, int C, size_t N, size_t HW, int is_log_sigma,
+                            float* probs, float* sigma_out, uint8_t* prediction, float* sigma_pred,
+                            hipStream_t stream);
+hipError_t launch_argmax_fg(const float* probs_nchw, int C, size_t N, size_t HW, uint8_t* prediction, float* p_fg,
+                            hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// calibration kernels (rcu_calib.hip)
+// ---------------------------------------------------------------------------------------------
+constexpr int MAX_BINS = 32;
+constexpr int MAX_THR = 16;
+struct EceResult {           // one per volume
+    unsigned long long count[MAX_BINS];
+    double sum_conf[MAX_BINS];
+    unsigned long long sum_pos[MAX_BINS];
+};
+size_t ece_workspace_bytes(size_t n_per_volume, int n_volumes);
+hipError_t launch_ece_hist(const float* p, const uint8_t* target, const uint8_t* mask, size_t n_per_volume,
+                           int n_volumes, const float* thr_host, int n_bins, EceResult* result_dev, void* workspace,
+                           hipStream_t stream);
+hipError_t launch_bin_ids(const float* p, size_t n, const float* thr_host, int n_bins, uint8_t* ids,
+                          hipStream_t stream);
+size_t unc_workspace_bytes(size_t n_per_volume, int n_volumes);
+// out_dev: [n_volumes][n_thr][8] u64 = tp, tn, fp, fn, tpu, tnu, fpu, fnu
+hipError_t launch_unc_counts(const void* unc, int unc_is_f64, const uint8_t* prediction, const uint8_t* target,
+                             const uint8_t* mask, size_t n_per_volume, int n_volumes, const double* thr_host,
+                             int n_thr, unsigned long long* out_dev, void* workspace, hipStream_t stream);
+hipError_t launch_norm_entropy(const float* p_fg, size_t n, double* out_f64, float* out_f32, hipStream_t stream);
+
+}  // namespace rcu

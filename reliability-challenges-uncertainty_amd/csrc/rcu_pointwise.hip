@@ -1,0 +1,326 @@
+// HBM-bound per-voxel kernels: input layout change, the fused 1x1 head + softmax + running MC
+// statistics, the statistics finalisation (mean / predictive entropy / mutual information /
+// variance) and the small aleatoric / argmax helpers.  One thread per voxel, voxel index fastest
+// across lanes, so every plane access is a fully coalesced 256-B wave transaction.
+//
+// Reference semantics:
+//   softmax over the class dim per pass                   rechun/dl/customsteps.py:24,33
+//   mean over T, entropy of the mean (nat log, 0 log 0=0) customsteps.py:57-61; torchhelper.py:53-54
+//   mutual info = H(mean) - mean_t H(p_t)                 customsteps.py:63-66
+//   variance = mean_c unbiased var_t(p_c)                 customsteps.py:68-71
+//   aleatoric sigma = |raw| or exp(raw)                   bin-dl/brats_test_aleatoric.py:63-73
+// The T probability volumes are never materialised: each pass adds its softmax output into the
+// statistics planes (sum p, optionally sum p^2 in double, optionally sum H).
+#include "rcu_kernels.h"
+
+namespace rcu {
+
+static constexpr int PW_THREADS = 256;
+
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + PW_THREADS - 1) / PW_THREADS); }
+
+// ------------------------------------------------------------------------------- NCHW -> padded NHWC
+__global__ __launch_bounds__(PW_THREADS) void pack_input_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                 int C, int CP, size_t HW, size_t V)
+{
+    const size_t v = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;
+    if (v >= V) return;
+    const size_t n = v / HW, hw = v % HW;
+    for (int c = 0; c < CP; c += 4) {
+        float4 q;
+        q.x = (c + 0 < C) ? x[(n * C + c + 0) * HW + hw] : 0.f;
+        q.y = (c + 1 < C) ? x[(n * C + c + 1) * HW + hw] : 0.f;
+        q.z = (c + 2 < C) ? x[(n * C + c + 2) * HW + hw] : 0.f;
+        q.w = (c + 3 < C) ? x[(n * C + c + 3) * HW + hw] : 0.f;
+        *reinterpret_cast<float4*>(out + v * CP + c) = q;
+    }
+}
+
+hipError_t launch_pack_input(const float* x, float* out, int N, int C, int CP, int H, int W, hipStream_t stream)
+{
+    const size_t HW = (size_t)H * W, V = HW * N;
+    hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(V)), dim3(PW_THREADS), 0, stream, x, out, C, CP, HW, V);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------- shared device helpers
+template <int C>
+__device__ __forceinline__ void softmax_inplace(float (&l)[C])
+{
+    float mx = l[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, l[c]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        l[c] = expf(l[c] - mx);
+        s += l[c];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) l[c] = l[c] / s;
+}
+
+template <int C>
+__device__ __forceinline__ float entropy_of(const float (&p)[C])
+{
+    float h = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) h += (p[c] > 0.f) ? p[c] * logf(p[c]) : 0.f;
+    return -h;
+}
+
+template <int C>
+__device__ __forceinline__ void accumulate_voxel(void* stats, size_t v, size_t V, int flags, const float (&p)[C])
+{
+    if (flags & MC_VAR) {
+        double* sd = reinterpret_cast<double*>(stats);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double pc = (double)p[c];
+            sd[(size_t)c * V + v] += pc;
+            sd[(size_t)(C + c) * V + v] += pc * pc;
+        }
+        if (flags & MC_MI) sd[(size_t)(2 * C) * V + v] += (double)entropy_of<C>(p);
+    } else {
+        float* sf = reinterpret_cast<float*>(stats);
+#pragma unroll
+        for (int c = 0; c < C; ++c) sf[(size_t)c * V + v] += p[c];
+        if (flags & MC_MI) sf[(size_t)C * V + v] += entropy_of<C>(p);
+    }
+}
+
+// ------------------------------------------------------------------------------- fused head
+// act[v][0..CPh) -> logits (1x1 conv, unet.py:161); optional twin on act[v][CPh..2CPh) -> sigma
+// (unet.py:164); optional softmax + statistics update so that logits never reach HBM.
+template <int C>
+__global__ __launch_bounds__(PW_THREADS) void head_kernel(const HeadArgs a)
+{
+    const size_t v = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;
+    if (v >= a.V) return;
+    const size_t n = v / a.HW, hw = v % a.HW;
+    const float* row = a.act + v * a.CP;
+    float l[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) l[c] = a.b_cls[c];
+    for (int k = 0; k < a.CPh; k += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(row + k);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float* w = a.w_cls + c * a.CPh + k;
+            l[c] = fmaf(w[0], x.x, l[c]);
+            l[c] = fmaf(w[1], x.y, l[c]);
+            l[c] = fmaf(w[2], x.z, l[c]);
+            l[c] = fmaf(w[3], x.w, l[c]);
+        }
+    }
+    if (a.logits != nullptr) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) a.logits[(n * C + c) * a.HW + hw] = l[c];
+    }
+    if (a.sigma != nullptr) {
+        float s[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) s[c] = a.b_sig[c];
+        for (int k = 0; k < a.CPh; k += 4) {
+            const float4 x = *reinterpret_cast<const float4*>(row + a.CPh + k);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float* w = a.w_sig + c * a.CPh + k;
+                s[c] = fmaf(w[0], x.x, s[c]);
+                s[c] = fmaf(w[1], x.y, s[c]);
+                s[c] = fmaf(w[2], x.z, s[c]);
+                s[c] = fmaf(w[3], x.w, s[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) a.sigma[(n * C + c) * a.HW + hw] = s[c];
+    }
+    if (a.stats != nullptr) {
+        softmax_inplace<C>(l);
+        accumulate_voxel<C>(a.stats, v, a.V, a.stats_flags, l);
+    }
+}
+
+#define RCU_DISPATCH_C(Cval, ...)                                    \
+    switch (Cval) {                                                  \
+        case 1: { constexpr int C_ = 1; __VA_ARGS__; break; }        \
+        case 2: { constexpr int C_ = 2; __VA_ARGS__; break; }        \
+        case 3: { constexpr int C_ = 3; __VA_ARGS__; break; }        \
+        case 4: { constexpr int C_ = 4; __VA_ARGS__; break; }        \
+        case 5: { constexpr int C_ = 5; __VA_ARGS__; break; }        \
+        case 6: { constexpr int C_ = 6; __VA_ARGS__; break; }        \
+        case 7: { constexpr int C_ = 7; __VA_ARGS__; break; }        \
+        case 8: { constexpr int C_ = 8; __VA_ARGS__; break; }        \
+        default: return hipErrorInvalidValue;                        \
+    }
+
+hipError_t launch_head(const HeadArgs& a, hipStream_t stream)
+{
+    RCU_DISPATCH_C(a.C, hipLaunchKernelGGL(head_kernel<C_>, dim3(grid_for(a.V)), dim3(PW_THREADS), 0, stream, a));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------- standalone accumulate
+template <int C>
+__global__ __launch_bounds__(PW_THREADS) void mc_accumulate_kernel(const float* __restrict__ in, void* stats, size_t HW,
+                                                                    size_t V, int flags)
+{
+    const size_t v = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;
+    if (v >= V) return;
+    const size_t n = v / HW, hw = v % HW;
+    float l[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) l[c] = in[(n * C + c) * HW + hw];
+    if (!(flags & MC_INPUT_PROBS)) softmax_inplace<C>(l);
+    accumulate_voxel<C>(stats, v, V, flags, l);
+}
+
+hipError_t launch_mc_accumulate(const float* in, void* stats, int C, size_t N, size_t HW, int flags, hipStream_t stream)
+{
+    const size_t V = N * HW;
+    RCU_DISPATCH_C(C, hipLaunchKernelGGL(mc_accumulate_kernel<C_>, dim3(grid_for(V)), dim3(PW_THREADS), 0, stream, in,
+                                         stats, HW, V, flags));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------- finalize
+template <int C>
+__global__ __launch_bounds__(PW_THREADS) void mc_finalize_kernel(const void* stats, size_t HW, size_t V, int T, int flags,
+                                                                  float* __restrict__ mean, float* __restrict__ entropy,
+                                                                  float* __restrict__ mi, float* __restrict__ var)
+{
+    const size_t v = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;
+    if (v >= V) return;
+    const size_t n = v / HW, hw = v % HW;
+    float p[C];
+    float sum_h = 0.f;
+    if (flags & MC_VAR) {
+        const double* sd = reinterpret_cast<const double*>(stats);
+        double vsum = 0.0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double s = sd[(size_t)c * V + v], q = sd[(size_t)(C + c) * V + v];
+            p[c] = (float)(s / (double)T);
+            vsum += (q - s * s / (double)T) / (double)(T - 1);   // unbiased, as torch.var (customsteps.py:70)
+        }
+        if (var != nullptr) var[v] = (float)(vsum / (double)C);
+        if (flags & MC_MI) sum_h = (float)sd[(size_t)(2 * C) * V + v];
+    } else {
+        const float* sf = reinterpret_cast<const float*>(stats);
+#pragma unroll
+        for (int c = 0; c < C; ++c) p[c] = sf[(size_t)c * V + v] / (float)T;
+        if (flags & MC_MI) sum_h = sf[(size_t)C * V + v];
+    }
+    if (mean != nullptr) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) mean[(n * C + c) * HW + hw] = p[c];
+    }
+    const float h = entropy_of<C>(p);
+    if (entropy != nullptr) entropy[v] = h;
+    if (mi != nullptr && (flags & MC_MI)) mi[v] = h - sum_h / (float)T;
+}
+
+hipError_t launch_mc_finalize(const void* stats, int C, size_t N, size_t HW, int T, int flags, float* mean,
+                              float* entropy, float* mi, float* var, hipStream_t stream)
+{
+    const size_t V = N * HW;
+    RCU_DISPATCH_C(C, hipLaunchKernelGGL(mc_finalize_kernel<C_>, dim3(grid_for(V)), dim3(PW_THREADS), 0, stream, stats,
+                                         HW, V, T, flags, mean, entropy, mi, var));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------- softmax / aleatoric / argmax
+template <int C>
+__global__ __launch_bounds__(PW_THREADS) void softmax_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              size_t HW, size_t V)
+{
+    const size_t v = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;
+    if (v >= V) return;
+    const size_t n = v / HW, hw = v % HW;
+    float l[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) l[c] = in[(n * C + c) * HW + hw];
+    softmax_inplace<C>(l);
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[(n * C + c) * HW + hw] = l[c];
+}
+
+hipError_t launch_softmax_nchw(const float* logits, float* probs, int C, size_t N, size_t HW, hipStream_t stream)
+{
+    const size_t V = N * HW;
+    RCU_DISPATCH_C(C, hipLaunchKernelGGL(softmax_kernel<C_>, dim3(grid_for(V)), dim3(PW_THREADS), 0, stream, logits,
+                                         probs, HW, V));
+    return hipGetLastError();
+}
+
+template <int C>
+__global__ __launch_bounds__(PW_THREADS) void aleatoric_kernel(const float* __restrict__ logits,
+                                                                const float* __restrict__ sigma_raw, size_t HW, size_t V,
+                                                                int is_log_sigma, float* __restrict__ probs,
+                                                                float* __restrict__ sigma_out,
+                                                                uint8_t* __restrict__ prediction,
+                                                                float* __restrict__ sigma_pred)
+{
+    const size_t v = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;
+    if (v >= V) return;
+    const size_t n = v / HW, hw = v % HW;
+    float l[C], s[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        l[c] = logits[(n * C + c) * HW + hw];
+        const float r = sigma_raw[(n * C + c) * HW + hw];
+        s[c] = is_log_sigma ? expf(r) : fabsf(r);
+    }
+    softmax_inplace<C>(l);
+    int best = 0;
+#pragma unroll
+    for (int c = 1; c < C; ++c) best = (l[c] > l[best]) ? c : best;   // first maximum, as np.argmax
+    float sp = s[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) sp = (best == c) ? s[c] : sp;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (probs != nullptr) probs[(n * C + c) * HW + hw] = l[c];
+        if (sigma_out != nullptr) sigma_out[(n * C + c) * HW + hw] = s[c];
+    }
+    if (prediction != nullptr) prediction[v] = (uint8_t)best;
+    if (sigma_pred != nullptr) sigma_pred[v] = sp;
+}
+
+hipError_t launch_aleatoric(const float* logits, const float* sigma_raw, int C, size_t N, size_t HW, int is_log_sigma,
+                            float* probs, float* sigma_out, uint8_t* prediction, float* sigma_pred, hipStream_t stream)
+{
+    const size_t V = N * HW;
+    RCU_DISPATCH_C(C, hipLaunchKernelGGL(aleatoric_kernel<C_>, dim3(grid_for(V)), dim3(PW_THREADS), 0, stream, logits,
+                                         sigma_raw, HW, V, is_log_sigma, probs, sigma_out, prediction, sigma_pred));
+    return hipGetLastError();
+}
+
+template <int C>
+__global__ __launch_bounds__(PW_THREADS) void argmax_fg_kernel(const float* __restrict__ probs, size_t HW, size_t V,
+                                                                uint8_t* __restrict__ prediction,
+                                                                float* __restrict__ p_fg)
+{
+    const size_t v = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;
+    if (v >= V) return;
+    const size_t n = v / HW, hw = v % HW;
+    float p[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] = probs[(n * C + c) * HW + hw];
+    int best = 0;
+#pragma unroll
+    for (int c = 1; c < C; ++c) best = (p[c] > p[best]) ? c : best;
+    if (prediction != nullptr) prediction[v] = (uint8_t)best;
+    if (p_fg != nullptr) p_fg[v] = p[C > 1 ? 1 : 0];   // foreground class (brats_test_default.py:99)
+}
+
+hipError_t launch_argmax_fg(const float* probs, int C, size_t N, size_t HW, uint8_t* prediction, float* p_fg,
+                            hipStream_t stream)
+{
+    const size_t V = N * HW;
+    RCU_DISPATCH_C(C, hipLaunchKernelGGL(argmax_fg_kernel<C_>, dim3(grid_for(V)), dim3(PW_THREADS), 0, stream, probs, HW,
+                                         V, prediction, p_fg));
+    return hipGetLastError();
+}
+
+}  // namespace rcu

@@ -1,0 +1,272 @@
+"""Model seam: a drop-in for the reference's ``UNet`` module whose forward runs on librcu_hip.
+
+Mirrors ``common/model/unet.py:123-186`` of the reference at the interface level:
+  * same constructor signature and defaults (unet.py:124-130);
+  * same ``state_dict`` keys and shapes, so ``load_state_dict(torch.load(ckpt)['state_dict'])``
+    (common/model/management.py:56-64) works unchanged -- a ``module.`` prefix is stripped;
+  * same ``Dropout2d`` sub-modules under the same names, so ``set_dropout_mode(model, True)``
+    (common/utils/torchhelper.py:44-50) switches MC-dropout on exactly as for the reference;
+  * ``model(images)`` with ``images`` float32 ``[N, Cin, H, W]`` on the GPU returns ``logits`` or
+    ``(logits, sigma)`` (unet.py:181-186).
+The sub-modules only hold parameters; all arithmetic happens in the HIP kernels (conv units with
+folded eval-mode BatchNorm, dropout as per-(sample, channel) factors drawn here with torch's device
+generator like ``feature_dropout`` does).  Inference only: no autograd, BatchNorm always in eval
+mode (the test context calls ``model.eval()``, common/trainloop/context.py:321).
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _Holder(nn.Module):
+    """Plain container; children are added by dotted path to reproduce the reference's key names."""
+
+
+def _add(root, path, module):
+    parts = path.split('.')
+    cur = root
+    for p in parts[:-1]:
+        if p not in cur._modules:
+            cur.add_module(p, _Holder())
+        cur = cur._modules[p]
+    cur.add_module(parts[-1], module)
+
+
+def _dropout_rule(dropout_center, level, depth, is_down):
+    # unet.py:74-82
+    if dropout_center is None:
+        return 'all'
+    if level == depth:
+        return 'no'
+    if level + dropout_center >= depth:
+        return 'last' if is_down else 'first'
+    return 'no'
+
+
+def _has_dropout(dropout, rule, i):
+    # unet.py:63-72 (two repetitions per block)
+    if dropout is None:
+        return False
+    return rule == 'all' or (rule == 'first' and i == 0) or (rule == 'last' and i == 1)
+
+
+class UNet(nn.Module):
+    DEFAULT_DEPTH = 4
+    DEFAULT_START_FILTERS = 16
+    DEFAULT_DROPOUT = 0.2
+
+    def __init__(self, nb_classes, in_channels, depth=DEFAULT_DEPTH, start_filters=DEFAULT_START_FILTERS,
+                 dropout=DEFAULT_DROPOUT, dropout_center: int = None, residual=False, sigma_out=False,
+                 provide_features=False, bn=True):
+        super().__init__()
+        if residual:
+            raise NotImplementedError('residual blocks are outside the MI355X hot path (no shipped config uses them)')
+        if provide_features:
+            raise NotImplementedError('provide_features (auxiliary_feat runs) is outside the MI355X hot path')
+        self.nb_classes, self.in_channels, self.depth = nb_classes, in_channels, depth
+        self.start_filters, self.dropout, self.dropout_center = start_filters, dropout, dropout_center
+        self.sigma_out, self.bn = sigma_out, bn
+        self.features = None
+        self._site_modules = []
+
+        def unit(prefix, cin, cout, with_dropout):
+            base = prefix + '.conv2d_batch_relu'
+            _add(self, base + '.conv', nn.Conv2d(cin, cout, 3, padding=1))
+            if with_dropout:
+                do = nn.Dropout2d(p=dropout)
+                _add(self, base + '.dropout', do)
+                self._site_modules.append(do)
+            if bn:
+                _add(self, base + '.bn', nn.BatchNorm2d(cout))
+
+        def block(prefix, cin, cout, rule):
+            for i in range(2):
+                unit('{}.{}'.format(prefix, i), cin if i == 0 else cout, cout, _has_dropout(dropout, rule, i))
+
+        cin, cout = in_channels, start_filters
+        for lvl in range(depth):
+            block('down_convs.{}.block.block'.format(lvl), cin, cout, _dropout_rule(dropout_center, lvl, depth, True))
+            cin, cout = cout, cout * 2
+        block('bottom_convs.block', cin, cout, _dropout_rule(dropout_center, depth, depth, True))
+        for j, lvl in enumerate(range(depth - 1, -1, -1)):
+            cin, cout = cout, cout // 2
+            block('up_convs.{}.block.block'.format(j), 2 * cout, cout,
+                  _dropout_rule(dropout_center, lvl, depth, False))
+            _add(self, 'up_convs.{}.upconv.1'.format(j), nn.Conv2d(cin, cout, 3, padding=1))
+        unit('conv_cls.0', cout, cout, dropout is not None)
+        _add(self, 'conv_cls.1', nn.Conv2d(cout, nb_classes, 1))
+        if sigma_out:
+            unit('conv_sigma.0', cout, cout, dropout is not None)
+            _add(self, 'conv_sigma.1', nn.Conv2d(cout, nb_classes, 1))
+        for p in self.parameters():
+            p.requires_grad = False
+        self._handles = {}       # (H, W) -> [handle, max_batch]
+        self._weights_version = 0
+        self.eval()
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        state_dict = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+        result = super().load_state_dict(state_dict, strict=strict, **kwargs)
+        self.weights_changed()
+        return result
+
+    def weights_changed(self):
+        """Call after editing parameters in place: the packed device copies are rebuilt lazily."""
+        self._weights_version += 1
+
+    def _release(self):
+        lib = _lib.load()
+        for handle, _, _ in self._handles.values():
+            lib.rcu_unet_destroy(handle)
+        self._handles = {}
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def _handle(self, h, w, n):
+        lib = _lib.load()
+        entry = self._handles.get((h, w))
+        if entry is not None and entry[1] >= n and entry[2] == self._weights_version:
+            return entry[0]
+        max_batch = n if entry is None else max(n, entry[1])
+        if entry is not None:
+            lib.rcu_unet_destroy(entry[0])
+            del self._handles[(h, w)]
+        desc = _lib.UnetDesc(nb_classes=self.nb_classes, in_channels=self.in_channels, depth=self.depth,
+                             start_filters=self.start_filters, has_dropout=int(self.dropout is not None),
+                             dropout_center=-1 if self.dropout_center is None else int(self.dropout_center),
+                             sigma_out=int(self.sigma_out), bn=int(self.bn), height=h, width=w, max_batch=max_batch)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.rcu_unet_create(ctypes.byref(desc), ctypes.byref(handle)))
+        try:
+            for key, value in self.state_dict().items():
+                if not torch.is_floating_point(value):
+                    continue  # num_batches_tracked
+                host = value.detach().to('cpu', torch.float32).contiguous()
+                _lib.check(lib.rcu_unet_load_weight(handle, key.encode(), ctypes.c_void_p(host.data_ptr()),
+                                                    host.numel()))
+            _lib.check(lib.rcu_unet_finalize_weights(handle))
+        except Exception:
+            lib.rcu_unet_destroy(handle)
+            raise
+        self._handles[(h, w)] = (handle, max_batch, self._weights_version)
+        return handle
+
+    # ------------------------------------------------------------------ dropout
+    def dropout_sites(self):
+        """[(state_dict-style name, channels)] in execution order."""
+        names = {id(m): n for n, m in self.named_modules()}
+        out = []
+        for m in self._site_modules:
+            name = names[id(m)]
+            conv = dict(self.named_modules())[name[:-len('.dropout')] + '.conv']
+            out.append((name, conv.out_channels))
+        return out
+
+    def mc_active(self):
+        return any(m.training for m in self._site_modules)
+
+    def sample_masks(self, n, device, generator=None):
+        """Concatenated ``[site][n][C_site]`` factors {0, 1/(1-p)} for one pass; sites whose Dropout2d
+        is in eval mode get ones.  Same law as torch's feature dropout (Bernoulli(1-p) / (1-p))."""
+        chunks = []
+        for m, (_, c) in zip(self._site_modules, self.dropout_sites()):
+            if m.training and m.p > 0:
+                if m.p >= 1:
+                    chunks.append(torch.zeros(n * c, device=device))
+                else:
+                    keep = 1.0 - m.p
+                    chunks.append(torch.empty(n * c, device=device).bernoulli_(keep, generator=generator).div_(keep))
+            else:
+                chunks.append(torch.ones(n * c, device=device))
+        return torch.cat(chunks) if chunks else None
+
+    def pack_masks(self, masks, n, device):
+        """List of per-site ``[n, C_site]`` arrays/tensors -> the concatenated device layout."""
+        sites = self.dropout_sites()
+        if len(masks) != len(sites):
+            raise ValueError('expected {} dropout masks, got {}'.format(len(sites), len(masks)))
+        flat = []
+        for m, (_, c) in zip(masks, sites):
+            t = torch.as_tensor(m, dtype=torch.float32)
+            if tuple(t.shape) != (n, c):
+                raise ValueError('mask shape {} does not match (n={}, channels={})'.format(tuple(t.shape), n, c))
+            flat.append(t.reshape(-1))
+        return torch.cat(flat).to(device).contiguous() if flat else None
+
+    # ------------------------------------------------------------------ forward
+    def _check_input(self, x):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError('expected a [N, {}, H, W] tensor'.format(self.in_channels))
+        if not x.is_cuda:
+            raise RuntimeError('rcu_amd.model.UNet only runs on the GPU (librcu_hip); got a {} tensor'.format(x.device))
+        return x.to(torch.float32).contiguous()
+
+    def forward(self, x, masks=None):
+        """``masks``: None -> eval mode, or sampled if any Dropout2d is in train mode
+        (set_dropout_mode); a concatenated device tensor / list of per-site arrays to inject."""
+        x = self._check_input(x)
+        n, _, h, w = x.shape
+        handle = self._handle(h, w, n)
+        if masks is None and self.mc_active():
+            masks = self.sample_masks(n, x.device)
+        elif isinstance(masks, (list, tuple)):
+            masks = self.pack_masks(masks, n, x.device)
+        logits = torch.empty((n, self.nb_classes, h, w), device=x.device, dtype=torch.float32)
+        sigma = torch.empty_like(logits) if self.sigma_out else None
+        _lib.check(_lib.load().rcu_unet_forward(handle, _lib.ptr(x), n, _lib.ptr(masks), _lib.ptr(logits),
+                                                _lib.ptr(sigma), _lib.current_stream()))
+        if self.sigma_out:
+            return logits, sigma
+        return logits
+
+    def forward_accumulate(self, x, stats, masks=None):
+        """One pass fused with softmax + accumulation into ``stats`` (rcu_amd.steps.McStatistics):
+        neither logits nor probabilities reach HBM."""
+        x = self._check_input(x)
+        n, _, h, w = x.shape
+        if (n, self.nb_classes, h * w) != (stats.n, stats.nb_classes, stats.hw):
+            raise ValueError('statistics blob shape does not match the batch')
+        handle = self._handle(h, w, n)
+        if masks is None and self.mc_active():
+            masks = self.sample_masks(n, x.device)
+        elif isinstance(masks, (list, tuple)):
+            masks = self.pack_masks(masks, n, x.device)
+        _lib.check(_lib.load().rcu_unet_forward_accumulate(handle, _lib.ptr(x), n, _lib.ptr(masks),
+                                                           _lib.ptr(stats.blob), stats.flags, _lib.current_stream()))
+        stats.count += 1
+
+    # ------------------------------------------------------------------ introspection (bench)
+    def layer_table(self, h, w, n=1):
+        lib = _lib.load()
+        handle = self._handle(h, w, n)
+        rows = []
+        for i in range(lib.rcu_unet_num_layers(handle)):
+            info = _lib.LayerInfo()
+            _lib.check(lib.rcu_unet_layer_info(handle, i, ctypes.byref(info)))
+            rows.append(dict(index=i, name=info.name.decode(), kernel=info.kernel.decode(), cin=info.cin,
+                             cout=info.cout, height=info.height, width=info.width, upsample=bool(info.upsample),
+                             pooled=bool(info.pooled), dual_source=bool(info.dual_source),
+                             flops_per_slice=info.flops_per_slice))
+        return rows
+
+    def run_layer(self, h, w, n, layer, masks=None):
+        _lib.check(_lib.load().rcu_unet_run_layer(self._handle(h, w, n), layer, n, _lib.ptr(masks),
+                                                  _lib.current_stream()))
+
+    def workspace_bytes(self, h, w, n):
+        return int(_lib.load().rcu_unet_workspace_bytes(self._handle(h, w, n)))
+
+
+model_registry = {'unet': UNet}  # common/model/factory.py:12-15 (postnet is out of scope)
+
+
+def get_model(model_type, **params):
+    return model_registry[model_type](**params)

@@ -1,0 +1,320 @@
+"""Step seam: batch steps with the reference's call protocol, computing on librcu_hip.
+
+Mirrors (names, arguments, output keys, error behaviour):
+  BatchStep                     common/trainloop/steps.py:14-17
+  SegmentationPredictStep       common/trainloop/steps.py:69-89
+  McPredictStep                 rechun/dl/customsteps.py:10-39
+  MultiPredictionSummary        rechun/dl/customsteps.py:42-71
+  EnsemblePredictionStep        bin-dl/brats_test_ensemble.py:72-94
+  AleatoricPredictStep          bin-dl/brats_test_aleatoric.py:51-73
+  BatchContext / TaskContext    common/trainloop/context.py:334-355
+A step is called as ``step(batch_context, task_context, context)``, reads
+``batch_context.input['images']`` and writes torch tensors with the channel dim at 1 into
+``batch_context.output``.
+
+MI355X-first difference: by default the T (or K) probability volumes are never stacked in HBM.
+``McPredictStep`` / ``EnsemblePredictionStep`` put a ``McStatistics`` object (per-voxel running
+sums, updated by the fused forward+softmax+accumulate kernel) under ``multi_probabilities`` and
+``MultiPredictionSummary`` finalises it.  ``materialize=True`` restores the reference behaviour
+(a real ``[T, N, C, H, W]`` tensor), and the summary accepts either form.
+"""
+import abc
+
+import torch
+
+from . import _lib
+from . import model as model_mod
+
+
+class BatchContext:
+    def __init__(self, batch: dict, batch_index: int) -> None:
+        self.input = batch
+        self.batch_index = batch_index
+        self.output = {}
+        self.metrics = {}
+        self.score = None
+        self.more = {}
+
+
+class TaskContext:
+    def __init__(self, epoch: int = 0, task_data=None, task_data_config=None) -> None:
+        self.epoch = epoch
+        self.data = task_data
+        self.data_config = task_data_config
+        self.scores = []
+        self.more = {}
+
+
+class Context:
+    """Base of the contexts a step accepts (reference: ctx.TorchTrainContext / ctx.TorchTestContext)."""
+
+
+class TorchTestContext(Context):
+    """The two attributes a step touches: ``model`` and ``device`` (common/trainloop/context.py:256-322).
+    The reference hard-codes 'cuda' in its scripts (bin-dl/brats_test_default.py:39)."""
+
+    def __init__(self, device_str: str = 'cuda', model=None) -> None:
+        self.device = torch.device(device_str)
+        self.model = model
+        self.more = {}
+
+
+def _type_error_msg(obj, *expected):
+    names = ','.join(e.__name__ for e in expected)
+    return 'expected type is "({})" but object is of type "{}"'.format(names, obj.__class__.__name__)
+
+
+def _check_context(context):
+    # The reference means to raise ValueError here (customsteps.py:17-18); its message helper trips over the
+    # tuple argument first (common/utils/messages.py:5) -- the intended ValueError is what we raise.
+    if not isinstance(context, Context):
+        raise ValueError(_type_error_msg(context, TorchTestContext))
+
+
+def set_dropout_mode(model, is_train=True):
+    """common/utils/torchhelper.py:44-50: toggles only the Dropout modules; BatchNorm stays in eval."""
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d, torch.nn.Dropout3d)):
+            if is_train:
+                m.train()
+            else:
+                m.eval()
+
+
+class McStatistics:
+    """Per-voxel sufficient statistics of the passes seen so far (the ``stats`` blob of include/rcu.h).
+    Plain additive: blobs of disjoint pass subsets merge by ``+`` (one RCCL sum-reduce, see
+    rcu_amd.distributed)."""
+
+    def __init__(self, n, nb_classes, height, width, device, do_mi=False, do_var=False):
+        self.n, self.nb_classes, self.height, self.width = n, nb_classes, height, width
+        self.hw = height * width
+        self.flags = (_lib.RCU_MC_MI if do_mi else 0) | (_lib.RCU_MC_VAR if do_var else 0)
+        lib = _lib.load()
+        nbytes = lib.rcu_mc_stats_bytes(n, self.hw, nb_classes, self.flags)
+        dtype = torch.float64 if do_var else torch.float32
+        self.blob = torch.empty(nbytes // (8 if do_var else 4), device=device, dtype=dtype)
+        self.count = 0
+        _lib.check(lib.rcu_mc_begin(_lib.ptr(self.blob), n, self.hw, nb_classes, self.flags, _lib.current_stream()))
+
+    @property
+    def do_mi(self):
+        return bool(self.flags & _lib.RCU_MC_MI)
+
+    @property
+    def do_var(self):
+        return bool(self.flags & _lib.RCU_MC_VAR)
+
+    def accumulate(self, tensor, is_probabilities=False):
+        """Add one ``[N, C, H, W]`` logits (softmax applied on the fly) or probability volume."""
+        t = tensor.to(torch.float32).contiguous()
+        if tuple(t.shape) != (self.n, self.nb_classes, self.height, self.width):
+            raise ValueError('expected shape {}'.format((self.n, self.nb_classes, self.height, self.width)))
+        flags = self.flags | (_lib.RCU_MC_INPUT_PROBS if is_probabilities else 0)
+        _lib.check(_lib.load().rcu_mc_accumulate(_lib.ptr(t), _lib.ptr(self.blob), self.n, self.hw, self.nb_classes,
+                                                 flags, _lib.current_stream()))
+        self.count += 1
+
+    def finalize(self, do_mi=False, do_var=False, count=None):
+        """-> dict with the reference's keys: probabilities, entropy[, mutual_info][, variance]."""
+        if do_mi and not self.do_mi:
+            raise ValueError('mutual information was not tracked (construct the predict step with do_mi=True)')
+        if do_var and not self.do_var:
+            raise ValueError('variance was not tracked (construct the predict step with do_var=True)')
+        t = self.count if count is None else count
+        dev = self.blob.device
+        shape1 = (self.n, 1, self.height, self.width)
+        mean = torch.empty((self.n, self.nb_classes, self.height, self.width), device=dev, dtype=torch.float32)
+        entropy = torch.empty(shape1, device=dev, dtype=torch.float32)
+        mi = torch.empty(shape1, device=dev, dtype=torch.float32) if do_mi else None
+        var = torch.empty(shape1, device=dev, dtype=torch.float32) if do_var else None
+        _lib.check(_lib.load().rcu_mc_finalize(_lib.ptr(self.blob), self.n, self.hw, self.nb_classes, int(t), self.flags,
+                                               _lib.ptr(mean), _lib.ptr(entropy), _lib.ptr(mi), _lib.ptr(var),
+                                               _lib.current_stream()))
+        out = {'probabilities': mean, 'entropy': entropy}
+        if do_mi:
+            out['mutual_info'] = mi
+        if do_var:
+            out['variance'] = var
+        return out
+
+
+def softmax(logits):
+    """F.softmax(logits, 1) on the HIP path."""
+    logits = logits.to(torch.float32).contiguous()
+    n, c, h, w = logits.shape
+    out = torch.empty_like(logits)
+    _lib.check(_lib.load().rcu_softmax(_lib.ptr(logits), _lib.ptr(out), n, h * w, c, _lib.current_stream()))
+    return out
+
+
+class BatchStep(abc.ABC):
+    @abc.abstractmethod
+    def __call__(self, batch_context: BatchContext, task_context: TaskContext, context: Context) -> None:
+        pass
+
+
+def _images_to_device(batch_context, context):
+    batch_context.input['images'] = batch_context.input['images'].float().to(context.device)
+    return batch_context.input['images']
+
+
+class SegmentationPredictStep(BatchStep):
+
+    def __init__(self, has_labels=False, do_probs=False) -> None:
+        super().__init__()
+        self.has_labels = has_labels
+        self.do_probs = do_probs
+
+    def __call__(self, batch_context, task_context, context) -> None:
+        _check_context(context)
+        images = _images_to_device(batch_context, context)
+        if self.has_labels:
+            batch_context.input['labels'] = batch_context.input['labels'].long().to(context.device)
+        logits = context.model(images)
+        batch_context.output['logits'] = logits
+        if self.do_probs:
+            batch_context.output['probabilities'] = softmax(logits)
+
+
+class McPredictStep(BatchStep):
+    """T stochastic passes (plus the deterministic 'weight scaling' pass the reference always runs
+    first, customsteps.py:22-25)."""
+
+    def __init__(self, mc_steps, do_mi=False, do_var=False, materialize=False, masks=None, ws_pass=True) -> None:
+        super().__init__()
+        self.mc_steps = mc_steps
+        self.do_mi, self.do_var = do_mi, do_var
+        self.materialize = materialize
+        self.masks = masks          # optional: list (one per pass) of mask sets to inject instead of sampling
+        self.ws_pass = ws_pass
+
+    def __call__(self, batch_context, task_context, context) -> None:
+        _check_context(context)
+        images = _images_to_device(batch_context, context)
+        model = context.model
+
+        if self.ws_pass:
+            batch_context.output['ws_probabilities'] = softmax(model(images))
+
+        set_dropout_mode(model, is_train=True)
+        try:
+            if self.materialize or not isinstance(model, model_mod.UNet):
+                probs = []
+                for i in range(self.mc_steps):
+                    logits = model(images) if self.masks is None else model(images, self.masks[i])
+                    probs.append(softmax(logits))
+                batch_context.output['multi_probabilities'] = torch.stack(probs)
+            else:
+                n, _, h, w = images.shape
+                stats = McStatistics(n, model.nb_classes, h, w, images.device, self.do_mi, self.do_var)
+                for i in range(self.mc_steps):
+                    model.forward_accumulate(images, stats, None if self.masks is None else self.masks[i])
+                batch_context.output['multi_probabilities'] = stats
+        finally:
+            set_dropout_mode(model, is_train=False)   # reset to eval for the next batch (customsteps.py:39)
+
+
+class EnsemblePredictionStep(BatchStep):
+    """context.model plus ``additional_models``, all in eval mode (brats_test_ensemble.py:78-94)."""
+
+    def __init__(self, additional_models, do_mi=False, do_var=False, materialize=False) -> None:
+        super().__init__()
+        self.additional_models = additional_models
+        self.do_mi, self.do_var = do_mi, do_var
+        self.materialize = materialize
+
+    def __call__(self, batch_context, task_context, context) -> None:
+        _check_context(context)
+        images = _images_to_device(batch_context, context)
+        members = [context.model] + list(self.additional_models)
+        fused = not self.materialize and all(isinstance(m, model_mod.UNet) for m in members)
+        if fused:
+            n, _, h, w = images.shape
+            stats = McStatistics(n, members[0].nb_classes, h, w, images.device, self.do_mi, self.do_var)
+            for m in members:
+                m.forward_accumulate(images, stats)
+            batch_context.output['multi_probabilities'] = stats
+        else:
+            batch_context.output['multi_probabilities'] = torch.stack([softmax(m(images)) for m in members])
+
+
+class MultiPredictionSummary(BatchStep):
+
+    def __init__(self, do_mi=False, do_var=False, remove_multi_probs=True) -> None:
+        super().__init__()
+        self.do_mi = do_mi
+        self.do_var = do_var
+        self.remove_multi_probs = remove_multi_probs
+
+    def __call__(self, batch_context, task_context, context) -> None:
+        if self.remove_multi_probs:
+            multi = batch_context.output.pop('multi_probabilities')
+        else:
+            multi = batch_context.output['multi_probabilities']
+        if isinstance(multi, McStatistics):
+            stats = multi
+        else:
+            t, n, c, h, w = multi.shape
+            stats = McStatistics(n, c, h, w, multi.device, self.do_mi, self.do_var)
+            for i in range(t):
+                stats.accumulate(multi[i], is_probabilities=True)
+        out = stats.finalize(self.do_mi, self.do_var)
+        batch_context.output['probabilities'] = out['probabilities']
+        batch_context.output['entropy'] = out['entropy']
+        if self.do_mi:
+            batch_context.output['mutual_info'] = out['mutual_info']
+        if self.do_var:
+            batch_context.output['variance'] = out['variance']
+
+
+class AleatoricPredictStep(BatchStep):
+
+    def __init__(self, is_log_sigma=False) -> None:
+        super().__init__()
+        self.is_log_sigma = is_log_sigma
+
+    def __call__(self, batch_context, task_context, context) -> None:
+        _check_context(context)
+        images = _images_to_device(batch_context, context)
+        mean_logits, sigma_raw = context.model(images)
+        batch_context.output['logits'] = mean_logits
+        n, c, h, w = mean_logits.shape
+        probs = torch.empty_like(mean_logits)
+        sigma = torch.empty_like(mean_logits)
+        _lib.check(_lib.load().rcu_aleatoric(_lib.ptr(mean_logits), _lib.ptr(sigma_raw.contiguous()), n, h * w, c,
+                                             int(self.is_log_sigma), _lib.ptr(probs), _lib.ptr(sigma), None, None,
+                                             _lib.current_stream()))
+        batch_context.output['sigma'] = sigma
+        batch_context.output['probabilities'] = probs
+
+
+def prediction_and_foreground(probabilities):
+    """``[N, C, H, W]`` probabilities -> (uint8 argmax ``[N, H, W]``, float32 foreground probability
+    ``[N, H, W]``): what the reference's writers derive with numpy before saving
+    ``*_prediction`` / ``*_probabilities`` (bin-dl/brats_test_default.py:96-99)."""
+    p = probabilities.to(torch.float32).contiguous()
+    n, c, h, w = p.shape
+    pred = torch.empty((n, h, w), device=p.device, dtype=torch.uint8)
+    fg = torch.empty((n, h, w), device=p.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcu_prediction_and_foreground(_lib.ptr(p), n, h * w, c, _lib.ptr(pred), _lib.ptr(fg),
+                                                         _lib.current_stream()))
+    return pred, fg
+
+
+def sigma_of_prediction(logits, sigma_raw, is_log_sigma=False):
+    """sigma of the predicted class per voxel (bin-dl/brats_test_aleatoric.py:95-97) -> (prediction u8, sigma f32)."""
+    logits = logits.to(torch.float32).contiguous()
+    sigma_raw = sigma_raw.to(torch.float32).contiguous()
+    n, c, h, w = logits.shape
+    pred = torch.empty((n, h, w), device=logits.device, dtype=torch.uint8)
+    sp = torch.empty((n, h, w), device=logits.device, dtype=torch.float32)
+    _lib.check(_lib.load().rcu_aleatoric(_lib.ptr(logits), _lib.ptr(sigma_raw), n, h * w, c, int(is_log_sigma), None,
+                                         None, _lib.ptr(pred), _lib.ptr(sp), _lib.current_stream()))
+    return pred, sp
+
+
+def channel_to_end(tensor):
+    """NCHW -> NHWC view, as the test loop applies before ``.cpu().numpy()`` (torchhelper.py:10-23; loops.py:214-220)."""
+    dims = tensor.dim()
+    return tensor.permute(0, *range(2, dims), 1)

@@ -1,0 +1,403 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden vectors.
+Run on the GPU box: ``python -m pytest tests -m gpu``.  fp32 tolerances are written at each check;
+integer / index outputs are compared bit-for-bit."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_params, golden_state
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 2e-4      # |logit| ~ 1..10 after 24 stacked fp32 convs in a different summation order
+PROB_TOL = 1e-4       # north_star: uncertainty maps within 1e-4 of the CPU reference
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a MI355X'
+    return torch.device('cuda')
+
+
+def _model(params, state, dev):
+    from rcu_amd.model import UNet
+    m = UNet(**params)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in state.items()})
+    return m.to(dev)
+
+
+def _maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+# ---------------------------------------------------------------------------------- U-Net forward
+def test_unet_eval_golden(golden, dev):
+    g = golden('g1_unet_eval')
+    m = _model(golden_params(g), golden_state(g), dev)
+    for tag in ('a', 'b'):
+        y = m(torch.from_numpy(g['x_' + tag]).to(dev)).cpu().numpy()
+        assert y.shape == g['logits_' + tag].shape
+        assert _maxdiff(y, g['logits_' + tag]) < LOGIT_TOL
+    g8 = golden('g1_unet_eval_sf8')
+    m8 = _model(golden_params(g8), golden_state(g8), dev)
+    assert _maxdiff(m8(torch.from_numpy(g8['x']).to(dev)).cpu().numpy(), g8['logits']) < LOGIT_TOL
+
+
+def test_unet_isic_golden(golden, dev):
+    g = golden('g5_unet_isic')
+    m = _model(golden_params(g), golden_state(g), dev)
+    assert _maxdiff(m(torch.from_numpy(g['x']).to(dev)).cpu().numpy(), g['logits']) < LOGIT_TOL
+
+
+def test_unet_mc_injected_masks_golden(golden, dev):
+    g = golden('g2_unet_mc')
+    m = _model(golden_params(g), golden_state(g), dev)
+    assert [s[0] for s in m.dropout_sites()] == list(g['sites'])
+    x = torch.from_numpy(g['x']).to(dev)
+    for t in range(int(g['T'])):
+        masks = [g['mask_{}_{}'.format(t, s)] for s in range(len(g['sites']))]
+        assert _maxdiff(m(x, masks).cpu().numpy(), g['logits_{}'.format(t)]) < LOGIT_TOL
+
+
+def test_unet_dropout_center_golden(golden, dev):
+    g = golden('g3_unet_center')
+    m = _model(golden_params(g), golden_state(g), dev)
+    assert [s[0] for s in m.dropout_sites()] == list(g['sites'])
+    x = torch.from_numpy(g['x']).to(dev)
+    masks = [g['mask_{}'.format(s)] for s in range(len(g['sites']))]
+    assert _maxdiff(m(x, masks).cpu().numpy(), g['logits']) < LOGIT_TOL
+    assert _maxdiff(m(x).cpu().numpy(), g['logits_eval']) < LOGIT_TOL
+
+
+def test_unet_sigma_head_golden(golden, dev):
+    from rcu_amd import steps
+    g = golden('g4_unet_sigma')
+    m = _model(golden_params(g), golden_state(g), dev)
+    logits, sigma = m(torch.from_numpy(g['x']).to(dev))
+    assert _maxdiff(logits.cpu().numpy(), g['logits']) < LOGIT_TOL
+    assert _maxdiff(sigma.cpu().numpy(), g['sigma_raw']) < LOGIT_TOL
+    bc = steps.BatchContext({'images': torch.from_numpy(g['x'])}, 0)
+    steps.AleatoricPredictStep()(bc, None, steps.TorchTestContext('cuda', m))
+    assert set(bc.output) == {'logits', 'sigma', 'probabilities'}
+    assert _maxdiff(bc.output['sigma'].cpu().numpy(), g['sigma_abs']) < LOGIT_TOL
+    assert _maxdiff(bc.output['probabilities'].cpu().numpy(), g['probabilities']) < PROB_TOL
+    # exact-input checks of the writer-side selection: feed the golden logits / sigma
+    pred, sp = steps.sigma_of_prediction(torch.from_numpy(g['logits']).to(dev), torch.from_numpy(g['sigma_raw']).to(dev))
+    assert np.array_equal(pred.cpu().numpy(), g['prediction'])
+    assert _maxdiff(sp.cpu().numpy(), g['sigma_pred']) < 1e-6
+
+
+@pytest.mark.parametrize('shape', [(2, 192, 128), (3, 48, 32), (1, 32, 48)])
+def test_unet_full_width_vs_oracle(dev, shape):
+    """start_filters=32 (the shipped width; no channel padding anywhere) incl. the BraTS slice size whose
+    bottom level (12x8) uses the two-slices-per-workgroup kernel; dropout masks sampled and injected."""
+    from oracle import unet_oracle as uo
+    n, h, w = shape
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
+    st = uo.synthetic_state(20, **params)
+    m = _model(params, st, dev)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 4, h, w, generator=g)
+    _, sites = uo.unet_plan(**params)
+    masks = uo.sample_masks(sites, n, 0.3, g)   # heavier dropout than the config to make masks matter
+    for mk in (None, masks):
+        ref = uo.unet_forward(st, x, mk, **params).numpy()
+        out = m(x.to(dev), mk).cpu().numpy()
+        assert _maxdiff(out, ref) < LOGIT_TOL
+        ps = torch.softmax(torch.from_numpy(out), 1).numpy()
+        pr = torch.softmax(torch.from_numpy(ref), 1).numpy()
+        assert _maxdiff(ps, pr) < PROB_TOL
+
+
+def test_unet_g11_reference_digest(golden, dev):
+    """Full-width weights rebuilt by replaying the reference constructor's draws; the committed strided
+    logits came from the reference itself."""
+    from oracle import unet_oracle as uo
+    g = golden('g11_fullsize_digest')
+    p = golden_params(g)
+    st = uo.reference_init_state(int(g['seed']), bn_seed=int(g['seed']) + 1000, **p)
+    y = _model(p, st, dev)(torch.from_numpy(g['x']).to(dev)).cpu().numpy().reshape(-1)
+    assert _maxdiff(y[::int(g['stride'])], g['logits_strided']) < LOGIT_TOL
+
+
+def test_unet_batch_split_invariance_and_errors(dev):
+    from oracle import unet_oracle as uo
+    from rcu_amd import _lib
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
+    m = _model(params, uo.synthetic_state(3, **params), dev)
+    x = torch.randn(6, 4, 48, 32, generator=torch.Generator().manual_seed(1)).to(dev)
+    full = m(x)
+    part = m(x[2:5].contiguous())
+    assert torch.equal(full[2:5], part)          # slices are independent and the kernels deterministic
+    assert torch.equal(m(x), full)
+    ones = [np.ones((6, c), np.float32) for _, c in m.dropout_sites()]
+    assert torch.equal(m(x, ones), full)         # all-ones masks == eval mode, bit for bit
+    with pytest.raises(_lib.RcuError):
+        m(torch.zeros(1, 4, 40, 32, device=dev))  # not divisible by 2^depth
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4, 32, 32))              # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        m(x, ones[:-1])
+
+
+# ---------------------------------------------------------------------------------- aggregation
+def test_mc_summary_golden(golden, dev):
+    from rcu_amd import steps
+    g = golden('g6_mc_summary')
+    for case in range(3):
+        multi = torch.from_numpy(g['multi_{}'.format(case)]).to(dev)
+        bc = steps.BatchContext({}, 0)
+        bc.output['multi_probabilities'] = multi
+        steps.MultiPredictionSummary(do_mi=True, do_var=True)(bc, None, None)
+        assert 'multi_probabilities' not in bc.output
+        for k, tol in (('probabilities', 1e-6), ('entropy', 2e-6), ('mutual_info', 2e-6), ('variance', 1e-7)):
+            ref = g['{}_{}'.format(k, case)]
+            assert bc.output[k].shape == ref.shape
+            assert _maxdiff(bc.output[k].cpu().numpy(), ref) < tol, k
+        # default flags: float32 statistics, two outputs only
+        bc = steps.BatchContext({}, 0)
+        bc.output['multi_probabilities'] = multi
+        steps.MultiPredictionSummary()(bc, None, None)
+        assert set(bc.output) == {'probabilities', 'entropy'}
+        assert _maxdiff(bc.output['probabilities'].cpu().numpy(), g['probabilities_{}'.format(case)]) < 1e-6
+        assert _maxdiff(bc.output['entropy'].cpu().numpy(), g['entropy_{}'.format(case)]) < 2e-6
+
+
+def test_mc_step_end_to_end_golden(golden, dev):
+    """McPredictStep + MultiPredictionSummary through the fused forward+softmax+accumulate path with the
+    reference's own dropout masks injected; also the materialised (reference-shaped) path."""
+    from rcu_amd import steps
+    g = golden('g7_mc_step')
+    m = _model(golden_params(g), golden_state(g), dev)
+    T, S = int(g['T']), len(g['sites'])
+    mask_sets = [[g['mask_{}_{}'.format(t, s)] for s in range(S)] for t in range(T)]
+    ctx = steps.TorchTestContext('cuda', m)
+    for materialize in (False, True):
+        bc = steps.BatchContext({'images': torch.from_numpy(g['x'])}, 0)   # float64 input: the step casts
+        steps.McPredictStep(T, do_mi=True, do_var=True, materialize=materialize, masks=mask_sets)(bc, None, ctx)
+        assert not m.mc_active()                                          # dropout switched back off
+        if materialize:
+            assert _maxdiff(bc.output['multi_probabilities'].cpu().numpy(), g['multi_probabilities']) < PROB_TOL
+        steps.MultiPredictionSummary(do_mi=True, do_var=True)(bc, None, ctx)
+        assert set(bc.output) == set(g['out_keys'])
+        for k in g['out_keys']:
+            assert _maxdiff(bc.output[k].cpu().numpy(), g['out::' + k]) < PROB_TOL, k
+    with pytest.raises(ValueError):
+        steps.McPredictStep(1)(steps.BatchContext({'images': torch.from_numpy(g['x'])}, 0), None, object())
+    bc = steps.BatchContext({'images': torch.from_numpy(g['x'])}, 0)
+    steps.McPredictStep(2)(bc, None, ctx)            # sampled masks, default statistics
+    with pytest.raises(ValueError):
+        steps.MultiPredictionSummary(do_var=True)(bc, None, ctx)   # variance was not tracked
+
+
+def test_mc_sampled_dropout_statistics(dev):
+    """Sampled masks follow Bernoulli(1-p)/(1-p) and MC passes differ from the eval pass."""
+    from oracle import unet_oracle as uo
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.25)
+    m = _model(params, uo.synthetic_state(4, **params), dev)
+    from rcu_amd import steps
+    steps.set_dropout_mode(m, True)
+    torch.manual_seed(0)
+    mk = m.sample_masks(64, dev)
+    vals = torch.unique(mk).cpu().numpy()
+    assert np.allclose(vals, [0.0, 1 / 0.75])
+    assert abs(float((mk > 0).float().mean()) - 0.75) < 0.01
+    x = torch.randn(2, 4, 32, 32, device=dev)
+    a, b = m(x), m(x)
+    assert not torch.equal(a, b)
+    steps.set_dropout_mode(m, False)
+    assert torch.equal(m(x), m(x))
+
+
+def test_ensemble_step(dev):
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
+    states = [uo.synthetic_state(20 + k, **params) for k in range(3)]
+    models = [_model(params, st, dev) for st in states]
+    x = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(2))
+    ref = so.multi_prediction_summary(
+        so.ensemble_probabilities([lambda xx, mk, st=st: uo.unet_forward(st, xx, mk, **params) for st in states], x),
+        True, True)
+    ctx = steps.TorchTestContext('cuda', models[0])
+    for materialize in (False, True):
+        bc = steps.BatchContext({'images': x.clone()}, 0)
+        steps.EnsemblePredictionStep(models[1:], do_mi=True, do_var=True, materialize=materialize)(bc, None, ctx)
+        steps.MultiPredictionSummary(do_mi=True, do_var=True)(bc, None, ctx)
+        for k in ('probabilities', 'entropy', 'mutual_info', 'variance'):
+            assert _maxdiff(bc.output[k].cpu().numpy(), ref[k].numpy()) < PROB_TOL, k
+
+
+def test_aggregation_properties_full_size(dev):
+    """BraTS-sized statistics (160 x 2 x 192 x 128): T identical passes -> mean == p, zero variance and
+    mutual information; a permutation of the passes gives the same float64 statistics."""
+    from rcu_amd import steps
+    n, c, h, w = 160, 2, 192, 128
+    g = torch.Generator(device='cuda').manual_seed(0)
+    logits = torch.randn(n, c, h, w, device=dev, generator=g) * 4
+    p = steps.softmax(logits)
+    assert float((p.sum(1) - 1).abs().max()) < 1e-6
+    st = steps.McStatistics(n, c, h, w, dev, do_mi=True, do_var=True)
+    for _ in range(5):
+        st.accumulate(logits)
+    out = st.finalize(True, True)
+    assert float((out['probabilities'] - p).abs().max()) < 1e-7
+    assert float(out['variance'].abs().max()) < 1e-12
+    assert float(out['mutual_info'].abs().max()) < 1e-6
+    others = [torch.randn(n, c, h, w, device=dev, generator=g) for _ in range(3)]
+    sa = steps.McStatistics(n, c, h, w, dev, do_mi=False, do_var=True)
+    sb = steps.McStatistics(n, c, h, w, dev, do_mi=False, do_var=True)
+    for t in others:
+        sa.accumulate(t)
+    for t in reversed(others):
+        sb.accumulate(t)
+    assert float((sa.blob - sb.blob).abs().max()) < 1e-12
+
+
+# ---------------------------------------------------------------------------------- calibration
+def test_ece_golden_bit_exact_bins(golden, dev):
+    from rcu_amd import evaluation as ev
+    g = golden('g8_ece')
+    for tag in ('a', 'b'):
+        assert np.array_equal(ev.bin_ids(g[tag + '_p']).astype(np.int64), g[tag + '_binids'])
+    p2 = np.stack([1 - g['a_p'], g['a_p']], -1)
+    for tag, mask in (('masked', g['a_mask']), ('nomask', None)):
+        bins = {}
+        ece = ev.ece_binary(p2, g['a_target'], mask=mask, out_bins=bins)
+        assert np.array_equal(bins['bins_count'], g['a_bins_count_' + tag])          # integers: exact
+        assert np.array_equal(bins['bins_non_zero'], g['a_bins_non_zero_' + tag])
+        assert np.array_equal(bins['bins_positive_fraction'], g['a_bins_positive_fraction_' + tag])
+        assert _maxdiff(bins['bins_avg_confidence'], g['a_bins_avg_confidence_' + tag]) < 1e-12   # f64 sum order
+        assert abs(ece - float(g['a_ece_' + tag])) < 1e-12
+    for tag in ('b', 'c'):
+        p = g[tag + '_p']
+        bins = {}
+        ece = ev.ece_binary(np.stack([1 - p, p], -1), g[tag + '_target'], out_bins=bins)
+        assert np.array_equal(bins['bins_count'], g[tag + '_bins_count'])
+        assert abs(ece - float(g[tag + '_ece'])) < 1e-12
+    for wgt in ('log_proportion', 'power_proportion', 'mean_proportion'):
+        assert abs(ev.ece_binary(p2, g['a_target'], mask=g['a_mask'], bin_weighting=wgt) - float(g['d_ece_' + wgt])) < 1e-12
+    assert abs(ev.ece_binary(p2, g['a_target'], threshold_range=(0.2, 0.9)) - float(g['d_ece_thresrange'])) < 1e-12
+    assert abs(ev.ece_binary(p2, g['a_target'], n_bins=5) - float(g['e_ece_5bins'])) < 1e-12
+    res = {}
+    ev.EceBinaryNumpy(with_mask=True, return_bins=True)({'target': g['a_target'], 'probabilities': p2,
+                                                         'mask': g['a_mask']}, res)
+    assert sorted(res.keys()) == list(g['d_keys'])
+    assert abs(res['ece'] - float(g['d_ece'])) < 1e-12
+    with pytest.raises(ValueError):
+        ev.ece_binary(np.zeros((4, 4, 3), np.float32), np.zeros((4, 4), np.uint8))
+
+
+def test_ece_edge_cases(dev):
+    from oracle import calib_oracle as co
+    from rcu_amd import evaluation as ev
+    rng = np.random.RandomState(0)
+    # ragged length (scalar path), everything masked out, single voxel
+    for n in (1, 7, 1023, 4097):
+        p = rng.rand(n).astype(np.float32)
+        t = (rng.rand(n) < 0.5).astype(np.uint8)
+        cnt, sc, sp = ev.calibration_histogram(p, t)
+        rc, rsc, rsp = co.calibration_histogram(p, t)
+        assert np.array_equal(cnt[0], rc) and np.array_equal(sp[0], rsp.astype(np.int64))
+        assert _maxdiff(sc[0], rsc) < 1e-10
+    p = rng.rand(64).astype(np.float32)
+    cnt, sc, sp = ev.calibration_histogram(p, np.ones(64, np.uint8), mask=np.zeros(64, bool))
+    assert cnt.sum() == 0 and sp.sum() == 0 and sc.sum() == 0
+
+
+def test_ece_full_size_batched_properties(dev):
+    """8 BraTS-sized volumes in one launch: checksum-of-checksums properties + oracle equality on one volume."""
+    from oracle import c_oracle
+    from oracle import calib_oracle as co
+    from rcu_amd import evaluation as ev
+    nv, n = 8, 160 * 192 * 128
+    g = torch.Generator(device='cuda').manual_seed(1)
+    p = torch.rand(nv, n, device=dev, generator=g)
+    p = torch.where(torch.rand(nv, n, device=dev, generator=g) < 0.8, p * 0.05, p)   # mostly background
+    t = (torch.rand(nv, n, device=dev, generator=g) < p).to(torch.uint8)
+    m = (torch.rand(nv, n, device=dev, generator=g) < 0.4).to(torch.uint8)
+    cnt, sc, sp = ev.calibration_histogram(p, t, mask=m, n_volumes=nv)
+    assert np.array_equal(cnt.sum(1), m.sum(1).cpu().numpy())
+    assert np.array_equal(sp.sum(1), (t * m).sum(1).cpu().numpy())
+    assert np.allclose(sc.sum(1), (p.double() * m).sum(1).cpu().numpy(), rtol=1e-12)
+    thr = co.float32_thresholds(10)
+    rc, rsc, rsp = c_oracle.ece_hist(p[3].cpu().numpy(), t[3].cpu().numpy(), m[3].cpu().numpy(), thr)
+    assert np.array_equal(cnt[3], rc.astype(np.int64)) and np.array_equal(sp[3], rsp.astype(np.int64))
+    assert np.allclose(sc[3], rsc, rtol=1e-12, atol=0)
+    e_gpu = ev.ece_from_histogram(cnt[3], sc[3], sp[3])
+    e_ref = co.ece_from_histogram(rc.astype(np.int64), rsc, rsp.astype(np.float64))
+    assert abs(e_gpu - e_ref) < 1e-12
+    cnt2, sc2, sp2 = ev.calibration_histogram(p, t, mask=m, n_volumes=nv)
+    assert np.array_equal(sc, sc2)    # run-to-run deterministic, float sums included
+
+
+def test_uncertainty_counts_golden(golden, dev):
+    from rcu_amd import evaluation as ev
+    g = golden('g9_uncertainty')
+    c = ev.uncertainty_counts(g['prediction'], g['target'], g['uncertainty'], tuple(g['thresholds']))
+    assert np.array_equal(c[0], g['counts'])
+    cm = ev.uncertainty_counts(g['prediction'], g['target'], g['uncertainty'], (0.5,), mask=g['mask'])
+    assert list(cm[0, 0]) == list(g['masked_counts_thr05'])
+    for i, thr in enumerate(g['thresholds']):
+        res = {}
+        ev.UncertaintyErrorDiceNumpy(float(thr))({'prediction': g['prediction'], 'target': g['target'],
+                                                 'uncertainty': g['uncertainty']}, res)
+        assert [res['dice'], res['recall'], res['precision']] == list(g['derived'][i])
+    tpl = ev.uncertainty(g['prediction'], g['target'], g['uncertainty'] > 0.3)
+    assert list(tpl) == list(g['counts'][3])
+    # device entropy vs the reference's float64 map: float tolerance; counts from it may only differ on
+    # voxels whose entropy sits within that tolerance of a threshold
+    ent = ev.normalised_entropy(g['p']).cpu().numpy()
+    assert ent.dtype == np.float64 and _maxdiff(ent, g['uncertainty']) < 1e-6
+    c2 = ev.uncertainty_counts(g['prediction'], g['target'], ent, tuple(g['thresholds']))[0]
+    near = sum(int(np.sum(np.abs(g['uncertainty'] - t) < 1e-6)) for t in g['thresholds'])
+    assert np.abs(c2 - g['counts']).sum() <= 2 * near
+    res = {}
+    ev.UncertaintyAndCorrectionSweep()({'prediction': g['prediction'], 'target': g['target'],
+                                        'uncertainty': g['uncertainty']}, res)
+    assert [res[t]['tpu'] for t in ev.UE_THRESHOLDS] == list(g['counts'][:, 4])
+
+
+def test_uncertainty_counts_full_size_properties(dev):
+    from oracle import c_oracle
+    from rcu_amd import evaluation as ev
+    n = 160 * 192 * 128
+    g = torch.Generator(device='cuda').manual_seed(2)
+    u = torch.rand(n, device=dev, generator=g, dtype=torch.float64) ** 3
+    pr = (torch.rand(n, device=dev, generator=g) < 0.1).to(torch.uint8)
+    tg = (torch.rand(n, device=dev, generator=g) < 0.1).to(torch.uint8)
+    c = ev.uncertainty_counts(pr, tg, u)[0]
+    assert np.all(c[:, :4].sum(1) == n)
+    assert np.all(np.diff(c[:, 4:].sum(1)) <= 0)           # fewer uncertain voxels as the threshold grows
+    assert np.all(c[:, 4:] <= c[:, :4])
+    ref = c_oracle.unc_counts(u.cpu().numpy(), pr.cpu().numpy(), tg.cpu().numpy(), None, ev.UE_THRESHOLDS)
+    assert np.array_equal(c, ref.astype(np.int64))
+
+
+def test_preparation_golden(golden, dev):
+    from rcu_amd import evaluation as ev
+    g = golden('g10_prep')
+    pred = g['prediction']
+    for entry, idp in (('probabilities', 'run'), ('confidence', 'run_rescale'), ('sigma', 'run_rescale')):
+        src = g['prob_prep_in_' + entry]
+        prep, id_ = ev.get_probability_preparation(entry, 'run')
+        out = prep({entry: src.copy(), 'prediction': pred.copy()})
+        assert id_ == idp and np.array_equal(out['probabilities'], g['prob_prep_out_' + entry])
+        prep_u, id_u = ev.get_uncertainty_preparation(entry, 'run', rescale_confidence='subject', rescale_sigma='subject')
+        out_u = prep_u({entry: src.copy(), 'prediction': pred.copy()})
+        assert id_u == idp
+        assert _maxdiff(out_u['uncertainty'], g['unc_prep_out_' + entry]) < 1e-6
+    with pytest.raises(ValueError):
+        ev.add_background_probability(np.array([0.5, 1.5]))
+    with pytest.raises(ValueError):
+        ev.ToEntropy()({'probabilities': np.zeros((2, 2, 3))})
+
+
+def test_prediction_and_foreground(dev):
+    from rcu_amd import steps
+    p = torch.rand(3, 2, 16, 16, device=dev)
+    p[0, :, 0, 0] = 0.5     # tie -> first maximum, as np.argmax
+    pred, fg = steps.prediction_and_foreground(p)
+    assert np.array_equal(pred.cpu().numpy(), np.argmax(p.permute(0, 2, 3, 1).cpu().numpy(), -1).astype(np.uint8))
+    assert torch.equal(fg, p[:, 1])
