@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MC-sample-volumes/s on a synthetic BraTS-shaped volume (4 x 160 x 192 x 128,
+i.e. 160 slices of 4 x 192 x 128), T = 20 MC-dropout passes, on N GPUs of one node.
+
+One step = the reference's hot path for one volume (rechun/dl/customsteps.py:16-71):
+    weight-scaling pass + T stochastic U-Net passes (softmax + running statistics fused in) ->
+    [N > 1: one RCCL sum-reduce of the per-voxel statistics] -> mean probability + predictive entropy.
+Inputs are resident in HBM when the timed region starts.  N > 1 shards the T+1 forward passes of
+every step over the ranks (strong scaling); run through
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (HIP events recorded on the
+launch stream inside the timed region, see rcu_unet_profile_begin in include/rcu.h); `cpu_baseline`
+is the oracle (a port of the reference's CPU path, pinned against golden vectors) timed on a bounded
+sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+SLICES, CHANNELS, HEIGHT, WIDTH = 160, 4, 192, 128
+MODEL_PARAMS = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)  # config/train_brats_baseline.yaml:7-12
+
+
+def make_model(seed, device):
+    """UNet(2, 4, 4, 32, 0.05) with torch's default init under the seed and randomised BatchNorm statistics
+     -- random-init weights of the named architecture; there are no checkpoints offline."""
+    from rcu_amd.model import UNet
+    torch.manual_seed(seed)
+    model = UNet(**MODEL_PARAMS)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+    model.weights_changed()
+    return model.to(device)
+
+
+def make_volume(seed, n=SLICES):
+    """x ~ N(0,1) zeroed outside a centred ellipsoid (= the ECE brain mask); target = smaller ellipsoid."""
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, CHANNELS, HEIGHT, WIDTH, generator=gen)
+    zz, yy, xx = torch.meshgrid(torch.linspace(-1, 1, SLICES)[:n] if n <= SLICES else torch.linspace(-1, 1, n),
+                                torch.linspace(-1, 1, HEIGHT), torch.linspace(-1, 1, WIDTH), indexing='ij')
+    r2 = (zz / 0.9) ** 2 + (yy / 0.85) ** 2 + (xx / 0.8) ** 2
+    mask = r2 < 1.0
+    target = ((zz / 0.35) ** 2 + ((yy - 0.1) / 0.3) ** 2 + ((xx + 0.1) / 0.3) ** 2 < 1.0).to(torch.uint8)
+    x = x * mask[:, None].float()
+    return x, mask, target
+
+
+def cpu_baseline(model, x_cpu, T, seed):
+    """The oracle's CPU path (torch-CPU conv stack + torch aggregation, batch 32 as in
+    config/test_brats_baseline_mc.yaml:11) on the first slices of the same volume."""
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = 8
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    _, sites = uo.unet_plan(**MODEL_PARAMS)
+    gen = torch.Generator().manual_seed(seed)
+    xs = x_cpu[:n].contiguous()
+    mask_sets = [uo.sample_masks(sites, n, MODEL_PARAMS['dropout'], gen) for _ in range(T)]
+    fwd = lambda xx, m: uo.unet_forward(state, xx, m, **MODEL_PARAMS)  # noqa: E731
+    fwd(xs[:2], None)  # warm-up (thread pool, primitive caches)
+    t0 = time.perf_counter()
+    ws, multi = so.mc_probabilities(fwd, xs, mask_sets)
+    out = so.multi_prediction_summary(multi)
+    dt = time.perf_counter() - t0
+    volumes = T * n / SLICES            # MC-sample-volume equivalents processed (ws pass timed, not counted)
+    return dict(value=volumes / dt, unit='MC-sample-volumes/s', cores=cores, kind='port',
+                sample='{} of {} slices x (T={} + ws pass) through oracle/ (torch-CPU, {} threads) in {:.1f} s'
+                .format(n, SLICES, T, cores, dt)), mask_sets, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--mc', type=int, default=20, help='T: stochastic passes per volume')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-ws', action='store_true', help='skip the deterministic weight-scaling pass')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus {} but WORLD_SIZE={}: launch N>1 through torch.distributed.run'.format(args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)   # "nccl" is RCCL on ROCm
+
+    from rcu_amd import distributed as rdist
+    from rcu_amd import evaluation as ev
+    from rcu_amd import steps
+
+    T = args.mc
+    seed = 20                                   # config seed (config/test_brats_baseline_mc.yaml:6)
+    model = make_model(seed, device)
+    x_cpu, mask_cpu, target_cpu = make_volume(seed)
+    x = x_cpu.to(device)
+    ctx = steps.TorchTestContext(str(device), model)
+    runner = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world)
+    torch.manual_seed(seed + rank)              # dropout masks: independent streams per rank
+
+    def one_step(k):
+        return runner.step(x, k)
+
+    for k in range(args.warmup):
+        one_step(k)
+    # per-kernel HIP events for this rank's forwards inside the timed region
+    my_forwards = sum(len(runner.jobs_of(k, rank)) for k in range(args.warmup, args.warmup + args.steps))
+    model.profile_begin(HEIGHT, WIDTH, SLICES, my_forwards)
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for k in range(args.warmup, args.warmup + args.steps):
+        out = one_step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    forwards, slot_ms = model.profile_collect(HEIGHT, WIDTH, SLICES)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (this rank's launches in the timed region)
+    layers = model.layer_table(HEIGHT, WIDTH, SLICES)
+    per_kernel = {}
+    for L, ms in zip(layers, slot_ms[1:1 + len(layers)]):
+        e = per_kernel.setdefault(L['kernel'], dict(ms=0.0, flops=0.0, launches=0))
+        e['ms'] += ms
+        e['flops'] += L['flops_per_slice'] * SLICES * forwards
+        e['launches'] += forwards
+    dominant = max(per_kernel, key=lambda k_: per_kernel[k_]['ms'])
+    d = per_kernel[dominant]
+    conv_ms = sum(e['ms'] for e in per_kernel.values())
+    conv_flops = sum(e['flops'] for e in per_kernel.values())
+    roofline = dict(bound='mfma', kernel=dominant, achieved=d['flops'] / (d['ms'] * 1e-3) / 1e12,
+                    peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=d['flops'] / (d['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    traffic=None, launches=d['launches'], avg_launch_ms=d['ms'] / max(d['launches'], 1),
+                    flops_per_launch=d['flops'] / max(d['launches'], 1),
+                    all_conv_kernels=dict(achieved=conv_flops / (conv_ms * 1e-3) / 1e12,
+                                          frac=conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                          ms_per_forward=conv_ms / max(forwards, 1)),
+                    other_ms_per_forward=dict(input_relayout=slot_ms[0] / max(forwards, 1),
+                                              head_softmax_accumulate=slot_ms[-1] / max(forwards, 1)),
+                    per_kernel={k_: dict(ms_per_forward=e['ms'] / max(forwards, 1),
+                                         tflops=e['flops'] / (e['ms'] * 1e-3) / 1e12) for k_, e in per_kernel.items()})
+    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        if dominant in pmc:
+            roofline['traffic'] = pmc[dominant]
+
+    # ---- parity numbers outside the timed region: ECE on the GPU maps vs the oracle on the same maps, and
+    # (with the CPU baseline) the end-to-end difference on the slices the CPU path processed
+    pred, p_fg = steps.prediction_and_foreground(out['probabilities'])
+    ece_gpu = ev.ece_binary(p_fg, target_cpu, mask=mask_cpu)
+    parity = dict(ece=ece_gpu)
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import calib_oracle as co
+        p_np = p_fg.cpu().numpy()
+        ece_oracle = co.ece_binary(np.stack([1 - p_np, p_np], -1), target_cpu.numpy(), mask=mask_cpu.numpy())
+        parity['ece_delta_same_maps'] = abs(ece_gpu - ece_oracle)
+        parity['bin_ids_equal'] = bool(np.array_equal(ev.bin_ids(p_np), co.bin_ids(p_np.reshape(-1))))
+        cpu, mask_sets, ref = cpu_baseline(model, x_cpu, T, seed)
+        n = ref['probabilities'].shape[0]
+        bc = steps.BatchContext({'images': x[:n].contiguous()}, 0)
+        steps.McPredictStep(T, masks=mask_sets)(bc, None, ctx)
+        steps.MultiPredictionSummary()(bc, None, ctx)
+        parity['max_abs_dprob_vs_cpu'] = float((bc.output['probabilities'].cpu() - ref['probabilities']).abs().max())
+        parity['max_abs_dentropy_vs_cpu'] = float((bc.output['entropy'].cpu() - ref['entropy']).abs().max())
+        pg = bc.output['probabilities'][:, 1].cpu().numpy()
+        pc = ref['probabilities'][:, 1].numpy()
+        tg, mk = target_cpu[:n].numpy(), mask_cpu[:n].numpy()
+        parity['ece_delta_vs_cpu'] = abs(ev.ece_binary(pg, tg, mask=mk) - co.ece_binary(np.stack([1 - pc, pc], -1), tg, mask=mk))
+
+    result = {
+        'metric': 'MC-sample-volumes/sec (4x160x192x128, T=20)',
+        'value': T * args.steps / elapsed,
+        'unit': 'MC-sample-volumes/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True,
+        'scaling': 'strong',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'BraTS baseline_mc: 2D U-Net(2,4,depth 4,start_filters 32,dropout 0.05) over 160 slices '
+                               'of 4x192x128, T={} MC-dropout passes{} + mean/entropy aggregation per step'
+                               .format(T, '' if args.no_ws else ' + weight-scaling pass'),
+                   'T': T, 'ws_pass': not args.no_ws, 'slices': SLICES, 'height': HEIGHT, 'width': WIDTH,
+                   'sharding': 'passes over ranks, one RCCL sum-reduce of the statistics per step' if world > 1 else 'none',
+                   'gflop_per_sample_volume': conv_flops / max(forwards, 1) / 1e9},
+        'roofline': roofline,
+        'cpu_baseline': cpu,
+        'parity': parity,
+    }
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -116,6 +116,13 @@ int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info* out);
 /* Runs only conv layer `layer` on the handle's current workspace contents (benchmark aid). */
 int rcu_unet_run_layer(rcu_unet* h, int layer, int n, const float* masks_dev, void* stream);
 
+/* Per-kernel timing of the next `max_forwards` forward calls with HIP events recorded on the caller's
+ * stream between launches (slot 0 = input re-layout, slots 1..L = conv layers in rcu_unet_layer_info
+ * order, slot L+1 = head kernel).  collect() waits for the recorded work, writes the summed
+ * milliseconds per slot (L+2 doubles) and the number of forwards covered, and re-arms the pool. */
+int rcu_unet_profile_begin(rcu_unet* h, int max_forwards);
+int rcu_unet_profile_collect(rcu_unet* h, double* ms_sum, int* forwards);
+
 /* ------------------------------------------------------------------------------------------
  * Step seam: per-voxel sufficient statistics over T passes / K members
  *   (McPredictStep + MultiPredictionSummary, customsteps.py:16-71; torchhelper.py:53-54)

@@ -60,6 +60,8 @@ SIGNATURES = {
     'rcu_unet_num_layers': (c_int, [c_void_p]),
     'rcu_unet_layer_info': (c_int, [c_void_p, c_int, POINTER(LayerInfo)]),
     'rcu_unet_run_layer': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'rcu_unet_profile_begin': (c_int, [c_void_p, c_int]),
+    'rcu_unet_profile_collect': (c_int, [c_void_p, POINTER(c_double), POINTER(c_int)]),
     'rcu_mc_stats_bytes': (c_size_t, [c_size_t, c_size_t, c_int, c_int]),
     'rcu_mc_begin': (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_int, c_void_p]),
     'rcu_mc_accumulate': (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_int, c_void_p]),
@@ -88,6 +90,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; import it first so that librcu_hip binds to the SAME HIP runtime
+    # (two runtimes in one process do not share a device context: pointers and streams would not be portable).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('{} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                            '(there is no CPU fallback)'.format(LIB_PATH))

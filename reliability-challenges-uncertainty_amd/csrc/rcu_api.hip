@@ -71,7 +71,12 @@ struct rcu_unet {
     bool finalized = false;
     int64_t workspace_bytes = 0;
     std::vector<void*> allocs;
+    // optional per-layer timing with HIP events on the caller's stream (rcu_unet_profile_*)
+    std::vector<hipEvent_t> prof_events;   // [max_forwards][slots], slots = layers + 3
+    int prof_capacity = 0, prof_used = 0;
 };
+
+static int prof_slots(const rcu_unet* h) { return (int)h->layers.size() + 3; }
 
 static int new_tensor(rcu_unet* h, int H, int W, int cp)
 {
@@ -248,6 +253,7 @@ extern "C" int rcu_unet_destroy(rcu_unet* h)
 {
     if (!h) return RCU_OK;
     for (void* p : h->allocs) (void)hipFree(p);
+    for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     delete h;
     return RCU_OK;
 }
@@ -417,11 +423,17 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
     if (!h->finalized) return fail(RCU_ERR_STATE, "rcu_unet_forward before rcu_unet_finalize_weights");
     if (n < 1 || n > h->d.max_batch) return fail(RCU_ERR_INVALID, "batch size outside 1..max_batch");
     if (sigma && !h->d.sigma_out) return fail(RCU_ERR_INVALID, "sigma output requested from a model without sigma_out");
+    hipEvent_t* ev = nullptr;
+    if (h->prof_capacity > 0 && h->prof_used < h->prof_capacity)
+        ev = h->prof_events.data() + (size_t)(h->prof_used++) * prof_slots(h);
+    if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
     RCU_HIP(launch_pack_input(x, h->tensors[h->t_input].dev, n, h->d.in_channels, h->in_cp, h->d.height, h->d.width,
                               stream));
+    if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
     for (const ConvLayer& L : h->layers) {
         int rc = run_layer(h, L, n, masks, stream);
         if (rc) return rc;
+        if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
     }
     HeadArgs a{};
     a.act = h->tensors[h->t_head].dev;
@@ -431,6 +443,45 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
     a.HW = (size_t)h->d.height * h->d.width;
     a.V = a.HW * n;
     RCU_HIP(launch_head(a, stream));
+    if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
+    return RCU_OK;
+}
+
+extern "C" int rcu_unet_profile_begin(rcu_unet* h, int max_forwards)
+{
+    if (!h || max_forwards < 0) return fail(RCU_ERR_INVALID, "rcu_unet_profile_begin: bad argument");
+    for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    h->prof_events.clear();
+    h->prof_capacity = h->prof_used = 0;
+    const size_t total = (size_t)max_forwards * prof_slots(h);
+    h->prof_events.resize(total);
+    for (size_t i = 0; i < total; ++i) {
+        hipError_t e = hipEventCreate(&h->prof_events[i]);
+        if (e != hipSuccess) {
+            h->prof_events.resize(i);
+            return hip_fail(e, "hipEventCreate");
+        }
+    }
+    h->prof_capacity = max_forwards;
+    return RCU_OK;
+}
+
+extern "C" int rcu_unet_profile_collect(rcu_unet* h, double* ms_sum, int* forwards)
+{
+    if (!h || !ms_sum || !forwards) return fail(RCU_ERR_INVALID, "rcu_unet_profile_collect: null argument");
+    const int slots = prof_slots(h);
+    for (int i = 0; i < slots - 1; ++i) ms_sum[i] = 0.0;
+    for (int f = 0; f < h->prof_used; ++f) {
+        hipEvent_t* ev = h->prof_events.data() + (size_t)f * slots;
+        RCU_HIP(hipEventSynchronize(ev[slots - 1]));
+        for (int i = 0; i < slots - 1; ++i) {
+            float ms = 0.f;
+            RCU_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            ms_sum[i] += ms;
+        }
+    }
+    *forwards = h->prof_used;
+    h->prof_used = 0;
     return RCU_OK;
 }
 

@@ -261,6 +261,20 @@ class UNet(nn.Module):
         _lib.check(_lib.load().rcu_unet_run_layer(self._handle(h, w, n), layer, n, _lib.ptr(masks),
                                                   _lib.current_stream()))
 
+    def profile_begin(self, h, w, n, max_forwards):
+        """Time every kernel of the next ``max_forwards`` forwards with HIP events on the current stream."""
+        _lib.check(_lib.load().rcu_unet_profile_begin(self._handle(h, w, n), max_forwards))
+
+    def profile_collect(self, h, w, n):
+        """-> (forwards covered, [summed ms per slot]): slot 0 input re-layout, 1..L conv layers, L+1 head."""
+        lib = _lib.load()
+        handle = self._handle(h, w, n)
+        slots = lib.rcu_unet_num_layers(handle) + 2
+        ms = (ctypes.c_double * slots)()
+        cnt = ctypes.c_int()
+        _lib.check(lib.rcu_unet_profile_collect(handle, ms, ctypes.byref(cnt)))
+        return cnt.value, list(ms)
+
     def workspace_bytes(self, h, w, n):
         return int(_lib.load().rcu_unet_workspace_bytes(self._handle(h, w, n)))
 

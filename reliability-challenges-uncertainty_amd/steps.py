@@ -86,16 +86,25 @@ class McStatistics:
     Plain additive: blobs of disjoint pass subsets merge by ``+`` (one RCCL sum-reduce, see
     rcu_amd.distributed)."""
 
-    def __init__(self, n, nb_classes, height, width, device, do_mi=False, do_var=False):
+    def __init__(self, n, nb_classes, height, width, device, do_mi=False, do_var=False, blob=None):
         self.n, self.nb_classes, self.height, self.width = n, nb_classes, height, width
         self.hw = height * width
         self.flags = (_lib.RCU_MC_MI if do_mi else 0) | (_lib.RCU_MC_VAR if do_var else 0)
-        lib = _lib.load()
-        nbytes = lib.rcu_mc_stats_bytes(n, self.hw, nb_classes, self.flags)
+        elems = self.blob_elements(n, nb_classes, self.hw, do_mi, do_var)
         dtype = torch.float64 if do_var else torch.float32
-        self.blob = torch.empty(nbytes // (8 if do_var else 4), device=device, dtype=dtype)
+        if blob is None:
+            blob = torch.empty(elems, device=device, dtype=dtype)
+        elif blob.numel() != elems or blob.dtype != dtype or not blob.is_contiguous():
+            raise ValueError('statistics blob must be a contiguous {} tensor of {} elements'.format(dtype, elems))
+        self.blob = blob
         self.count = 0
-        _lib.check(lib.rcu_mc_begin(_lib.ptr(self.blob), n, self.hw, nb_classes, self.flags, _lib.current_stream()))
+        _lib.check(_lib.load().rcu_mc_begin(_lib.ptr(self.blob), n, self.hw, nb_classes, self.flags,
+                                            _lib.current_stream()))
+
+    @staticmethod
+    def blob_elements(n, nb_classes, hw, do_mi=False, do_var=False):
+        flags = (_lib.RCU_MC_MI if do_mi else 0) | (_lib.RCU_MC_VAR if do_var else 0)
+        return _lib.load().rcu_mc_stats_bytes(n, hw, nb_classes, flags) // (8 if do_var else 4)
 
     @property
     def do_mi(self):

@@ -1,0 +1,103 @@
+"""CPU-side checks of the boundary: the shared library loads and exports every symbol include/rcu.h
+declares, argument validation works without a GPU, and the host-side mirrors keep the reference's names."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import rcu_amd.build as b
+    b.build()
+    from rcu_amd import _lib
+    return _lib
+
+
+def test_every_declared_symbol_is_exported(lib):
+    header = open(os.path.join(ROOT, 'include', 'rcu.h')).read()
+    declared = set(re.findall(r'\b(rcu_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations found'
+    so = lib.load()
+    for name in declared:
+        assert hasattr(so, name), name
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+    assert b'gfx950' in so.rcu_version()
+
+
+def test_thresholds_match_reference_bit_patterns(lib):
+    thr = np.array(list(lib.ece_thresholds(10)), dtype=np.float32)
+    assert [hex(v) for v in thr.view(np.uint32)] == ['0x3dcccccd', '0x3e4ccccd', '0x3e99999a', '0x3ecccccd',
+                                                     '0x3f000001', '0x3f19999a', '0x3f333334', '0x3f4ccccd',
+                                                     '0x3f666667']
+    from oracle import calib_oracle as co
+    for nb in (2, 5, 10, 15, 32):
+        assert np.array_equal(np.array(list(lib.ece_thresholds(nb)), dtype=np.float32)[:nb - 1],
+                              co.float32_thresholds(nb))
+
+
+def test_argument_validation_without_gpu(lib):
+    so = lib.load()
+    desc = lib.UnetDesc(nb_classes=2, in_channels=4, depth=4, start_filters=32, has_dropout=1, dropout_center=-1,
+                        sigma_out=0, bn=1, height=40, width=32, max_batch=1)
+    handle = ctypes.c_void_p()
+    assert so.rcu_unet_create(ctypes.byref(desc), ctypes.byref(handle)) == -1      # 40 % 16 != 0
+    assert b'2^depth' in so.rcu_last_error()
+    desc.height, desc.nb_classes = 32, 9
+    assert so.rcu_unet_create(ctypes.byref(desc), ctypes.byref(handle)) == -1
+    with pytest.raises(lib.RcuError):
+        lib.check(so.rcu_mc_finalize(None, 1, 1, 2, 1, 0, None, None, None, None, None))
+    assert so.rcu_mc_stats_bytes(160, 192 * 128, 2, 0) == 160 * 192 * 128 * 2 * 4
+    assert so.rcu_mc_stats_bytes(160, 192 * 128, 2, 3) == 160 * 192 * 128 * 5 * 8
+    assert so.rcu_ece_workspace_bytes(160 * 192 * 128, 1) > 0
+
+
+def test_model_mirror_keeps_reference_surface():
+    from rcu_amd import steps
+    from rcu_amd.model import UNet, get_model
+    m = get_model('unet', nb_classes=2, in_channels=3, depth=4, start_filters=32, dropout=0.05, sigma_out=True)
+    assert isinstance(m, UNet) and len(m.state_dict()) == 152
+    assert len(m.dropout_sites()) == 20 and not m.mc_active()
+    steps.set_dropout_mode(m, True)
+    assert m.mc_active() and all(not mod.training for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d))
+    steps.set_dropout_mode(m, False)
+    m.load_state_dict({'module.' + k: v for k, v in m.state_dict().items()})       # DataParallel prefix
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 32))                                                # CPU tensor: no fallback
+    with pytest.raises(NotImplementedError):
+        UNet(2, 4, residual=True)
+    center = UNet(2, 4, depth=4, start_filters=32, dropout=0.5, dropout_center=4)
+    assert len(center.dropout_sites()) == 9
+    nodrop = UNet(2, 4, dropout=None)
+    assert nodrop.dropout_sites() == []
+    with pytest.raises(ValueError):
+        steps.McPredictStep(2)(steps.BatchContext({'images': torch.zeros(1, 4, 32, 32)}, 0), None, object())
+
+
+def test_host_side_metric_arithmetic_matches_oracle(golden):
+    """ECE-from-histogram and correction metrics are host arithmetic: check them against the oracle on the
+    golden histograms without touching the GPU."""
+    from oracle import calib_oracle as co
+    from rcu_amd import evaluation as ev
+    g = golden('g8_ece')
+    cnt, sc, sp = co.calibration_histogram(*co.select_foreground(np.stack([1 - g['a_p'], g['a_p']], -1),
+                                                                 g['a_target'], g['a_mask']))
+    for w in ('proportion', 'log_proportion', 'power_proportion', 'mean_proportion'):
+        bins = {}
+        e = ev.ece_from_histogram(cnt, sc, sp.astype(np.int64), 3, bins, w)
+        assert e == co.ece_from_histogram(cnt, sc, sp, w, 3)
+    assert e is not None and np.array_equal(bins['bins_count'], g['a_bins_count_masked'])
+    g9 = golden('g9_uncertainty')
+    for row in g9['counts']:
+        a, b = ev.correction_results(row), co.correction_metrics(row)
+        assert set(a) == set(b)
+        for k in a:
+            assert a[k] == b[k] or (np.isnan(a[k]) and np.isnan(b[k])), k
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            ev.ece_binary(np.zeros((2, 2), np.float32), np.zeros((2, 2), np.uint8))  # needs the GPU: fails loudly

@@ -1,0 +1,109 @@
+"""The N>1 path on CPU: world_size-2 gloo processes run ShardedMcRunner with an oracle-backed engine
+(tests may use the oracle; the product engine is HIP-only) and must reproduce the single-process
+result -- shard sizes uneven, weight-scaling pass on either rank, rotation over steps."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PARAMS = dict(nb_classes=2, in_channels=4, depth=4, start_filters=4, dropout=0.3)
+T = 5
+
+
+class OracleEngine:
+    """Same interface as rcu_amd.distributed.HipEngine, arithmetic by the oracle (float32 sums)."""
+
+    def __init__(self, state):
+        from oracle import unet_oracle as uo
+        self.state, self.uo = state, uo
+
+    def buffers(self, x, with_ws):
+        n, _, h, w = x.shape
+        c = PARAMS['nb_classes']
+        flat = torch.zeros(n * c * h * w * (2 if with_ws else 1))
+        stats = flat[:n * c * h * w].view(n, c, h, w)
+        ws = flat[n * c * h * w:].view(n, c, h, w) if with_ws else None
+        return flat, stats, ws, False
+
+    def ws_pass(self, x, ws_out):
+        ws_out.copy_(torch.softmax(self.uo.unet_forward(self.state, x, None, **PARAMS), 1))
+
+    def mc_pass(self, x, stats, masks=None):
+        stats += torch.softmax(self.uo.unet_forward(self.state, x, masks, **PARAMS), 1)
+
+    def finalize(self, stats, count):
+        from oracle import summary_oracle as so
+        p = stats / count
+        return {'probabilities': p, 'entropy': so.torch_entropy(p, dim=1, keepdim=True)}
+
+
+def _inputs():
+    from oracle import unet_oracle as uo
+    state = uo.synthetic_state(7, **PARAMS)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 4, 32, 32, generator=g)
+    _, sites = uo.unet_plan(**PARAMS)
+    mask_sets = [uo.sample_masks(sites, 2, 0.3, g) for _ in range(T)]
+    return state, x, mask_sets
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from rcu_amd.distributed import ShardedMcRunner
+    torch.set_num_threads(2)
+    state, x, mask_sets = _inputs()
+    runner = ShardedMcRunner(None, T, ws_pass=True, rank=rank, world=world, engine=OracleEngine(state))
+    for step in range(3):
+        out = runner.step(x, step, mask_sets)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, 'step{}.npz'.format(step)), **{k: v.numpy() for k, v in out.items()})
+        else:
+            assert out is None
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def test_job_partition_properties():
+    sys.path.insert(0, ROOT)
+    from rcu_amd.distributed import ShardedMcRunner
+    for world in (1, 2, 3, 4, 8):
+        for ws in (True, False):
+            r = ShardedMcRunner(None, 20, ws_pass=ws, rank=0, world=world, engine=object())
+            for step in range(5):
+                shards = [r.jobs_of(step, k) for k in range(world)]
+                flat = sorted(j for s in shards for j in s)
+                assert flat == ([0] if ws else []) + list(range(1, 21))        # every job exactly once
+                assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+            if world == 8 and ws:   # 21 jobs over 8 ranks: the rotation evens the remainder out over 8 steps
+                total = [sum(len(r.jobs_of(step, k)) for step in range(8)) for k in range(world)]
+                assert total == [21] * 8
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    state, x, mask_sets = _inputs()
+    ws, multi = so.mc_probabilities(lambda xx, m: uo.unet_forward(state, xx, m, **PARAMS), x, mask_sets)
+    ref = so.multi_prediction_summary(multi)
+    for step in range(3):
+        got = np.load(os.path.join(str(tmp_path), 'step{}.npz'.format(step)))
+        assert np.max(np.abs(got['ws_probabilities'] - ws.numpy())) < 1e-6
+        assert np.max(np.abs(got['probabilities'] - ref['probabilities'].numpy())) < 1e-6
+        assert np.max(np.abs(got['entropy'] - ref['entropy'].numpy())) < 2e-6
