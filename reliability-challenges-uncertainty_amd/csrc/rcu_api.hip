@@ -96,6 +96,13 @@ static bool unit_has_dropout(const rcu_unet_desc& d, int level, bool is_down, in
     return false;
 }
 
+// floats of one packed [9][BN][KC+4] weight tile, rounded up to 256 threads x float4
+static size_t conv_tile_floats(const ConvConfigInfo& ci)
+{
+    const size_t units = (size_t)9 * ci.BN * (ci.KC + 4) / 4;
+    return (units + 255) / 256 * 256 * 4;
+}
+
 static int pick_config(const ConvLayer& L)
 {
     if (L.c1p + L.c2p == 8) return CONV_CFG_T8x16_N32_K8;
@@ -333,7 +340,7 @@ static int fold_conv(rcu_unet* h, const ConvLayer& L, const std::string& conv, c
         betab[co0 + co] = A * (*b)[co];
         beta[co0 + co] = B;
     }
-    const size_t tile_floats = (size_t)9 * BN * KCP;
+    const size_t tile_floats = conv_tile_floats(ci);   // padded to a whole number of float4 per thread
     for (int co = 0; co < L.cout; ++co) {
         const int cop = co0 + co;
         const int ntile = cop / BN, nn = cop % BN;
@@ -357,7 +364,8 @@ extern "C" int rcu_unet_finalize_weights(rcu_unet* h)
         const ConvConfigInfo& ci = conv_config_info(L.cfg);
         const int KCP = ci.KC + 4;
         const int nchunks = (L.c1p + L.c2p) / ci.KC;
-        L.wpack_floats = (size_t)nchunks * L.NT * 9 * ci.BN * KCP;
+        L.wpack_floats = (size_t)nchunks * L.NT * conv_tile_floats(ci);
+        (void)KCP;
         std::vector<float> wpack(L.wpack_floats, 0.f);
         const int cpad = L.NT * ci.BN;
         std::vector<float> alpha(cpad, 0.f), betab(cpad, 0.f), beta(cpad, 0.f);

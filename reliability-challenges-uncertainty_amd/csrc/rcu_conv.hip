@@ -24,6 +24,7 @@
 namespace rcu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: struct float4 copies become memcpy and pin arrays to scratch
 
 template <int TS_, int TH_, int TW_, int BN_, int KC_, int WM_, int WN_>
 struct ConvTile {
@@ -42,7 +43,12 @@ struct ConvTile {
     static constexpr int NA = (A_UNITS + THREADS - 1) / THREADS;
     static constexpr int W_UNITS = W_FLOATS / 4;
     static constexpr int NW = (W_UNITS + THREADS - 1) / THREADS;
-    static constexpr int LDS_BYTES = (A_FLOATS + W_FLOATS) * 4;
+    // Both regions are rounded up to a whole number of float4 per thread so that staging is branch-free
+    // (the packed weight tiles in global memory carry the same padding).
+    static constexpr int A_UNITS_PAD = NA * THREADS;
+    static constexpr int W_UNITS_PAD = NW * THREADS;
+    static constexpr int A_REGION = A_UNITS_PAD * 4;         // floats
+    static constexpr int LDS_BYTES = (A_UNITS_PAD + W_UNITS_PAD) * 16;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(NBLK % WM == 0 && (BN / 32) % WN == 0, "wave tiling");
     static_assert(TH % 4 == 0 && TW % 8 == 0 && KC % 8 == 0, "block geometry");
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;
-    float* const Ws = smem + T::A_FLOATS;
+    float* const Ws = smem + T::A_REGION;
     constexpr int KC = T::KC, KCP = T::KCP, MT = T::MT, NTW = T::NTW;
 
     const int tid = threadIdx.x;
@@ -73,12 +79,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
     const int sg = mtile / a.tiles_y;
     const int n0 = sg * T::TS, y0 = ty * T::TH, x0 = tx * T::TW;
 
-    // ---- per-thread staging plan for the input tile (fixed over the K loop)
+    // ---- per-thread staging plan for the input tile (fixed over the K loop).  Units outside the
+    // image (zero padding) or outside the tile read element 0 and are multiplied by 0.
     const int Hs = a.upsample ? (a.H >> 1) : a.H;
     const int Ws_ = a.upsample ? (a.W >> 1) : a.W;
-    uint32_t pix1[T::NA], pix2[T::NA];
+    uint32_t off1[T::NA], off2[T::NA];
     int adst[T::NA];
-    bool aval[T::NA];
+    float akeep[T::NA];
 #pragma unroll
     for (int j = 0; j < T::NA; ++j) {
         const int u = tid + j * T::THREADS;
@@ -88,47 +95,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
         const int rem = q % T::HW_;
         const int yy = rem / (T::TW + 2), xx = rem % (T::TW + 2);
         const int n = n0 + s, gy = y0 + yy - 1, gx = x0 + xx - 1;
-        const bool in_tile = u < T::A_UNITS;
-        aval[j] = in_tile && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        adst[j] = in_tile ? q * KCP + sub * 4 : -1;
+        const bool ok = u < T::A_UNITS && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         const int sy = a.upsample ? (gy >> 1) : gy, sx = a.upsample ? (gx >> 1) : gx;
-        pix1[j] = aval[j] ? (uint32_t)((n * Hs + sy) * Ws_ + sx) : 0u;
-        pix2[j] = aval[j] ? (uint32_t)((n * a.H + gy) * a.W + gx) : 0u;
-        pix1[j] = pix1[j] * (uint32_t)a.C1 + sub * 4;
-        pix2[j] = pix2[j] * (uint32_t)a.C2 + sub * 4;
+        akeep[j] = ok ? 1.f : 0.f;
+        adst[j] = u < T::A_UNITS ? q * KCP + sub * 4 : u * 4;   // tail units land in the region's padding
+        off1[j] = ok ? (uint32_t)((n * Hs + sy) * Ws_ + sx) * (uint32_t)a.C1 + sub * 4 : 0u;
+        off2[j] = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) * (uint32_t)a.C2 + sub * 4 : 0u;
     }
 
     const int nchunks = (a.C1 + a.C2) / KC;
-    const float4* wbase = reinterpret_cast<const float4*>(a.wpack) + (size_t)ntile * T::W_UNITS;
-    const size_t wchunk_stride = (size_t)a.NT * T::W_UNITS;   // float4 units per Cin chunk
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack) + (size_t)ntile * T::W_UNITS_PAD + tid;
+    const size_t wchunk_stride = (size_t)a.NT * T::W_UNITS_PAD;   // float4 units per Cin chunk
 
-    float4 ra[T::NA], rw[T::NW];
-    auto prefetch = [&](int kc) {
-        const int c0 = kc * KC;
-        const bool first = c0 < a.C1;
-        const float* sp = first ? a.src1 + c0 : a.src2 + (c0 - a.C1);
-#pragma unroll
-        for (int j = 0; j < T::NA; ++j) {
-            const uint32_t off = first ? pix1[j] : pix2[j];
-            ra[j] = aval[j] ? *reinterpret_cast<const float4*>(sp + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const float4* wp = wbase + (size_t)kc * wchunk_stride;
-#pragma unroll
-        for (int j = 0; j < T::NW; ++j) {
-            const int u = tid + j * T::THREADS;
-            if (T::W_UNITS % T::THREADS == 0 || u < T::W_UNITS) rw[j] = wp[u];
-        }
-    };
-    auto stage = [&]() {
-#pragma unroll
-        for (int j = 0; j < T::NA; ++j)
-            if (T::A_UNITS % T::THREADS == 0 || adst[j] >= 0) *reinterpret_cast<float4*>(As + adst[j]) = ra[j];
-#pragma unroll
-        for (int j = 0; j < T::NW; ++j) {
-            const int u = tid + j * T::THREADS;
-            if (T::W_UNITS % T::THREADS == 0 || u < T::W_UNITS) reinterpret_cast<float4*>(Ws)[u] = rw[j];
-        }
-    };
+    f32x4 ra[T::NA], rw[T::NW];
+#define RCU_PREFETCH(kc_)                                                                         \
+    {                                                                                             \
+        const int c0_ = (kc_) * KC;                                                               \
+        const bool first_ = c0_ < a.C1;                                                           \
+        const float* sp_ = first_ ? a.src1 + c0_ : a.src2 + (c0_ - a.C1);                         \
+        _Pragma("unroll") for (int j = 0; j < T::NA; ++j)                                         \
+            ra[j] = *reinterpret_cast<const f32x4*>(sp_ + (first_ ? off1[j] : off2[j]));         \
+        const f32x4* wq_ = wp + (size_t)(kc_) * wchunk_stride;                                   \
+        _Pragma("unroll") for (int j = 0; j < T::NW; ++j) rw[j] = wq_[j * T::THREADS];            \
+    }
+#define RCU_STAGE()                                                                               \
+    {                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < T::NA; ++j) {                                       \
+            *reinterpret_cast<f32x4*>(As + adst[j]) = ra[j] * akeep[j];                           \
+        }                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < T::NW; ++j)                                         \
+            reinterpret_cast<f32x4*>(Ws)[tid + j * T::THREADS] = rw[j];                           \
+    }
 
     // ---- fragment addresses (float offsets into As / Ws)
     const int m = lane & 31, half = lane >> 5;
@@ -152,25 +149,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-    prefetch(0);
+    RCU_PREFETCH(0);
     for (int kc = 0; kc < nchunks; ++kc) {
         __syncthreads();   // previous chunk fully consumed
-        stage();
+        RCU_STAGE();
         __syncthreads();
-        if (kc + 1 < nchunks) prefetch(kc + 1);   // lands while this chunk is multiplied
+        if (kc + 1 < nchunks) RCU_PREFETCH(kc + 1);   // lands while this chunk is multiplied
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int tapA = ((tap / 3) * (T::TW + 2) + (tap % 3)) * KCP;
             const int tapB = tap * T::BN * KCP;
 #pragma unroll
             for (int k8 = 0; k8 < KC / 8; ++k8) {
-                float4 av[MT], bv[NTW];
+                f32x4 av[MT], bv[NTW];
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
-                    av[mi] = *reinterpret_cast<const float4*>(As + a_addr[mi] + tapA + k8 * 8);
+                    av[mi] = *reinterpret_cast<const f32x4*>(As + a_addr[mi] + tapA + k8 * 8);
 #pragma unroll
                 for (int ni = 0; ni < NTW; ++ni)
-                    bv[ni] = *reinterpret_cast<const float4*>(Ws + b_addr[ni] + tapB + k8 * 8);
+                    bv[ni] = *reinterpret_cast<const f32x4*>(Ws + b_addr[ni] + tapB + k8 * 8);
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -183,6 +180,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
             }
         }
     }
+
+#undef RCU_PREFETCH
+#undef RCU_STAGE
 
     // ---- epilogue: lane = output channel (lane & 31), 4x4 pixel patch per lane
     const int Hp = a.H >> 1, Wp = a.W >> 1;

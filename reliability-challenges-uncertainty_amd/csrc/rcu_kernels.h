@@ -14,7 +14,7 @@ namespace rcu {
 struct ConvArgs {
     const float* src1;   // [N][Hs][Ws][C1]   first  K-range (channels [0, C1))
     const float* src2;   // [N][H ][W ][C2]   second K-range (cat-free decoder), may be null (C2 = 0)
-    const float* wpack;  // [Cin/KC][NT][9][BN][KC+4]  (see pack_conv_weights in rcu_api.hip)
+    const float* wpack;  // [Cin/KC][NT] tiles of [9][BN][KC+4] floats, each padded to 1024-float multiples (rcu_api.hip)
     const float* alpha;  // [CoutP]  folded BN scale               (1 for bias-only convs)
     const float* betab;  // [CoutP]  alpha * conv bias
     const float* beta;   // [CoutP]  folded BN shift               (0 for bias-only convs)
