@@ -47,8 +47,9 @@ struct ConvTile {
     // (the packed weight tiles in global memory carry the same padding).
     static constexpr int A_UNITS_PAD = NA * THREADS;
     static constexpr int W_UNITS_PAD = NW * THREADS;
-    static constexpr int A_REGION = A_UNITS_PAD * 4;         // floats
-    static constexpr int LDS_BYTES = (A_UNITS_PAD + W_UNITS_PAD) * 16;
+    static constexpr int A_DUMP = (A_FLOATS + 3) / 4 * 4;    // 64 float4 slots where the tail units land
+    static constexpr int A_REGION = A_DUMP + 64 * 4;         // floats
+    static constexpr int LDS_BYTES = A_REGION * 4 + W_UNITS_PAD * 16;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(NBLK % WM == 0 && (BN / 32) % WN == 0, "wave tiling");
     static_assert(TH % 4 == 0 && TW % 8 == 0 && KC % 8 == 0, "block geometry");
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
         const bool ok = u < T::A_UNITS && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         const int sy = a.upsample ? (gy >> 1) : gy, sx = a.upsample ? (gx >> 1) : gx;
         akeep[j] = ok ? 1.f : 0.f;
-        adst[j] = u < T::A_UNITS ? q * KCP + sub * 4 : u * 4;   // tail units land in the region's padding
+        adst[j] = u < T::A_UNITS ? q * KCP + sub * 4 : T::A_DUMP + (tid & 63) * 4;   // tail units: dump slots
         off1[j] = ok ? (uint32_t)((n * Hs + sy) * Ws_ + sx) * (uint32_t)a.C1 + sub * 4 : 0u;
         off2[j] = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) * (uint32_t)a.C2 + sub * 4 : 0u;
     }
