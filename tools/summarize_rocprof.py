@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (gpurun_out/, scratch) into the small files kept under profiles/.
+
+  python tools/summarize_rocprof.py stats  <dir>/<prefix>_kernel_stats.csv  profiles/<name>_kernel_stats.csv
+  python tools/summarize_rocprof.py pmc    <fetch_dir> <write_dir> [<sq_dir>]  profiles/<name>_pmc.json
+
+`pmc` also refreshes profiles/pmc_traffic.json (bytes per launch per conv instantiation, read by bench.py):
+HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE / WRITE_SIZE are in KiB and on gfx950 FETCH_SIZE
+reports half of the bytes of wide coalesced reads (/opt/skills/guides/MI355X_MICROARCH.md, section HBM);
+the factor is exact for streaming reads (checked here on pack_input_kernel: 62.9 MB read -> 30.7 MKiB reported)
+and an upper bound for partially coalesced ones.
+"""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r'conv3x3_igemm<rcu::ConvTile<(\d+), (\d+), (\d+), (\d+), (\d+)', name)
+    if m:
+        ts, th, tw, bn, kc = m.groups()
+        tile = ('S{}'.format(ts) if ts != '1' else '') + 'T{}x{}'.format(th, tw)
+        return 'conv3x3_igemm<{},N{},K{}>'.format(tile, bn, kc)
+    m = re.search(r'rcu::(\w+)', name)
+    if m:
+        return m.group(1)
+    return name[:100]
+
+
+def stats(src, dst):
+    rows = list(csv.DictReader(open(src)))
+    with open(dst, 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+        for r in rows:
+            w.writerow([short(r['Name']), r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'],
+                        r['MaxNs']])
+
+
+def per_kernel(path, wanted):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] not in wanted:
+            continue
+        k = short(r['Kernel_Name'])
+        agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+        calls[k].add(r['Dispatch_Id'])
+        agg[k]['_ns'] += 0
+    return {k: dict(launches=len(calls[k]), **{c: v / len(calls[k]) for c, v in d.items() if not c.startswith('_')})
+            for k, d in agg.items()}
+
+
+def pmc(args):
+    out_path = args[-1]
+    dirs = args[:-1]
+    find = lambda d: [os.path.join(d, f) for f in os.listdir(d) if f.endswith('counter_collection.csv')][0]  # noqa: E731
+    fetch = per_kernel(find(dirs[0]), {'FETCH_SIZE'})
+    write = per_kernel(find(dirs[1]), {'WRITE_SIZE'})
+    result = {}
+    for k in fetch:
+        if not (k.startswith('conv3x3') or k.endswith('_kernel')):
+            continue
+        f, w = fetch[k]['FETCH_SIZE'], write.get(k, {}).get('WRITE_SIZE', 0.0)
+        result[k] = dict(launches=fetch[k]['launches'], fetch_size_kib_per_launch=f, write_size_kib_per_launch=w,
+                         hbm_bytes_per_launch=(2 * f + w) * 1024)
+    if len(dirs) > 2:
+        names = {'SQ_WAVES', 'SQ_BUSY_CYCLES', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE',
+                 'SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES', 'GRBM_GUI_ACTIVE'}
+        sq = per_kernel(find(dirs[2]), names)
+        for k, d in sq.items():
+            if k in result:
+                result[k]['sq'] = {c: d[c] for c in d if c != 'launches'}
+                if d.get('GRBM_GUI_ACTIVE'):
+                    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
+                    result[k]['mfma_util'] = d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024 / (d['GRBM_GUI_ACTIVE'] / 8)
+                if d.get('SQ_LDS_IDX_ACTIVE'):
+                    result[k]['lds_bank_conflict_frac'] = d.get('SQ_LDS_BANK_CONFLICT', 0) / d['SQ_LDS_IDX_ACTIVE']
+    with open(out_path, 'w') as f:
+        json.dump(result, f, indent=1, sort_keys=True)
+    traffic = {k: v['hbm_bytes_per_launch'] for k, v in result.items() if k.startswith('conv3x3')}
+    with open(os.path.join(os.path.dirname(out_path), 'pmc_traffic.json'), 'w') as f:
+        json.dump(traffic, f, indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'stats':
+        stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == 'pmc':
+        pmc(sys.argv[2:])
+    else:
+        raise SystemExit(__doc__)
