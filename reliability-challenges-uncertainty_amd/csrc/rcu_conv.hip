@@ -21,17 +21,32 @@
 // ds_read_b128 fragment reads are bank-conflict free.  Exact fp32 (MFMA f32 == fmaf chain).
 #include "rcu_kernels.h"
 
+#include <type_traits>
+
 namespace rcu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: struct float4 copies become memcpy and pin arrays to scratch
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 
 template <int TS_, int TH_, int TW_, int BN_, int KC_, int WM_, int WN_>
 struct ConvTile {
     static constexpr int TS = TS_, TH = TH_, TW = TW_, BN = BN_, KC = KC_, WM = WM_, WN = WN_;
     static constexpr int THREADS = 256;
     static constexpr int KCP = KC + 4;                      // padded row length (floats)
-    static constexpr int HW_ = (TH + 2) * (TW + 2);         // halo pixels per slice tile
+    // Halo row pitch in pixels.  A 32-pixel MFMA row block is a 4x8 patch; with a pitch = 8 (mod 16) the four
+    // 4-pixel runs a ds_read_b128 lane group touches fall on distinct LDS slots (conflict-free A fragment reads).
+    static constexpr int PITCH = (TW == 16) ? 24 : TW + 2;
+    static constexpr int HW_ = (TH + 2) * PITCH;            // halo pixels per slice tile (incl. pitch padding)
     static constexpr int HPIX = TS * HW_;
     static constexpr int A_FLOATS = HPIX * KCP;
     static constexpr int W_FLOATS = 9 * BN * KCP;
@@ -39,7 +54,8 @@ struct ConvTile {
     static constexpr int NBLK = TS * BPS;
     static constexpr int MT = NBLK / WM;                    // pixel blocks per wave
     static constexpr int NTW = BN / 32 / WN;                // channel blocks per wave
-    static constexpr int A_UNITS = HPIX * (KC / 4);         // float4 units of the input tile
+    static constexpr int HREAL = TS * (TH + 2) * (TW + 2);  // halo pixels that are really loaded
+    static constexpr int A_UNITS = HREAL * (KC / 4);        // float4 units of the input tile
     static constexpr int NA = (A_UNITS + THREADS - 1) / THREADS;
     static constexpr int W_UNITS = W_FLOATS / 4;
     static constexpr int NW = (W_UNITS + THREADS - 1) / THREADS;
@@ -92,14 +108,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
         const int u = tid + j * T::THREADS;
         const int q = u / (KC / 4);
         const int sub = u % (KC / 4);
-        const int s = q / T::HW_;
-        const int rem = q % T::HW_;
+        const int s = q / ((T::TH + 2) * (T::TW + 2));
+        const int rem = q % ((T::TH + 2) * (T::TW + 2));
         const int yy = rem / (T::TW + 2), xx = rem % (T::TW + 2);
+        const int qdst = (s * (T::TH + 2) + yy) * T::PITCH + xx;
         const int n = n0 + s, gy = y0 + yy - 1, gx = x0 + xx - 1;
         const bool ok = u < T::A_UNITS && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         const int sy = a.upsample ? (gy >> 1) : gy, sx = a.upsample ? (gx >> 1) : gx;
         akeep[j] = ok ? 1.f : 0.f;
-        adst[j] = u < T::A_UNITS ? q * KCP + sub * 4 : T::A_DUMP + (tid & 63) * 4;   // tail units: dump slots
+        adst[j] = u < T::A_UNITS ? qdst * KCP + sub * 4 : T::A_DUMP + (tid & 63) * 4;   // tail units: dump slots
         off1[j] = ok ? (uint32_t)((n * Hs + sy) * Ws_ + sx) * (uint32_t)a.C1 + sub * 4 : 0u;
         off2[j] = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) * (uint32_t)a.C2 + sub * 4 : 0u;
     }
@@ -136,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
         const int blk = wm * MT + mi;
         const int s = blk / T::BPS, rb = blk % T::BPS;
         const int by = rb / (T::TW / 8), bx = rb % (T::TW / 8);
-        const int pixel = (s * (T::TH + 2) + 4 * by + (m >> 3)) * (T::TW + 2) + 8 * bx + (m & 7);
+        const int pixel = (s * (T::TH + 2) + 4 * by + (m >> 3)) * T::PITCH + 8 * bx + (m & 7);
         a_addr[mi] = pixel * KCP + half * 4;
     }
 #pragma unroll
@@ -156,30 +173,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
         RCU_STAGE();
         __syncthreads();
         if (kc + 1 < nchunks) RCU_PREFETCH(kc + 1);   // lands while this chunk is multiplied
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int tapA = ((tap / 3) * (T::TW + 2) + (tap % 3)) * KCP;
-            const int tapB = tap * T::BN * KCP;
-#pragma unroll
-            for (int k8 = 0; k8 < KC / 8; ++k8) {
-                f32x4 av[MT], bv[NTW];
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-                    av[mi] = *reinterpret_cast<const f32x4*>(As + a_addr[mi] + tapA + k8 * 8);
-#pragma unroll
-                for (int ni = 0; ni < NTW; ++ni)
-                    bv[ni] = *reinterpret_cast<const f32x4*>(Ws + b_addr[ni] + tapB + k8 * 8);
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NTW; ++ni) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].x, bv[ni].x, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].y, bv[ni].y, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].z, bv[ni].z, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi].w, bv[ni].w, acc[mi][ni], 0, 0, 0);
-                    }
-            }
+        // 9 taps x KC/8 steps, software pipelined: the fragments of step s+1 are read from LDS before the
+        // MFMAs of step s are issued, so one wave alone keeps its SIMD's matrix pipe busy.
+        constexpr int STEPS = 9 * (KC / 8);
+        f32x4 av[2][MT], bv[2][NTW];
+#define RCU_FRAGS(step_, buf_)                                                                              \
+        {                                                                                                       \
+            constexpr int tap_ = (step_) / (KC / 8), k8_ = (step_) % (KC / 8);                                  \
+            constexpr int tapA_ = ((tap_ / 3) * T::PITCH + (tap_ % 3)) * KCP + k8_ * 8;                         \
+            constexpr int tapB_ = tap_ * T::BN * KCP + k8_ * 8;                                                 \
+            _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                                                   \
+                av[buf_][mi] = *reinterpret_cast<const f32x4*>(As + a_addr[mi] + tapA_);                        \
+            _Pragma("unroll") for (int ni = 0; ni < NTW; ++ni)                                                  \
+                bv[buf_][ni] = *reinterpret_cast<const f32x4*>(Ws + b_addr[ni] + tapB_);                        \
         }
+        RCU_FRAGS(0, 0);
+        static_for<0, STEPS>([&](auto step_c) {
+            constexpr int step = decltype(step_c)::value;
+            constexpr int cur = step & 1;
+            if constexpr (step + 1 < STEPS) RCU_FRAGS(step + 1, cur ^ 1);
+            // pin the order: hipcc's scheduler otherwise sinks every ds_read down to its first use (lgkmcnt(0)
+            // right before each MFMA group), which serialises LDS latency with the matrix pipe
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NTW; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mi].x, bv[cur][ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mi].y, bv[cur][ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mi].z, bv[cur][ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mi].w, bv[cur][ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        });
+#undef RCU_FRAGS
     }
 
 #undef RCU_PREFETCH
