@@ -96,15 +96,20 @@ static bool unit_has_dropout(const rcu_unet_desc& d, int level, bool is_down, in
     return false;
 }
 
-// floats of one packed [9][BN][KC+4] weight tile, rounded up to 256 threads x float4
+// floats of one packed [TAPS][BN][KC+4] weight tile, rounded up to 256 threads x float4
 static size_t conv_tile_floats(const ConvConfigInfo& ci)
 {
-    const size_t units = (size_t)9 * ci.BN * (ci.KC + 4) / 4;
+    const size_t units = (size_t)ci.TAPS * ci.BN * (ci.KC + 4) / 4;
     return (units + 255) / 256 * 256 * 4;
 }
 
 static int pick_config(const ConvLayer& L)
 {
+    if (L.upsample) {   // sub-pixel form; L.H x L.W is the OUTPUT grid, tiles run over the low-res input grid
+        if (L.coutp <= 32) return CONV_CFG_UP_T8x16_N32_K32;
+        if (L.H == 24 && L.W == 16) return CONV_CFG_UP_S2T12x8_N64_K32;
+        return CONV_CFG_UP_T8x16_N64_K32;
+    }
     if (L.c1p + L.c2p == 8) return CONV_CFG_T8x16_N32_K8;
     if (L.coutp > 32) {
         if (L.H == 12 && L.W == 8) return CONV_CFG_S2T12x8_N64_K16;
@@ -341,15 +346,33 @@ static int fold_conv(rcu_unet* h, const ConvLayer& L, const std::string& conv, c
         beta[co0 + co] = B;
     }
     const size_t tile_floats = conv_tile_floats(ci);   // padded to a whole number of float4 per thread
+    const int ncls = L.upsample ? 4 : 1;
+    // Sub-pixel up-conv: output parity a (rows) folds the 3 kernel rows onto 2 low-res rows,
+    //   a = 0: low-res row y-1 <- {dy 0},   row y   <- {dy 1, 2}
+    //   a = 1: low-res row y   <- {dy 0, 1}, row y+1 <- {dy 2}            (same for columns with b)
+    auto fold_set = [](int parity, int t, int d) { return parity == 0 ? (t == 0 ? d == 0 : d >= 1) : (t == 0 ? d <= 1 : d == 2); };
     for (int co = 0; co < L.cout; ++co) {
         const int cop = co0 + co;
         const int ntile = cop / BN, nn = cop % BN;
         for (int ci_ = 0; ci_ < cin; ++ci_) {
             const int kp = ci_ < L.cin1 ? ci_ : L.c1p + (ci_ - L.cin1);   // position in the padded K range
             const int chunk = kp / KC, kq = kp % KC;
-            for (int tap = 0; tap < 9; ++tap) {
-                const size_t dst = ((size_t)chunk * L.NT + ntile) * tile_floats + ((size_t)tap * BN + nn) * KCP + kq;
-                wpack[dst] = (*w)[((size_t)co * cin + ci_) * 9 + tap];
+            const float* w9 = w->data() + ((size_t)co * cin + ci_) * 9;
+            for (int cls = 0; cls < ncls; ++cls) {
+                const size_t tile0 = ((size_t)chunk * (ncls * L.NT) + (size_t)cls * L.NT + ntile) * tile_floats;
+                for (int tap = 0; tap < ci.TAPS; ++tap) {
+                    float v;
+                    if (!L.upsample) {
+                        v = w9[tap];
+                    } else {
+                        const int a = cls >> 1, b = cls & 1, ty = tap >> 1, tx = tap & 1;
+                        v = 0.f;
+                        for (int dy = 0; dy < 3; ++dy)
+                            for (int dx = 0; dx < 3; ++dx)
+                                if (fold_set(a, ty, dy) && fold_set(b, tx, dx)) v += w9[dy * 3 + dx];
+                    }
+                    wpack[tile0 + ((size_t)tap * BN + nn) * KCP + kq] = v;
+                }
             }
         }
     }
@@ -364,7 +387,7 @@ extern "C" int rcu_unet_finalize_weights(rcu_unet* h)
         const ConvConfigInfo& ci = conv_config_info(L.cfg);
         const int KCP = ci.KC + 4;
         const int nchunks = (L.c1p + L.c2p) / ci.KC;
-        L.wpack_floats = (size_t)nchunks * L.NT * conv_tile_floats(ci);
+        L.wpack_floats = (size_t)nchunks * L.NT * (L.upsample ? 4 : 1) * conv_tile_floats(ci);
         (void)KCP;
         std::vector<float> wpack(L.wpack_floats, 0.f);
         const int cpad = L.NT * ci.BN;
@@ -412,14 +435,16 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     a.mask2 = (masks && L.site2 >= 0) ? masks + (size_t)n * h->site_offset[L.site2] : nullptr;
     a.out = h->tensors[L.t_out].dev;
     a.pooled = L.t_pool >= 0 ? h->tensors[L.t_pool].dev : nullptr;
-    a.N = n; a.H = L.H; a.W = L.W;
+    const int gh = L.upsample ? L.H / 2 : L.H, gw = L.upsample ? L.W / 2 : L.W;   // tile grid = input grid
+    a.N = n; a.H = gh; a.W = gw;
     a.C1 = L.c1p; a.C2 = L.c2p; a.CoutP = L.coutp;
     a.Cmask = L.cout; a.Csplit = L.csplit; a.Cmask2 = L.cout;
-    a.upsample = L.upsample; a.relu = L.relu;
-    a.tiles_y = (L.H + ci.TH - 1) / ci.TH;
-    a.tiles_x = (L.W + ci.TW - 1) / ci.TW;
+    a.relu = L.relu;
+    a.tiles_y = (gh + ci.TH - 1) / ci.TH;
+    a.tiles_x = (gw + ci.TW - 1) / ci.TW;
     a.slice_groups = (n + ci.TS - 1) / ci.TS;
     a.NT = L.NT;
+    a.NTW_total = L.NT * (L.upsample ? 4 : 1);
     RCU_HIP(launch_conv3x3(L.cfg, a, stream));
     return RCU_OK;
 }

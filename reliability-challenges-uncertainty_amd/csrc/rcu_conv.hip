@@ -7,18 +7,23 @@
 // (common/model/unet.py:8-23) with BN folded to (alpha, beta) and the Dropout2d factor m_{n,c}
 // in {0, 1/(1-p)} supplied per (slice, channel).  Optional extras, all fused into the same pass:
 //   * second output = 2x2 max-pool of the result                  (DownConv, unet.py:85-95)
-//   * nearest x2 up-sampling folded into the input addressing     (UpConv,   unet.py:105; helpers.py:15)
 //   * K split over two source tensors instead of torch.cat        (UpConv,   unet.py:118)
+//   * nearest x2 up-sampling + conv3x3 (UpConv, unet.py:105; helpers.py:15) in its sub-pixel form: the
+//     output pixel (2y+a, 2x+b) only sees the 2x2 low-resolution neighbourhood (y+a-1.., x+b-1..), so
+//     the layer is four 2x2-tap convolutions on the LOW-resolution grid (one per parity class (a,b))
+//     with tap weights pre-summed on the host: 4 instead of 9 taps, 2.25x fewer FLOPs executed, and
+//     the zero padding of the up-sampled grid coincides with zero padding of the low-resolution grid.
 //
-// GEMM view: M = pixels (N*H*W), N = output channels, K = 9 taps x Cin.  v_mfma_f32_32x32x2_f32:
+// GEMM view: M = pixels (N*H*W), N = output channels, K = taps x Cin.  v_mfma_f32_32x32x2_f32:
 // A operand = 32 pixels (one 4-row x 8-column patch), B operand = 32 output channels.  With that
 // pixel->row map every lane ends up owning a 4x4 pixel patch of one output channel, so the 2x2
 // max-pool needs no cross-lane traffic and every store instruction writes 2 x 128 contiguous bytes.
 //
 // Per workgroup (256 threads = 4 waves, 2 workgroups per CU): an input tile with a 1-pixel halo and
 // the weight slice of one Cin chunk are staged through LDS (register-staged: the global loads of
-// chunk k+1 are in flight while chunk k is multiplied); rows are padded by 4 floats so the
-// ds_read_b128 fragment reads are bank-conflict free.  Exact fp32 (MFMA f32 == fmaf chain).
+// chunk k+1 are in flight while chunk k is multiplied); rows are padded by 4 floats and the halo
+// row pitch is 8 (mod 16) pixels so the ds_read_b128 fragment reads are bank-conflict free; the
+// fragment reads of step s+1 are issued before the MFMAs of step s.  Exact fp32 (MFMA f32 == fmaf chain).
 #include "rcu_kernels.h"
 
 #include <type_traits>
@@ -26,7 +31,8 @@
 namespace rcu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: struct float4 copies become memcpy and pin arrays to scratch
+// native vector type: copies of HIP's struct float4 become memcpy in the IR and pin staging arrays to scratch
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f)
@@ -37,10 +43,10 @@ __device__ __forceinline__ void static_for(F&& f)
     }
 }
 
-
-template <int TS_, int TH_, int TW_, int BN_, int KC_, int WM_, int WN_>
+template <int TS_, int TH_, int TW_, int BN_, int KC_, int WM_, int WN_, int TAPS_>
 struct ConvTile {
-    static constexpr int TS = TS_, TH = TH_, TW = TW_, BN = BN_, KC = KC_, WM = WM_, WN = WN_;
+    static constexpr int TS = TS_, TH = TH_, TW = TW_, BN = BN_, KC = KC_, WM = WM_, WN = WN_, TAPS = TAPS_;
+    static constexpr int TAPW = (TAPS == 9) ? 3 : 2;        // taps per window row
     static constexpr int THREADS = 256;
     static constexpr int KCP = KC + 4;                      // padded row length (floats)
     // Halo row pitch in pixels.  A 32-pixel MFMA row block is a 4x8 patch; with a pitch = 8 (mod 16) the four
@@ -49,7 +55,7 @@ struct ConvTile {
     static constexpr int HW_ = (TH + 2) * PITCH;            // halo pixels per slice tile (incl. pitch padding)
     static constexpr int HPIX = TS * HW_;
     static constexpr int A_FLOATS = HPIX * KCP;
-    static constexpr int W_FLOATS = 9 * BN * KCP;
+    static constexpr int W_FLOATS = TAPS * BN * KCP;
     static constexpr int BPS = (TH / 4) * (TW / 8);         // 32-pixel blocks per slice tile
     static constexpr int NBLK = TS * BPS;
     static constexpr int MT = NBLK / WM;                    // pixel blocks per wave
@@ -61,7 +67,6 @@ struct ConvTile {
     static constexpr int NW = (W_UNITS + THREADS - 1) / THREADS;
     // Both regions are rounded up to a whole number of float4 per thread so that staging is branch-free
     // (the packed weight tiles in global memory carry the same padding).
-    static constexpr int A_UNITS_PAD = NA * THREADS;
     static constexpr int W_UNITS_PAD = NW * THREADS;
     static constexpr int A_DUMP = (A_FLOATS + 3) / 4 * 4;    // 64 float4 slots where the tail units land
     static constexpr int A_REGION = A_DUMP + 64 * 4;         // floats
@@ -69,15 +74,18 @@ struct ConvTile {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(NBLK % WM == 0 && (BN / 32) % WN == 0, "wave tiling");
     static_assert(TH % 4 == 0 && TW % 8 == 0 && KC % 8 == 0, "block geometry");
+    static_assert(TAPS == 9 || TAPS == 4, "3x3 window or the 2x2 window of the sub-pixel up-conv");
+    static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 };
 
 template <class T>
-__global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
+__global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As = smem;
     float* const Ws = smem + T::A_REGION;
     constexpr int KC = T::KC, KCP = T::KCP, MT = T::MT, NTW = T::NTW;
+    constexpr bool SUBPIXEL = (T::TAPS == 4);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -85,11 +93,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
     const int wn = wave % T::WN;
     const int wm = wave / T::WN;
 
-    // ---- workgroup -> (channel tile, pixel tile).  Channel tile fastest: with the round-robin
-    // workgroup->XCD dispatch an XCD then keeps seeing the same few weight slices in its L2.
+    // ---- workgroup -> (channel tile [, parity class], pixel tile).  Channel tile fastest: with the
+    // round-robin workgroup->XCD dispatch an XCD then keeps seeing the same few weight slices in its L2.
     const int bid = blockIdx.x;
-    const int ntile = bid % a.NT;
-    int mtile = bid / a.NT;
+    const int wtile = bid % a.NTW_total;        // weight tile index = cls * NT + ntile
+    const int ntile = wtile % a.NT;
+    const int cls = wtile / a.NT;               // parity class (sub-pixel mode), else 0
+    const int pa = cls >> 1, pb = cls & 1;
+    int mtile = bid / a.NTW_total;
     const int tx = mtile % a.tiles_x;
     mtile /= a.tiles_x;
     const int ty = mtile % a.tiles_y;
@@ -98,8 +109,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
 
     // ---- per-thread staging plan for the input tile (fixed over the K loop).  Units outside the
     // image (zero padding) or outside the tile read element 0 and are multiplied by 0.
-    const int Hs = a.upsample ? (a.H >> 1) : a.H;
-    const int Ws_ = a.upsample ? (a.W >> 1) : a.W;
     uint32_t off1[T::NA], off2[T::NA];
     int adst[T::NA];
     float akeep[T::NA];
@@ -114,16 +123,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
         const int qdst = (s * (T::TH + 2) + yy) * T::PITCH + xx;
         const int n = n0 + s, gy = y0 + yy - 1, gx = x0 + xx - 1;
         const bool ok = u < T::A_UNITS && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const int sy = a.upsample ? (gy >> 1) : gy, sx = a.upsample ? (gx >> 1) : gx;
+        const uint32_t pix = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) : 0u;
         akeep[j] = ok ? 1.f : 0.f;
         adst[j] = u < T::A_UNITS ? qdst * KCP + sub * 4 : T::A_DUMP + (tid & 63) * 4;   // tail units: dump slots
-        off1[j] = ok ? (uint32_t)((n * Hs + sy) * Ws_ + sx) * (uint32_t)a.C1 + sub * 4 : 0u;
-        off2[j] = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) * (uint32_t)a.C2 + sub * 4 : 0u;
+        off1[j] = ok ? pix * (uint32_t)a.C1 + sub * 4 : 0u;
+        off2[j] = ok ? pix * (uint32_t)a.C2 + sub * 4 : 0u;
     }
 
     const int nchunks = (a.C1 + a.C2) / KC;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack) + (size_t)ntile * T::W_UNITS_PAD + tid;
-    const size_t wchunk_stride = (size_t)a.NT * T::W_UNITS_PAD;   // float4 units per Cin chunk
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack) + (size_t)wtile * T::W_UNITS_PAD + tid;
+    const size_t wchunk_stride = (size_t)a.NTW_total * T::W_UNITS_PAD;   // float4 units per Cin chunk
 
     f32x4 ra[T::NA], rw[T::NW];
 #define RCU_PREFETCH(kc_)                                                                         \
@@ -132,15 +141,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
         const bool first_ = c0_ < a.C1;                                                           \
         const float* sp_ = first_ ? a.src1 + c0_ : a.src2 + (c0_ - a.C1);                         \
         _Pragma("unroll") for (int j = 0; j < T::NA; ++j)                                         \
-            ra[j] = *reinterpret_cast<const f32x4*>(sp_ + (first_ ? off1[j] : off2[j]));         \
-        const f32x4* wq_ = wp + (size_t)(kc_) * wchunk_stride;                                   \
+            ra[j] = *reinterpret_cast<const f32x4*>(sp_ + (first_ ? off1[j] : off2[j]));          \
+        const f32x4* wq_ = wp + (size_t)(kc_) * wchunk_stride;                                    \
         _Pragma("unroll") for (int j = 0; j < T::NW; ++j) rw[j] = wq_[j * T::THREADS];            \
     }
 #define RCU_STAGE()                                                                               \
     {                                                                                             \
-        _Pragma("unroll") for (int j = 0; j < T::NA; ++j) {                                       \
+        _Pragma("unroll") for (int j = 0; j < T::NA; ++j)                                         \
             *reinterpret_cast<f32x4*>(As + adst[j]) = ra[j] * akeep[j];                           \
-        }                                                                                         \
         _Pragma("unroll") for (int j = 0; j < T::NW; ++j)                                         \
             reinterpret_cast<f32x4*>(Ws)[tid + j * T::THREADS] = rw[j];                           \
     }
@@ -153,7 +161,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
         const int blk = wm * MT + mi;
         const int s = blk / T::BPS, rb = blk % T::BPS;
         const int by = rb / (T::TW / 8), bx = rb % (T::TW / 8);
-        const int pixel = (s * (T::TH + 2) + 4 * by + (m >> 3)) * T::PITCH + 8 * bx + (m & 7);
+        // window origin of this lane's pixel inside the halo tile; the sub-pixel classes shift it by (a, b)
+        const int pixel = (s * (T::TH + 2) + 4 * by + (m >> 3) + pa) * T::PITCH + 8 * bx + (m & 7) + pb;
         a_addr[mi] = pixel * KCP + half * 4;
     }
 #pragma unroll
@@ -173,14 +182,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
         RCU_STAGE();
         __syncthreads();
         if (kc + 1 < nchunks) RCU_PREFETCH(kc + 1);   // lands while this chunk is multiplied
-        // 9 taps x KC/8 steps, software pipelined: the fragments of step s+1 are read from LDS before the
+        // TAPS x KC/8 steps, software pipelined: the fragments of step s+1 are read from LDS before the
         // MFMAs of step s are issued, so one wave alone keeps its SIMD's matrix pipe busy.
-        constexpr int STEPS = 9 * (KC / 8);
+        constexpr int STEPS = T::TAPS * (KC / 8);
         f32x4 av[2][MT], bv[2][NTW];
 #define RCU_FRAGS(step_, buf_)                                                                              \
         {                                                                                                       \
             constexpr int tap_ = (step_) / (KC / 8), k8_ = (step_) % (KC / 8);                                  \
-            constexpr int tapA_ = ((tap_ / 3) * T::PITCH + (tap_ % 3)) * KCP + k8_ * 8;                         \
+            constexpr int tapA_ = ((tap_ / T::TAPW) * T::PITCH + (tap_ % T::TAPW)) * KCP + k8_ * 8;             \
             constexpr int tapB_ = tap_ * T::BN * KCP + k8_ * 8;                                                 \
             _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                                                   \
                 av[buf_][mi] = *reinterpret_cast<const f32x4*>(As + a_addr[mi] + tapA_);                        \
@@ -207,11 +216,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
         });
 #undef RCU_FRAGS
     }
-
 #undef RCU_PREFETCH
 #undef RCU_STAGE
 
-    // ---- epilogue: lane = output channel (lane & 31), 4x4 pixel patch per lane
+    // ---- epilogue: lane = output channel (lane & 31), 4x4 pixel patch per lane.
+    // Output grid: (H, W), or (2H, 2W) with the lane's pixels at (2y+a, 2x+b) in sub-pixel mode.
+    constexpr int OS = SUBPIXEL ? 2 : 1;
+    const int OH = a.H * OS, OW = a.W * OS;
+    const bool full_tile = (y0 + T::TH <= a.H) && (x0 + T::TW <= a.W) && (n0 + T::TS <= a.N);
+    const size_t row_stride = (size_t)OW * a.CoutP * OS, col_stride = (size_t)a.CoutP * OS;
     const int Hp = a.H >> 1, Wp = a.W >> 1;
 #pragma unroll
     for (int ni = 0; ni < NTW; ++ni) {
@@ -237,12 +250,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
                 float t = acc[mi][ni][i] * scale + shift;
                 v[i] = a.relu ? fmaxf(t, 0.f) : t;
             }
+            float* const obase = a.out + ((size_t)(n * OH + yb * OS + pa) * OW + xb * OS + pb) * a.CoutP + co;
+            if (full_tile) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int y = yb + (i >> 2), x = xb + (i & 3);
-                if (y < a.H && x < a.W) a.out[((size_t)(n * a.H + y) * a.W + x) * a.CoutP + co] = v[i];
+                for (int i = 0; i < 16; ++i) obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (yb + (i >> 2) < a.H && xb + (i & 3) < a.W)
+                        obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];
             }
-            if (a.pooled != nullptr) {
+            if (!SUBPIXEL && a.pooled != nullptr) {
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
@@ -257,16 +275,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm(const ConvArgs a)
     }
 }
 
-using Cfg0 = ConvTile<1, 8, 16, 64, 16, 2, 2>;
-using Cfg1 = ConvTile<1, 8, 16, 32, 32, 4, 1>;
-using Cfg2 = ConvTile<1, 8, 16, 32, 8, 4, 1>;
-using Cfg3 = ConvTile<2, 12, 8, 64, 16, 2, 2>;
+using Cfg0 = ConvTile<1, 8, 16, 64, 16, 2, 2, 9>;
+using Cfg1 = ConvTile<1, 8, 16, 32, 32, 4, 1, 9>;
+using Cfg2 = ConvTile<1, 8, 16, 32, 8, 4, 1, 9>;
+using Cfg3 = ConvTile<2, 12, 8, 64, 16, 2, 2, 9>;
+using Cfg4 = ConvTile<1, 8, 16, 64, 32, 2, 2, 4>;
+using Cfg5 = ConvTile<1, 8, 16, 32, 32, 4, 1, 4>;
+using Cfg6 = ConvTile<2, 12, 8, 64, 32, 2, 2, 4>;
 
 static const ConvConfigInfo kInfo[CONV_CFG_COUNT] = {
-    {Cfg0::TS, Cfg0::TH, Cfg0::TW, Cfg0::BN, Cfg0::KC, "conv3x3_igemm<T8x16,N64,K16>"},
-    {Cfg1::TS, Cfg1::TH, Cfg1::TW, Cfg1::BN, Cfg1::KC, "conv3x3_igemm<T8x16,N32,K32>"},
-    {Cfg2::TS, Cfg2::TH, Cfg2::TW, Cfg2::BN, Cfg2::KC, "conv3x3_igemm<T8x16,N32,K8>"},
-    {Cfg3::TS, Cfg3::TH, Cfg3::TW, Cfg3::BN, Cfg3::KC, "conv3x3_igemm<S2T12x8,N64,K16>"},
+    {Cfg0::TS, Cfg0::TH, Cfg0::TW, Cfg0::BN, Cfg0::KC, Cfg0::TAPS, "conv3x3_igemm<T8x16,N64,K16>"},
+    {Cfg1::TS, Cfg1::TH, Cfg1::TW, Cfg1::BN, Cfg1::KC, Cfg1::TAPS, "conv3x3_igemm<T8x16,N32,K32>"},
+    {Cfg2::TS, Cfg2::TH, Cfg2::TW, Cfg2::BN, Cfg2::KC, Cfg2::TAPS, "conv3x3_igemm<T8x16,N32,K8>"},
+    {Cfg3::TS, Cfg3::TH, Cfg3::TW, Cfg3::BN, Cfg3::KC, Cfg3::TAPS, "conv3x3_igemm<S2T12x8,N64,K16>"},
+    {Cfg4::TS, Cfg4::TH, Cfg4::TW, Cfg4::BN, Cfg4::KC, Cfg4::TAPS, "upconv_subpixel_igemm<T8x16,N64,K32>"},
+    {Cfg5::TS, Cfg5::TH, Cfg5::TW, Cfg5::BN, Cfg5::KC, Cfg5::TAPS, "upconv_subpixel_igemm<T8x16,N32,K32>"},
+    {Cfg6::TS, Cfg6::TH, Cfg6::TW, Cfg6::BN, Cfg6::KC, Cfg6::TAPS, "upconv_subpixel_igemm<S2T12x8,N64,K32>"},
 };
 
 const ConvConfigInfo& conv_config_info(int cfg) { return kInfo[cfg]; }
@@ -276,13 +300,13 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t stream)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm<T>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const unsigned grid = (unsigned)a.NT * a.tiles_x * a.tiles_y * a.slice_groups;
-    hipLaunchKernelGGL(conv3x3_igemm<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a);
+    const unsigned grid = (unsigned)a.NTW_total * a.tiles_x * a.tiles_y * a.slice_groups;
+    hipLaunchKernelGGL(conv_igemm<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
@@ -293,6 +317,9 @@ hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream)
         case CONV_CFG_T8x16_N32_K32: return launch_cfg<Cfg1>(a, stream);
         case CONV_CFG_T8x16_N32_K8: return launch_cfg<Cfg2>(a, stream);
         case CONV_CFG_S2T12x8_N64_K16: return launch_cfg<Cfg3>(a, stream);
+        case CONV_CFG_UP_T8x16_N64_K32: return launch_cfg<Cfg4>(a, stream);
+        case CONV_CFG_UP_T8x16_N32_K32: return launch_cfg<Cfg5>(a, stream);
+        case CONV_CFG_UP_S2T12x8_N64_K32: return launch_cfg<Cfg6>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -12,36 +12,40 @@ namespace rcu {
 // Activations are NHWC fp32 with the channel count padded to a multiple of 32 (the network input to
 // a multiple of 8); padded channels hold zeros.  One launch covers every slice of the batch.
 struct ConvArgs {
-    const float* src1;   // [N][Hs][Ws][C1]   first  K-range (channels [0, C1))
-    const float* src2;   // [N][H ][W ][C2]   second K-range (cat-free decoder), may be null (C2 = 0)
-    const float* wpack;  // [Cin/KC][NT] tiles of [9][BN][KC+4] floats, each padded to 1024-float multiples (rcu_api.hip)
+    const float* src1;   // [N][H][W][C1]   first  K-range (channels [0, C1))
+    const float* src2;   // [N][H][W][C2]   second K-range (cat-free decoder), may be null (C2 = 0)
+    const float* wpack;  // [Cin/KC][NTW_total] tiles of [TAPS][BN][KC+4] floats, each padded to 1024-float multiples
     const float* alpha;  // [CoutP]  folded BN scale               (1 for bias-only convs)
     const float* betab;  // [CoutP]  alpha * conv bias
     const float* beta;   // [CoutP]  folded BN shift               (0 for bias-only convs)
     const float* mask;   // [N][Cmask] dropout factors {0, 1/(1-p)} of this site, or null (eval / no site)
     const float* mask2;  // second site for output channels >= Csplit (fused cls+sigma head unit), or null
-    float* out;          // [N][H][W][CoutP]
+    float* out;          // [N][H][W][CoutP]; sub-pixel up-conv kernels: [N][2H][2W][CoutP]
     float* pooled;       // [N][H/2][W/2][CoutP] or null
-    int N, H, W;         // output grid (= input grid; for upsample: src1 grid is H/2 x W/2)
+    int N, H, W;         // input grid = pixel-tile grid
     int C1, C2;          // padded channel counts of the two sources
     int CoutP;           // padded output channels (multiple of 32)
     int Cmask;           // real channel count of the dropout site (mask row length)
     int Csplit, Cmask2;  // mask2 row = [N][Cmask2], applies to channel co - Csplit
-    int upsample;        // 1: src1 is read at (y>>1, x>>1)  (nearest x2 fused into the load)
     int relu;            // 1: max(0, .) epilogue
-    int tiles_y, tiles_x, slice_groups, NT;
+    int tiles_y, tiles_x, slice_groups;
+    int NT;              // output-channel tiles
+    int NTW_total;       // weight tiles per Cin chunk = NT (3x3) or 4 * NT (sub-pixel: one set per parity class)
 };
 
 enum ConvConfig {
-    CONV_CFG_T8x16_N64_K16 = 0,   // 8x16-pixel tile, 64 couts, Cin chunks of 16   (workhorse)
-    CONV_CFG_T8x16_N32_K32 = 1,   // 8x16-pixel tile, 32 couts, Cin chunks of 32   (32-channel layers)
-    CONV_CFG_T8x16_N32_K8 = 2,    // first layer: Cin padded to 8
-    CONV_CFG_S2T12x8_N64_K16 = 3, // two whole 12x8 slices per workgroup           (BraTS bottom level)
+    CONV_CFG_T8x16_N64_K16 = 0,      // 8x16-pixel tile, 64 couts, Cin chunks of 16   (workhorse)
+    CONV_CFG_T8x16_N32_K32 = 1,      // 8x16-pixel tile, 32 couts, Cin chunks of 32   (32-channel layers)
+    CONV_CFG_T8x16_N32_K8 = 2,       // first layer: Cin padded to 8
+    CONV_CFG_S2T12x8_N64_K16 = 3,    // two whole 12x8 slices per workgroup           (BraTS bottom level)
+    CONV_CFG_UP_T8x16_N64_K32 = 4,   // sub-pixel up-conv (2x2 taps on the low-res grid), 64 couts
+    CONV_CFG_UP_T8x16_N32_K32 = 5,   // sub-pixel up-conv, 32 couts
+    CONV_CFG_UP_S2T12x8_N64_K32 = 6, // sub-pixel up-conv out of the 12x8 bottom level
     CONV_CFG_COUNT
 };
 
 struct ConvConfigInfo {
-    int TS, TH, TW, BN, KC;
+    int TS, TH, TW, BN, KC, TAPS;
     const char* kernel_name;
 };
 const ConvConfigInfo& conv_config_info(int cfg);
