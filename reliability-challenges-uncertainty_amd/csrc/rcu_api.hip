@@ -106,16 +106,16 @@ static size_t conv_tile_floats(const ConvConfigInfo& ci)
 static int pick_config(const ConvLayer& L)
 {
     if (L.upsample) {   // sub-pixel form; L.H x L.W is the OUTPUT grid, tiles run over the low-res input grid
-        if (L.coutp <= 32) return CONV_CFG_UP_T8x16_N32_K32;
-        if (L.H == 24 && L.W == 16) return CONV_CFG_UP_S2T12x8_N64_K32;
-        return CONV_CFG_UP_T8x16_N64_K32;
+        if (L.coutp <= 32) return CONV_CFG_UP_T8x16_N32;
+        if (L.H == 24 && L.W == 16) return CONV_CFG_UP_S2T12x8_N64;
+        return CONV_CFG_UP_T8x16_N64;
     }
-    if (L.c1p + L.c2p == 8) return CONV_CFG_T8x16_N32_K8;
+    if (L.c1p + L.c2p == 8) return CONV_CFG_T8x16_N32_FIRST;
     if (L.coutp > 32) {
-        if (L.H == 12 && L.W == 8) return CONV_CFG_S2T12x8_N64_K16;
-        return CONV_CFG_T8x16_N64_K16;
+        if (L.H == 12 && L.W == 8) return CONV_CFG_S2T12x8_N64;
+        return CONV_CFG_T8x16_N64;
     }
-    return CONV_CFG_T8x16_N32_K32;
+    return CONV_CFG_T8x16_N32;
 }
 
 static void add_unit(rcu_unet* h, const std::string& prefix, int cin1, int c1p, int cin2, int c2p, int cout, int H, int W,

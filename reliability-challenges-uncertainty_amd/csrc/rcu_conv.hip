@@ -43,9 +43,10 @@ __device__ __forceinline__ void static_for(F&& f)
     }
 }
 
-template <int TS_, int TH_, int TW_, int BN_, int KC_, int WM_, int WN_, int TAPS_>
+template <int TS_, int TH_, int TW_, int BN_, int KC_, int WM_, int WN_, int TAPS_, int DB_>
 struct ConvTile {
     static constexpr int TS = TS_, TH = TH_, TW = TW_, BN = BN_, KC = KC_, WM = WM_, WN = WN_, TAPS = TAPS_;
+    static constexpr bool DB = DB_ != 0;                     // LDS double buffering: one barrier per Cin chunk
     static constexpr int TAPW = (TAPS == 9) ? 3 : 2;        // taps per window row
     static constexpr int THREADS = 256;
     static constexpr int KCP = KC + 4;                      // padded row length (floats)
@@ -68,9 +69,10 @@ struct ConvTile {
     // Both regions are rounded up to a whole number of float4 per thread so that staging is branch-free
     // (the packed weight tiles in global memory carry the same padding).
     static constexpr int W_UNITS_PAD = NW * THREADS;
-    static constexpr int A_DUMP = (A_FLOATS + 3) / 4 * 4;    // 64 float4 slots where the tail units land
-    static constexpr int A_REGION = A_DUMP + 64 * 4;         // floats
-    static constexpr int LDS_BYTES = A_REGION * 4 + W_UNITS_PAD * 16;
+    static constexpr int A_DUMP = (A_FLOATS + 3) / 4 * 4;    // 16 float4 slots where the tail units land
+    static constexpr int A_REGION = A_DUMP + 16 * 4;         // floats
+    static constexpr int BUF_FLOATS = A_REGION + W_UNITS_PAD * 4;
+    static constexpr int LDS_BYTES = BUF_FLOATS * 4 * (DB ? 2 : 1);
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(NBLK % WM == 0 && (BN / 32) % WN == 0, "wave tiling");
     static_assert(TH % 4 == 0 && TW % 8 == 0 && KC % 8 == 0, "block geometry");
@@ -82,8 +84,6 @@ template <class T>
 __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const As = smem;
-    float* const Ws = smem + T::A_REGION;
     constexpr int KC = T::KC, KCP = T::KCP, MT = T::MT, NTW = T::NTW;
     constexpr bool SUBPIXEL = (T::TAPS == 4);
 
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
         const bool ok = u < T::A_UNITS && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         const uint32_t pix = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) : 0u;
         akeep[j] = ok ? 1.f : 0.f;
-        adst[j] = u < T::A_UNITS ? qdst * KCP + sub * 4 : T::A_DUMP + (tid & 63) * 4;   // tail units: dump slots
+        adst[j] = u < T::A_UNITS ? qdst * KCP + sub * 4 : T::A_DUMP + (tid & 15) * 4;   // tail units: dump slots
         off1[j] = ok ? pix * (uint32_t)a.C1 + sub * 4 : 0u;
         off2[j] = ok ? pix * (uint32_t)a.C2 + sub * 4 : 0u;
     }
@@ -145,12 +145,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
         const f32x4* wq_ = wp + (size_t)(kc_) * wchunk_stride;                                    \
         _Pragma("unroll") for (int j = 0; j < T::NW; ++j) rw[j] = wq_[j * T::THREADS];            \
     }
-#define RCU_STAGE()                                                                               \
+#define RCU_STAGE(buf_)                                                                           \
     {                                                                                             \
+        float* const As_ = smem + (buf_) * T::BUF_FLOATS;                                         \
         _Pragma("unroll") for (int j = 0; j < T::NA; ++j)                                         \
-            *reinterpret_cast<f32x4*>(As + adst[j]) = ra[j] * akeep[j];                           \
+            *reinterpret_cast<f32x4*>(As_ + adst[j]) = ra[j] * akeep[j];                          \
         _Pragma("unroll") for (int j = 0; j < T::NW; ++j)                                         \
-            reinterpret_cast<f32x4*>(Ws)[tid + j * T::THREADS] = rw[j];                           \
+            reinterpret_cast<f32x4*>(As_ + T::A_REGION)[tid + j * T::THREADS] = rw[j];            \
     }
 
     // ---- fragment addresses (float offsets into As / Ws)
@@ -176,15 +177,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
+    // K loop over Cin chunks.
+    //  single-buffered: barrier / regs -> LDS / barrier / issue the loads of chunk k+1 / multiply chunk k
+    //  double-buffered: multiply chunk k out of buffer k&1 while this wave's share of chunk k+1 goes
+    //                   regs -> LDS into the other buffer and the loads of chunk k+2 are issued; ONE barrier
+    //                   per chunk, and no wave ever waits for its own LDS writes before issuing MFMAs.
+    constexpr int STEPS = T::TAPS * (KC / 8);
     RCU_PREFETCH(0);
-    for (int kc = 0; kc < nchunks; ++kc) {
-        __syncthreads();   // previous chunk fully consumed
-        RCU_STAGE();
+    if (T::DB) {
+        RCU_STAGE(0);
+        if (nchunks > 1) RCU_PREFETCH(1);
         __syncthreads();
-        if (kc + 1 < nchunks) RCU_PREFETCH(kc + 1);   // lands while this chunk is multiplied
+    }
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int cur_buf = T::DB ? (kc & 1) : 0;
+        if (!T::DB) {
+            __syncthreads();   // previous chunk fully consumed
+            RCU_STAGE(0);
+            __syncthreads();
+            if (kc + 1 < nchunks) RCU_PREFETCH(kc + 1);   // lands while this chunk is multiplied
+        }
+        const float* const Ac = smem + cur_buf * T::BUF_FLOATS;
+        const float* const Wc = Ac + T::A_REGION;
         // TAPS x KC/8 steps, software pipelined: the fragments of step s+1 are read from LDS before the
         // MFMAs of step s are issued, so one wave alone keeps its SIMD's matrix pipe busy.
-        constexpr int STEPS = T::TAPS * (KC / 8);
         f32x4 av[2][MT], bv[2][NTW];
 #define RCU_FRAGS(step_, buf_)                                                                              \
         {                                                                                                       \
@@ -192,15 +208,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
             constexpr int tapA_ = ((tap_ / T::TAPW) * T::PITCH + (tap_ % T::TAPW)) * KCP + k8_ * 8;             \
             constexpr int tapB_ = tap_ * T::BN * KCP + k8_ * 8;                                                 \
             _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                                                   \
-                av[buf_][mi] = *reinterpret_cast<const f32x4*>(As + a_addr[mi] + tapA_);                        \
+                av[buf_][mi] = *reinterpret_cast<const f32x4*>(Ac + a_addr[mi] + tapA_);                        \
             _Pragma("unroll") for (int ni = 0; ni < NTW; ++ni)                                                  \
-                bv[buf_][ni] = *reinterpret_cast<const f32x4*>(Ws + b_addr[ni] + tapB_);                        \
+                bv[buf_][ni] = *reinterpret_cast<const f32x4*>(Wc + b_addr[ni] + tapB_);                        \
         }
         RCU_FRAGS(0, 0);
         static_for<0, STEPS>([&](auto step_c) {
             constexpr int step = decltype(step_c)::value;
             constexpr int cur = step & 1;
             if constexpr (step + 1 < STEPS) RCU_FRAGS(step + 1, cur ^ 1);
+            if constexpr (T::DB && step == 0) {
+                // behind the first fragment reads, ahead of the MFMAs: next chunk regs -> other LDS buffer,
+                // then refill the registers with the chunk after that
+                if (kc + 1 < nchunks) RCU_STAGE(cur_buf ^ 1);
+                if (kc + 2 < nchunks) RCU_PREFETCH(kc + 2);
+            }
             // pin the order: hipcc's scheduler otherwise sinks every ds_read down to its first use (lgkmcnt(0)
             // right before each MFMA group), which serialises LDS latency with the matrix pipe
             __builtin_amdgcn_sched_barrier(0);
@@ -215,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
                 }
         });
 #undef RCU_FRAGS
+        if (T::DB) __syncthreads();   // everyone done with buffer k&1 and with writing buffer (k+1)&1
     }
 #undef RCU_PREFETCH
 #undef RCU_STAGE
@@ -275,22 +298,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
     }
 }
 
-using Cfg0 = ConvTile<1, 8, 16, 64, 16, 2, 2, 9>;
-using Cfg1 = ConvTile<1, 8, 16, 32, 32, 4, 1, 9>;
-using Cfg2 = ConvTile<1, 8, 16, 32, 8, 4, 1, 9>;
-using Cfg3 = ConvTile<2, 12, 8, 64, 16, 2, 2, 9>;
-using Cfg4 = ConvTile<1, 8, 16, 64, 32, 2, 2, 4>;
-using Cfg5 = ConvTile<1, 8, 16, 32, 32, 4, 1, 4>;
-using Cfg6 = ConvTile<2, 12, 8, 64, 32, 2, 2, 4>;
+using Cfg0 = ConvTile<1, 8, 16, 64, 8, 2, 2, 9, 1>;
+using Cfg1 = ConvTile<1, 8, 16, 32, 8, 4, 1, 9, 1>;
+using Cfg2 = ConvTile<1, 8, 16, 32, 8, 4, 1, 9, 0>;
+using Cfg3 = ConvTile<2, 12, 8, 64, 16, 2, 2, 9, 0>;
+using Cfg4 = ConvTile<1, 8, 16, 64, 16, 2, 2, 4, 1>;
+using Cfg5 = ConvTile<1, 8, 16, 32, 16, 4, 1, 4, 1>;
+using Cfg6 = ConvTile<2, 12, 8, 64, 8, 2, 2, 4, 1>;
 
 static const ConvConfigInfo kInfo[CONV_CFG_COUNT] = {
-    {Cfg0::TS, Cfg0::TH, Cfg0::TW, Cfg0::BN, Cfg0::KC, Cfg0::TAPS, "conv3x3_igemm<T8x16,N64,K16>"},
-    {Cfg1::TS, Cfg1::TH, Cfg1::TW, Cfg1::BN, Cfg1::KC, Cfg1::TAPS, "conv3x3_igemm<T8x16,N32,K32>"},
+    {Cfg0::TS, Cfg0::TH, Cfg0::TW, Cfg0::BN, Cfg0::KC, Cfg0::TAPS, "conv3x3_igemm<T8x16,N64,K8,db>"},
+    {Cfg1::TS, Cfg1::TH, Cfg1::TW, Cfg1::BN, Cfg1::KC, Cfg1::TAPS, "conv3x3_igemm<T8x16,N32,K8,db>"},
     {Cfg2::TS, Cfg2::TH, Cfg2::TW, Cfg2::BN, Cfg2::KC, Cfg2::TAPS, "conv3x3_igemm<T8x16,N32,K8>"},
     {Cfg3::TS, Cfg3::TH, Cfg3::TW, Cfg3::BN, Cfg3::KC, Cfg3::TAPS, "conv3x3_igemm<S2T12x8,N64,K16>"},
-    {Cfg4::TS, Cfg4::TH, Cfg4::TW, Cfg4::BN, Cfg4::KC, Cfg4::TAPS, "upconv_subpixel_igemm<T8x16,N64,K32>"},
-    {Cfg5::TS, Cfg5::TH, Cfg5::TW, Cfg5::BN, Cfg5::KC, Cfg5::TAPS, "upconv_subpixel_igemm<T8x16,N32,K32>"},
-    {Cfg6::TS, Cfg6::TH, Cfg6::TW, Cfg6::BN, Cfg6::KC, Cfg6::TAPS, "upconv_subpixel_igemm<S2T12x8,N64,K32>"},
+    {Cfg4::TS, Cfg4::TH, Cfg4::TW, Cfg4::BN, Cfg4::KC, Cfg4::TAPS, "upconv_subpixel_igemm<T8x16,N64,K16,db>"},
+    {Cfg5::TS, Cfg5::TH, Cfg5::TW, Cfg5::BN, Cfg5::KC, Cfg5::TAPS, "upconv_subpixel_igemm<T8x16,N32,K16,db>"},
+    {Cfg6::TS, Cfg6::TH, Cfg6::TW, Cfg6::BN, Cfg6::KC, Cfg6::TAPS, "upconv_subpixel_igemm<S2T12x8,N64,K8,db>"},
 };
 
 const ConvConfigInfo& conv_config_info(int cfg) { return kInfo[cfg]; }
@@ -313,13 +336,13 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t stream)
 hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream)
 {
     switch (cfg) {
-        case CONV_CFG_T8x16_N64_K16: return launch_cfg<Cfg0>(a, stream);
-        case CONV_CFG_T8x16_N32_K32: return launch_cfg<Cfg1>(a, stream);
-        case CONV_CFG_T8x16_N32_K8: return launch_cfg<Cfg2>(a, stream);
-        case CONV_CFG_S2T12x8_N64_K16: return launch_cfg<Cfg3>(a, stream);
-        case CONV_CFG_UP_T8x16_N64_K32: return launch_cfg<Cfg4>(a, stream);
-        case CONV_CFG_UP_T8x16_N32_K32: return launch_cfg<Cfg5>(a, stream);
-        case CONV_CFG_UP_S2T12x8_N64_K32: return launch_cfg<Cfg6>(a, stream);
+        case CONV_CFG_T8x16_N64: return launch_cfg<Cfg0>(a, stream);
+        case CONV_CFG_T8x16_N32: return launch_cfg<Cfg1>(a, stream);
+        case CONV_CFG_T8x16_N32_FIRST: return launch_cfg<Cfg2>(a, stream);
+        case CONV_CFG_S2T12x8_N64: return launch_cfg<Cfg3>(a, stream);
+        case CONV_CFG_UP_T8x16_N64: return launch_cfg<Cfg4>(a, stream);
+        case CONV_CFG_UP_T8x16_N32: return launch_cfg<Cfg5>(a, stream);
+        case CONV_CFG_UP_S2T12x8_N64: return launch_cfg<Cfg6>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }

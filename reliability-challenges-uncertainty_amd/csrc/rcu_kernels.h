@@ -34,13 +34,13 @@ struct ConvArgs {
 };
 
 enum ConvConfig {
-    CONV_CFG_T8x16_N64_K16 = 0,      // 8x16-pixel tile, 64 couts, Cin chunks of 16   (workhorse)
-    CONV_CFG_T8x16_N32_K32 = 1,      // 8x16-pixel tile, 32 couts, Cin chunks of 32   (32-channel layers)
-    CONV_CFG_T8x16_N32_K8 = 2,       // first layer: Cin padded to 8
-    CONV_CFG_S2T12x8_N64_K16 = 3,    // two whole 12x8 slices per workgroup           (BraTS bottom level)
-    CONV_CFG_UP_T8x16_N64_K32 = 4,   // sub-pixel up-conv (2x2 taps on the low-res grid), 64 couts
-    CONV_CFG_UP_T8x16_N32_K32 = 5,   // sub-pixel up-conv, 32 couts
-    CONV_CFG_UP_S2T12x8_N64_K32 = 6, // sub-pixel up-conv out of the 12x8 bottom level
+    CONV_CFG_T8x16_N64 = 0,          // 8x16-pixel tile, 64 couts, Cin chunks of 8, LDS double-buffered (workhorse)
+    CONV_CFG_T8x16_N32 = 1,          // 8x16-pixel tile, 32 couts, Cin chunks of 8, double-buffered (32-channel layers)
+    CONV_CFG_T8x16_N32_FIRST = 2,    // first layer: Cin padded to 8 = a single chunk
+    CONV_CFG_S2T12x8_N64 = 3,        // two whole 12x8 slices per workgroup, chunks of 16 (BraTS bottom level)
+    CONV_CFG_UP_T8x16_N64 = 4,       // sub-pixel up-conv (2x2 taps on the low-res grid), 64 couts, chunks of 16
+    CONV_CFG_UP_T8x16_N32 = 5,       // sub-pixel up-conv, 32 couts
+    CONV_CFG_UP_S2T12x8_N64 = 6,     // sub-pixel up-conv out of the 12x8 bottom level, chunks of 8
     CONV_CFG_COUNT
 };
 
