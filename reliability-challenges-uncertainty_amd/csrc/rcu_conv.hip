@@ -298,6 +298,262 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Streaming variant (double-buffered tiles only): a workgroup walks over several output tiles
+// (items g, g + G, g + 2G, ... of the flat tile list) and runs ONE software pipeline across all of
+// their Cin chunks: while chunk i is multiplied, chunk i+1 goes registers -> other LDS buffer and the
+// loads of chunk i+2 are issued -- also when i+1 / i+2 belong to the NEXT tile.  The first-load latency,
+// the index arithmetic and the workgroup launch of every tile but the first are hidden behind MFMAs.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct TilePlan {
+    uint32_t off1[T::NA], off2[T::NA];
+    float akeep[T::NA];
+    int wtile, ntile, pa, pb, n0, y0, x0;
+};
+
+template <class T>
+__device__ __forceinline__ void make_plan(TilePlan<T>& p, const ConvArgs& a, int item, int tid)
+{
+    p.wtile = item % a.NTW_total;
+    p.ntile = p.wtile % a.NT;
+    const int cls = p.wtile / a.NT;
+    p.pa = cls >> 1;
+    p.pb = cls & 1;
+    int mtile = item / a.NTW_total;
+    const int tx = mtile % a.tiles_x;
+    mtile /= a.tiles_x;
+    const int ty = mtile % a.tiles_y;
+    const int sg = mtile / a.tiles_y;
+    p.n0 = sg * T::TS;
+    p.y0 = ty * T::TH;
+    p.x0 = tx * T::TW;
+#pragma unroll
+    for (int j = 0; j < T::NA; ++j) {
+        const int u = tid + j * T::THREADS;
+        const int q = u / (T::KC / 4);
+        const int sub = u % (T::KC / 4);
+        const int s = q / ((T::TH + 2) * (T::TW + 2));
+        const int rem = q % ((T::TH + 2) * (T::TW + 2));
+        const int yy = rem / (T::TW + 2), xx = rem % (T::TW + 2);
+        const int n = p.n0 + s, gy = p.y0 + yy - 1, gx = p.x0 + xx - 1;
+        const bool ok = u < T::A_UNITS && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const uint32_t pix = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) : 0u;
+        p.akeep[j] = ok ? 1.f : 0.f;
+        p.off1[j] = ok ? pix * (uint32_t)a.C1 + sub * 4 : 0u;
+        p.off2[j] = ok ? pix * (uint32_t)a.C2 + sub * 4 : 0u;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256, 2) void conv_igemm_stream(const ConvArgs a, const int total_items)
+{
+    static_assert(T::DB, "streaming kernel needs the double-buffered LDS layout");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KC = T::KC, KCP = T::KCP, MT = T::MT, NTW = T::NTW;
+    constexpr bool SUBPIXEL = (T::TAPS == 4);
+    constexpr int STEPS = T::TAPS * (KC / 8);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wn = wave % T::WN;
+    const int wm = wave / T::WN;
+    const int m = lane & 31, half = lane >> 5;
+    const int nchunks = (a.C1 + a.C2) / KC;   // >= 2 (checked by the launcher)
+    const size_t wchunk_stride = (size_t)a.NTW_total * T::W_UNITS_PAD;
+    const f32x4* const wbase = reinterpret_cast<const f32x4*>(a.wpack) + tid;
+
+    // LDS destination of every staging unit is tile independent
+    int adst[T::NA];
+#pragma unroll
+    for (int j = 0; j < T::NA; ++j) {
+        const int u = tid + j * T::THREADS;
+        const int q = u / (KC / 4), sub = u % (KC / 4);
+        const int s = q / ((T::TH + 2) * (T::TW + 2));
+        const int rem = q % ((T::TH + 2) * (T::TW + 2));
+        const int qdst = (s * (T::TH + 2) + rem / (T::TW + 2)) * T::PITCH + rem % (T::TW + 2);
+        adst[j] = u < T::A_UNITS ? qdst * KCP + sub * 4 : T::A_DUMP + (tid & 15) * 4;
+    }
+    int b_addr[NTW];
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) b_addr[ni] = ((wn * NTW + ni) * 32 + m) * KCP + half * 4;
+
+    TilePlan<T> cur, nxt;
+    int item = blockIdx.x;
+    make_plan<T>(cur, a, item, tid);
+    bool has_next = item + (int)gridDim.x < total_items;
+    make_plan<T>(nxt, a, has_next ? item + (int)gridDim.x : item, tid);
+
+    f32x4 ra[T::NA], rw[T::NW];
+    float rkeep[T::NA];   // zero-padding factors of the data currently held in ra
+#define RCU_PREFETCH_P(plan_, kc_)                                                                 \
+    {                                                                                              \
+        const int c0_ = (kc_) * KC;                                                                \
+        const bool first_ = c0_ < a.C1;                                                            \
+        const float* sp_ = first_ ? a.src1 + c0_ : a.src2 + (c0_ - a.C1);                          \
+        _Pragma("unroll") for (int j = 0; j < T::NA; ++j) {                                        \
+            ra[j] = *reinterpret_cast<const f32x4*>(sp_ + (first_ ? plan_.off1[j] : plan_.off2[j])); \
+            rkeep[j] = plan_.akeep[j];                                                             \
+        }                                                                                          \
+        const f32x4* wq_ = wbase + (size_t)plan_.wtile * T::W_UNITS_PAD + (size_t)(kc_) * wchunk_stride; \
+        _Pragma("unroll") for (int j = 0; j < T::NW; ++j) rw[j] = wq_[j * T::THREADS];             \
+    }
+#define RCU_STAGE_P(buf_)                                                                          \
+    {                                                                                              \
+        float* const As_ = smem + (buf_) * T::BUF_FLOATS;                                          \
+        _Pragma("unroll") for (int j = 0; j < T::NA; ++j)                                          \
+            *reinterpret_cast<f32x4*>(As_ + adst[j]) = ra[j] * rkeep[j];                           \
+        _Pragma("unroll") for (int j = 0; j < T::NW; ++j)                                          \
+            reinterpret_cast<f32x4*>(As_ + T::A_REGION)[tid + j * T::THREADS] = rw[j];             \
+    }
+
+    RCU_PREFETCH_P(cur, 0);
+    RCU_STAGE_P(0);
+    RCU_PREFETCH_P(cur, 1);
+    __syncthreads();
+
+    int it = 0;   // flat chunk counter: LDS buffer = it & 1
+    for (;;) {
+        int a_addr[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int blk = wm * MT + mi;
+            const int s = blk / T::BPS, rb = blk % T::BPS;
+            const int by = rb / (T::TW / 8), bx = rb % (T::TW / 8);
+            const int pixel = (s * (T::TH + 2) + 4 * by + (m >> 3) + cur.pa) * T::PITCH + 8 * bx + (m & 7) + cur.pb;
+            a_addr[mi] = pixel * KCP + half * 4;
+        }
+        f32x16 acc[MT][NTW];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NTW; ++ni)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+        for (int kc = 0; kc < nchunks; ++kc, ++it) {
+            const int cur_buf = it & 1;
+            const float* const Ac = smem + cur_buf * T::BUF_FLOATS;
+            const float* const Wc = Ac + T::A_REGION;
+            f32x4 av[2][MT], bv[2][NTW];
+#define RCU_FRAGS(step_, buf_)                                                                              \
+            {                                                                                                   \
+                constexpr int tap_ = (step_) / (KC / 8), k8_ = (step_) % (KC / 8);                              \
+                constexpr int tapA_ = ((tap_ / T::TAPW) * T::PITCH + (tap_ % T::TAPW)) * KCP + k8_ * 8;         \
+                constexpr int tapB_ = tap_ * T::BN * KCP + k8_ * 8;                                             \
+                _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                                               \
+                    av[buf_][mi] = *reinterpret_cast<const f32x4*>(Ac + a_addr[mi] + tapA_);                    \
+                _Pragma("unroll") for (int ni = 0; ni < NTW; ++ni)                                              \
+                    bv[buf_][ni] = *reinterpret_cast<const f32x4*>(Wc + b_addr[ni] + tapB_);                    \
+            }
+            RCU_FRAGS(0, 0);
+            static_for<0, STEPS>([&](auto step_c) {
+                constexpr int step = decltype(step_c)::value;
+                constexpr int cb = step & 1;
+                if constexpr (step + 1 < STEPS) RCU_FRAGS(step + 1, cb ^ 1);
+                if constexpr (step == 0) {
+                    // chunk it+1 (held in registers) -> other buffer; then load chunk it+2.  Both may belong
+                    // to the next tile of this workgroup.
+                    if (kc + 1 < nchunks || has_next) RCU_STAGE_P(cur_buf ^ 1);
+                    if (kc + 2 < nchunks) {
+                        RCU_PREFETCH_P(cur, kc + 2);
+                    } else if (has_next) {
+                        RCU_PREFETCH_P(nxt, kc + 2 - nchunks);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NTW; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][mi].x, bv[cb][ni].x, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][mi].y, bv[cb][ni].y, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][mi].z, bv[cb][ni].z, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][mi].w, bv[cb][ni].w, acc[mi][ni], 0, 0, 0);
+                    }
+            });
+#undef RCU_FRAGS
+            __syncthreads();   // everyone done with buffer it&1 and with writing buffer (it+1)&1
+        }
+
+        // ---- epilogue of the finished tile (registers only; the next tile's first chunk is already in LDS)
+        {
+            constexpr int OS = SUBPIXEL ? 2 : 1;
+            const int OH = a.H * OS, OW = a.W * OS;
+            const bool full_tile = (cur.y0 + T::TH <= a.H) && (cur.x0 + T::TW <= a.W) && (cur.n0 + T::TS <= a.N);
+            const size_t row_stride = (size_t)OW * a.CoutP * OS, col_stride = (size_t)a.CoutP * OS;
+            const int Hp = a.H >> 1, Wp = a.W >> 1;
+#pragma unroll
+            for (int ni = 0; ni < NTW; ++ni) {
+                const int co = cur.ntile * T::BN + (wn * NTW + ni) * 32 + m;
+                if (co >= a.CoutP) continue;
+                const float al = a.alpha[co], bb = a.betab[co], be = a.beta[co];
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const int blk = wm * MT + mi;
+                    const int s = blk / T::BPS, rb = blk % T::BPS;
+                    const int by = rb / (T::TW / 8), bx = rb % (T::TW / 8);
+                    const int n = cur.n0 + s;
+                    if (n >= a.N) continue;
+                    float mk = 1.f;
+                    if (a.mask != nullptr && co < a.Cmask) mk = a.mask[(size_t)n * a.Cmask + co];
+                    if (a.mask2 != nullptr && co >= a.Csplit && co - a.Csplit < a.Cmask2)
+                        mk = a.mask2[(size_t)n * a.Cmask2 + (co - a.Csplit)];
+                    const float scale = al * mk, shift = bb * mk + be;
+                    const int yb = cur.y0 + 4 * by, xb = cur.x0 + 8 * bx + 4 * half;
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float t = acc[mi][ni][i] * scale + shift;
+                        v[i] = a.relu ? fmaxf(t, 0.f) : t;
+                    }
+                    float* const obase =
+                        a.out + ((size_t)(n * OH + yb * OS + cur.pa) * OW + xb * OS + cur.pb) * a.CoutP + co;
+                    if (full_tile) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (yb + (i >> 2) < a.H && xb + (i & 3) < a.W)
+                                obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];
+                    }
+                    if (!SUBPIXEL && a.pooled != nullptr) {
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                            for (int pc = 0; pc < 2; ++pc) {
+                                const int i0 = (2 * pr) * 4 + 2 * pc;
+                                const float mx = fmaxf(fmaxf(v[i0], v[i0 + 1]), fmaxf(v[i0 + 4], v[i0 + 5]));
+                                const int py = (yb >> 1) + pr, px = (xb >> 1) + pc;
+                                if (py < Hp && px < Wp)
+                                    a.pooled[((size_t)(n * Hp + py) * Wp + px) * a.CoutP + co] = mx;
+                            }
+                    }
+                }
+            }
+        }
+
+        if (!has_next) break;
+        // advance: next tile becomes current; plan the one after it
+        item += (int)gridDim.x;
+#pragma unroll
+        for (int j = 0; j < T::NA; ++j) {
+            cur.off1[j] = nxt.off1[j];
+            cur.off2[j] = nxt.off2[j];
+            cur.akeep[j] = nxt.akeep[j];
+        }
+        cur.wtile = nxt.wtile; cur.ntile = nxt.ntile; cur.pa = nxt.pa; cur.pb = nxt.pb;
+        cur.n0 = nxt.n0; cur.y0 = nxt.y0; cur.x0 = nxt.x0;
+        has_next = item + (int)gridDim.x < total_items;
+        make_plan<T>(nxt, a, has_next ? item + (int)gridDim.x : item, tid);
+    }
+#undef RCU_PREFETCH_P
+#undef RCU_STAGE_P
+}
+
 using Cfg0 = ConvTile<1, 8, 16, 64, 8, 2, 2, 9, 1>;
 using Cfg1 = ConvTile<1, 8, 16, 32, 8, 4, 1, 9, 1>;
 using Cfg2 = ConvTile<1, 8, 16, 32, 8, 4, 1, 9, 0>;
@@ -322,14 +578,29 @@ template <class T>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t stream)
 {
     static bool attr_set = false;
-    if (!attr_set) {
+    const unsigned items = (unsigned)a.NTW_total * a.tiles_x * a.tiles_y * a.slice_groups;
+    if constexpr (T::DB) {
+        if ((a.C1 + a.C2) / T::KC >= 2) {
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_stream<T>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+                if (e != hipSuccess) return e;
+                attr_set = true;
+            }
+            // two resident workgroups per CU, each streaming through its share of the tiles
+            const unsigned grid = items < 2u * 256u ? items : 2u * 256u;
+            hipLaunchKernelGGL(conv_igemm_stream<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);
+            return hipGetLastError();
+        }
+    }
+    static bool attr_set_plain = false;
+    if (!attr_set_plain) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set_plain = true;
     }
-    const unsigned grid = (unsigned)a.NTW_total * a.tiles_x * a.tiles_y * a.slice_groups;
-    hipLaunchKernelGGL(conv_igemm<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(conv_igemm<T>, dim3(items), dim3(T::THREADS), T::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
