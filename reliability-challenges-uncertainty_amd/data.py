@@ -1,0 +1,270 @@
+"""Data side of the test scripts: datasets, transforms, collation, loader.
+
+The reference reads BraTS from a pymia HDF5 file and ISIC from a folder of jpg / png files
+(common/trainloop/data.py:27-154, common/trainloop/factory.py:10-71, rechun/dl/customdatasets.py:12-112).
+pymia and h5py are not available here and data ingestion is outside the hot path, so:
+
+  * ``VolumeDataset`` -- slice-wise access to a directory of ``<subject>.npz`` volumes (``images [D,H,W,C]``,
+    ``labels [D,H,W]``, optional geometry).  It yields per slice the entries the reference's extractors
+    produce for ``indexing: slice`` (images, subject / slice index, volume shape) and serves the
+    ``direct_extractor`` entries (labels, properties, subject name) per subject.
+  * ``IsicDataset`` -- the folder dataset of the reference (``<prefix>_Data/*.jpg``,
+    ``<prefix>_Part1_GroundTruth/*_segmentation.png``), one sample per subject.
+  * the transform registry entries the shipped YAML files use: permute, squeeze, unsqueeze, rescale.
+A ``.h5`` dataset path raises with a pointer to ``convert`` instead of failing somewhere inside.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+import torch.utils.data as torch_data
+
+from . import nifti
+
+
+# ------------------------------------------------------------------------------------ transforms
+class Permute:
+    def __init__(self, permutation, entries=('images', 'labels')):
+        self.permutation, self.entries = tuple(permutation), tuple(entries)
+
+    def __call__(self, sample):
+        for e in self.entries:
+            if e in sample:
+                sample[e] = np.transpose(sample[e], self.permutation)
+        return sample
+
+
+class Squeeze:
+    def __init__(self, entries=('images', 'labels'), squeeze_axis=None):
+        self.entries, self.axis = tuple(entries), squeeze_axis
+
+    def __call__(self, sample):
+        for e in self.entries:
+            if e in sample:
+                sample[e] = np.squeeze(sample[e], self.axis)
+        return sample
+
+
+class UnSqueeze:
+    def __init__(self, axis=-1, entries=('images', 'labels')):
+        self.entries, self.axis = tuple(entries), axis
+
+    def __call__(self, sample):
+        for e in self.entries:
+            if e in sample:
+                sample[e] = np.expand_dims(sample[e], self.axis)
+        return sample
+
+
+class IntensityRescale:
+    """min-max rescale of each entry to [lower, upper] (pymia IntensityRescale; parity unpinned)."""
+
+    def __init__(self, lower, upper, entries=('images',)):
+        self.lower, self.upper, self.entries = lower, upper, tuple(entries)
+
+    def __call__(self, sample):
+        for e in self.entries:
+            if e in sample:
+                a = sample[e].astype(np.float32)
+                lo, hi = a.min(), a.max()
+                a = (a - lo) / (hi - lo) if hi > lo else np.zeros_like(a)
+                sample[e] = a * (self.upper - self.lower) + self.lower
+        return sample
+
+
+class Compose:
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, sample):
+        for t in self.transforms:
+            sample = t(sample)
+        return sample
+
+
+transform_registry = {'permute': Permute, 'squeeze': Squeeze, 'unsqueeze': UnSqueeze, 'rescale': IntensityRescale}
+
+
+def get_transform(params):
+    """common/trainloop/factory.py:18-27 for a Parameter or a list of them (None -> identity)."""
+    if params is None:
+        return Compose([])
+    if isinstance(params, (list, tuple)):
+        return Compose([get_transform(p) for p in params])
+    if params.type not in transform_registry:
+        raise ValueError('transform type "{}" unknown'.format(params.type))
+    return transform_registry[params.type](**params.params)
+
+
+# -------------------------------------------------------------------------------------- datasets
+def write_volume(dataset_dir, subject, images, labels=None, properties=None):
+    """Store one subject of a VolumeDataset: ``images`` float32 ``[D,H,W,C]``, ``labels`` uint8 ``[D,H,W]``."""
+    os.makedirs(dataset_dir, exist_ok=True)
+    arrays = {'images': np.asarray(images, dtype=np.float32)}
+    if labels is not None:
+        arrays['labels'] = np.asarray(labels, dtype=np.uint8)
+    if properties is not None:
+        arrays.update(origin=np.asarray(properties.origin), spacing=np.asarray(properties.spacing),
+                      direction=np.asarray(properties.direction))
+    np.savez(os.path.join(dataset_dir, subject + '.npz'), **arrays)
+
+
+class VolumeDataset(torch_data.Dataset):
+    """One sample = one slice (axis 0) of one subject; subjects in sorted order, optionally a subset."""
+
+    def __init__(self, dataset_dir, transform=None, subject_subset=None):
+        if str(dataset_dir).endswith(('.h5', '.hdf5')):
+            raise ValueError('"{}": pymia HDF5 datasets cannot be read in this environment (no h5py / pymia); export the '
+                             'volumes with rcu_amd.data.write_volume(<dir>, subject, images, labels) and point '
+                             '`dataset:` at that directory'.format(dataset_dir))
+        files = sorted(glob.glob(os.path.join(dataset_dir, '*.npz')))
+        self.subjects = [os.path.splitext(os.path.basename(f))[0] for f in files]
+        if subject_subset is not None:
+            keep = set(subject_subset)
+            files = [f for f, s in zip(files, self.subjects) if s in keep]
+            self.subjects = [s for s in self.subjects if s in keep]
+        if not files:
+            raise ValueError('no <subject>.npz volumes found in "{}"'.format(dataset_dir))
+        self.files = files
+        self.transform = transform if transform is not None else Compose([])
+        self.index = []          # (subject index, slice index)
+        self.shapes = []
+        for si, f in enumerate(files):
+            with np.load(f) as z:
+                shape = z['images'].shape
+            self.shapes.append(shape)
+            self.index.extend((si, k) for k in range(shape[0]))
+        self._cache = (None, None)
+
+    def _volume(self, si):
+        if self._cache[0] != si:
+            with np.load(self.files[si]) as z:
+                self._cache = (si, {k: z[k] for k in z.files})
+        return self._cache[1]
+
+    def __len__(self):
+        return len(self.index)
+
+    def __getitem__(self, i):
+        si, k = self.index[i]
+        vol = self._volume(si)
+        sample = {'images': vol['images'][k], 'subject_index': si, 'slice_index': k,
+                  'shape': tuple(self.shapes[si][:3]), 'sample_index': i}
+        return self.transform(sample)
+
+    def direct_extract(self, subject_index, entries=('labels', 'properties', 'subject')):
+        """Per-subject entries of the ``direct_extractor`` list (names, data(labels), files, properties, subject)."""
+        vol = self._volume(subject_index)
+        out = {}
+        if 'labels' in entries and 'labels' in vol:
+            out['labels'] = vol['labels']
+        if 'properties' in entries:
+            d, h, w = self.shapes[subject_index][:3]
+            out['properties'] = nifti.ImageProperties((w, h, d), vol.get('origin'), vol.get('spacing'),
+                                                      vol.get('direction'))
+        if 'subject' in entries:
+            out['subject'] = self.subjects[subject_index]
+        return out
+
+
+class IsicDataset(torch_data.Dataset):
+    """rechun/dl/customdatasets.py:12-95: ids are the first 12 characters of the file names."""
+    LABEL_DIR_POST_FIX = '_Part1_GroundTruth'
+    IMAGE_DIR_POST_FIX = '_Data'
+
+    def __init__(self, data_dir_with_task_prefix, transform=None, subject_subset=None):
+        from PIL import Image  # noqa: F401  (fail early if PIL is missing)
+        self.prefix = data_dir_with_task_prefix
+        self.transform = transform if transform is not None else Compose([])
+        img_dir, label_dir = self.prefix + self.IMAGE_DIR_POST_FIX, self.prefix + self.LABEL_DIR_POST_FIX
+        if not (os.path.isdir(img_dir) and os.path.isdir(label_dir)):
+            raise ValueError('expected the directories "{}" and "{}"'.format(img_dir, label_dir))
+        by_id = {}
+        for path in glob.glob(os.path.join(img_dir, '*')) + glob.glob(os.path.join(label_dir, '*')):
+            name = os.path.basename(path)
+            if name.endswith('_segmentation.png'):
+                by_id.setdefault(name[:12], {})['gt'] = path
+            elif name.endswith('.jpg'):
+                by_id.setdefault(name[:12], {})['image'] = path
+        if subject_subset is not None:
+            by_id = {k: v for k, v in by_id.items() if k in set(subject_subset)}
+        self.files_by_id = {k: v for k, v in by_id.items() if 'gt' in v and 'image' in v}
+        self.ids = sorted(self.files_by_id)
+
+    def __len__(self):
+        return len(self.ids)
+
+    def get_files_by_id(self, id_):
+        f = self.files_by_id[id_]
+        return {'image_paths': f['image'], 'label_paths': f['gt']}
+
+    def __getitem__(self, index):
+        from PIL import Image
+        id_ = self.ids[index]
+        f = self.files_by_id[id_]
+        sample = {'ids': id_,
+                  'labels': np.array(Image.open(f['gt']).convert('L'))[..., np.newaxis].astype(np.uint8),
+                  'images': np.array(Image.open(f['image'])).astype(np.float32),
+                  'image_paths': f['image'], 'label_paths': f['gt'], 'subject_index': index, 'sample_index': index}
+        return self.transform(sample)
+
+
+# ---------------------------------------------------------------------------- collate and loading
+class CollateDict:
+    """Stack the tensor entries, keep everything else as per-sample lists (common/data/collate.py:4-16)."""
+
+    def __init__(self, entries=('labels', 'images')):
+        self.entries = entries
+
+    def __call__(self, batch):
+        out = {}
+        for key in batch[0]:
+            if key in self.entries:
+                out[key] = torch_data.dataloader.default_collate([b[key] for b in batch])
+            else:
+                out[key] = [b[key] for b in batch]
+        return out
+
+
+class Data:
+    def __init__(self, dataset, loader):
+        self.dataset = dataset
+        self.loader = loader
+        self.nb_batches = len(loader)
+
+
+def load_split(file, k=None):
+    """common/data/split.py:84-93."""
+    with open(file, 'r') as f:
+        d = json.load(f)
+    train, valid, test = d['train'], d['valid'], d['test']
+    if k is not None:
+        train, valid = train[k], valid[k]
+        test = [] if test is None else test[k]
+    return train, valid, test
+
+
+class BuildVolumeDataset:
+    def __call__(self, data_config, **kwargs):
+        return VolumeDataset(data_config.dataset, get_transform(data_config.transform), kwargs.get('entries'))
+
+
+class BuildIsicDataset:
+    def __call__(self, data_config, **kwargs):
+        return IsicDataset(data_config.dataset, get_transform(data_config.transform), kwargs.get('entries'))
+
+
+class BuildData:
+    """dataset -> sequential (or shuffled) loader with the dict collate (common/trainloop/data.py:140-154)."""
+
+    def __init__(self, build_dataset, **kwargs):
+        self.build_dataset = build_dataset
+        self.kwargs = kwargs
+
+    def __call__(self, data_config, **kwargs):
+        dataset = self.build_dataset(data_config, **{**self.kwargs, **kwargs})
+        loader = torch_data.DataLoader(dataset, batch_size=data_config.batch_size, shuffle=bool(data_config.shuffle),
+                                       num_workers=0, collate_fn=CollateDict())
+        return Data(dataset, loader)

@@ -1,0 +1,426 @@
+"""Evaluation-script surface: what ``bin-eval/eval_uncertainty.py`` of the reference does, on the GPU.
+
+Mirrors
+  CSV hooks            rechun/eval/hook.py:10-116 (WriteCsvHook, WriteBinsCsvHook, WriteSummaryCsvHook)
+  file / run registry  rechun/eval/evaldata.py:8-103, common/data/collector.py:120-174, rechun/directories.py:56-71
+  loader               rechun/eval/analysis.py:15-125 (probabilities / target>0 / prediction / T2 brain mask, cached)
+  actions + driver     bin-eval/eval_uncertainty.py:13-244 (minmax, ece_dice, calib, bnf_ue)
+so that the CSV files ``bin-analysis/*`` consumes keep their names, columns and row order.  The volumes
+are read with rcu_amd.nifti, the per-voxel work (histograms, counts, entropy) runs through
+rcu_amd.evaluation on the GPU; the ``bnf_ue`` action evaluates its 11 thresholds in ONE pass per subject
+and fans the result out to the 11 per-threshold CSV files the reference writes.
+"""
+import abc
+import csv
+import glob
+import os
+import time
+
+import numpy as np
+
+from . import evaluation as ev
+from . import nifti
+
+# rechun/directories.py:56-71
+ECE_FOREGROUND_NAME = 'ece_foreground'
+ECE_NAME = 'ece'
+CALIB_NAME = 'calibration'
+UNCERTAINTY_NAME = 'uncertainty'
+MINMAX_NAME = 'minmax'
+CALIBRATION_PLACEHOLDER = 'eval_calibration_{}.csv'
+UNCERTAINTY_PLACEHOLDER = 'eval_uncertainty_{}_th{}.csv'
+ECE_PLACEHOLDER = 'eval_ece_{}.csv'
+MINMAX_PLACEHOLDER = 'eval_summary_minmax_{}.csv'
+
+CONFIDENCE_ENTRY = {'baseline': 'probabilities', 'baseline_mc': 'probabilities', 'center': 'probabilities',
+                    'center_mc': 'probabilities', 'ensemble': 'probabilities', 'auxiliary_feat': 'confidence',
+                    'auxiliary_segm': 'confidence', 'aleatoric': 'sigma'}   # evaldata.py:21-47
+
+
+# ------------------------------------------------------------------------------------- CSV hooks
+class EvalHook:
+    def on_run_start(self, run_id: str):
+        pass
+
+    def on_subject(self, results: dict, subject_name: str, run_id: str):
+        pass
+
+    def on_run_end(self, results_history: dict, run_id: str):
+        pass
+
+
+class ReducedComposeEvalHook(EvalHook):
+    """Calls only the methods a member hook really overrides (common/trainloop/hooks.py:116-133)."""
+
+    def __init__(self, hooks: list) -> None:
+        for name in ('on_run_start', 'on_subject', 'on_run_end'):
+            fns = [getattr(h, name) for h in hooks if getattr(type(h), name) is not getattr(EvalHook, name)]
+            setattr(self, name, self._chain(fns))
+
+    @staticmethod
+    def _chain(fns):
+        def call(*args, **kwargs):
+            for fn in fns:
+                fn(*args, **kwargs)
+        return call
+
+
+class WriteCsvHook(EvalHook):
+    """One row per subject: ``test_id, subject_name, <entries>``; list-valued results are unfolded to
+    ``key_<i>`` columns with zero-padded indices (hook.py:28-72)."""
+
+    def __init__(self, file_path: str, entries=None) -> None:
+        self.file_path = file_path
+        self.rows = []
+        self.entries = None if entries is None else list(entries)
+        self.header = None
+
+    @staticmethod
+    def _unfold_results(results):
+        flat = {}
+        for key, value in results.items():
+            if isinstance(value, np.ndarray):
+                value = value.tolist()
+            if isinstance(value, (list, tuple)):
+                digits = len(str(len(value)))
+                for i, v in enumerate(value):
+                    flat['{}_{:0{}d}'.format(key, i, digits)] = v
+            else:
+                flat[key] = value
+        return flat
+
+    def on_subject(self, results: dict, subject_name: str, run_id: str):
+        flat = self._unfold_results(results)
+        if self.entries is None:
+            self.entries = list(flat.keys())
+        if self.header is None:
+            self.header = ['test_id', 'subject_name'] + self.entries
+        self.rows.append([run_id, subject_name] + [flat[e] for e in self.entries])
+
+    def on_run_end(self, results_history: dict, run_id: str):
+        with open(self.file_path, 'w', newline='') as f:
+            writer = csv.writer(f)
+            writer.writerow(self.header)
+            writer.writerows(self.rows)
+
+
+class WriteBinsCsvHook(WriteCsvHook):
+    """Re-expands the non-empty-bin arrays to all bins before unfolding (hook.py:75-93)."""
+
+    def on_subject(self, results: dict, subject_name: str, run_id: str):
+        non_zero = results['bins_non_zero']
+        for key in ('bins_count', 'bins_avg_confidence', 'bins_positive_fraction'):
+            full = np.zeros_like(non_zero, dtype=results[key].dtype)
+            full[non_zero] = results[key]
+            results[key] = full
+        super().on_subject(results, subject_name, run_id)
+
+
+class WriteSummaryCsvHook(EvalHook):
+    """``confidence_entry, min, max`` over the whole run (hook.py:96-116)."""
+
+    def __init__(self, file_path: str, entries=('min', 'max'), summary_fn=(np.min, np.max),
+                 confidence_entry='probabilities') -> None:
+        if len(entries) != len(summary_fn):
+            raise ValueError('entries and summary_fn must be of same length')
+        self.file_path = file_path
+        self.entries = list(entries)
+        self.summary_fn = list(summary_fn)
+        self.confidence_entry = confidence_entry
+
+    def on_run_end(self, results_history: dict, run_id: str):
+        with open(self.file_path, 'w', newline='') as f:
+            writer = csv.writer(f)
+            writer.writerow(['confidence_entry'] + self.entries)
+            writer.writerow([self.confidence_entry] + [fn(results_history[e]) for e, fn in
+                                                       zip(self.entries, self.summary_fn)])
+
+
+def read_min_max(min_max_file: str):
+    """rechun/eval/helper.py:50-55."""
+    with open(min_max_file, 'r') as f:
+        reader = csv.reader(f)
+        next(reader)
+        _, min_, max_ = next(reader)
+    return float(min_), float(max_)
+
+
+# ------------------------------------------------------------------------------ files and runs
+class SubjectFiles:
+    """subject id + {category: {entry: path}} (the part of pymia's SubjectFile the path uses)."""
+
+    def __init__(self, subject, **categories):
+        self.subject = subject
+        self.categories = {k: dict(v) for k, v in categories.items()}
+
+
+def collect_predictions(prediction_path, post_fixes, categories):
+    """``**/<subject>_<postfix>.nii.gz`` under a prediction directory (collector.py:120-161)."""
+    by_id = {}
+    for pf in post_fixes:
+        tail = '_{}.nii.gz'.format(pf)
+        for path in glob.glob(os.path.join(prediction_path, '**', '*' + tail), recursive=True):
+            by_id.setdefault(os.path.basename(path)[:-len(tail)], {})[pf] = path
+    out = []
+    for subject, files in by_id.items():
+        if set(files) != set(post_fixes):
+            raise AssertionError('id "{}" has not all required entries "({})"'.format(subject, list(post_fixes)))
+        cats = {}
+        for pf, cat in zip(post_fixes, categories):
+            cats.setdefault(cat, {})[pf] = files[pf]
+        out.append(SubjectFiles(subject, **cats))
+    return out
+
+
+def collect_brats_ground_truth(root_dir):
+    """``**/<subject>/<subject>_{flair,t1,t2,t1ce,seg}.nii.gz`` (collector.py:17-71); subject = directory name."""
+    out = []
+    for flair in sorted(glob.glob(os.path.join(root_dir, '**', '*_flair.nii.gz'), recursive=True)):
+        stem = flair[:-len('_flair.nii.gz')]
+        images = {'flair': flair, 't1': stem + '_t1.nii.gz', 't2': stem + '_t2.nii.gz', 't1c': stem + '_t1ce.nii.gz'}
+        labels = {'gt': stem + '_seg.nii.gz'} if os.path.exists(stem + '_seg.nii.gz') else {}
+        out.append(SubjectFiles(os.path.basename(os.path.dirname(flair)), images=images, labels=labels))
+    return out
+
+
+def combine(files_from, files_to):
+    """collector.py:164-174: add the categories of ``files_from`` to the same subject in ``files_to``."""
+    by_id = {sf.subject: sf for sf in files_from}
+    for sf in files_to:
+        for cat, entries in by_id[sf.subject].categories.items():
+            sf.categories.setdefault(cat, {}).update(entries)
+    return files_to
+
+
+class EvalData:
+    def __init__(self, id_, eval_path, confidence_entry='probabilities', subject_files=None) -> None:
+        self.id_ = id_
+        self.eval_path = eval_path
+        self.confidence_entry = confidence_entry
+        self.subject_files = subject_files if subject_files is not None else []
+
+
+def get_eval_data(run_id, prediction_dir, ground_truth_files, expected_subjects=None):
+    """One run: collect ``*_prediction`` + ``*_<confidence entry>`` files and join them with the ground truth."""
+    entry = EvalData(run_id, prediction_dir, CONFIDENCE_ENTRY.get(run_id, 'probabilities'))
+    preds = collect_predictions(prediction_dir, ['prediction', entry.confidence_entry], ['labels', 'misc'])
+    preds = combine(ground_truth_files, preds)
+    if expected_subjects is not None:
+        assert set(expected_subjects) == set(sf.subject for sf in preds)
+    entry.subject_files = sorted(preds, key=lambda sf: sf.subject)
+    return entry
+
+
+# -------------------------------------------------------------------------------------- loader
+class Loader:
+    """Per-subject cached reads (analysis.py:15-125)."""
+
+    class Params:
+        def __init__(self, misc_entry='probabilities', need_target=True, need_prediction=True, need_t2_mask=False):
+            self.misc_entry = misc_entry
+            self.need_target = need_target
+            self.need_prediction = need_prediction
+            self.need_t2_mask = need_t2_mask
+
+    def __init__(self) -> None:
+        self.cached = {}
+        self.cached_subject = None
+
+    def _get(self, key, fn):
+        if key not in self.cached:
+            self.cached[key] = fn()
+        return self.cached[key].copy()
+
+    def get_data(self, sf: SubjectFiles, params):
+        if sf.subject != self.cached_subject:
+            self.cached.clear()
+            self.cached_subject = sf.subject
+        to_eval = {params.misc_entry: self._get(params.misc_entry,
+                                                lambda: nifti.read(sf.categories['misc'][params.misc_entry])[0])}
+        if params.need_target:   # labels 0..4 are binarised (analysis.py:88-89)
+            to_eval['target'] = self._get('target', lambda: (nifti.read(sf.categories['labels']['gt'])[0] > 0)
+                                          .astype(np.uint8))
+        if params.need_prediction:
+            to_eval['prediction'] = self._get('prediction', lambda: nifti.read(sf.categories['labels']['prediction'],
+                                                                               np.uint8)[0])
+        if params.need_t2_mask:
+            to_eval['mask'] = self._get('mask', lambda: nifti.read(sf.categories['images']['t2'])[0] > 0)
+        return to_eval
+
+
+# ------------------------------------------------------------------------------------- actions
+class EvalCase:
+    def __init__(self, metric, hook, id_='') -> None:
+        self.result_history = {}
+        self.metric = metric
+        self.hook = hook
+        self.id_ = id_
+
+    def record(self, results, subject_name, id_):
+        self.hook.on_subject(results, subject_name, id_)
+        for k, v in results.items():
+            self.result_history.setdefault(k, []).append(v)
+
+    def do_eval(self, to_eval, subject_name, id_):
+        results = {}
+        self.metric(to_eval, results)
+        self.record(results, subject_name, id_)
+
+
+class EvalAction(abc.ABC):
+    def __init__(self) -> None:
+        self.load_params = None
+        self.prepare = None
+        self.eval_cases = []
+        self.id_ = ''
+
+    @abc.abstractmethod
+    def setup_eval(self, eval_data: EvalData):
+        pass
+
+    def start_eval(self):
+        print(self.id_ + ', '.join(c.id_ for c in self.eval_cases if c.id_ != ''))
+        for case in self.eval_cases:
+            case.hook.on_run_start(self.id_)
+
+    def eval_subject(self, sf, loader):
+        to_eval = loader.get_data(sf, self.load_params)
+        if self.prepare:
+            to_eval = self.prepare(to_eval)
+        for case in self.eval_cases:
+            case.do_eval(to_eval, sf.subject, self.id_)
+
+    def finish_eval(self):
+        for case in self.eval_cases:
+            case.hook.on_run_end(case.result_history, self.id_)
+
+
+def _minmax_for(min_max_dir, run_id, rescale):
+    if rescale != 'global':
+        return None
+    return read_min_max(os.path.join(min_max_dir, MINMAX_PLACEHOLDER.format(run_id)))
+
+
+class SaveMinMaxAction(EvalAction):
+    def __init__(self, min_max_dir: str) -> None:
+        super().__init__()
+        self.min_max_dir = min_max_dir
+        os.makedirs(min_max_dir, exist_ok=True)
+
+    def setup_eval(self, eval_data):
+        self.id_ = eval_data.id_
+        self.prepare = ev.MoveEntry(eval_data.confidence_entry, 'probabilities')
+        self.load_params = Loader.Params(eval_data.confidence_entry)
+        metric = ev.ComposeEvaluation([ev.LambdaEvaluation(lambda x: x.min(), ('probabilities',), 'min'),
+                                       ev.LambdaEvaluation(lambda x: x.max(), ('probabilities',), 'max')])
+        hook = WriteSummaryCsvHook(os.path.join(self.min_max_dir, MINMAX_PLACEHOLDER.format(self.id_)),
+                                   confidence_entry=eval_data.confidence_entry)
+        self.eval_cases = [EvalCase(metric, hook)]
+
+
+class EceAction(EvalAction):
+    def __init__(self, base_dir, details, rescale_confidence='subject', rescale_sigma='subject', min_max_dir=None):
+        super().__init__()
+        self.rescale_confidence, self.rescale_sigma, self.min_max_dir = rescale_confidence, rescale_sigma, min_max_dir
+        self.need_t2_mask = details == 'foreground'
+        self.out_dir = os.path.join(base_dir, ECE_FOREGROUND_NAME if self.need_t2_mask else ECE_NAME)
+        os.makedirs(self.out_dir, exist_ok=True)
+
+    def setup_eval(self, eval_data):
+        rescale = self.rescale_confidence if eval_data.confidence_entry == 'confidence' else self.rescale_sigma
+        mm = None if eval_data.confidence_entry == 'probabilities' else _minmax_for(self.min_max_dir, eval_data.id_, rescale)
+        self.prepare, self.id_ = ev.get_probability_preparation(eval_data.confidence_entry, eval_data.id_,
+                                                                self.rescale_confidence, self.rescale_sigma, mm)
+        self.load_params = Loader.Params(eval_data.confidence_entry, need_t2_mask=self.need_t2_mask)
+        metric = ev.ComposeEvaluation([ev.EceBinaryNumpy(threshold_range=None, with_mask=self.need_t2_mask),
+                                       ev.DiceNumpy(), ev.ConfusionMatrix()])
+        hook = WriteCsvHook(os.path.join(self.out_dir, ECE_PLACEHOLDER.format(self.id_)),
+                            entries=('ece', 'dice', 'tp', 'tn', 'fp', 'fn', 'n'))
+        self.eval_cases = [EvalCase(metric, hook)]
+
+
+class EceCalibrationAction(EvalAction):
+    def __init__(self, base_dir, details='', rescale_confidence='subject', rescale_sigma='subject', min_max_dir=None):
+        super().__init__()
+        self.need_mask = details == 'foreground'
+        self.rescale_confidence, self.rescale_sigma, self.min_max_dir = rescale_confidence, rescale_sigma, min_max_dir
+        self.out_dir = os.path.join(base_dir, CALIB_NAME)
+        os.makedirs(self.out_dir, exist_ok=True)
+
+    def setup_eval(self, eval_data):
+        rescale = self.rescale_confidence if eval_data.confidence_entry == 'confidence' else self.rescale_sigma
+        mm = None if eval_data.confidence_entry == 'probabilities' else _minmax_for(self.min_max_dir, eval_data.id_, rescale)
+        self.prepare, self.id_ = ev.get_probability_preparation(eval_data.confidence_entry, eval_data.id_,
+                                                                self.rescale_confidence, self.rescale_sigma, mm)
+        self.load_params = Loader.Params(eval_data.confidence_entry, need_t2_mask=self.need_mask)
+        metric = ev.ComposeEvaluation([ev.EceBinaryNumpy(threshold_range=None, return_bins=True,
+                                                         with_mask=self.need_mask), ev.DiceNumpy()])
+        hook = WriteBinsCsvHook(os.path.join(self.out_dir, CALIBRATION_PLACEHOLDER.format(self.id_)))
+        self.eval_cases = [EvalCase(metric, hook)]
+
+
+class CorrectionAction(EvalAction):
+    """11 CSV files (one per threshold) from one GPU pass per subject."""
+
+    def __init__(self, thresholds, base_dir, rescale_confidence='', rescale_sigma='global', min_max_dir=None):
+        super().__init__()
+        self.thresholds = list(thresholds)
+        self.rescale_confidence, self.rescale_sigma, self.min_max_dir = rescale_confidence, rescale_sigma, min_max_dir
+        self.out_dir = os.path.join(base_dir, UNCERTAINTY_NAME)
+        os.makedirs(self.out_dir, exist_ok=True)
+
+    def setup_eval(self, eval_data):
+        rescale = self.rescale_confidence if eval_data.confidence_entry == 'confidence' else self.rescale_sigma
+        mm = None if eval_data.confidence_entry == 'probabilities' else _minmax_for(self.min_max_dir, eval_data.id_, rescale)
+        self.prepare, self.id_ = ev.get_uncertainty_preparation(eval_data.confidence_entry, eval_data.id_,
+                                                                self.rescale_confidence, self.rescale_sigma, mm)
+        self.load_params = Loader.Params(eval_data.confidence_entry)
+        self.sweep = ev.UncertaintyAndCorrectionSweep(self.thresholds)
+        self.eval_cases = []
+        for thr in self.thresholds:
+            thr_str = '{:.2f}'.format(thr).replace('.', '')
+            hook = WriteCsvHook(os.path.join(self.out_dir, UNCERTAINTY_PLACEHOLDER.format(self.id_, thr_str)), None)
+            self.eval_cases.append(EvalCase(None, hook))
+
+    def eval_subject(self, sf, loader):
+        to_eval = loader.get_data(sf, self.load_params)
+        if self.prepare:
+            to_eval = self.prepare(to_eval)
+        results = {}
+        self.sweep(to_eval, results)
+        for thr, case in zip(self.thresholds, self.eval_cases):
+            case.record(results[thr], sf.subject, self.id_)
+
+
+def get_actions(action_names, min_max_dir, base_dir, ece_details):
+    """bin-eval/eval_uncertainty.py:226-244."""
+    actions = []
+    for name in action_names:
+        if name == 'minmax':
+            actions.append(SaveMinMaxAction(min_max_dir))
+        elif name == 'ece_dice':
+            actions.append(EceAction(base_dir, ece_details, 'subject', 'global', min_max_dir))
+        elif name == 'calib':
+            actions.append(EceCalibrationAction(base_dir, ece_details, 'subject', 'global', min_max_dir))
+        elif name == 'bnf_ue':
+            actions.append(CorrectionAction(ev.UE_THRESHOLDS, base_dir, 'subject', 'global', min_max_dir))
+    return actions
+
+
+def evaluate_runs(eval_data_list, action_names, base_dir, ece_details=''):
+    """The subject loop of bin-eval/eval_uncertainty.py:13-50 for already collected runs."""
+    actions = get_actions(action_names, os.path.join(base_dir, MINMAX_NAME), base_dir, ece_details)
+    for entry in eval_data_list:
+        for action in actions:
+            action.setup_eval(entry)
+        for action in actions:
+            action.start_eval()
+        for i, sf in enumerate(entry.subject_files):
+            print('[{}/{}] {}'.format(i + 1, len(entry.subject_files), sf.subject), end=' ', flush=True)
+            loader = Loader()
+            start = time.time()
+            for action in actions:
+                action.eval_subject(sf, loader)
+            print('({}s)'.format(time.time() - start))
+        for action in actions:
+            action.finish_eval()

@@ -1,0 +1,166 @@
+"""The reference's test / evaluation command lines, running on librcu_hip.
+
+Each function is the ``main`` of the same-named reference script (flags unchanged):
+    bin-dl/brats_test_default.py   -config_file / -config_id      (bin-dl/brats_test_default.py:22-61, 113-117)
+    bin-dl/brats_test_ensemble.py  -config_file                   (bin-dl/brats_test_ensemble.py:25-69)
+    bin-dl/brats_test_aleatoric.py -config_file                   (bin-dl/brats_test_aleatoric.py:24-48)
+    bin-dl/isic_test_default.py / isic_test_ensemble.py / isic_test_aleatoric.py
+    bin-eval/eval_uncertainty.py   --ds --ids --act               (bin-eval/eval_uncertainty.py:13-50, 248-288)
+Config ids map to the same YAML names under ``<project>/config``; paths inside the YAML stay relative to the
+working directory, as in the reference.  Datasets: see rcu_amd.data (volume directories instead of pymia HDF5).
+"""
+import logging
+import os
+
+import numpy as np
+
+from . import data as data_mod
+from . import evalrun
+from . import evaluation as ev
+from . import loops
+from . import management as mgt
+from . import nifti
+from . import steps
+
+PROJECT_DIR = os.environ.get('RCU_PROJECT_DIR', os.getcwd())
+CONFIG_DIR = os.path.join(PROJECT_DIR, 'config')
+
+
+def _config_path(dataset, config_id, default='baseline'):
+    if config_id in ('baseline', 'baseline_mc', 'center', 'center_mc'):
+        return os.path.join(CONFIG_DIR, 'test_{}_{}.yaml'.format(dataset, config_id))
+    if config_id in ('cv0', 'cv1', 'cv2', 'cv3', 'cv4'):
+        return os.path.join(CONFIG_DIR, 'baseline_cv', 'test_{}_baseline_cv{}.yaml'.format(dataset, config_id[-1]))
+    return os.path.join(CONFIG_DIR, 'test_{}_{}.yaml'.format(dataset, default))
+
+
+class EvalSubjectStep(loops.SubjectStep):
+    """Dice of the arg-max prediction (brats_test_default.py:63-77; isic_test_default.py:70-86)."""
+
+    def __init__(self, squeeze_labels=False, keep_prediction=False):
+        self.evaluate = ev.ComposeEvaluation([ev.DiceNumpy()])
+        self.squeeze_labels, self.keep_prediction = squeeze_labels, keep_prediction
+
+    def __call__(self, subject_context, task_context, context) -> None:
+        probabilities = subject_context.subject_data['probabilities']
+        prediction = np.argmax(probabilities, axis=-1)
+        if self.keep_prediction:
+            subject_context.subject_data['prediction'] = prediction
+        target = subject_context.subject_data['labels']
+        if self.squeeze_labels:
+            target = target.squeeze(-1)
+        results = {}
+        self.evaluate({'prediction': prediction, 'probabilities': probabilities, 'target': target}, results)
+        subject_context.metrics.update(results)
+
+
+class WriteHook(loops.TestLoopHook):
+    """``{subject}_probabilities|_prediction[|_sigma].nii.gz`` from a background thread
+    (brats_test_default.py:80-108; brats_test_aleatoric.py:76-110; isic_test_default.py:89-124)."""
+
+    def __init__(self, with_sigma=False, link_inputs=False, in_background=True):
+        self.with_sigma, self.link_inputs, self.in_background = with_sigma, link_inputs, in_background
+
+    def on_test_subject_end(self, subject_context, task_context, context):
+        if not isinstance(context, loops.TorchTestContext):
+            raise ValueError('expected type is "TorchTestContext" but object is of type "{}"'.format(type(context).__name__))
+        data = subject_context.subject_data
+        subject = data.get('subject', subject_context.subject_index)
+        nifti.write_subject(context.test_dir, subject, data['probabilities'], data.get('properties'),
+                            data['sigma'] if self.with_sigma else None, in_background=self.in_background)
+        if self.link_inputs:   # ISIC: symlink image and label next to the outputs
+            files = context.test_data.dataset.get_files_by_id(subject_context.subject_index)
+            for key in ('label_paths', 'image_paths'):
+                src = os.path.abspath(files[key])
+                dst = os.path.join(context.test_dir, os.path.basename(src))
+                if not os.path.lexists(dst):
+                    os.symlink(src, dst)
+
+    def on_termination(self, context):
+        nifti.join_all()
+
+
+class PrepareSubjectStep(steps.BatchStep):
+    def __call__(self, batch_context, task_context, context) -> None:
+        batch_context.output['labels'] = batch_context.input['labels'].unsqueeze(1)   # isic_test_default.py:62-66
+
+
+def _default_steps(context):
+    if hasattr(context.config.others, 'mc'):
+        return [steps.McPredictStep(context.config.others.mc), steps.MultiPredictionSummary()]
+    return [steps.SegmentationPredictStep(do_probs=True)]
+
+
+def _hooks(write_hook):
+    return loops.ReducedComposeTestLoopHook([loops.ConsoleTestLogHook(), loops.WriteTestMetricsCsvHook('metrics.csv'),
+                                             write_hook])
+
+
+def _load_additional_models(context):
+    """others.model_dir (list) + others.test_at -> extra ensemble members (brats_test_ensemble.py:37-57)."""
+    others = context.config.others
+    if not hasattr(others, 'model_dir') or not hasattr(others, 'test_at'):
+        raise ValueError('missing "model_dir" or "test_at" entry in the configuration (others)')
+    model_dirs = [others.model_dir] if isinstance(others.model_dir, str) else list(others.model_dir)
+    models = []
+    for i, model_dir in enumerate(model_dirs):
+        logging.info('load additional model [{}/{}] {}'.format(i + 1, len(model_dirs), os.path.basename(model_dir)))
+        mf = mgt.ModelFiles.from_model_dir(model_dir)
+        model = mgt.load_model_from_parameters(mf.model_path())
+        mgt.load_checkpoint(mgt.find_checkpoint_file(mf.weight_checkpoint_dir, others.test_at), model)
+        models.append(model.to(context.device).eval())
+    return models
+
+
+def _run(context, dataset, test_steps, write_hook, entries, device=None):
+    if dataset == 'brats':
+        build = data_mod.BuildData(build_dataset=data_mod.BuildVolumeDataset())
+        test = loops.Test(test_steps, [loops.ExtractSubjectInfoStep(), EvalSubjectStep()], loops.SubjectAssembler(),
+                          entries=entries)
+    else:
+        build = data_mod.BuildData(build_dataset=data_mod.BuildIsicDataset())
+        test = loops.Test(test_steps + [PrepareSubjectStep()], [EvalSubjectStep(squeeze_labels=True, keep_prediction=True)],
+                          loops.Subject2dAssembler(), entries=entries)
+    test(context, build, hook=_hooks(write_hook))
+    return context
+
+
+def test_default(dataset, config_file=None, config_id=None, device='cuda'):
+    context = loops.TorchTestContext(device)
+    context.load_from_config(config_file or _config_path(dataset, config_id))
+    entries = ('probabilities',) if dataset == 'brats' else None
+    return _run(context, dataset, _default_steps(context), WriteHook(link_inputs=dataset == 'isic'), entries)
+
+
+def test_ensemble(dataset, config_file=None, device='cuda'):
+    context = loops.TorchTestContext(device)
+    context.load_from_config(config_file or os.path.join(CONFIG_DIR, 'test_{}_ensemble.yaml'.format(dataset)))
+    members = _load_additional_models(context)
+    test_steps = [steps.EnsemblePredictionStep(members), steps.MultiPredictionSummary()]
+    return _run(context, dataset, test_steps, WriteHook(link_inputs=dataset == 'isic'), None)
+
+
+def test_aleatoric(dataset, config_file=None, device='cuda'):
+    context = loops.TorchTestContext(device)
+    context.load_from_config(config_file or os.path.join(CONFIG_DIR, 'test_{}_aleatoric.yaml'.format(dataset)))
+    return _run(context, dataset, [steps.AleatoricPredictStep()], WriteHook(with_sigma=True, link_inputs=dataset == 'isic'),
+                None)
+
+
+test_default.__test__ = test_ensemble.__test__ = test_aleatoric.__test__ = False   # not pytest tests
+
+
+def eval_uncertainty(dataset, run_dirs: dict, ground_truth_dir, base_dir, actions=('minmax', 'ece_dice', 'calib', 'bnf_ue'),
+                     expected_subjects=None):
+    """``run_dirs``: run id (baseline, baseline_mc, ..., aleatoric) -> prediction directory.  BraTS evaluates
+    inside the T2 brain mask (``ece_details='foreground'``), ISIC on all pixels (eval_uncertainty.py:19-26)."""
+    if dataset not in ('brats', 'isic'):
+        raise ValueError('chose "brats" or "isic" as dataset')
+    if dataset == 'brats':
+        gts = evalrun.collect_brats_ground_truth(ground_truth_dir)
+        details = 'foreground'
+    else:
+        raise NotImplementedError('ISIC evaluation reads png ground truth; only the BraTS NIfTI tree is wired up')
+    entries = [evalrun.get_eval_data(run_id, path, gts, expected_subjects) for run_id, path in run_dirs.items()]
+    evalrun.evaluate_runs(entries, list(actions), base_dir, details)
+    return entries

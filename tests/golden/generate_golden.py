@@ -508,12 +508,68 @@ def g11_fullsize_digest():
          state_keys=np.array(keys), sha256_here=np.array(sha))
 
 
+def g12_eval_csv():
+    """CSV text the reference's eval hooks (rechun/eval/hook.py:28-116) write for fixed result dicts."""
+    import tempfile
+    import rechun.eval.hook as ref_hook
+    import common.evalutation.numpyfunctions as ref_np
+    rng = np.random.RandomState(22)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        # WriteCsvHook with explicit entries (EceAction) and with entries=None + list-valued results
+        h1 = ref_hook.WriteCsvHook(os.path.join(tmp, 'a.csv'), entries=('ece', 'dice', 'tp', 'tn', 'fp', 'fn', 'n'))
+        h2 = ref_hook.WriteCsvHook(os.path.join(tmp, 'b.csv'), None)
+        h3 = ref_hook.WriteBinsCsvHook(os.path.join(tmp, 'c.csv'))
+        h4 = ref_hook.WriteSummaryCsvHook(os.path.join(tmp, 'd.csv'), confidence_entry='sigma')
+        hist = {}
+        subjects = ['Brats18_A_1', 'Brats18_B_1', 'Brats18_C_1']
+        inputs = []
+        for i, sub in enumerate(subjects):
+            p = rng.rand(4, 8, 8).astype(np.float32)
+            if i == 1:
+                p = p * 0.4          # leaves the upper bins empty
+            t = (rng.rand(4, 8, 8) < p).astype(np.uint8)
+            bins = {}
+            ece = ref_np.ece_binary(np.stack([1 - p, p], -1), t, out_bins=bins)
+            res1 = {'ece': ece, 'dice': 0.5 + 0.1 * i, 'tp': 10 + i, 'tn': 200 - i, 'fp': 3 * i, 'fn': 7, 'n': 256,
+                    'extra': 'ignored'}
+            res2 = {'tpu': 3 + i, 'values': np.array([0.25, 0.5 * i]), 'flag': bool(i % 2), 'twelve': list(range(12))}
+            res3 = dict(bins)
+            res3['ece'] = ece
+            res3['dice'] = 0.25 * i
+            h1.on_subject(dict(res1), sub, 'baseline_mc')
+            h2.on_subject(dict(res2), sub, 'baseline_mc')
+            h3.on_subject(res3, sub, 'baseline_mc')
+            for k, v in (('min', float(p.min())), ('max', float(p.max()))):
+                hist.setdefault(k, []).append(v)
+            inputs.append((p, t))
+        for h in (h1, h2, h3):
+            h.on_run_end({}, 'baseline_mc')
+        h4.on_run_end(hist, 'aleatoric')
+        for name in 'abcd':
+            with open(os.path.join(tmp, name + '.csv'), newline='') as f:
+                out['csv_' + name] = np.array(f.read())
+    for i, (p, t) in enumerate(inputs):
+        out['p_{}'.format(i)] = p
+        out['t_{}'.format(i)] = t
+    out['subjects'] = np.array(subjects)
+    out['hist_min'] = np.array(hist['min'])
+    out['hist_max'] = np.array(hist['max'])
+    import rechun.directories as ref_dirs
+    out['names'] = np.array([ref_dirs.ECE_FOREGROUND_NAME, ref_dirs.ECE_NAME, ref_dirs.CALIB_NAME, ref_dirs.UNCERTAINTY_NAME,
+                             ref_dirs.MINMAX_NAME, ref_dirs.CALIBRATION_PLACEHOLDER, ref_dirs.UNCERTAINTY_PLACEHOLDER,
+                             ref_dirs.ECE_PLACEHOLDER, ref_dirs.MINMAX_PLACEHOLDER])
+    save('g12_eval_csv', **out)
+
+
 def main():
     install_reference()
     torch.set_num_threads(4)
     torch.set_grad_enabled(False)
     for fn in (g1_unet_eval, g2_unet_mc, g3_unet_center, g4_unet_sigma, g5_unet_isic, g6_mc_summary,
-               g7_mc_step_end2end, g8_ece, g9_uncertainty, g10_prep, g11_fullsize_digest):
+               g7_mc_step_end2end, g8_ece, g9_uncertainty, g10_prep, g11_fullsize_digest, g12_eval_csv):
+        if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
+            continue
         fn()
 
 

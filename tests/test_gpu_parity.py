@@ -401,3 +401,63 @@ def test_prediction_and_foreground(dev):
     pred, fg = steps.prediction_and_foreground(p)
     assert np.array_equal(pred.cpu().numpy(), np.argmax(p.permute(0, 2, 3, 1).cpu().numpy(), -1).astype(np.uint8))
     assert torch.equal(fg, p[:, 1])
+
+
+# ---------------------------------------------------------------------------------- eval driver (8f-1, 8f-2)
+def test_eval_driver_csvs_against_oracle(dev, tmp_path):
+    """The four actions of bin-eval/eval_uncertainty.py on a tiny synthetic BraTS-style tree: NIfTI files in,
+    the reference's CSV files out; numbers checked against the numpy oracle."""
+    import csv
+    from oracle import calib_oracle as co
+    from rcu_amd import evalrun, nifti
+    rng = np.random.RandomState(5)
+    gt_root, run_dir, base = tmp_path / 'gt' / 'HGG', tmp_path / 'pred', tmp_path / 'eval'
+    run_dir.mkdir(parents=True)
+    truth = {}
+    for sub in ('Brats18_A_1', 'Brats18_B_1'):
+        (gt_root / sub).mkdir(parents=True)
+        t2 = (rng.rand(6, 16, 16) * (rng.rand(6, 16, 16) > 0.3)).astype(np.float32)
+        seg = (rng.rand(6, 16, 16) < 0.3).astype(np.uint8) * rng.randint(1, 5, (6, 16, 16)).astype(np.uint8)
+        p = rng.rand(6, 16, 16).astype(np.float32)
+        pred = (p > 0.5).astype(np.uint8)
+        for mod, arr in (('flair', t2), ('t1', t2), ('t2', t2), ('t1ce', t2), ('seg', seg)):
+            nifti.write(str(gt_root / sub / '{}_{}.nii.gz'.format(sub, mod)), arr)
+        nifti.write(str(run_dir / '{}_probabilities.nii.gz'.format(sub)), p)
+        nifti.write(str(run_dir / '{}_prediction.nii.gz'.format(sub)), pred)
+        truth[sub] = (p, pred, (seg > 0).astype(np.uint8), t2 > 0)
+    gts = evalrun.collect_brats_ground_truth(str(tmp_path / 'gt'))
+    entry = evalrun.get_eval_data('baseline_mc', str(run_dir), gts, expected_subjects=list(truth))
+    evalrun.evaluate_runs([entry], ['minmax', 'ece_dice', 'calib', 'bnf_ue'], str(base), 'foreground')
+
+    def rows(path):
+        with open(path, newline='') as f:
+            return list(csv.DictReader(f))
+
+    ece_rows = rows(str(base / 'ece_foreground' / 'eval_ece_baseline_mc.csv'))
+    assert [r['subject_name'] for r in ece_rows] == sorted(truth)
+    for r in ece_rows:
+        p, pred, tgt, mask = truth[r['subject_name']]
+        assert abs(float(r['ece']) - co.ece_binary(np.stack([1 - p, p], -1), tgt, mask=mask)) < 1e-12
+        tp, tn, fp, fn, n = co.confusion_counts(pred, tgt)
+        assert [int(r[k]) for k in ('tp', 'tn', 'fp', 'fn', 'n')] == [tp, tn, fp, fn, n]
+        assert abs(float(r['dice']) - co.dice_from_counts(tp, fp, fn)) < 1e-15
+    cal = rows(str(base / 'calibration' / 'eval_calibration_baseline_mc.csv'))
+    for r in cal:
+        p, pred, tgt, mask = truth[r['subject_name']]
+        cnt, _, _ = co.calibration_histogram(*co.select_foreground(np.stack([1 - p, p], -1), tgt, mask))
+        assert [int(r['bins_count_{:02d}'.format(b)]) for b in range(10)] == list(cnt)
+    mm = evalrun.read_min_max(str(base / 'minmax' / 'eval_summary_minmax_baseline_mc.csv'))
+    # written as str(np.float32) like the reference does: shortest float32 repr
+    assert mm == (float(str(min(v[0].min() for v in truth.values()))), float(str(max(v[0].max() for v in truth.values()))))
+    for thr in co.UE_THRESHOLDS:
+        name = 'eval_uncertainty_baseline_mc_th{}.csv'.format('{:.2f}'.format(thr).replace('.', ''))
+        for r in rows(str(base / 'uncertainty' / name)):
+            p, pred, tgt, _ = truth[r['subject_name']]
+            unc = co.normalised_entropy(co.add_background_probability(p))
+            ref = co.correction_metrics(co.uncertainty_counts(pred.astype(bool), tgt.astype(bool), unc > thr))
+            near = int(np.sum(np.abs(unc - thr) < 1e-6))        # device logf vs numpy log: last-ulp ties only
+            for k in ('tp', 'tn', 'fp', 'fn'):
+                assert int(r[k]) == ref[k]
+            for k in ('tpu', 'tnu', 'fpu', 'fnu'):
+                assert abs(int(r[k]) - ref[k]) <= near
+            assert set(r) >= {'corrected_dice', 'corrected_accuracy', 'corrected_add_dice', 'dice_benefit_correct'}

@@ -1,0 +1,133 @@
+"""End-to-end runs of the drop-in test scripts on the GPU: YAML config -> model dir + checkpoint ->
+volume dataset -> Test loop -> NIfTI + metrics.csv, then the evaluation driver on what was written."""
+import csv
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_script_surface_cpu import BRATS_MC_YAML
+
+pytestmark = pytest.mark.gpu
+PARAMS = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
+
+
+def _setup(tmp_path, mc=None, sigma=False, seeds=(20,)):
+    from oracle import unet_oracle as uo
+    from rcu_amd import data as data_mod
+    from rcu_amd import management as mgt
+    from rcu_amd import nifti
+    rng = np.random.RandomState(3)
+    params = dict(PARAMS, sigma_out=True) if sigma else dict(PARAMS)
+    vols = {}
+    for i in range(2):
+        name = 'Brats18_T{}_1'.format(i)
+        images = rng.randn(6 + i, 32, 32, 4).astype(np.float32)
+        labels = (rng.rand(6 + i, 32, 32) < 0.3).astype(np.uint8)
+        props = nifti.ImageProperties((32, 32, 6 + i), (1.0, -2.0, 3.0), (1.0, 1.0, 2.5))
+        data_mod.write_volume(str(tmp_path / 'ds'), name, images, labels, props)
+        vols[name] = (images, labels, props)
+    states, dirs = [], []
+    for seed in seeds:
+        st = uo.synthetic_state(seed, **params)
+        mf = mgt.ModelFiles(str(tmp_path / 'train_{}'.format(seed)), 'm{}'.format(seed))
+        mgt.save_model(mf, 'unet', params, st, epoch=2)
+        states.append(st)
+        dirs.append(mf.model_dir)
+    split = str(tmp_path / 'split.json')
+    with open(split, 'w') as f:
+        json.dump({'train': [], 'valid': [], 'test': list(vols)}, f)
+    text = BRATS_MC_YAML.format(test_dir=str(tmp_path / 'out'), model_dir=dirs[0], split=split, dataset=str(tmp_path / 'ds'))
+    text = text.replace('batch_size: 32', 'batch_size: 4')
+    if mc is None:
+        text = text.replace('  others:\n    mc: 20\n', '  others: {}\n')
+    else:
+        text = text.replace('mc: 20', 'mc: {}'.format(mc))
+    if len(dirs) > 1:
+        extra = ''.join('    - {}\n'.format(d) for d in dirs[1:])
+        text = text.replace('  others: {}\n', '  others:\n    model_dir:\n{}    test_at: best\n'.format(extra))
+    cfg_path = str(tmp_path / 'test_cfg.yaml')
+    with open(cfg_path, 'w') as f:
+        f.write(text)
+    return cfg_path, vols, states, params
+
+
+def _outputs(context, vols):
+    from rcu_amd import nifti
+    out = {}
+    for name in vols:
+        p, props = nifti.read(os.path.join(context.test_dir, name + '_probabilities.nii.gz'))
+        pred, _ = nifti.read(os.path.join(context.test_dir, name + '_prediction.nii.gz'))
+        out[name] = (p, pred, props)
+    return out
+
+
+def test_brats_default_deterministic_and_mc(tmp_path):
+    from oracle import unet_oracle as uo
+    from oracle import calib_oracle as co
+    from rcu_amd import scripts
+    cfg_path, vols, states, params = _setup(tmp_path)
+    ctx = scripts.test_default('brats', cfg_path, None)
+    assert os.path.basename(ctx.test_dir).endswith('_brats_test_baseline_mc')
+    for f in ('config.yaml', 'log.txt', 'metrics.csv', 'split.json'):
+        assert os.path.exists(os.path.join(ctx.test_dir, f)), f
+    outs = _outputs(ctx, vols)
+    rows = list(csv.DictReader(open(os.path.join(ctx.test_dir, 'metrics.csv'))))
+    assert [r['subject'] for r in rows] == sorted(vols)
+    for name, (images, labels, props) in vols.items():
+        x = torch.from_numpy(images).permute(0, 3, 1, 2)
+        ref = torch.softmax(uo.unet_forward(states[0], x, None, **params), 1)[:, 1].numpy()
+        p, pred, rprops = outs[name]
+        assert p.dtype == np.float32 and pred.dtype == np.uint8 and rprops == props
+        assert np.max(np.abs(p - ref)) < 1e-4
+        agree = np.mean(pred == (ref > 0.5))
+        assert agree > 0.999
+        tp, tn, fp, fn, n = co.confusion_counts(pred, labels)
+        row = [r for r in rows if r['subject'] == name][0]
+        assert abs(float(row['dice']) - co.dice_from_counts(tp, fp, fn)) < 1e-12
+    # MC-dropout config: same script, others.mc set; probabilities stay close to the deterministic pass
+    cfg_mc, vols2, _, _ = _setup(tmp_path / 'mc', mc=6)
+    ctx2 = scripts.test_default('brats', cfg_mc, None)
+    outs2 = _outputs(ctx2, vols2)
+    for name in vols2:
+        assert np.all((outs2[name][0] >= 0) & (outs2[name][0] <= 1))
+        assert 0 < np.max(np.abs(outs2[name][0] - outs[name][0])) < 0.5
+
+
+def test_brats_ensemble_and_aleatoric_then_eval(tmp_path):
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import nifti, scripts
+    cfg_path, vols, states, params = _setup(tmp_path / 'ens', seeds=(20, 21, 22))
+    ctx = scripts.test_ensemble('brats', cfg_path)
+    outs = _outputs(ctx, vols)
+    for name, (images, _, _) in vols.items():
+        x = torch.from_numpy(images).permute(0, 3, 1, 2)
+        multi = so.ensemble_probabilities([lambda xx, m, st=st: uo.unet_forward(st, xx, m, **params) for st in states], x)
+        ref = multi.mean(0)[:, 1].numpy()
+        assert np.max(np.abs(outs[name][0] - ref)) < 1e-4
+    cfg_al, vols_al, st_al, params_al = _setup(tmp_path / 'al', sigma=True)
+    ctx_al = scripts.test_aleatoric('brats', cfg_al)
+    for name, (images, _, _) in vols_al.items():
+        x = torch.from_numpy(images).permute(0, 3, 1, 2)
+        logits, sigma = uo.unet_forward(st_al[0], x, None, **params_al)
+        pred = logits.argmax(1)
+        ref_sigma = torch.gather(sigma.abs(), 1, pred[:, None])[:, 0].numpy()
+        got = nifti.read(os.path.join(ctx_al.test_dir, name + '_sigma.nii.gz'))[0]
+        close = np.abs(got - ref_sigma) < 1e-4
+        assert close.mean() > 0.999      # voxels whose two classes tie within fp32 noise may pick the other sigma
+    # evaluation driver on the ensemble run: needs a BraTS-style ground-truth tree
+    gt = tmp_path / 'gt' / 'HGG'
+    for name, (images, labels, props) in vols.items():
+        (gt / name).mkdir(parents=True)
+        for mod, arr in (('flair', images[..., 0]), ('t1', images[..., 1]), ('t2', images[..., 2]), ('t1ce', images[..., 3]),
+                         ('seg', labels * 4)):
+            nifti.write(str(gt / name / '{}_{}.nii.gz'.format(name, mod)), arr, props)
+    scripts.eval_uncertainty('brats', {'ensemble': ctx.test_dir}, str(tmp_path / 'gt'), str(tmp_path / 'eval'),
+                             expected_subjects=list(vols))
+    assert len(glob.glob(str(tmp_path / 'eval' / 'uncertainty' / 'eval_uncertainty_ensemble_th*.csv'))) == 11
+    rows = list(csv.DictReader(open(str(tmp_path / 'eval' / 'ece_foreground' / 'eval_ece_ensemble.csv'))))
+    assert [r['subject_name'] for r in rows] == sorted(vols) and all(0 <= float(r['ece']) <= 1 for r in rows)

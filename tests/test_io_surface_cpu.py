@@ -1,0 +1,121 @@
+"""NIfTI-1 codec and evaluation CSV surface -- CPU only."""
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from rcu_amd import evalrun, nifti
+
+
+def test_nifti_round_trip_lossless_and_geometry(tmp_path):
+    rng = np.random.RandomState(0)
+    props = nifti.ImageProperties((12, 10, 6), origin=(-90.5, 126.0, -72.0), spacing=(1.0, 1.5, 2.0),
+                                  direction=(1, 0, 0, 0, 1, 0, 0, 0, 1))
+    for dtype in (np.float32, np.uint8, np.int16, np.float64):
+        a = (rng.rand(6, 10, 12) * 200).astype(dtype)
+        path = str(tmp_path / 'v_{}.nii.gz'.format(np.dtype(dtype).name))
+        nifti.write(path, a, props)
+        b, p2 = nifti.read(path)
+        assert b.dtype == dtype and np.array_equal(a, b)        # lossless (the only property the path needs)
+        assert p2 == props
+    # rotated direction (90 degrees about z) survives too
+    rot = nifti.ImageProperties((12, 10, 6), (1, 2, 3), (0.5, 0.5, 3.0), (0, -1, 0, 1, 0, 0, 0, 0, 1))
+    nifti.write(str(tmp_path / 'r.nii'), np.zeros((6, 10, 12), np.uint8), rot)
+    assert nifti.read(str(tmp_path / 'r.nii'))[1] == rot
+    # 2-D (ISIC) images and the pixel-type cast of sitk.ReadImage(path, sitkUInt8)
+    img = rng.rand(16, 24).astype(np.float32)
+    nifti.write(str(tmp_path / 'i.nii.gz'), img)
+    back, p = nifti.read(str(tmp_path / 'i.nii.gz'))
+    assert np.array_equal(back, img) and p.size == (24, 16)
+    assert nifti.read(str(tmp_path / 'i.nii.gz'), np.uint8)[0].dtype == np.uint8
+
+
+def test_nifti_header_follows_the_spec(tmp_path):
+    a = np.arange(2 * 3 * 4, dtype=np.float32).reshape(2, 3, 4)
+    path = str(tmp_path / 'h.nii.gz')
+    nifti.write(path, a, nifti.ImageProperties((4, 3, 2), (10, 20, 30), (2, 3, 4)))
+    raw = gzip.open(path, 'rb').read()
+    assert struct.unpack_from('<i', raw, 0)[0] == 348 and raw[344:348] == b'n+1\x00'
+    assert struct.unpack_from('<8h', raw, 40) == (3, 4, 3, 2, 1, 1, 1, 1)
+    assert struct.unpack_from('<2h', raw, 70) == (16, 32)                      # float32, 32 bits
+    assert struct.unpack_from('<f', raw, 108)[0] == 352.0
+    assert struct.unpack_from('<4f', raw, 76)[1:] == (2.0, 3.0, 4.0)
+    # ITK writes LPS geometry into NIfTI's RAS frame: x and y flip sign
+    assert struct.unpack_from('<4f', raw, 280) == (-2.0, 0.0, 0.0, -10.0)
+    assert struct.unpack_from('<4f', raw, 296) == (0.0, -3.0, 0.0, -20.0)
+    assert struct.unpack_from('<4f', raw, 312) == (0.0, 0.0, 4.0, 30.0)
+    assert np.array_equal(np.frombuffer(raw, np.float32, 24, 352), a.reshape(-1))   # x fastest
+    with pytest.raises(ValueError):
+        nifti.write(path, a, nifti.ImageProperties((2, 3, 4)))
+    with pytest.raises(ValueError):
+        nifti.write(path, a.astype(np.complex64))
+
+
+def test_write_subject_files(tmp_path):
+    rng = np.random.RandomState(1)
+    p = rng.rand(4, 8, 8, 2).astype(np.float32)
+    sigma = rng.rand(4, 8, 8, 2).astype(np.float32)
+    nifti.write_subject(str(tmp_path), 'subj', p, None, sigma)
+    nifti.join_all()
+    fg = nifti.read(str(tmp_path / 'subj_probabilities.nii.gz'))[0]
+    pred = nifti.read(str(tmp_path / 'subj_prediction.nii.gz'))[0]
+    sg = nifti.read(str(tmp_path / 'subj_sigma.nii.gz'))[0]
+    assert np.array_equal(fg, p[..., 1]) and pred.dtype == np.uint8
+    assert np.array_equal(pred, np.argmax(p, -1))
+    assert np.array_equal(sg, np.where(pred == 1, sigma[..., 1], sigma[..., 0]))
+
+
+def test_eval_csv_hooks_match_reference_files(golden, tmp_path):
+    from oracle import calib_oracle as co
+    g = golden('g12_eval_csv')
+    h1 = evalrun.WriteCsvHook(str(tmp_path / 'a.csv'), entries=('ece', 'dice', 'tp', 'tn', 'fp', 'fn', 'n'))
+    h2 = evalrun.WriteCsvHook(str(tmp_path / 'b.csv'), None)
+    h3 = evalrun.WriteBinsCsvHook(str(tmp_path / 'c.csv'))
+    h4 = evalrun.WriteSummaryCsvHook(str(tmp_path / 'd.csv'), confidence_entry='sigma')
+    composed = evalrun.ReducedComposeEvalHook([h3])
+    for i, sub in enumerate(g['subjects']):
+        p, t = g['p_{}'.format(i)], g['t_{}'.format(i)]
+        bins = {}
+        ece = co.ece_binary(np.stack([1 - p, p], -1), t, out_bins=bins)   # oracle here: the hooks are what is tested
+        h1.on_subject({'ece': ece, 'dice': 0.5 + 0.1 * i, 'tp': 10 + i, 'tn': 200 - i, 'fp': 3 * i, 'fn': 7, 'n': 256,
+                       'extra': 'ignored'}, str(sub), 'baseline_mc')
+        h2.on_subject({'tpu': 3 + i, 'values': np.array([0.25, 0.5 * i]), 'flag': bool(i % 2),
+                       'twelve': list(range(12))}, str(sub), 'baseline_mc')
+        res3 = dict(bins)
+        res3['ece'] = ece
+        res3['dice'] = 0.25 * i
+        composed.on_subject(res3, str(sub), 'baseline_mc')
+    for h in (h1, h2):
+        h.on_run_end({}, 'baseline_mc')
+    composed.on_run_end({}, 'baseline_mc')
+    composed.on_run_start('baseline_mc')     # not overridden by the member: a no-op
+    h4.on_run_end({'min': list(g['hist_min']), 'max': list(g['hist_max'])}, 'aleatoric')
+    for name in 'abcd':
+        with open(str(tmp_path / (name + '.csv')), newline='') as f:
+            assert f.read() == str(g['csv_' + name]), name
+    assert evalrun.read_min_max(str(tmp_path / 'd.csv')) == (float(g['hist_min'].min()), float(g['hist_max'].max()))
+    assert [evalrun.ECE_FOREGROUND_NAME, evalrun.ECE_NAME, evalrun.CALIB_NAME, evalrun.UNCERTAINTY_NAME,
+            evalrun.MINMAX_NAME, evalrun.CALIBRATION_PLACEHOLDER, evalrun.UNCERTAINTY_PLACEHOLDER,
+            evalrun.ECE_PLACEHOLDER, evalrun.MINMAX_PLACEHOLDER] == list(g['names'])
+
+
+def test_prediction_collection(tmp_path):
+    run = tmp_path / 'run'
+    gt = tmp_path / 'gt' / 'HGG'
+    for sub in ('Brats18_X_1', 'Brats18_Y_1'):
+        (gt / sub).mkdir(parents=True)
+        for mod in ('flair', 't1', 't2', 't1ce', 'seg'):
+            nifti.write(str(gt / sub / '{}_{}.nii.gz'.format(sub, mod)), np.zeros((2, 4, 4), np.uint8))
+        run.mkdir(exist_ok=True)
+        for pf in ('prediction', 'probabilities'):
+            nifti.write(str(run / '{}_{}.nii.gz'.format(sub, pf)), np.zeros((2, 4, 4), np.uint8))
+    gts = evalrun.collect_brats_ground_truth(str(tmp_path / 'gt'))
+    entry = evalrun.get_eval_data('baseline_mc', str(run), gts, expected_subjects=['Brats18_X_1', 'Brats18_Y_1'])
+    assert [sf.subject for sf in entry.subject_files] == ['Brats18_X_1', 'Brats18_Y_1']
+    sf = entry.subject_files[0]
+    assert set(sf.categories) == {'labels', 'misc', 'images'} and set(sf.categories['labels']) == {'prediction', 'gt'}
+    os.remove(str(run / 'Brats18_Y_1_prediction.nii.gz'))
+    with pytest.raises(AssertionError):
+        evalrun.collect_predictions(str(run), ['prediction', 'probabilities'], ['labels', 'misc'])

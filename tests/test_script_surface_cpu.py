@@ -1,0 +1,227 @@
+"""Config / model-directory / loop / dataset surface of the test scripts -- CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rcu_amd import config as cfg
+from rcu_amd import data as data_mod
+from rcu_amd import loops
+from rcu_amd import management as mgt
+
+# same schema and idioms as the reference's config/test_brats_baseline_mc.yaml (bare-string, {type: params} and
+# parameter-less entries, free-form `others`, meta section)
+BRATS_MC_YAML = """
+config:
+  test_name: brats_test_baseline_mc
+  test_dir: {test_dir}
+  model_dir: {model_dir}
+  split: '{split}'
+  seed: 20
+  test_at: best
+  others:
+    mc: 20
+  test_data:
+    batch_size: 32
+    dataset: {dataset}
+    direct_extractor:
+    - names
+    - data:
+        categories:
+        - labels
+    - files
+    - properties
+    - subject
+    direct_transform:
+    - squeeze:
+        entries:
+        - labels
+    extractor:
+    - indexing:
+        do_pickle: true
+    - shape
+    - data
+    indexing:
+      slice: {{}}
+    num_workers: 0
+    shuffle: false
+    transform:
+    - permute:
+        entries:
+        - images
+        permutation:
+        - 2
+        - 0
+        - 1
+    - squeeze:
+        entries:
+        - images
+meta:
+  type: test-config
+  version: 0
+"""
+
+
+def _write_cfg(tmp_path, **kw):
+    path = str(tmp_path / 'test_brats_baseline_mc.yaml')
+    defaults = dict(test_dir=str(tmp_path / 'out'), model_dir=str(tmp_path / 'train' / 'model_x'), split='',
+                    dataset=str(tmp_path / 'ds'))
+    defaults.update(kw)
+    with open(path, 'w') as f:
+        f.write(BRATS_MC_YAML.format(**defaults))
+    return path
+
+
+def test_yaml_config_loads_and_round_trips(tmp_path):
+    c = cfg.load(_write_cfg(tmp_path))
+    assert c.test_name == 'brats_test_baseline_mc' and c.seed == 20 and c.test_at == 'best'
+    assert c.others.mc == 20 and hasattr(c.others, 'mc') and not hasattr(c.others, 'model_dir')
+    td = c.test_data
+    assert td.batch_size == 32 and td.shuffle is False and td.num_workers == 0
+    assert td.indexing.type == 'slice' and td.indexing.params == {}
+    assert [p.type for p in td.extractor] == ['indexing', 'shape', 'data'] and td.extractor[0].params == {'do_pickle': True}
+    assert [p.type for p in td.direct_extractor] == ['names', 'data', 'files', 'properties', 'subject']
+    assert td.transform[0].type == 'permute' and td.transform[0].params['permutation'] == [2, 0, 1]
+    out = str(tmp_path / 'copy' / 'config.yaml')
+    cfg.save(out, c)
+    c2 = cfg.load(out)
+    assert c2.to_dict() == c.to_dict()
+    assert c2.to_dict()['test_data']['direct_extractor'][0] == 'names'      # parameter-less entries stay bare strings
+    cfg.save(str(tmp_path / 'c.json'), c)
+    assert cfg.load(str(tmp_path / 'c.json')).to_dict() == c.to_dict()
+    with open(str(tmp_path / 'train.yaml'), 'w') as f:
+        f.write('config: {}\nmeta: {type: train-config, version: 0}\n')
+    with pytest.raises(ValueError):
+        cfg.load(str(tmp_path / 'train.yaml'))
+
+
+def test_model_directory_and_checkpoint_resolution(tmp_path):
+    mf = mgt.ModelFiles.from_model_dir(str(tmp_path / 'train' / 'model_190101-120000') + '/')
+    assert mf.identifier == '190101-120000' and mf.model_path().endswith('model_190101-120000/model.json')
+    assert os.path.basename(mf.build_checkpoint_path(7)) == 'checkpoint_ep007.pth'
+    assert os.path.basename(mf.build_checkpoint_path(7, is_best=True)) == 'checkpoint_ep007-best.pth'
+    os.makedirs(mf.weight_checkpoint_dir)
+    for name in ('checkpoint_ep003.pth', 'checkpoint_ep012.pth', 'checkpoint_ep009-best.pth'):
+        open(os.path.join(mf.weight_checkpoint_dir, name), 'w').close()
+    d = mf.weight_checkpoint_dir
+    assert os.path.basename(mgt.find_checkpoint_file(d, 'best')) == 'checkpoint_ep009-best.pth'
+    assert os.path.basename(mgt.find_checkpoint_file(d, 'last')) == 'checkpoint_ep012.pth'
+    assert os.path.basename(mgt.find_checkpoint_file(d, 3)) == 'checkpoint_ep003.pth'
+    assert mgt.find_checkpoint_file(d, 5) is None
+    with pytest.raises(ValueError):
+        mgt.find_checkpoint_file(d, 'newest')
+    with pytest.raises(AttributeError):
+        mgt.find_checkpoint_file(d, 1.5)
+    # model.json + checkpoint round trip through the HIP-backed UNet mirror (state_dict keys are the reference's)
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=4, dropout=0.05)
+    from rcu_amd.model import UNet
+    src = UNet(**params)
+    mf2 = mgt.ModelFiles(str(tmp_path / 'train2'), 'm')
+    ckpt = mgt.save_model(mf2, 'unet', params, {'module.' + k: v for k, v in src.state_dict().items()}, epoch=4)
+    assert ckpt == mgt.find_checkpoint_file(mf2.weight_checkpoint_dir, 'best')
+    model = mgt.load_model_from_parameters(mf2.model_path())
+    rest = mgt.load_checkpoint(ckpt, model)
+    assert rest['epoch'] == 4 and 'state_dict' not in rest
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), src.state_dict().values()))
+    with pytest.raises(ValueError):
+        mgt.load_checkpoint(str(tmp_path / 'missing.pth'), model)
+
+
+def _make_dataset(root, n_subjects=2, depth=5):
+    rng = np.random.RandomState(0)
+    vols = {}
+    for i in range(n_subjects):
+        name = 'Brats18_S{}_1'.format(i)
+        images = rng.randn(depth + i, 16, 16, 4).astype(np.float32)
+        labels = (rng.rand(depth + i, 16, 16) < 0.2).astype(np.uint8)
+        data_mod.write_volume(str(root), name, images, labels)
+        vols[name] = (images, labels)
+    return vols
+
+
+def test_volume_dataset_slices_and_assembler(tmp_path):
+    vols = _make_dataset(tmp_path / 'ds')
+    c = cfg.load(_write_cfg(tmp_path))
+    c.test_data.batch_size = 4
+    built = data_mod.BuildData(data_mod.BuildVolumeDataset())(c.test_data)
+    assert len(built.dataset) == 5 + 6 and built.nb_batches == 3
+    asm = loops.SubjectAssembler()
+    ready_order = []
+    for b, batch in enumerate(built.loader):
+        assert batch['images'].shape[1:] == (4, 16, 16) and batch['images'].dtype == torch.float32   # permuted to C,H,W
+        out = {'probabilities': batch['images'].permute(0, 2, 3, 1).numpy()}                           # channel-last
+        asm.add_batch(out, batch, last_batch=b == built.nb_batches - 1)
+        for si in sorted(asm.subjects_ready):
+            vol = asm.get_assembled_subject(si)
+            info = built.dataset.direct_extract(si)
+            ready_order.append(info['subject'])
+            assert np.array_equal(vol['probabilities'], vols[info['subject']][0])
+            assert np.array_equal(info['labels'], vols[info['subject']][1])
+            assert info['properties'].size == (16, 16, vol['probabilities'].shape[0])
+    assert ready_order == ['Brats18_S0_1', 'Brats18_S1_1'] and not asm.volumes
+    sub = data_mod.VolumeDataset(str(tmp_path / 'ds'), subject_subset=['Brats18_S1_1'])
+    assert sub.subjects == ['Brats18_S1_1'] and len(sub) == 6
+    with pytest.raises(ValueError):
+        data_mod.VolumeDataset(str(tmp_path / 'brats18_test_reduced_norm.h5'))
+
+
+def test_isic_folder_dataset(tmp_path):
+    from PIL import Image
+    img_dir, lab_dir = tmp_path / 'ISIC-2017_Test_v2_Data', tmp_path / 'ISIC-2017_Test_v2_Part1_GroundTruth'
+    img_dir.mkdir()
+    lab_dir.mkdir()
+    rng = np.random.RandomState(1)
+    for k in (3, 1):
+        id_ = 'ISIC_000000{}'.format(k)
+        Image.fromarray(rng.randint(0, 255, (32, 48, 3)).astype(np.uint8)).save(str(img_dir / (id_ + '.jpg')))
+        Image.fromarray(((rng.rand(32, 48) > 0.5) * 255).astype(np.uint8)).save(str(lab_dir / (id_ + '_segmentation.png')))
+    tf = data_mod.get_transform([cfg.Parameter('rescale', entries=['images', 'labels'], lower=0, upper=1),
+                                 cfg.Parameter('permute', entries=['images', 'labels'], permutation=[2, 0, 1]),
+                                 cfg.Parameter('squeeze')])
+    ds = data_mod.IsicDataset(str(tmp_path / 'ISIC-2017_Test_v2'), tf)
+    assert ds.ids == ['ISIC_0000001', 'ISIC_0000003']
+    s = ds[0]
+    assert s['images'].shape == (3, 32, 48) and s['labels'].shape == (32, 48)
+    assert 0.0 <= s['images'].min() and s['images'].max() <= 1.0 and set(np.unique(s['labels'])) <= {0.0, 1.0}
+    asm = loops.Subject2dAssembler()
+    batch = data_mod.CollateDict()([ds[0], ds[1]])
+    asm.add_batch({'probabilities': np.zeros((2, 32, 48, 2), np.float32)}, batch)
+    assert asm.subjects_ready == {'ISIC_0000001', 'ISIC_0000003'}
+    assert asm.get_assembled_subject('ISIC_0000003')['probabilities'].shape == (32, 48, 2)
+    with pytest.raises(ValueError):
+        data_mod.get_transform(cfg.Parameter('relabel'))
+
+
+def test_hook_composition_and_metrics_csv(tmp_path):
+    calls = []
+
+    class A(loops.TestLoopHook):
+        def on_test_start(self, task_context, context):
+            calls.append('A.start')
+
+    class B(loops.TestLoopHook):
+        def on_test_start(self, task_context, context):
+            calls.append('B.start')
+
+        def on_termination(self, context):
+            calls.append('B.term')
+
+    h = loops.ReducedComposeTestLoopHook([A(), B()])
+    h.on_test_start(None, None)
+    h.on_termination(None)
+    h.on_startup()
+    assert calls == ['A.start', 'B.start', 'B.term']
+    ctx = loops.TorchTestContext('cpu')
+    ctx.test_dir = str(tmp_path)
+    tc = loops.TaskContext(0, None, None)
+    tc.history = loops.History()
+    w = loops.WriteTestMetricsCsvHook('metrics.csv')
+    w.on_test_start(tc, ctx)
+    for name, dice in (('s1', 0.5), ('s2', 0.75)):
+        sc = loops.SubjectContext(0, {'subject': name})
+        sc.metrics = {'dice': dice, 'acc': 1.0}
+        tc.history.add(sc.metrics, 'subject_metrics')
+        w.on_test_subject_end(sc, tc, ctx)
+    w.on_test_end(tc, ctx)
+    assert open(str(tmp_path / 'metrics.csv')).read().splitlines() == ['subject,acc,dice', 's1,1.0,0.5', 's2,1.0,0.75']
