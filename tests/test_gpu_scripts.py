@@ -131,3 +131,74 @@ def test_brats_ensemble_and_aleatoric_then_eval(tmp_path):
     assert len(glob.glob(str(tmp_path / 'eval' / 'uncertainty' / 'eval_uncertainty_ensemble_th*.csv'))) == 11
     rows = list(csv.DictReader(open(str(tmp_path / 'eval' / 'ece_foreground' / 'eval_ece_ensemble.csv'))))
     assert [r['subject_name'] for r in rows] == sorted(vols) and all(0 <= float(r['ece']) <= 1 for r in rows)
+
+
+ISIC_MC_YAML = """
+config:
+  test_name: isic_test_baseline_mc
+  test_dir: {test_dir}
+  model_dir: {model_dir}
+  split: ''
+  seed: 20
+  test_at: best
+  others:
+    mc: 2
+  test_data:
+    batch_size: 1
+    dataset: {dataset}
+    num_workers: 1
+    shuffle: false
+    transform:
+    - rescale:
+        entries:
+        - images
+        - labels
+        lower: 0
+        upper: 1
+    - permute:
+        entries:
+        - images
+        - labels
+        permutation:
+        - 2
+        - 0
+        - 1
+    - squeeze
+meta:
+  type: test-config
+  version: 0
+"""
+
+
+def test_isic_default_script_mc2(tmp_path):
+    """BASELINE.json configs[0]: ISIC baseline_mc, 1 x 3 x 256 x 256, T = 2, through the isic_test_default surface."""
+    from PIL import Image
+    from oracle import unet_oracle as uo
+    from rcu_amd import management as mgt
+    from rcu_amd import nifti, scripts
+    params = dict(nb_classes=2, in_channels=3, depth=4, start_filters=32, dropout=0.05)
+    prefix = tmp_path / 'isic_small' / 'ISIC-2017_Test_v2'
+    img_dir, lab_dir = str(prefix) + '_Data', str(prefix) + '_Part1_GroundTruth'
+    os.makedirs(img_dir)
+    os.makedirs(lab_dir)
+    rng = np.random.RandomState(4)
+    ids = ['ISIC_0000010', 'ISIC_0000011']
+    for id_ in ids:
+        Image.fromarray(rng.randint(0, 255, (256, 256, 3)).astype(np.uint8)).save(os.path.join(img_dir, id_ + '.jpg'))
+        Image.fromarray(((rng.rand(256, 256) > 0.6) * 255).astype(np.uint8)).save(os.path.join(lab_dir, id_ + '_segmentation.png'))
+    st = uo.synthetic_state(20, **params)
+    mf = mgt.ModelFiles(str(tmp_path / 'train'), 'isic')
+    mgt.save_model(mf, 'unet', params, st)
+    cfg_path = str(tmp_path / 'test_isic_baseline_mc.yaml')
+    with open(cfg_path, 'w') as f:
+        f.write(ISIC_MC_YAML.format(test_dir=str(tmp_path / 'out'), model_dir=mf.model_dir, dataset=str(prefix)))
+    ctx = scripts.test_default('isic', cfg_path, None)
+    rows = list(csv.DictReader(open(os.path.join(ctx.test_dir, 'metrics.csv'))))
+    assert [r['subject'] for r in rows] == ids and all(0 <= float(r['dice']) <= 1 for r in rows)
+    for id_ in ids:
+        p = nifti.read(os.path.join(ctx.test_dir, id_ + '_probabilities.nii.gz'))[0]
+        pred = nifti.read(os.path.join(ctx.test_dir, id_ + '_prediction.nii.gz'))[0]
+        assert p.shape == (256, 256) and pred.shape == (256, 256) and p.dtype == np.float32
+        assert np.array_equal(pred, (p > 0.5).astype(np.uint8)) or np.mean(pred == (p > 0.5)) > 0.9999
+        assert os.path.islink(os.path.join(ctx.test_dir, id_ + '.jpg'))
+        assert os.path.islink(os.path.join(ctx.test_dir, id_ + '_segmentation.png'))
