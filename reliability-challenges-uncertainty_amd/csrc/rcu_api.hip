@@ -106,7 +106,7 @@ static size_t conv_tile_floats(const ConvConfigInfo& ci)
 static int pick_config(const ConvLayer& L)
 {
     if (L.upsample) {   // sub-pixel form; L.H x L.W is the OUTPUT grid, tiles run over the low-res input grid
-        if (L.coutp <= 32) return CONV_CFG_UP_T8x16_N32;
+        if (L.coutp <= 32) return ((L.H / 2) % 16 == 0 && (L.W / 2) % 16 == 0) ? CONV_CFG_UP_T16x16_N32 : CONV_CFG_UP_T8x16_N32;
         if (L.H == 24 && L.W == 16) return CONV_CFG_UP_S2T12x8_N64;
         return CONV_CFG_UP_T8x16_N64;
     }
@@ -115,7 +115,7 @@ static int pick_config(const ConvLayer& L)
         if (L.H == 12 && L.W == 8) return CONV_CFG_S2T12x8_N64;
         return CONV_CFG_T8x16_N64;
     }
-    return CONV_CFG_T8x16_N32;
+    return (L.H % 16 == 0 && L.W % 16 == 0) ? CONV_CFG_T16x16_N32 : CONV_CFG_T8x16_N32;
 }
 
 static void add_unit(rcu_unet* h, const std::string& prefix, int cin1, int c1p, int cin2, int c2p, int cout, int H, int W,

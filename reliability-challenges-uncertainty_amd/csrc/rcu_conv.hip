@@ -561,6 +561,8 @@ using Cfg3 = ConvTile<2, 12, 8, 64, 16, 2, 2, 9, 0>;
 using Cfg4 = ConvTile<1, 8, 16, 64, 16, 2, 2, 4, 1>;
 using Cfg5 = ConvTile<1, 8, 16, 32, 16, 4, 1, 4, 1>;
 using Cfg6 = ConvTile<2, 12, 8, 64, 8, 2, 2, 4, 1>;
+using Cfg7 = ConvTile<1, 16, 16, 32, 8, 4, 1, 9, 1>;
+using Cfg8 = ConvTile<1, 16, 16, 32, 8, 4, 1, 4, 1>;
 
 static const ConvConfigInfo kInfo[CONV_CFG_COUNT] = {
     {Cfg0::TS, Cfg0::TH, Cfg0::TW, Cfg0::BN, Cfg0::KC, Cfg0::TAPS, "conv3x3_igemm<T8x16,N64,K8,db>"},
@@ -570,6 +572,8 @@ static const ConvConfigInfo kInfo[CONV_CFG_COUNT] = {
     {Cfg4::TS, Cfg4::TH, Cfg4::TW, Cfg4::BN, Cfg4::KC, Cfg4::TAPS, "upconv_subpixel_igemm<T8x16,N64,K16,db>"},
     {Cfg5::TS, Cfg5::TH, Cfg5::TW, Cfg5::BN, Cfg5::KC, Cfg5::TAPS, "upconv_subpixel_igemm<T8x16,N32,K16,db>"},
     {Cfg6::TS, Cfg6::TH, Cfg6::TW, Cfg6::BN, Cfg6::KC, Cfg6::TAPS, "upconv_subpixel_igemm<S2T12x8,N64,K8,db>"},
+    {Cfg7::TS, Cfg7::TH, Cfg7::TW, Cfg7::BN, Cfg7::KC, Cfg7::TAPS, "conv3x3_igemm<T16x16,N32,K8,db>"},
+    {Cfg8::TS, Cfg8::TH, Cfg8::TW, Cfg8::BN, Cfg8::KC, Cfg8::TAPS, "upconv_subpixel_igemm<T16x16,N32,K8,db>"},
 };
 
 const ConvConfigInfo& conv_config_info(int cfg) { return kInfo[cfg]; }
@@ -614,6 +618,8 @@ hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream)
         case CONV_CFG_UP_T8x16_N64: return launch_cfg<Cfg4>(a, stream);
         case CONV_CFG_UP_T8x16_N32: return launch_cfg<Cfg5>(a, stream);
         case CONV_CFG_UP_S2T12x8_N64: return launch_cfg<Cfg6>(a, stream);
+        case CONV_CFG_T16x16_N32: return launch_cfg<Cfg7>(a, stream);
+        case CONV_CFG_UP_T16x16_N32: return launch_cfg<Cfg8>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }

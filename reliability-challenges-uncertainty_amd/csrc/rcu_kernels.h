@@ -41,6 +41,8 @@ enum ConvConfig {
     CONV_CFG_UP_T8x16_N64 = 4,       // sub-pixel up-conv (2x2 taps on the low-res grid), 64 couts, chunks of 16
     CONV_CFG_UP_T8x16_N32 = 5,       // sub-pixel up-conv, 32 couts
     CONV_CFG_UP_S2T12x8_N64 = 6,     // sub-pixel up-conv out of the 12x8 bottom level, chunks of 8
+    CONV_CFG_T16x16_N32 = 7,         // 16x16-pixel tile, 32 couts: halves the weight staging per MFMA of the 32-channel layers
+    CONV_CFG_UP_T16x16_N32 = 8,      // sub-pixel up-conv, 32 couts, 16x16 low-res tile
     CONV_CFG_COUNT
 };
 
