@@ -136,10 +136,12 @@ def main():
     torch.manual_seed(seed + rank)              # dropout masks: independent streams per rank
 
     def one_step(k):
-        return runner.step(x, k)
+        # N>1: the reduce runs on RCCL's stream and the root finalises on a side stream, so the ranks'
+        # compute streams do not meet at every volume (rcu_amd.distributed.ShardedMcRunner.step_async)
+        return runner.step_async(x, k)
 
     for k in range(args.warmup):
-        one_step(k)
+        one_step(k).result()
     # per-kernel HIP events for this rank's forwards inside the timed region
     my_forwards = sum(len(runner.jobs_of(k, rank)) for k in range(args.warmup, args.warmup + args.steps))
     model.profile_begin(HEIGHT, WIDTH, SLICES, my_forwards)
@@ -149,9 +151,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = None
-    for k in range(args.warmup, args.warmup + args.steps):
-        out = one_step(k)
+    pending = [one_step(k) for k in range(args.warmup, args.warmup + args.steps)]
+    out = [p.result() for p in pending][-1]
+    runner.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -172,20 +174,25 @@ def main():
     layers = model.layer_table(HEIGHT, WIDTH, SLICES)
     per_kernel = {}
     for L, ms in zip(layers, slot_ms[1:1 + len(layers)]):
-        e = per_kernel.setdefault(L['kernel'], dict(ms=0.0, flops=0.0, launches=0))
+        e = per_kernel.setdefault(L['kernel'], dict(ms=0.0, flops=0.0, issued=0.0, launches=0))
         e['ms'] += ms
         e['flops'] += L['flops_per_slice'] * SLICES * forwards
+        e['issued'] += L['mfma_flops_per_slice'] * SLICES * forwards
         e['launches'] += forwards
     dominant = max(per_kernel, key=lambda k_: per_kernel[k_]['ms'])
     d = per_kernel[dominant]
     conv_ms = sum(e['ms'] for e in per_kernel.values())
     conv_flops = sum(e['flops'] for e in per_kernel.values())
+    conv_issued = sum(e['issued'] for e in per_kernel.values())
     roofline = dict(bound='mfma', kernel=dominant, achieved=d['flops'] / (d['ms'] * 1e-3) / 1e12,
                     peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=d['flops'] / (d['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                     traffic=None, launches=d['launches'], avg_launch_ms=d['ms'] / max(d['launches'], 1),
                     flops_per_launch=d['flops'] / max(d['launches'], 1),
+                    # flops the kernel actually issues to the MFMA pipe (padded channels, whole tiles) / peak:
+                    mfma_pipe_frac=d['issued'] / (d['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                     all_conv_kernels=dict(achieved=conv_flops / (conv_ms * 1e-3) / 1e12,
                                           frac=conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                          mfma_pipe_frac=conv_issued / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                           ms_per_forward=conv_ms / max(forwards, 1)),
                     other_ms_per_forward=dict(input_relayout=slot_ms[0] / max(forwards, 1),
                                               head_softmax_accumulate=slot_ms[-1] / max(forwards, 1)),

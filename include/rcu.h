@@ -109,7 +109,9 @@ typedef struct rcu_layer_info {
     char kernel[64];
     int32_t cin, cout, height, width;
     int32_t upsample, pooled, dual_source;
-    double flops_per_slice;
+    double flops_per_slice;       /* algorithmic: 2*cin*cout*9*H*W of the layer as the reference computes it */
+    double mfma_flops_per_slice;  /* what the kernel issues to the MFMA pipe (padded channels; 4 of 9 taps for the
+                                     sub-pixel up-convolution; whole tiles) */
 } rcu_layer_info;
 int rcu_unet_num_layers(const rcu_unet* h);
 int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info* out);

@@ -34,7 +34,7 @@ class UnetDesc(Structure):
 class LayerInfo(Structure):
     _fields_ = [('name', c_char * 96), ('kernel', c_char * 64), ('cin', c_int32), ('cout', c_int32),
                 ('height', c_int32), ('width', c_int32), ('upsample', c_int32), ('pooled', c_int32),
-                ('dual_source', c_int32), ('flops_per_slice', c_double)]
+                ('dual_source', c_int32), ('flops_per_slice', c_double), ('mfma_flops_per_slice', c_double)]
 
 
 class EceResult(Structure):

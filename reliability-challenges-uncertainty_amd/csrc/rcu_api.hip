@@ -546,6 +546,15 @@ extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info*
     out->height = L.H; out->width = L.W;
     out->upsample = L.upsample; out->pooled = L.t_pool >= 0; out->dual_source = L.t_src2 >= 0;
     out->flops_per_slice = 2.0 * out->cin * out->cout * 9.0 * L.H * L.W;
+    {
+        // executed on the matrix pipe: padded K and N, full tiles, 4 taps per output pixel for the sub-pixel form
+        const ConvConfigInfo ci = conv_config_info(L.cfg);
+        const int lh = L.upsample ? L.H / 2 : L.H, lw = L.upsample ? L.W / 2 : L.W;   // grid the tiles walk
+        const double tiles = (double)((lh + ci.TH - 1) / ci.TH) * ((lw + ci.TW - 1) / ci.TW);
+        const double px = tiles * ci.TH * ci.TW * (L.upsample ? 4.0 : 1.0);
+        const double ncols = (double)L.NT * ci.BN;
+        out->mfma_flops_per_slice = 2.0 * (L.c1p + L.c2p) * ncols * ci.TAPS * px;
+    }
     return RCU_OK;
 }
 

@@ -26,7 +26,6 @@
 // fragment reads of step s+1 are issued before the MFMAs of step s.  Exact fp32 (MFMA f32 == fmaf chain).
 #include "rcu_kernels.h"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace rcu {
@@ -555,283 +554,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_stream(const ConvArgs a, co
 #undef RCU_STAGE_P
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// Loader-wave variant of the streaming kernel.  Measured on gfx950 (tools/microbench/issue_bench.hip):
-// a buffer/global load blocks the issuing wave for ~150 cycles and a ds_write_b128 for ~60, during
-// which that wave issues no MFMA -- but a co-resident MFMA wave is NOT slowed by another wave's loads
-// or LDS writes.  So the staging moves out of the MFMA waves: a workgroup is 4 MFMA waves (one per
-// SIMD) + 2 loader waves.  Loaders bring chunk i+2 into registers and write chunk i+1 into the other
-// LDS buffer while the MFMA waves multiply chunk i (only ds_read + MFMA in their stream); one
-// workgroup barrier per chunk orders the two roles.
-// ------------------------------------------------------------------------------------------------
-template <class T, int LW>
-struct WsGeom {
-    static constexpr int LTHREADS = 64 * LW;                               // LW loader waves
-    static constexpr int NA = (T::A_UNITS + LTHREADS - 1) / LTHREADS;
-    static constexpr int NW = T::W_UNITS_PAD / LTHREADS;
-    static_assert(T::W_UNITS_PAD % LTHREADS == 0, "weight tile padding");
-};
-
-struct TileCoord {
-    int wtile, ntile, pa, pb, n0, y0, x0;
-};
-
-template <class T>
-__device__ __forceinline__ TileCoord tile_coord(const ConvArgs& a, int item)
-{
-    TileCoord c;
-    c.wtile = item % a.NTW_total;
-    c.ntile = c.wtile % a.NT;
-    const int cls = c.wtile / a.NT;
-    c.pa = cls >> 1;
-    c.pb = cls & 1;
-    int mtile = item / a.NTW_total;
-    const int tx = mtile % a.tiles_x;
-    mtile /= a.tiles_x;
-    const int ty = mtile % a.tiles_y;
-    const int sg = mtile / a.tiles_y;
-    c.n0 = sg * T::TS;
-    c.y0 = ty * T::TH;
-    c.x0 = tx * T::TW;
-    return c;
-}
-
-template <class T, int LW>
-__global__ __launch_bounds__(256 + 64 * LW, 2) void conv_igemm_ws(const ConvArgs a, const int total_items, const int pace)
-{
-    static_assert(T::DB, "needs the double-buffered LDS layout");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KC = T::KC, KCP = T::KCP, MT = T::MT, NTW = T::NTW;
-    constexpr bool SUBPIXEL = (T::TAPS == 4);
-    constexpr int STEPS = T::TAPS * (KC / 8);
-    using G = WsGeom<T, LW>;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int nchunks = (a.C1 + a.C2) / KC;   // >= 2 (checked by the launcher)
-    const int stride = (int)gridDim.x;
-    int item = blockIdx.x;
-
-    if (wave >= 4) {
-        // =============================================================== loader waves
-        const int lt = tid - 256;   // 0..127
-        int adst[G::NA];
-#pragma unroll
-        for (int j = 0; j < G::NA; ++j) {
-            const int u = lt + j * G::LTHREADS;
-            const int q = u / (KC / 4), sub = u % (KC / 4);
-            const int s = q / ((T::TH + 2) * (T::TW + 2));
-            const int rem = q % ((T::TH + 2) * (T::TW + 2));
-            const int qdst = (s * (T::TH + 2) + rem / (T::TW + 2)) * T::PITCH + rem % (T::TW + 2);
-            adst[j] = u < T::A_UNITS ? qdst * KCP + sub * 4 : T::A_DUMP + (lt & 15) * 4;
-        }
-        const size_t wchunk_stride = (size_t)a.NTW_total * T::W_UNITS_PAD;
-        const f32x4* const wbase = reinterpret_cast<const f32x4*>(a.wpack) + lt;
-
-        uint32_t off1[G::NA], off2[G::NA];
-        float keep[G::NA];
-        int wtile = 0;
-        auto plan = [&](int it_item) {
-            const TileCoord c = tile_coord<T>(a, it_item);
-            wtile = c.wtile;
-#pragma unroll
-            for (int j = 0; j < G::NA; ++j) {
-                const int u = lt + j * G::LTHREADS;
-                const int q = u / (KC / 4), sub = u % (KC / 4);
-                const int s = q / ((T::TH + 2) * (T::TW + 2));
-                const int rem = q % ((T::TH + 2) * (T::TW + 2));
-                const int yy = rem / (T::TW + 2), xx = rem % (T::TW + 2);
-                const int n = c.n0 + s, gy = c.y0 + yy - 1, gx = c.x0 + xx - 1;
-                const bool ok = u < T::A_UNITS && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                const uint32_t pix = ok ? (uint32_t)((n * a.H + gy) * a.W + gx) : 0u;
-                keep[j] = ok ? 1.f : 0.f;
-                off1[j] = ok ? pix * (uint32_t)a.C1 + sub * 4 : 0u;
-                off2[j] = ok ? pix * (uint32_t)a.C2 + sub * 4 : 0u;
-            }
-        };
-        f32x4 ra[G::NA];
-        float rkeep[G::NA];
-        const f32x4* wsrc = wbase;   // weight tile of the chunk whose halo sits in ra
-        const int lw = __builtin_amdgcn_readfirstlane(lt >> 6);
-        // halo: global -> registers (zeroing of the padding needs the VALU); weights: global -> LDS by DMA, the packed
-        // tile is already the LDS image so every wave instruction moves one contiguous KiB
-#define RCU_WS_LOAD(kc_)                                                                           \
-        {                                                                                              \
-            const int c0_ = (kc_) * KC;                                                                \
-            const bool first_ = c0_ < a.C1;                                                            \
-            const float* sp_ = first_ ? a.src1 + c0_ : a.src2 + (c0_ - a.C1);                          \
-            _Pragma("unroll") for (int j = 0; j < G::NA; ++j) {                                        \
-                ra[j] = *reinterpret_cast<const f32x4*>(sp_ + (first_ ? off1[j] : off2[j]));           \
-                rkeep[j] = keep[j];                                                                    \
-            }                                                                                          \
-            wsrc = wbase + (size_t)wtile * T::W_UNITS_PAD + (size_t)(kc_) * wchunk_stride;             \
-        }
-#define RCU_WS_STORE(buf_)                                                                         \
-        {                                                                                              \
-            float* const As_ = smem + (buf_) * T::BUF_FLOATS;                                          \
-            _Pragma("unroll") for (int j = 0; j < G::NW; ++j)                                          \
-                __builtin_amdgcn_global_load_lds(                                                      \
-                    (const __attribute__((address_space(1))) void*)(wsrc + j * G::LTHREADS),           \
-                    (__attribute__((address_space(3))) void*)(As_ + T::A_REGION + (lw * 64 + j * G::LTHREADS) * 4), \
-                    16, 0, 0);                                                                         \
-            _Pragma("unroll") for (int j = 0; j < G::NA; ++j)                                          \
-                *reinterpret_cast<f32x4*>(As_ + adst[j]) = ra[j] * rkeep[j];                           \
-        }
-        plan(item);
-        RCU_WS_LOAD(0);
-        RCU_WS_STORE(0);
-        RCU_WS_LOAD(1);
-        __syncthreads();   // barrier 0: chunk 0 visible
-        int it = 0;
-        for (;;) {
-            const bool has_next = item + stride < total_items;
-            for (int kc = 0; kc < nchunks; ++kc, ++it) {
-                // registers hold chunk it+1 (if any): publish it, then fetch chunk it+2
-                const bool have1 = (kc + 1 < nchunks) || has_next;
-                if (have1) RCU_WS_STORE((it + 1) & 1);
-                if (kc + 2 < nchunks) {
-                    RCU_WS_LOAD(kc + 2);
-                } else if (has_next) {
-                    if (kc + 2 == nchunks) plan(item + stride);   // first chunk of the next tile
-                    RCU_WS_LOAD(kc + 2 - nchunks);
-                }
-                __syncthreads();
-            }
-            if (!has_next) break;
-            item += stride;
-        }
-#undef RCU_WS_LOAD
-#undef RCU_WS_STORE
-        return;
-    }
-
-    // =================================================================== MFMA waves
-    const int wn = wave % T::WN;
-    const int wm = wave / T::WN;
-    const int m = lane & 31, half = lane >> 5;
-    int b_addr[NTW];
-#pragma unroll
-    for (int ni = 0; ni < NTW; ++ni) b_addr[ni] = ((wn * NTW + ni) * 32 + m) * KCP + half * 4;
-    __syncthreads();   // barrier 0
-    int it = 0;
-    for (;;) {
-        const TileCoord cur = tile_coord<T>(a, item);
-        const bool has_next = item + stride < total_items;
-        int a_addr[MT];
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int blk = wm * MT + mi;
-            const int s = blk / T::BPS, rb = blk % T::BPS;
-            const int by = rb / (T::TW / 8), bx = rb % (T::TW / 8);
-            const int pixel = (s * (T::TH + 2) + 4 * by + (m >> 3) + cur.pa) * T::PITCH + 8 * bx + (m & 7) + cur.pb;
-            a_addr[mi] = pixel * KCP + half * 4;
-        }
-        f32x16 acc[MT][NTW];
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NTW; ++ni)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
-
-        for (int kc = 0; kc < nchunks; ++kc, ++it) {
-            const float* const Ac = smem + (it & 1) * T::BUF_FLOATS;
-            const float* const Wc = Ac + T::A_REGION;
-            f32x4 av[2][MT], bv[2][NTW];
-#define RCU_FRAGS(step_, buf_)                                                                              \
-            {                                                                                                   \
-                constexpr int tap_ = (step_) / (KC / 8), k8_ = (step_) % (KC / 8);                              \
-                constexpr int tapA_ = ((tap_ / T::TAPW) * T::PITCH + (tap_ % T::TAPW)) * KCP + k8_ * 8;         \
-                constexpr int tapB_ = tap_ * T::BN * KCP + k8_ * 8;                                             \
-                _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                                               \
-                    av[buf_][mi] = *reinterpret_cast<const f32x4*>(Ac + a_addr[mi] + tapA_);                    \
-                _Pragma("unroll") for (int ni = 0; ni < NTW; ++ni)                                              \
-                    bv[buf_][ni] = *reinterpret_cast<const f32x4*>(Wc + b_addr[ni] + tapB_);                    \
-            }
-            RCU_FRAGS(0, 0);
-            static_for<0, STEPS>([&](auto step_c) {
-                constexpr int step = decltype(step_c)::value;
-                constexpr int cb = step & 1;
-                if constexpr (step + 1 < STEPS) RCU_FRAGS(step + 1, cb ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NTW; ++ni) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][mi].x, bv[cb][ni].x, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][mi].y, bv[cb][ni].y, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][mi].z, bv[cb][ni].z, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][mi].w, bv[cb][ni].w, acc[mi][ni], 0, 0, 0);
-                    }
-            });
-#undef RCU_FRAGS
-            __syncthreads();
-        }
-
-        // ---- epilogue (registers only)
-        {
-            constexpr int OS = SUBPIXEL ? 2 : 1;
-            const int OH = a.H * OS, OW = a.W * OS;
-            const bool full_tile = (cur.y0 + T::TH <= a.H) && (cur.x0 + T::TW <= a.W) && (cur.n0 + T::TS <= a.N);
-            const size_t row_stride = (size_t)OW * a.CoutP * OS, col_stride = (size_t)a.CoutP * OS;
-            const int Hp = a.H >> 1, Wp = a.W >> 1;
-#pragma unroll
-            for (int ni = 0; ni < NTW; ++ni) {
-                const int co = cur.ntile * T::BN + (wn * NTW + ni) * 32 + m;
-                if (co >= a.CoutP) continue;
-                const float al = a.alpha[co], bb = a.betab[co], be = a.beta[co];
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi) {
-                    const int blk = wm * MT + mi;
-                    const int s = blk / T::BPS, rb = blk % T::BPS;
-                    const int by = rb / (T::TW / 8), bx = rb % (T::TW / 8);
-                    const int n = cur.n0 + s;
-                    if (n >= a.N) continue;
-                    float mk = 1.f;
-                    if (a.mask != nullptr && co < a.Cmask) mk = a.mask[(size_t)n * a.Cmask + co];
-                    if (a.mask2 != nullptr && co >= a.Csplit && co - a.Csplit < a.Cmask2)
-                        mk = a.mask2[(size_t)n * a.Cmask2 + (co - a.Csplit)];
-                    const float scale = al * mk, shift = bb * mk + be;
-                    const int yb = cur.y0 + 4 * by, xb = cur.x0 + 8 * bx + 4 * half;
-                    float v[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float t = acc[mi][ni][i] * scale + shift;
-                        v[i] = a.relu ? fmaxf(t, 0.f) : t;
-                    }
-                    float* const obase =
-                        a.out + ((size_t)(n * OH + yb * OS + cur.pa) * OW + xb * OS + cur.pb) * a.CoutP + co;
-                    if (full_tile) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            if (yb + (i >> 2) < a.H && xb + (i & 3) < a.W)
-                                obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];
-                    }
-                    if (!SUBPIXEL && a.pooled != nullptr) {
-#pragma unroll
-                        for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-                            for (int pc = 0; pc < 2; ++pc) {
-                                const int i0 = (2 * pr) * 4 + 2 * pc;
-                                const float mx = fmaxf(fmaxf(v[i0], v[i0 + 1]), fmaxf(v[i0 + 4], v[i0 + 5]));
-                                const int py = (yb >> 1) + pr, px = (xb >> 1) + pc;
-                                if (py < Hp && px < Wp)
-                                    a.pooled[((size_t)(n * Hp + py) * Wp + px) * a.CoutP + co] = mx;
-                            }
-                    }
-                }
-            }
-        }
-        if (!has_next) break;
-        item += stride;
-    }
-}
-
 using Cfg0 = ConvTile<1, 8, 16, 64, 8, 2, 2, 9, 1>;
 using Cfg1 = ConvTile<1, 8, 16, 32, 8, 4, 1, 9, 1>;
 using Cfg2 = ConvTile<1, 8, 16, 32, 8, 4, 1, 9, 0>;
@@ -871,19 +593,6 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t stream)
             }
             // two resident workgroups per CU, each streaming through its share of the tiles
             const unsigned grid = items < 2u * 256u ? items : 2u * 256u;
-            static const int ws_waves = [] { const char* e = getenv("RCU_CONV_WS"); return e == nullptr ? 0 : atoi(e); }();
-            if (ws_waves == 2 || ws_waves == 4) {
-                const void* fn = ws_waves == 2 ? reinterpret_cast<const void*>(&conv_igemm_ws<T, 2>)
-                                               : reinterpret_cast<const void*>(&conv_igemm_ws<T, 4>);
-                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-                if (e != hipSuccess) return e;
-                static const int pace = [] { const char* e = getenv("RCU_WS_PACE"); return e == nullptr ? 0 : atoi(e); }();
-                if (ws_waves == 2)
-                    hipLaunchKernelGGL((conv_igemm_ws<T, 2>), dim3(grid), dim3(384), T::LDS_BYTES, stream, a, (int)items, pace);
-                else
-                    hipLaunchKernelGGL((conv_igemm_ws<T, 4>), dim3(grid), dim3(512), T::LDS_BYTES, stream, a, (int)items, pace);
-                return hipGetLastError();
-            }
             hipLaunchKernelGGL(conv_igemm_stream<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);
             return hipGetLastError();
         }

@@ -11,8 +11,13 @@ but the one that computed them), so there is exactly one collective per volume.
 
 Job j of step k (j = 0 is the weight-scaling pass, 1..T the MC passes) runs on rank
 (j + k * jobs_per_step) mod world: the rotation evens out the remainder of T+1 over the ranks
-across consecutive volumes.
+across consecutive volumes.  To let it do so the ranks must not meet at every volume: ``step_async``
+issues the reduce on RCCL's own stream, finalises on a side stream of the root and hands back a
+``PendingSummary``; the compute stream of every rank goes straight on to its share of the next
+volume (T+1 = 21 jobs on 8 GPUs: 21 forward passes per rank per 8 volumes instead of 3 per volume).
 """
+import collections
+
 import torch
 import torch.distributed as dist
 
@@ -75,16 +80,20 @@ class ShardedMcRunner:
         jobs = self.job_list()
         return [j for i, j in enumerate(jobs) if (i + step * len(jobs)) % self.world == rank]
 
-    def step(self, x, step_index=0, mask_sets=None):
-        """One volume.  Returns the summary dict on the root rank (probabilities, entropy, ... and
-        ws_probabilities when enabled), None elsewhere.  ``mask_sets``: optional list of T injected
-        mask sets, indexed by MC pass."""
+    def _run_jobs(self, x, step_index, mask_sets):
         flat, stats, ws, ws_apart = self.engine.buffers(x, self.ws_pass)
         for job in self.jobs_of(step_index, self.rank):
             if job == 0:
                 self.engine.ws_pass(x, ws)
             else:
                 self.engine.mc_pass(x, stats, None if mask_sets is None else mask_sets[job - 1])
+        return flat, stats, ws, ws_apart
+
+    def step(self, x, step_index=0, mask_sets=None):
+        """One volume.  Returns the summary dict on the root rank (probabilities, entropy, ... and
+        ws_probabilities when enabled), None elsewhere.  ``mask_sets``: optional list of T injected
+        mask sets, indexed by MC pass."""
+        flat, stats, ws, ws_apart = self._run_jobs(x, step_index, mask_sets)
         if self.world > 1:
             dist.reduce(flat, dst=self.root, op=dist.ReduceOp.SUM)          # statistics (+ ws) in one collective
             if ws_apart:
@@ -95,3 +104,72 @@ class ShardedMcRunner:
         if ws is not None:
             out['ws_probabilities'] = ws
         return out
+
+    def step_async(self, x, step_index=0, mask_sets=None, depth=2):
+        """Like ``step`` but does not make this rank's compute stream wait for the other ranks: returns a
+        ``PendingSummary`` whose ``result()`` is the summary dict on the root (None elsewhere).  At most
+        ``depth`` reduces stay in flight per rank; their buffers are kept alive until they completed."""
+        if self.world == 1:
+            return PendingSummary(self.step(x, step_index, mask_sets))
+        if not hasattr(self, '_inflight'):
+            self._inflight = collections.deque()
+            self._side = torch.cuda.Stream(device=x.device) if x.is_cuda else None
+        while len(self._inflight) >= depth:
+            self._inflight.popleft().retire()
+        flat, stats, ws, ws_apart = self._run_jobs(x, step_index, mask_sets)
+        works = [dist.reduce(flat, dst=self.root, op=dist.ReduceOp.SUM, async_op=True)]
+        if ws_apart:
+            works.append(dist.reduce(ws, dst=self.root, op=dist.ReduceOp.SUM, async_op=True))
+        pending = PendingSummary(None, works=works, keep=(flat, ws))
+        if self.rank == self.root:
+            if self._side is not None:
+                with torch.cuda.stream(self._side):
+                    for w in works:
+                        w.wait()                       # the SIDE stream waits for RCCL's stream, compute does not
+                    out = self.engine.finalize(stats, self.mc_steps)
+                    pending.ready = torch.cuda.Event()
+                    pending.ready.record(self._side)
+                for t in (flat, ws):
+                    if t is not None:
+                        t.record_stream(self._side)
+                pending.works = []
+            else:
+                for w in works:
+                    w.wait()
+                out = self.engine.finalize(stats, self.mc_steps)
+                pending.works = []
+            if ws is not None:
+                out['ws_probabilities'] = ws
+            pending.value = out
+        self._inflight.append(pending)
+        return pending
+
+    def drain(self):
+        """Retire every reduce still in flight (call before destroying the process group)."""
+        while getattr(self, '_inflight', None):
+            self._inflight.popleft().retire()
+
+
+class PendingSummary:
+    """Result of ``ShardedMcRunner.step_async``."""
+
+    def __init__(self, value, works=(), keep=()):
+        self.value, self.works, self.keep = value, list(works), keep
+        self.ready = None
+
+    def retire(self):
+        """Order the calling rank's current stream after the collective and drop the buffers."""
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.ready is not None:
+            torch.cuda.current_stream().wait_event(self.ready)
+            for t in (self.value or {}).values():
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(torch.cuda.current_stream())
+            self.ready = None
+        self.keep = ()
+
+    def result(self):
+        self.retire()
+        return self.value

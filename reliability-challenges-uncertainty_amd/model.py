@@ -254,7 +254,8 @@ class UNet(nn.Module):
             rows.append(dict(index=i, name=info.name.decode(), kernel=info.kernel.decode(), cin=info.cin,
                              cout=info.cout, height=info.height, width=info.width, upsample=bool(info.upsample),
                              pooled=bool(info.pooled), dual_source=bool(info.dual_source),
-                             flops_per_slice=info.flops_per_slice))
+                             flops_per_slice=info.flops_per_slice,
+                             mfma_flops_per_slice=info.mfma_flops_per_slice))
         return rows
 
     def run_layer(self, h, w, n, layer, masks=None):

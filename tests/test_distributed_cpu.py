@@ -68,6 +68,15 @@ def _worker(rank, world, port, out_dir):
             np.savez(os.path.join(out_dir, 'step{}.npz'.format(step)), **{k: v.numpy() for k, v in out.items()})
         else:
             assert out is None
+    # pipelined form: results collected after all steps were issued
+    pend = [runner.step_async(x, step, mask_sets) for step in range(3)]
+    for step, p in enumerate(pend):
+        out = p.result()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, 'async{}.npz'.format(step)), **{k: v.numpy() for k, v in out.items()})
+        else:
+            assert out is None
+    runner.drain()
     dist.destroy_process_group()
 
 
@@ -102,8 +111,8 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     state, x, mask_sets = _inputs()
     ws, multi = so.mc_probabilities(lambda xx, m: uo.unet_forward(state, xx, m, **PARAMS), x, mask_sets)
     ref = so.multi_prediction_summary(multi)
-    for step in range(3):
-        got = np.load(os.path.join(str(tmp_path), 'step{}.npz'.format(step)))
+    for name in ['step{}.npz'.format(k) for k in range(3)] + ['async{}.npz'.format(k) for k in range(3)]:
+        got = np.load(os.path.join(str(tmp_path), name))
         assert np.max(np.abs(got['ws_probabilities'] - ws.numpy())) < 1e-6
         assert np.max(np.abs(got['probabilities'] - ref['probabilities'].numpy())) < 1e-6
         assert np.max(np.abs(got['entropy'] - ref['entropy'].numpy())) < 2e-6

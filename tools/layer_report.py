@@ -26,17 +26,21 @@ def main():
     torch.cuda.synchronize()
     cnt, ms = model.profile_collect(bench.HEIGHT, bench.WIDTH, n)
     layers = model.layer_table(bench.HEIGHT, bench.WIDTH, n)
-    print('{:<52} {:>4}->{:<4} {:>3}x{:<3} {:<34} {:>8} {:>7} {:>6}'.format('layer', 'cin', 'cout', 'H', 'W', 'kernel', 'ms', 'TF/s', '%peak'))
-    tot_ms = tot_fl = 0.0
+    print('{:<52} {:>4}->{:<4} {:>3}x{:<3} {:<34} {:>8} {:>7} {:>6}'.format('layer', 'cin', 'cout', 'H', 'W', 'kernel', 'ms', 'TF/s', '%peak') + '  pipe%')
+    tot_ms = tot_fl = tot_is = 0.0
     for L, t in zip(layers, ms[1:1 + len(layers)]):
         t /= cnt
         fl = L['flops_per_slice'] * n
         tot_ms += t
         tot_fl += fl
-        print('{:<52} {:>4}->{:<4} {:>3}x{:<3} {:<34} {:>8.3f} {:>7.1f} {:>6.1f}'.format(
-            L['name'][:52], L['cin'], L['cout'], L['height'], L['width'], L['kernel'], t, fl / t / 1e9, fl / t / 1e9 / 1.573))
+        issued = L['mfma_flops_per_slice'] * n
+        tot_is += issued
+        print('{:<52} {:>4}->{:<4} {:>3}x{:<3} {:<34} {:>8.3f} {:>7.1f} {:>6.1f} {:>6.1f}'.format(
+            L['name'][:52], L['cin'], L['cout'], L['height'], L['width'], L['kernel'], t, fl / t / 1e9, fl / t / 1e9 / 1.573,
+            issued / t / 1e9 / 1.573))
     print('input re-layout {:.3f} ms, head {:.3f} ms'.format(ms[0] / cnt, ms[-1] / cnt))
-    print('conv total {:.3f} ms  {:.1f} TF/s  ({:.1f}% of 157.3)'.format(tot_ms, tot_fl / tot_ms / 1e9, tot_fl / tot_ms / 1e9 / 1.573))
+    print('conv total {:.3f} ms  {:.1f} TF/s algorithmic ({:.1f}% of 157.3); MFMA pipe issue {:.1f}%'.format(
+        tot_ms, tot_fl / tot_ms / 1e9, tot_fl / tot_ms / 1e9 / 1.573, tot_is / tot_ms / 1e9 / 1.573))
 
 
 if __name__ == '__main__':

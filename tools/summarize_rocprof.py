@@ -19,11 +19,13 @@ import sys
 
 
 def short(name):
-    m = re.search(r'conv3x3_igemm<rcu::ConvTile<(\d+), (\d+), (\d+), (\d+), (\d+)', name)
+    """Demangled rocprof kernel name -> the kernel_name string of rcu_unet_layer_info / bench.py."""
+    m = re.search(r'conv_igemm(?:_stream)?<rcu::ConvTile<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', name)
     if m:
-        ts, th, tw, bn, kc = m.groups()
+        ts, th, tw, bn, kc, _wm, _wn, taps, db = m.groups()
         tile = ('S{}'.format(ts) if ts != '1' else '') + 'T{}x{}'.format(th, tw)
-        return 'conv3x3_igemm<{},N{},K{}>'.format(tile, bn, kc)
+        base = 'upconv_subpixel_igemm' if taps == '4' else 'conv3x3_igemm'
+        return '{}<{},N{},K{}{}>'.format(base, tile, bn, kc, ',db' if db == '1' else '')
     m = re.search(r'rcu::(\w+)', name)
     if m:
         return m.group(1)
@@ -62,7 +64,7 @@ def pmc(args):
     write = per_kernel(find(dirs[1]), {'WRITE_SIZE'})
     result = {}
     for k in fetch:
-        if not (k.startswith('conv3x3') or k.endswith('_kernel')):
+        if not (k.startswith(('conv3x3', 'upconv')) or k.endswith('_kernel')):
             continue
         f, w = fetch[k]['FETCH_SIZE'], write.get(k, {}).get('WRITE_SIZE', 0.0)
         result[k] = dict(launches=fetch[k]['launches'], fetch_size_kib_per_launch=f, write_size_kib_per_launch=w,
@@ -81,7 +83,7 @@ def pmc(args):
                     result[k]['lds_bank_conflict_frac'] = d.get('SQ_LDS_BANK_CONFLICT', 0) / d['SQ_LDS_IDX_ACTIVE']
     with open(out_path, 'w') as f:
         json.dump(result, f, indent=1, sort_keys=True)
-    traffic = {k: v['hbm_bytes_per_launch'] for k, v in result.items() if k.startswith('conv3x3')}
+    traffic = {k: v['hbm_bytes_per_launch'] for k, v in result.items() if k.startswith(('conv3x3', 'upconv'))}
     with open(os.path.join(os.path.dirname(out_path), 'pmc_traffic.json'), 'w') as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
 
