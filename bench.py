@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PEAK_HBM_GBS = 8000.0            # same guide: HBM3E peak (about 6.3 TB/s is what a streaming kernel reaches)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 SLICES, CHANNELS, HEIGHT, WIDTH = 160, 4, 192, 128
 MODEL_PARAMS = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)  # config/train_brats_baseline.yaml:7-12
@@ -100,6 +101,53 @@ def cpu_baseline(model, x_cpu, T, seed, budget_s=20.0):
     return dict(value=volumes / dt, unit='MC-sample-volumes/s', cores=threads, kind='port',
                 sample='{} of {} slices x ({} MC passes + ws pass) through oracle/ (torch-CPU, {} of {} host threads) '
                        'in {:.1f} s'.format(n, SLICES, t_cpu, threads, avail, dt)), mask_sets, out
+
+
+def calibration_kernels(device, volumes=160, reps=5):
+    """ECE histogram and uncertainty-error counts over a test-split sized batch (160 BraTS volumes, as
+    bin-eval/eval_uncertainty.py processes them), timed with events on the launch stream.  ALGORITHMIC bytes per
+    voxel: 4 (confidence / uncertainty f32) + 1 (target) + 1 (mask) for the histogram, + 1 (prediction) for the
+    counts."""
+    import ctypes
+    from rcu_amd import _lib
+    lib = _lib.load()
+    n = SLICES * HEIGHT * WIDTH
+    g = torch.Generator(device=device).manual_seed(5)
+    p = torch.rand((volumes, n), device=device, generator=g)
+    t = (torch.rand((volumes, n), device=device, generator=g) < p).to(torch.uint8)
+    m = (torch.rand((volumes, n), device=device, generator=g) < 0.4).to(torch.uint8)      # brain mask share
+    pred = (p > 0.5).to(torch.uint8)
+    stream = _lib.current_stream()
+    out = {}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    thr = _lib.ece_thresholds(10)
+    res = torch.empty(volumes * ctypes.sizeof(_lib.EceResult), device=device, dtype=torch.uint8)
+    ws = torch.empty(max(lib.rcu_ece_workspace_bytes(n, volumes), 8), device=device, dtype=torch.uint8)
+    ms = timed(lambda: _lib.check(lib.rcu_ece_hist(_lib.ptr(p), _lib.ptr(t), _lib.ptr(m), n, volumes, thr, 10,
+                                                   _lib.ptr(res), _lib.ptr(ws), stream)))
+    nbytes = volumes * n * 6
+    out['ece_hist'] = dict(bound='hbm', ms=ms, achieved=nbytes / ms / 1e6, peak=PEAK_HBM_GBS, unit='GB/s',
+                           frac=nbytes / ms / 1e6 / PEAK_HBM_GBS, bytes=nbytes, volumes=volumes)
+    ue = (ctypes.c_double * 11)(*[0.05 * k for k in range(1, 11)] + [0.95])
+    cnt = torch.empty((volumes, 11, 8), device=device, dtype=torch.int64)
+    ws2 = torch.empty(max(lib.rcu_unc_workspace_bytes(n, volumes), 8), device=device, dtype=torch.uint8)
+    ms = timed(lambda: _lib.check(lib.rcu_unc_counts(_lib.ptr(p), 0, _lib.ptr(pred), _lib.ptr(t), _lib.ptr(m), n, volumes,
+                                                     ue, 11, _lib.ptr(cnt), _lib.ptr(ws2), stream)))
+    nbytes = volumes * n * 7
+    out['unc_counts'] = dict(bound='hbm', ms=ms, achieved=nbytes / ms / 1e6, peak=PEAK_HBM_GBS, unit='GB/s',
+                             frac=nbytes / ms / 1e6 / PEAK_HBM_GBS, bytes=nbytes, volumes=volumes, thresholds=11)
+    return out
 
 
 def main():
@@ -198,6 +246,16 @@ def main():
                                               head_softmax_accumulate=slot_ms[-1] / max(forwards, 1)),
                     per_kernel={k_: dict(ms_per_forward=e['ms'] / max(forwards, 1),
                                          tflops=e['flops'] / (e['ms'] * 1e-3) / 1e12) for k_, e in per_kernel.items()})
+    # the fused head (1x1 classifier conv + softmax + entropy + accumulate into the statistics): an HBM scan.
+    # It reads the 32-channel feature map instead of logits (the logits never exist in HBM) and
+    # read-modify-writes the S=2 float32 statistics planes (94.4 MB per sample-volume if
+    # logits were materialised; here 4*V*32 + 2*2*4*V bytes, V = voxels).
+    vox = SLICES * HEIGHT * WIDTH
+    head_bytes = 4.0 * vox * 32 + 2 * 2 * 4.0 * vox
+    head_ms = slot_ms[-1] / max(forwards, 1)
+    roofline['aggregation'] = dict(bound='hbm', kernel='head_kernel', achieved=head_bytes / head_ms / 1e6, peak=PEAK_HBM_GBS,
+                                   unit='GB/s', frac=head_bytes / head_ms / 1e6 / PEAK_HBM_GBS, bytes_per_launch=head_bytes,
+                                   avg_launch_ms=head_ms)
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
@@ -247,6 +305,7 @@ def main():
                    'sharding': 'passes over ranks, one RCCL sum-reduce of the statistics per step' if world > 1 else 'none',
                    'gflop_per_sample_volume': conv_flops / max(forwards, 1) / 1e9},
         'roofline': roofline,
+        'calibration_kernels': calibration_kernels(device) if world == 1 else None,
         'cpu_baseline': cpu,
         'parity': parity,
     }

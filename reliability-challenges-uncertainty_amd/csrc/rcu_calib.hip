@@ -7,12 +7,13 @@
 //                                                  common/evalutation/numpyfunctions.py:86-107
 //   normalised entropy of [1-p, p]                 rechun/eval/analysis.py:196-203; numpyfunctions.py:166-168
 //
-// Both histograms are HBM scans over 6-10 bytes per voxel.  Neighbouring voxels almost always fall
-// into the same bin, so the histogram update is a wavefront reduction: each wave repeatedly picks
-// the key of its first unprocessed lane, ballots the lanes sharing it, and adds one popcount (and
-// one 64-lane sum of the confidences) to a per-wave LDS slot -- no atomics, a handful of
-// iterations per 64 voxels.  Per-workgroup partials are combined by a second kernel in a fixed
-// order, so counts are exact and the confidence sums are run-to-run deterministic.
+// Both histograms are HBM scans over 6-10 bytes per voxel and must not be instruction-bound (a wave64 VALU
+// instruction takes 4 cycles, so the budget at HBM speed is about 35 instructions per voxel).  Every lane owns a
+// private column [bin][lane] of a per-wave LDS histogram and adds to it with ds_add (no return value, no
+// conflicts, no cross-lane traffic in the streaming loop); once per workgroup the 64 columns of each wave are
+// folded by an xor-butterfly wavefront reduction, then the waves, then (second kernel) the workgroups, every
+// stage in a fixed order: counts are exact and the confidence sums are run-to-run deterministic.
+// Uncertainty thresholds that are not ascending take the general kernel (wavefront ballots per distinct key).
 // Bin indices are bit-exact with np.digitize: p is compared against the float32 thresholds
 // t_k = min{float32 t : t >= edge_k}.
 #include "rcu_kernels.h"
@@ -21,7 +22,7 @@ namespace rcu {
 
 static constexpr int CB_THREADS = 256;
 static constexpr int CB_WAVES = CB_THREADS / 64;
-static constexpr int ELEMS_PER_BLOCK = CB_THREADS * 16;   // 4 rounds of 4 consecutive voxels per thread
+static constexpr int ELEMS_PER_BLOCK = CB_THREADS * 64;   // 16 rounds of 4 consecutive voxels per thread
 
 struct BinThresholds {
     float t[MAX_BINS - 1];
@@ -58,26 +59,25 @@ size_t ece_workspace_bytes(size_t n_per_volume, int n_volumes)
     return (size_t)blocks_per_volume(n_per_volume) * n_volumes * MAX_BINS * sizeof(EcePartial);
 }
 
-// One voxel per lane: fold the wave's voxels into the per-wave LDS histogram.
-__device__ __forceinline__ void ece_wave_update(bool active, int bin, bool pos, float p, unsigned* w_cnt, unsigned* w_pos,
-                                                double* w_sum, int lane)
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned x)
 {
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int b = __shfl(bin, leader, 64);
-        const bool mine = active && (bin == b);
-        const unsigned long long grp = __ballot(mine);
-        const unsigned c = (unsigned)__popcll(grp);
-        const unsigned cp = (unsigned)__popcll(__ballot(mine && pos));
-        const double s = wave_sum(mine ? (double)p : 0.0);
-        if (lane == 0) {
-            w_cnt[b] += c;
-            w_pos[b] += cp;
-            w_sum[b] += s;
-        }
-        todo &= ~grp;
-    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// Dynamic LDS of the histogram kernel: [wave][bin][lane] double sums, [wave][bin][lane] packed counts
+// (count | positives << 16; a lane sees at most ELEMS_PER_BLOCK / CB_THREADS = 64 voxels), lookup table.
+static inline size_t ece_lds_bytes(int n_bins) { return (size_t)CB_WAVES * n_bins * 64 * 12 + (size_t)(n_bins + 1) * 4; }
+
+// bin = #{k : p >= t_k}, computed as a candidate floor(p * n_bins) plus one table lookup.  The edges are
+// k (1 + 1e-8) / n_bins, so p >= t_k implies p * n_bins > k and (k being representable, rounding monotonic)
+// the float product is >= k: the candidate is the bin or the bin + 1; lut[c] = t_{c-1} (lut[0] = -inf) decides.
+__device__ __forceinline__ int bin_lookup(float p, int n_bins, const float* lut)
+{
+    int c = (int)(p * (float)n_bins);          // NaN -> 0, +-inf saturate
+    c = max(0, min(c, n_bins - 1));
+    return c - ((p < lut[c]) ? 1 : 0);
 }
 
 template <bool VEC>
@@ -85,46 +85,84 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
                                                                const uint8_t* __restrict__ mask, size_t n,
                                                                const BinThresholds th, EcePartial* __restrict__ partial)
 {
+    extern __shared__ double ece_smem[];
     __shared__ unsigned s_cnt[CB_WAVES][MAX_BINS];
     __shared__ unsigned s_pos[CB_WAVES][MAX_BINS];
     __shared__ double s_sum[CB_WAVES][MAX_BINS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < CB_WAVES * MAX_BINS; i += CB_THREADS) {
-        (&s_cnt[0][0])[i] = 0;
-        (&s_pos[0][0])[i] = 0;
-        (&s_sum[0][0])[i] = 0.0;
+    const int nb = th.n_bins;
+    double* const col_sum = ece_smem + (size_t)wave * nb * 64 + lane;                       // + bin * 64
+    unsigned* const col_cp = reinterpret_cast<unsigned*>(ece_smem + (size_t)CB_WAVES * nb * 64) + (size_t)wave * nb * 64 + lane;
+    float* const lut = reinterpret_cast<float*>(reinterpret_cast<unsigned*>(ece_smem + (size_t)CB_WAVES * nb * 64) +
+                                                (size_t)CB_WAVES * nb * 64);
+    for (int b = 0; b < nb; ++b) {
+        col_sum[b * 64] = 0.0;
+        col_cp[b * 64] = 0u;
     }
+    if (tid <= nb) lut[tid] = (tid == 0) ? -INFINITY : th.t[min(tid, MAX_BINS - 1) - 1];
     __syncthreads();
     const size_t vol = blockIdx.y;
     const float* pv = p + vol * n;
     const uint8_t* tv = target + vol * n;
     const uint8_t* mv = mask ? mask + vol * n : nullptr;
     const size_t base = (size_t)blockIdx.x * ELEMS_PER_BLOCK;
-    if (VEC) {
+    auto add = [&](bool active, float q, bool pos) {
+        if (active) {
+            const int b = bin_lookup(q, nb, lut);
+            __hip_atomic_fetch_add(col_sum + b * 64, (double)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(col_cp + b * 64, pos ? 0x10001u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    };
+    constexpr int ROUNDS = ELEMS_PER_BLOCK / (CB_THREADS * 4), BATCH = 4;
+    if (VEC && base + ELEMS_PER_BLOCK <= n) {
+        // whole block inside the volume: the loads of BATCH rounds are issued before the first is consumed
+        // (6 KiB per wave in flight; with a bounds check per round the compiler waits for every round)
+        for (int r0 = 0; r0 < ROUNDS; r0 += BATCH) {
+            float4 q[BATCH];
+            uchar4 t4[BATCH], m4[BATCH];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const size_t e = base + ((size_t)r * CB_THREADS + tid) * 4;
-            const bool in = e < n;   // n % 4 == 0 on this path
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            uchar4 t4 = make_uchar4(0, 0, 0, 0), m4 = make_uchar4(1, 1, 1, 1);
-            if (in) {
-                q = *reinterpret_cast<const float4*>(pv + e);
-                t4 = *reinterpret_cast<const uchar4*>(tv + e);
-                if (mv) m4 = *reinterpret_cast<const uchar4*>(mv + e);
+            for (int i = 0; i < BATCH; ++i) {
+                const size_t e = base + ((size_t)(r0 + i) * CB_THREADS + tid) * 4;
+                q[i] = *reinterpret_cast<const float4*>(pv + e);
+                t4[i] = *reinterpret_cast<const uchar4*>(tv + e);
+                m4[i] = mv ? *reinterpret_cast<const uchar4*>(mv + e) : make_uchar4(1, 1, 1, 1);
             }
-            ece_wave_update(in && m4.x, bin_of(q.x, th), t4.x != 0, q.x, s_cnt[wave], s_pos[wave], s_sum[wave], lane);
-            ece_wave_update(in && m4.y, bin_of(q.y, th), t4.y != 0, q.y, s_cnt[wave], s_pos[wave], s_sum[wave], lane);
-            ece_wave_update(in && m4.z, bin_of(q.z, th), t4.z != 0, q.z, s_cnt[wave], s_pos[wave], s_sum[wave], lane);
-            ece_wave_update(in && m4.w, bin_of(q.w, th), t4.w != 0, q.w, s_cnt[wave], s_pos[wave], s_sum[wave], lane);
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                add(m4[i].x != 0, q[i].x, t4[i].x != 0);
+                add(m4[i].y != 0, q[i].y, t4[i].y != 0);
+                add(m4[i].z != 0, q[i].z, t4[i].z != 0);
+                add(m4[i].w != 0, q[i].w, t4[i].w != 0);
+            }
+        }
+    } else if (VEC) {
+        for (int r = 0; r < ROUNDS; ++r) {
+            const size_t e = base + ((size_t)r * CB_THREADS + tid) * 4;
+            if (e < n) {   // n % 4 == 0 on this path
+                const float4 q = *reinterpret_cast<const float4*>(pv + e);
+                const uchar4 t4 = *reinterpret_cast<const uchar4*>(tv + e);
+                uchar4 m4 = make_uchar4(1, 1, 1, 1);
+                if (mv) m4 = *reinterpret_cast<const uchar4*>(mv + e);
+                add(m4.x != 0, q.x, t4.x != 0);
+                add(m4.y != 0, q.y, t4.y != 0);
+                add(m4.z != 0, q.z, t4.z != 0);
+                add(m4.w != 0, q.w, t4.w != 0);
+            }
         }
     } else {
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < ELEMS_PER_BLOCK / CB_THREADS; ++r) {
             const size_t e = base + (size_t)r * CB_THREADS + tid;
-            const bool in = e < n;
-            const float q = in ? pv[e] : 0.f;
-            const bool act = in && (mv ? mv[e] != 0 : true);
-            const bool pos = in && tv[e] != 0;
-            ece_wave_update(act, bin_of(q, th), pos, q, s_cnt[wave], s_pos[wave], s_sum[wave], lane);
+            if (e < n) add(mv ? mv[e] != 0 : true, pv[e], tv[e] != 0);
+        }
+    }
+    for (int b = 0; b < nb; ++b) {   // wavefront reduction of the 64 columns of this wave
+        const unsigned cp = col_cp[b * 64];
+        const unsigned c = wave_sum_u32(cp & 0xffffu), cpos = wave_sum_u32(cp >> 16);
+        const double sm = wave_sum(col_sum[b * 64]);
+        if (lane == 0) {
+            s_cnt[wave][b] = c;
+            s_pos[wave][b] = cpos;
+            s_sum[wave][b] = sm;
         }
     }
     __syncthreads();
@@ -133,32 +171,52 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
         out.count = 0;
         out.sum_pos = 0;
         out.sum_conf = 0.0;
-        for (int w = 0; w < CB_WAVES; ++w) {   // fixed order
-            out.count += s_cnt[w][tid];
-            out.sum_pos += s_pos[w][tid];
-            out.sum_conf += s_sum[w][tid];
+        if (tid < nb) {
+            for (int w = 0; w < CB_WAVES; ++w) {   // fixed order
+                out.count += s_cnt[w][tid];
+                out.sum_pos += s_pos[w][tid];
+                out.sum_conf += s_sum[w][tid];
+            }
         }
         partial[((size_t)vol * gridDim.x + blockIdx.x) * MAX_BINS + tid] = out;
     }
 }
 
-__global__ __launch_bounds__(64) void ece_reduce_kernel(const EcePartial* __restrict__ partial, unsigned nblocks,
-                                                         EceResult* __restrict__ result)
+// Second stage, one workgroup per volume: thread (row, bin) adds the partials of blocks row, row + ROWS, ... in
+// that order, then bin's thread adds the rows in order.
+static constexpr int RED_THREADS = 256;
+
+__global__ __launch_bounds__(RED_THREADS) void ece_reduce_kernel(const EcePartial* __restrict__ partial, unsigned nblocks,
+                                                                  EceResult* __restrict__ result)
 {
-    const int b = threadIdx.x;
-    if (b >= MAX_BINS) return;
+    constexpr int ROWS = RED_THREADS / MAX_BINS;
+    __shared__ unsigned long long s_c[ROWS][MAX_BINS], s_p[ROWS][MAX_BINS];
+    __shared__ double s_s[ROWS][MAX_BINS];
+    const int b = threadIdx.x % MAX_BINS, row = threadIdx.x / MAX_BINS;
     const size_t vol = blockIdx.x;
     unsigned long long c = 0, sp = 0;
     double sc = 0.0;
-    for (unsigned k = 0; k < nblocks; ++k) {   // fixed order -> deterministic
+    for (unsigned k = row; k < nblocks; k += ROWS) {
         const EcePartial q = partial[((size_t)vol * nblocks + k) * MAX_BINS + b];
         c += q.count;
         sp += q.sum_pos;
         sc += q.sum_conf;
     }
-    result[vol].count[b] = c;
-    result[vol].sum_pos[b] = sp;
-    result[vol].sum_conf[b] = sc;
+    s_c[row][b] = c;
+    s_p[row][b] = sp;
+    s_s[row][b] = sc;
+    __syncthreads();
+    if (row == 0) {
+        c = 0, sp = 0, sc = 0.0;
+        for (int r = 0; r < ROWS; ++r) {
+            c += s_c[r][b];
+            sp += s_p[r][b];
+            sc += s_s[r][b];
+        }
+        result[vol].count[b] = c;
+        result[vol].sum_pos[b] = sp;
+        result[vol].sum_conf[b] = sc;
+    }
 }
 
 hipError_t launch_ece_hist(const float* p, const uint8_t* target, const uint8_t* mask, size_t n, int n_volumes,
@@ -176,13 +234,19 @@ hipError_t launch_ece_hist(const float* p, const uint8_t* target, const uint8_t*
     const bool vec = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(p) % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(target) % 4 == 0) &&
                      (mask == nullptr || reinterpret_cast<uintptr_t>(mask) % 4 == 0);
+    const size_t lds = ece_lds_bytes(n_bins);
+    const void* fn = vec ? reinterpret_cast<const void*>(&ece_hist_kernel<true>) : reinterpret_cast<const void*>(&ece_hist_kernel<false>);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (vec)
-        hipLaunchKernelGGL(ece_hist_kernel<true>, dim3(nb, n_volumes), dim3(CB_THREADS), 0, stream, p, target, mask, n, th,
+        hipLaunchKernelGGL(ece_hist_kernel<true>, dim3(nb, n_volumes), dim3(CB_THREADS), lds, stream, p, target, mask, n, th,
                            part);
     else
-        hipLaunchKernelGGL(ece_hist_kernel<false>, dim3(nb, n_volumes), dim3(CB_THREADS), 0, stream, p, target, mask, n,
+        hipLaunchKernelGGL(ece_hist_kernel<false>, dim3(nb, n_volumes), dim3(CB_THREADS), lds, stream, p, target, mask, n,
                            th, part);
-    hipLaunchKernelGGL(ece_reduce_kernel, dim3(n_volumes), dim3(64), 0, stream, part, nb, result_dev);
+    hipLaunchKernelGGL(ece_reduce_kernel, dim3(n_volumes), dim3(RED_THREADS), 0, stream, part, nb, result_dev);
     return hipGetLastError();
 }
 
@@ -250,7 +314,7 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_kernel(const U* __restr
     const uint8_t* tv = target + vol * n;
     const uint8_t* mv = mask ? mask + vol * n : nullptr;
     const size_t base = (size_t)blockIdx.x * ELEMS_PER_BLOCK;
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < ELEMS_PER_BLOCK / CB_THREADS; ++r) {
         const size_t e = base + (size_t)r * CB_THREADS + tid;
         const bool in = e < n;
         bool act = in;
@@ -274,23 +338,139 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_kernel(const U* __restr
     }
 }
 
-__global__ __launch_bounds__(128) void unc_reduce_kernel(const unsigned long long* __restrict__ partial, unsigned nblocks,
-                                                          int n_thr, unsigned long long* __restrict__ out)
+// Ascending thresholds: m = #{t : u > th_t} identifies the set of exceeded thresholds (the first m), so one
+// ds_add into the lane's private column [m][cell] records the voxel; count_uncertain[t][cell] = sum_{m > t} col[m][cell]
+// and the base counts are the column sums.  Writes the same partial layout as the general kernel.
+__device__ __forceinline__ void load4(const float* src, float (&q)[4])
 {
-    const int slot = threadIdx.x;   // [t][cell]
-    const size_t vol = blockIdx.x;
-    __shared__ unsigned long long s[UNC_SLOTS];
-    if (slot < UNC_SLOTS) {
+    const float4 v = *reinterpret_cast<const float4*>(src);
+    q[0] = v.x, q[1] = v.y, q[2] = v.z, q[3] = v.w;
+}
+__device__ __forceinline__ void load4(const double* src, double (&q)[4])
+{
+    const double2 a = *reinterpret_cast<const double2*>(src), b = *reinterpret_cast<const double2*>(src + 2);
+    q[0] = a.x, q[1] = a.y, q[2] = b.x, q[3] = b.y;
+}
+
+template <typename U>
+__global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* __restrict__ unc, const uint8_t* __restrict__ pred,
+                                                                        const uint8_t* __restrict__ target,
+                                                                        const uint8_t* __restrict__ mask, size_t n,
+                                                                        const UncThresholds th,
+                                                                        unsigned long long* __restrict__ partial)
+{
+    extern __shared__ unsigned unc_smem[];           // [wave][(n_thr + 1) * 2][lane], two 16-bit cell counters per word
+    __shared__ unsigned s_w[CB_WAVES][UNC_SLOTS];    // per wave: [m][cell] totals
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncol = (th.n_thr + 1) * 2;
+    unsigned* const col = unc_smem + (size_t)wave * ncol * 64 + lane;
+    for (int k = 0; k < ncol; ++k) col[k * 64] = 0u;
+    const size_t vol = blockIdx.y;
+    const U* uv = unc + vol * n;
+    const uint8_t* pv = pred + vol * n;
+    const uint8_t* tv = target + vol * n;
+    const uint8_t* mv = mask ? mask + vol * n : nullptr;
+    const size_t base = (size_t)blockIdx.x * ELEMS_PER_BLOCK;
+    auto add = [&](bool active, double u, bool pr, bool tg) {
+        if (active) {
+            int m = 0;
+            for (int t = 0; t < th.n_thr; ++t) m += (u > th.t[t]) ? 1 : 0;
+            const int cell = tg ? (pr ? 0 : 3) : (pr ? 2 : 1);
+            __hip_atomic_fetch_add(col + (m * 2 + (cell >> 1)) * 64, 1u << ((cell & 1) * 16), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    };
+    const bool vec = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(uv) % (4 * sizeof(U)) == 0) &&
+                     (reinterpret_cast<uintptr_t>(pv) % 4 == 0) && (reinterpret_cast<uintptr_t>(tv) % 4 == 0) &&
+                     (mv == nullptr || reinterpret_cast<uintptr_t>(mv) % 4 == 0);
+    constexpr int ROUNDS = ELEMS_PER_BLOCK / (CB_THREADS * 4), BATCH = 4;
+    if (vec && base + ELEMS_PER_BLOCK <= n) {
+        for (int r0 = 0; r0 < ROUNDS; r0 += BATCH) {   // loads of BATCH rounds in flight together
+            U q[BATCH][4];
+            uchar4 p4[BATCH], t4[BATCH], m4[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const size_t e = base + ((size_t)(r0 + i) * CB_THREADS + tid) * 4;
+                load4(uv + e, q[i]);
+                p4[i] = *reinterpret_cast<const uchar4*>(pv + e);
+                t4[i] = *reinterpret_cast<const uchar4*>(tv + e);
+                m4[i] = mv ? *reinterpret_cast<const uchar4*>(mv + e) : make_uchar4(1, 1, 1, 1);
+            }
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                add(m4[i].x != 0, (double)q[i][0], p4[i].x != 0, t4[i].x != 0);
+                add(m4[i].y != 0, (double)q[i][1], p4[i].y != 0, t4[i].y != 0);
+                add(m4[i].z != 0, (double)q[i][2], p4[i].z != 0, t4[i].z != 0);
+                add(m4[i].w != 0, (double)q[i][3], p4[i].w != 0, t4[i].w != 0);
+            }
+        }
+    } else if (vec) {
+        for (int r = 0; r < ROUNDS; ++r) {
+            const size_t e = base + ((size_t)r * CB_THREADS + tid) * 4;
+            if (e < n) {
+                U q[4];
+                load4(uv + e, q);
+                const uchar4 p4 = *reinterpret_cast<const uchar4*>(pv + e);
+                const uchar4 t4 = *reinterpret_cast<const uchar4*>(tv + e);
+                uchar4 m4 = make_uchar4(1, 1, 1, 1);
+                if (mv) m4 = *reinterpret_cast<const uchar4*>(mv + e);
+                add(m4.x != 0, (double)q[0], p4.x != 0, t4.x != 0);
+                add(m4.y != 0, (double)q[1], p4.y != 0, t4.y != 0);
+                add(m4.z != 0, (double)q[2], p4.z != 0, t4.z != 0);
+                add(m4.w != 0, (double)q[3], p4.w != 0, t4.w != 0);
+            }
+        }
+    } else {
+        for (int r = 0; r < ELEMS_PER_BLOCK / CB_THREADS; ++r) {
+            const size_t e = base + (size_t)r * CB_THREADS + tid;
+            if (e < n) add(mv ? mv[e] != 0 : true, (double)uv[e], pv[e] != 0, tv[e] != 0);
+        }
+    }
+    for (int k = 0; k < ncol; ++k) {   // wavefront reduction of this wave's 64 columns
+        const unsigned v = col[k * 64];
+        const unsigned lo = wave_sum_u32(v & 0xffffu), hi = wave_sum_u32(v >> 16);
+        if (lane == 0) {
+            s_w[wave][2 * k] = lo;
+            s_w[wave][2 * k + 1] = hi;
+        }
+    }
+    __syncthreads();
+    if (tid < UNC_SLOTS) {
+        const int t = tid / 4, cell = tid % 4;   // output slot [t][cell]; t == n_thr is the base row
         unsigned long long c = 0;
-        for (unsigned k = 0; k < nblocks; ++k) c += partial[((size_t)vol * nblocks + k) * UNC_SLOTS + slot];
-        s[slot] = c;
+        if (t <= th.n_thr) {
+            const int m_lo = (t < th.n_thr) ? t + 1 : 0;
+            for (int w = 0; w < CB_WAVES; ++w)
+                for (int m = m_lo; m <= th.n_thr; ++m) c += s_w[w][m * 4 + cell];
+        }
+        partial[((size_t)vol * gridDim.x + blockIdx.x) * UNC_SLOTS + tid] = c;
+    }
+}
+
+__global__ __launch_bounds__(RED_THREADS) void unc_reduce_kernel(const unsigned long long* __restrict__ partial,
+                                                                  unsigned nblocks, int n_thr,
+                                                                  unsigned long long* __restrict__ out)
+{
+    constexpr int ROWS = RED_THREADS / UNC_SLOTS;    // threads beyond ROWS * UNC_SLOTS idle
+    __shared__ unsigned long long s[ROWS][UNC_SLOTS];
+    const int slot = threadIdx.x % UNC_SLOTS, row = threadIdx.x / UNC_SLOTS;
+    const size_t vol = blockIdx.x;
+    if (row < ROWS) {
+        unsigned long long c = 0;
+        for (unsigned k = row; k < nblocks; k += ROWS) c += partial[((size_t)vol * nblocks + k) * UNC_SLOTS + slot];
+        s[row][slot] = c;
     }
     __syncthreads();
     const int t = slot / 4, cell = slot % 4;
-    if (slot < UNC_SLOTS && t < n_thr) {
+    if (row == 0 && t < n_thr) {
+        unsigned long long base = 0, cu = 0;
+        for (int r = 0; r < ROWS; ++r) {
+            base += s[r][n_thr * 4 + cell];
+            cu += s[r][slot];
+        }
         unsigned long long* o = out + ((size_t)vol * n_thr + t) * 8;
-        o[cell] = s[n_thr * 4 + cell];   // tp, tn, fp, fn (same for every threshold)
-        o[4 + cell] = s[slot];           // tpu, tnu, fpu, fnu
+        o[cell] = base;      // tp, tn, fp, fn (same for every threshold)
+        o[4 + cell] = cu;    // tpu, tnu, fpu, fnu
     }
 }
 
@@ -305,13 +485,23 @@ hipError_t launch_unc_counts(const void* unc, int unc_is_f64, const uint8_t* pre
     const unsigned nb = blocks_per_volume(n);
     if (nb == 0) return hipMemsetAsync(out_dev, 0, sizeof(unsigned long long) * 8 * n_thr * n_volumes, stream);
     unsigned long long* part = reinterpret_cast<unsigned long long*>(workspace);
-    if (unc_is_f64)
+    bool ascending = true;
+    for (int t = 1; t < n_thr; ++t) ascending = ascending && (thr_host[t - 1] <= thr_host[t]);
+    if (ascending) {
+        const size_t lds = (size_t)CB_WAVES * (n_thr + 1) * 2 * 64 * sizeof(unsigned);
+        if (unc_is_f64)
+            hipLaunchKernelGGL(unc_counts_sorted_kernel<double>, dim3(nb, n_volumes), dim3(CB_THREADS), lds, stream,
+                               reinterpret_cast<const double*>(unc), prediction, target, mask, n, th, part);
+        else
+            hipLaunchKernelGGL(unc_counts_sorted_kernel<float>, dim3(nb, n_volumes), dim3(CB_THREADS), lds, stream,
+                               reinterpret_cast<const float*>(unc), prediction, target, mask, n, th, part);
+    } else if (unc_is_f64)
         hipLaunchKernelGGL(unc_counts_kernel<double>, dim3(nb, n_volumes), dim3(CB_THREADS), 0, stream,
                            reinterpret_cast<const double*>(unc), prediction, target, mask, n, th, part);
     else
         hipLaunchKernelGGL(unc_counts_kernel<float>, dim3(nb, n_volumes), dim3(CB_THREADS), 0, stream,
                            reinterpret_cast<const float*>(unc), prediction, target, mask, n, th, part);
-    hipLaunchKernelGGL(unc_reduce_kernel, dim3(n_volumes), dim3(128), 0, stream, part, nb, n_thr, out_dev);
+    hipLaunchKernelGGL(unc_reduce_kernel, dim3(n_volumes), dim3(RED_THREADS), 0, stream, part, nb, n_thr, out_dev);
     return hipGetLastError();
 }
 

@@ -80,6 +80,18 @@ struct ConvTile {
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 };
 
+// Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  The `group` consecutive work
+// items of one pixel tile (its channel tiles / sub-pixel classes) read the same input tile, so renumber the
+// workgroups such that those run on ONE XCD -- the tile then comes from HBM once instead of once per XCD -- while
+// successive groups still go round the XCDs (a partial last round stays spread over the whole chip).
+__device__ __forceinline__ int xcd_virtual_block(int group)
+{
+    const int g = (int)gridDim.x, b = (int)blockIdx.x;
+    if ((g & 7) != 0 || ((g >> 3) % group) != 0) return b;
+    const int xcd = b & 7, slot = b >> 3;
+    return ((slot / group) * 8 + xcd) * group + slot % group;
+}
+
 template <class T>
 __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
 {
@@ -93,9 +105,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
     const int wn = wave % T::WN;
     const int wm = wave / T::WN;
 
-    // ---- workgroup -> (channel tile [, parity class], pixel tile).  Channel tile fastest: with the
-    // round-robin workgroup->XCD dispatch an XCD then keeps seeing the same few weight slices in its L2.
-    const int bid = blockIdx.x;
+    // ---- workgroup -> (channel tile [, parity class], pixel tile), channel tile fastest; xcd_virtual_block
+    // puts the workgroups that share one input tile on one XCD.
+    const int bid = xcd_virtual_block(a.NTW_total < 4 ? 4 : a.NTW_total);   // >= 4: x-neighbours share halo columns
     const int wtile = bid % a.NTW_total;        // weight tile index = cls * NT + ntile
     const int ntile = wtile % a.NT;
     const int cls = wtile / a.NT;               // parity class (sub-pixel mode), else 0
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_stream(const ConvArgs a, co
     for (int ni = 0; ni < NTW; ++ni) b_addr[ni] = ((wn * NTW + ni) * 32 + m) * KCP + half * 4;
 
     TilePlan<T> cur, nxt;
-    int item = blockIdx.x;
+    int item = xcd_virtual_block(a.NTW_total < 4 ? 4 : a.NTW_total);
     make_plan<T>(cur, a, item, tid);
     bool has_next = item + (int)gridDim.x < total_items;
     make_plan<T>(nxt, a, has_next ? item + (int)gridDim.x : item, tid);

@@ -375,6 +375,55 @@ def test_uncertainty_counts_full_size_properties(dev):
     assert np.array_equal(c, ref.astype(np.int64))
 
 
+def test_ece_histogram_other_bin_counts_and_threshold_neighbours(dev):
+    """The histogram kernel finds the bin by floor(p * n_bins) + one table lookup; it must agree with the
+    compare-against-every-threshold definition (bin_ids kernel, oracle digitize) for every n_bins, in
+    particular on each float32 threshold and its two neighbours, on 0, 1, just above 1, NaN and inf."""
+    from oracle import calib_oracle as co
+    from rcu_amd import evaluation as ev
+    rng = np.random.RandomState(3)
+    for n_bins in (1, 2, 3, 7, 10, 15, 16, 17, 32):
+        thr = np.asarray(co.float32_thresholds(n_bins), dtype=np.float32)
+        special = [np.float32(0), np.float32(1), np.nextafter(np.float32(1), np.float32(2)), np.float32(1e-30),
+                   np.float32(-0.0)]
+        for t in thr:
+            special += [t, np.nextafter(t, np.float32(0)), np.nextafter(t, np.float32(2))]
+        p = np.concatenate([np.asarray(special, np.float32), rng.rand(5000).astype(np.float32),
+                            (np.arange(0, n_bins + 1) / n_bins).astype(np.float32)])
+        tg = (rng.rand(p.size) < 0.5).astype(np.uint8)
+        ids = ev.bin_ids(p, n_bins).astype(np.int64)
+        valid = p <= 1.0          # above 1 + 1e-8 the reference indexes past the last bin; the build clamps
+        assert np.array_equal(ids[valid], co.bin_ids(p[valid], n_bins))
+        assert ids.max() <= n_bins - 1
+        cnt, sc, sp = ev.calibration_histogram(p, tg, n_bins=n_bins)
+        assert np.array_equal(cnt[0], np.bincount(ids, minlength=n_bins))
+        assert np.array_equal(sp[0], np.bincount(ids, weights=tg, minlength=n_bins).astype(np.int64))
+        assert np.allclose(sc[0], np.bincount(ids, weights=p.astype(np.float64), minlength=n_bins), rtol=1e-13, atol=0)
+    weird = np.asarray([np.nan, np.inf, -np.inf, -1.0, 2.0], np.float32)
+    cnt, _, _ = ev.calibration_histogram(weird, np.zeros(5, np.uint8))
+    assert np.array_equal(cnt[0], np.bincount(ev.bin_ids(weird).astype(np.int64), minlength=10))
+
+
+def test_uncertainty_counts_threshold_order_and_dtypes(dev):
+    """Ascending thresholds take the private-column kernel, any other order the general one; float32 and
+    float64 maps, ragged length, masks -- all against the C oracle."""
+    from oracle import c_oracle
+    from rcu_amd import evaluation as ev
+    rng = np.random.RandomState(4)
+    for n in (5, 4096, 70001):
+        u64 = rng.rand(n) ** 2
+        pr = (rng.rand(n) < 0.3).astype(np.uint8)
+        tg = (rng.rand(n) < 0.3).astype(np.uint8)
+        m = (rng.rand(n) < 0.7).astype(np.uint8)
+        for thr in (ev.UE_THRESHOLDS, tuple(reversed(ev.UE_THRESHOLDS)), (0.5, 0.1, 0.9, 0.1), (0.25,),
+                    tuple(np.linspace(0.01, 0.99, 16))):
+            for u in (u64, u64.astype(np.float32)):
+                for mask in (None, m):
+                    got = ev.uncertainty_counts(pr, tg, u, thr, mask=mask)[0]
+                    ref = c_oracle.unc_counts(u.astype(np.float64), pr, tg, mask, thr)
+                    assert np.array_equal(got, ref.astype(np.int64)), (n, thr, u.dtype, mask is None)
+
+
 def test_preparation_golden(golden, dev):
     from rcu_amd import evaluation as ev
     g = golden('g10_prep')
