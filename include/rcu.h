@@ -125,6 +125,28 @@ int rcu_unet_run_layer(rcu_unet* h, int layer, int n, const float* masks_dev, vo
 int rcu_unet_profile_begin(rcu_unet* h, int max_forwards);
 int rcu_unet_profile_collect(rcu_unet* h, double* ms_sum, int* forwards);
 
+/* Feature map of the last forward call = the input of conv_cls (UNet.features when provide_features is set,
+ * common/model/unet.py:178-179): NHWC float32 in the handle's workspace, `channels` real channels at a pitch
+ * of `channel_pitch` floats per voxel; valid until the next forward call on this handle. */
+int rcu_unet_features(const rcu_unet* h, const float** features_dev, int* channels, int* channel_pitch);
+
+/* ------------------------------------------------------------------------------------------
+ * PostNet -- auxiliary confidence network on the U-Net features
+ *   (common/model/postnet.py:6-18; bin-dl/brats_test_auxiliary_feat.py:74-77, isic_test_auxiliary_feat.py)
+ *   nb_convs x [Conv2d 1x1 C->C, BatchNorm2d (eval), ReLU] + Conv2d 1x1 C->nb_classes, C <= 32, nb_classes <= 32.
+ *   Weights by state_dict name: convs.<i>.conv2d_batch_relu.{conv.weight,conv.bias,bn.weight,bn.bias,
+ *   bn.running_mean,bn.running_var}, conv_logits.{weight,bias}.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rcu_postnet rcu_postnet;
+int rcu_postnet_create(int in_channels, int nb_classes, int nb_convs, int bn, rcu_postnet** out);
+void rcu_postnet_destroy(rcu_postnet* h);
+int rcu_postnet_load_weight(rcu_postnet* h, const char* name, const float* host_data, size_t count);
+int rcu_postnet_finalize_weights(rcu_postnet* h);
+/* features: NHWC float32 [n*hw][channel_pitch] (channel_pitch >= 32, multiple of 4; channels beyond in_channels are
+ * ignored); logits_dev: float32 [n][nb_classes][hw]. */
+int rcu_postnet_forward(rcu_postnet* h, const float* features_dev, int channel_pitch, int n, int hw, float* logits_dev,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Step seam: per-voxel sufficient statistics over T passes / K members
  *   (McPredictStep + MultiPredictionSummary, customsteps.py:16-71; torchhelper.py:53-54)

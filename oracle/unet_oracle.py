@@ -82,8 +82,9 @@ def strip_module_prefix(state):
     return {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state.items()}
 
 
-def unet_forward(state, x, masks=None, **params):
-    """x: float32 [N, Cin, H, W] -> logits [N, C, H, W] or (logits, sigma) when sigma_out.
+def unet_forward(state, x, masks=None, return_features=False, **params):
+    """x: float32 [N, Cin, H, W] -> logits [N, C, H, W] or (logits, sigma) when sigma_out; with
+    ``return_features`` also the input of conv_cls (UNet.features, unet.py:178-179) as the last element.
     ``state``: mapping name -> tensor/ndarray with the reference's state_dict keys.
     ``masks``: None or a list (one per dropout site, execution order) of [N, C_site] factors."""
     state = {k: torch.as_tensor(v) for k, v in strip_module_prefix(state).items()}
@@ -124,9 +125,44 @@ def unet_forward(state, x, masks=None, **params):
             x = trunk
         elif kind == 'head':
             outs[op['out']] = F.conv2d(x, state[op['key'] + '.weight'], state[op['key'] + '.bias'])
-    if 'sigma' in outs:
-        return outs['logits'], outs['sigma']
-    return outs['logits']
+    result = (outs['logits'], outs['sigma']) if 'sigma' in outs else (outs['logits'],)
+    if return_features:
+        result = result + (trunk,)
+    return result if len(result) > 1 else result[0]
+
+
+def postnet_forward(state, x, nb_convs=3):
+    """common/model/postnet.py:6-18: nb_convs x [Conv2d 1x1 C->C, BatchNorm2d (eval), ReLU] + Conv2d 1x1 (dropout
+    None as in every shipped config: Conv2dBnRelu gets no dropout module, unet.py:14-15)."""
+    state = {k: torch.as_tensor(v) for k, v in strip_module_prefix(state).items()}
+    x = torch.as_tensor(x, dtype=torch.float32)
+    for i in range(nb_convs):
+        k = 'convs.{}.conv2d_batch_relu'.format(i)
+        x = F.conv2d(x, state[k + '.conv.weight'], state[k + '.conv.bias'])
+        x = F.batch_norm(x, state[k + '.bn.running_mean'], state[k + '.bn.running_var'], state[k + '.bn.weight'],
+                         state[k + '.bn.bias'], False, 0.0, BN_EPS)
+        x = F.relu(x)
+    return F.conv2d(x, state['conv_logits.weight'], state['conv_logits.bias'])
+
+
+def postnet_synthetic_state(seed, in_channels, nb_classes, nb_convs=3):
+    """Deterministic PostNet weights with the reference's keys (same recipe as synthetic_state)."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    state = {}
+    bound = 1.0 / math.sqrt(in_channels)
+    for i in range(nb_convs):
+        k = 'convs.{}.conv2d_batch_relu'.format(i)
+        state[k + '.conv.weight'] = (torch.rand(in_channels, in_channels, 1, 1, generator=g) * 2 - 1) * bound
+        state[k + '.conv.bias'] = (torch.rand(in_channels, generator=g) * 2 - 1) * bound
+        state[k + '.bn.weight'] = torch.rand(in_channels, generator=g) * 0.5 + 0.75
+        state[k + '.bn.bias'] = torch.randn(in_channels, generator=g) * 0.1
+        state[k + '.bn.running_mean'] = torch.randn(in_channels, generator=g) * 0.1
+        state[k + '.bn.running_var'] = torch.rand(in_channels, generator=g) + 0.5
+        state[k + '.bn.num_batches_tracked'] = torch.tensor(1)
+    state['conv_logits.weight'] = (torch.rand(nb_classes, in_channels, 1, 1, generator=g) * 2 - 1) * bound
+    state['conv_logits.bias'] = (torch.rand(nb_classes, generator=g) * 2 - 1) * bound
+    return state
 
 
 def sample_masks(sites, n, p, generator):

@@ -57,6 +57,12 @@ SIGNATURES = {
     'rcu_unet_finalize_weights': (c_int, [c_void_p]),
     'rcu_unet_forward': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'rcu_unet_forward_accumulate': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    'rcu_unet_features': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int), POINTER(c_int)]),
+    'rcu_postnet_create': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
+    'rcu_postnet_destroy': (None, [c_void_p]),
+    'rcu_postnet_load_weight': (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
+    'rcu_postnet_finalize_weights': (c_int, [c_void_p]),
+    'rcu_postnet_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'rcu_unet_num_layers': (c_int, [c_void_p]),
     'rcu_unet_layer_info': (c_int, [c_void_p, c_int, POINTER(LayerInfo)]),
     'rcu_unet_run_layer': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -115,6 +121,21 @@ def check(status):
 def ptr(t):
     """Device (or host) address of a torch tensor, None -> NULL."""
     return None if t is None else c_void_p(t.data_ptr())
+
+
+class _DeviceMemory:
+    """Borrowed device memory for torch.as_tensor (CUDA array interface v2); ``owner`` keeps the allocation alive."""
+
+    def __init__(self, address, shape, owner):
+        self.__cuda_array_interface__ = {'shape': tuple(int(v) for v in shape), 'typestr': '<f4',
+                                         'data': (int(address), False), 'version': 2, 'strides': None}
+        self.owner = owner
+
+
+def device_view(address, shape, device, owner=None):
+    """float32 torch tensor over library-owned device memory (no copy)."""
+    import torch
+    return torch.as_tensor(_DeviceMemory(address, shape, owner), device=device)
 
 
 def current_stream():

@@ -532,6 +532,135 @@ extern "C" int rcu_unet_forward_accumulate(rcu_unet* h, const float* x_dev, int 
                         static_cast<hipStream_t>(stream));
 }
 
+extern "C" int rcu_unet_features(const rcu_unet* h, const float** features_dev, int* channels, int* channel_pitch)
+{
+    if (!h || !features_dev) return fail(RCU_ERR_INVALID, "rcu_unet_features: null argument");
+    if (!h->finalized) return fail(RCU_ERR_STATE, "rcu_unet_features before rcu_unet_finalize_weights");
+    for (const ConvLayer& L : h->layers)
+        if (L.name == "conv_cls.0.conv2d_batch_relu.conv") {
+            *features_dev = h->tensors[L.t_src1].dev;
+            if (channels) *channels = L.cin1;
+            if (channel_pitch) *channel_pitch = L.c1p;
+            return RCU_OK;
+        }
+    return fail(RCU_ERR_STATE, "rcu_unet_features: no conv_cls layer in the plan");
+}
+
+// ------------------------------------------------------------------------------------------------
+// PostNet
+// ------------------------------------------------------------------------------------------------
+struct rcu_postnet {
+    int in_channels = 0, nb_classes = 0, nb_convs = 0, bn = 1;
+    std::map<std::string, std::vector<float>> host_weights;
+    float* packed = nullptr;
+    bool finalized = false;
+};
+
+extern "C" int rcu_postnet_create(int in_channels, int nb_classes, int nb_convs, int bn, rcu_postnet** out)
+{
+    if (!out) return fail(RCU_ERR_INVALID, "rcu_postnet_create: null argument");
+    if (in_channels < 1 || in_channels > 32)
+        return fail(RCU_ERR_INVALID, "PostNet kernel handles 1..32 feature channels (U-Net start_filters <= 32)");
+    if (nb_classes < 1 || nb_classes > 32) return fail(RCU_ERR_INVALID, "PostNet kernel handles 1..32 classes");
+    if (nb_convs < 0 || nb_convs + 1 > PN_MAX_LAYERS)
+        return fail(RCU_ERR_INVALID, "PostNet kernel handles at most " + std::to_string(PN_MAX_LAYERS - 1) + " hidden convs");
+    rcu_postnet* h = new rcu_postnet;
+    h->in_channels = in_channels; h->nb_classes = nb_classes; h->nb_convs = nb_convs; h->bn = bn ? 1 : 0;
+    *out = h;
+    return RCU_OK;
+}
+
+extern "C" void rcu_postnet_destroy(rcu_postnet* h)
+{
+    if (!h) return;
+    if (h->packed) (void)hipFree(h->packed);
+    delete h;
+}
+
+extern "C" int rcu_postnet_load_weight(rcu_postnet* h, const char* name, const float* data, size_t count)
+{
+    if (!h || !name || (!data && count)) return fail(RCU_ERR_INVALID, "rcu_postnet_load_weight: null argument");
+    std::string key(name);
+    if (key.rfind("module.", 0) == 0) key = key.substr(7);
+    h->host_weights[key].assign(data, data + count);
+    h->finalized = false;
+    return RCU_OK;
+}
+
+static int postnet_weight(rcu_postnet* h, const std::string& key, size_t count, const std::vector<float>** out)
+{
+    auto it = h->host_weights.find(key);
+    if (it == h->host_weights.end()) return fail(RCU_ERR_WEIGHTS, "missing weight tensor '" + key + "'");
+    if (it->second.size() != count)
+        return fail(RCU_ERR_WEIGHTS, "weight tensor '" + key + "' has " + std::to_string(it->second.size()) +
+                                         " elements, expected " + std::to_string(count));
+    *out = &it->second;
+    return RCU_OK;
+}
+
+// folded 32x32 (zero padded) layer -> the LDS image of rcu_postnet.hip: weights [j][lane][4], bias [j][h][4]
+static void postnet_pack_layer(const float (*w)[32], const float* b, float* dst)
+{
+    for (int j = 0; j < 4; ++j)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 4; ++e) dst[(j * 64 + lane) * 4 + e] = w[lane & 31][8 * j + 4 * (lane >> 5) + e];
+    float* bd = dst + 4 * 64 * 4;
+    for (int j = 0; j < 4; ++j)
+        for (int hf = 0; hf < 2; ++hf)
+            for (int e = 0; e < 4; ++e) bd[(j * 2 + hf) * 4 + e] = b[8 * j + 4 * hf + e];
+}
+
+extern "C" int rcu_postnet_finalize_weights(rcu_postnet* h)
+{
+    if (!h) return fail(RCU_ERR_INVALID, "rcu_postnet_finalize_weights: null handle");
+    const int C = h->in_channels, L = h->nb_convs + 1;
+    std::vector<float> packed((size_t)L * PN_LAYER_FLOATS, 0.f);
+    for (int l = 0; l < L; ++l) {
+        const bool last = (l == h->nb_convs);
+        const std::string pre = last ? "conv_logits" : "convs." + std::to_string(l) + ".conv2d_batch_relu.conv";
+        const int cout = last ? h->nb_classes : C;
+        const std::vector<float>*w, *b;
+        int rc = postnet_weight(h, pre + ".weight", (size_t)cout * C, &w);
+        if (rc) return rc;
+        if ((rc = postnet_weight(h, pre + ".bias", cout, &b))) return rc;
+        float wf[32][32] = {}, bf[32] = {};
+        for (int o = 0; o < cout; ++o) {
+            float alpha = 1.f, beta = 0.f, mean = 0.f;
+            if (!last && h->bn) {   // Conv -> BatchNorm(eval): y = gamma (conv - mean) / sqrt(var + eps) + beta
+                const std::string bp = "convs." + std::to_string(l) + ".conv2d_batch_relu.bn";
+                const std::vector<float>*g, *be, *rm, *rv;
+                if ((rc = postnet_weight(h, bp + ".weight", C, &g))) return rc;
+                if ((rc = postnet_weight(h, bp + ".bias", C, &be))) return rc;
+                if ((rc = postnet_weight(h, bp + ".running_mean", C, &rm))) return rc;
+                if ((rc = postnet_weight(h, bp + ".running_var", C, &rv))) return rc;
+                alpha = (float)((double)(*g)[o] / std::sqrt((double)(*rv)[o] + 1e-5));
+                beta = (*be)[o];
+                mean = (*rm)[o];
+            }
+            for (int i = 0; i < C; ++i) wf[o][i] = alpha * (*w)[(size_t)o * C + i];
+            bf[o] = alpha * ((*b)[o] - mean) + beta;
+        }
+        postnet_pack_layer(wf, bf, packed.data() + (size_t)l * PN_LAYER_FLOATS);
+    }
+    if (!h->packed) RCU_HIP(hipMalloc(reinterpret_cast<void**>(&h->packed), packed.size() * sizeof(float)));
+    RCU_HIP(hipMemcpy(h->packed, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->finalized = true;
+    return RCU_OK;
+}
+
+extern "C" int rcu_postnet_forward(rcu_postnet* h, const float* features_dev, int channel_pitch, int n, int hw,
+                                   float* logits_dev, void* stream)
+{
+    if (!h || !features_dev || !logits_dev) return fail(RCU_ERR_INVALID, "rcu_postnet_forward: null argument");
+    if (!h->finalized) return fail(RCU_ERR_STATE, "rcu_postnet_forward before rcu_postnet_finalize_weights");
+    if (n < 0 || hw < 1) return fail(RCU_ERR_INVALID, "rcu_postnet_forward: bad shape");
+    if (channel_pitch < 32 || channel_pitch % 4)
+        return fail(RCU_ERR_INVALID, "rcu_postnet_forward: channel pitch must be >= 32 floats and a multiple of 4");
+    RCU_HIP(launch_postnet(features_dev, channel_pitch, (size_t)n * hw, hw, h->packed, h->nb_convs + 1, h->nb_classes,
+                           logits_dev, static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}
+
 extern "C" int rcu_unet_num_layers(const rcu_unet* h) { return h ? (int)h->layers.size() : 0; }
 
 extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info* out)

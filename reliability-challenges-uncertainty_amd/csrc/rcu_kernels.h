@@ -115,4 +115,12 @@ hipError_t launch_unc_counts(const void* unc, int unc_is_f64, const uint8_t* pre
                              int n_thr, unsigned long long* out_dev, void* workspace, hipStream_t stream);
 hipError_t launch_norm_entropy(const float* p_fg, size_t n, double* out_f64, float* out_f32, hipStream_t stream);
 
+// ---------------------------------------------------------------------------------------------
+// PostNet: fused 1x1-conv stack on the U-Net feature map (rcu_postnet.hip)
+// ---------------------------------------------------------------------------------------------
+constexpr int PN_LAYER_FLOATS = 4 * 64 * 4 + 4 * 2 * 4;   // packed weights + bias of one 32x32 layer
+constexpr int PN_MAX_LAYERS = 12;
+hipError_t launch_postnet(const float* x_nhwc, int channel_pitch, size_t nvox, int hw, const float* packed, int n_layers,
+                          int nb_classes, float* logits_nchw, hipStream_t stream);
+
 }  // namespace rcu

@@ -114,7 +114,8 @@ def write_volume(dataset_dir, subject, images, labels=None, properties=None):
 class VolumeDataset(torch_data.Dataset):
     """One sample = one slice (axis 0) of one subject; subjects in sorted order, optionally a subset."""
 
-    def __init__(self, dataset_dir, transform=None, subject_subset=None):
+    def __init__(self, dataset_dir, transform=None, subject_subset=None, slice_categories=('images',)):
+        self.slice_categories = tuple(slice_categories)
         if str(dataset_dir).endswith(('.h5', '.hdf5')):
             raise ValueError('"{}": pymia HDF5 datasets cannot be read in this environment (no h5py / pymia); export the '
                              'volumes with rcu_amd.data.write_volume(<dir>, subject, images, labels) and point '
@@ -152,6 +153,8 @@ class VolumeDataset(torch_data.Dataset):
         vol = self._volume(si)
         sample = {'images': vol['images'][k], 'subject_index': si, 'slice_index': k,
                   'shape': tuple(self.shapes[si][:3]), 'sample_index': i}
+        if 'labels' in self.slice_categories:     # extractor `data: {categories: [images, labels]}` (auxiliary_segm)
+            sample['labels'] = vol['labels'][k]
         return self.transform(sample)
 
     def direct_extract(self, subject_index, entries=('labels', 'properties', 'subject')):
@@ -174,8 +177,9 @@ class IsicDataset(torch_data.Dataset):
     LABEL_DIR_POST_FIX = '_Part1_GroundTruth'
     IMAGE_DIR_POST_FIX = '_Data'
 
-    def __init__(self, data_dir_with_task_prefix, transform=None, subject_subset=None):
+    def __init__(self, data_dir_with_task_prefix, transform=None, subject_subset=None, prediction_dir=None):
         from PIL import Image  # noqa: F401  (fail early if PIL is missing)
+        self.prediction_dir = prediction_dir
         self.prefix = data_dir_with_task_prefix
         self.transform = transform if transform is not None else Compose([])
         img_dir, label_dir = self.prefix + self.IMAGE_DIR_POST_FIX, self.prefix + self.LABEL_DIR_POST_FIX
@@ -191,6 +195,15 @@ class IsicDataset(torch_data.Dataset):
         if subject_subset is not None:
             by_id = {k: v for k, v in by_id.items() if k in set(subject_subset)}
         self.files_by_id = {k: v for k, v in by_id.items() if 'gt' in v and 'image' in v}
+        if prediction_dir is not None:   # customdatasets.py:33-35, 104-109: `<id>_prediction.nii.gz` of an earlier run
+            for path in glob.glob(os.path.join(prediction_dir, '*_prediction.nii.gz')):
+                id_ = os.path.basename(path)[:-len('_prediction.nii.gz')]
+                if id_ in self.files_by_id:
+                    self.files_by_id[id_]['prediction'] = path
+            missing = [k for k, v in self.files_by_id.items() if 'prediction' not in v]
+            if missing:
+                raise ValueError('no prediction file in "{}" for {} subject(s), e.g. {}'.format(prediction_dir, len(missing),
+                                                                                              missing[0]))
         self.ids = sorted(self.files_by_id)
 
     def __len__(self):
@@ -208,6 +221,9 @@ class IsicDataset(torch_data.Dataset):
                   'labels': np.array(Image.open(f['gt']).convert('L'))[..., np.newaxis].astype(np.uint8),
                   'images': np.array(Image.open(f['image'])).astype(np.float32),
                   'image_paths': f['image'], 'label_paths': f['gt'], 'subject_index': index, 'sample_index': index}
+        if self.prediction_dir is not None:   # customdatasets.py:64-69: labels max is 255
+            prediction = nifti.read(f['prediction'])[0] * 255
+            sample['labels'] = np.concatenate((sample['labels'], prediction[..., np.newaxis].astype(np.uint8)), axis=-1)
         return self.transform(sample)
 
 
@@ -246,14 +262,25 @@ def load_split(file, k=None):
     return train, valid, test
 
 
+def _slice_categories(extractor):
+    """Categories of the per-slice `data` extractor entry (default: images only, pymia DataExtractor)."""
+    entries = extractor if isinstance(extractor, (list, tuple)) else ([] if extractor is None else [extractor])
+    for e in entries:
+        if getattr(e, 'type', None) == 'data' and 'categories' in e.params:
+            return tuple(e.params['categories'])
+    return ('images',)
+
+
 class BuildVolumeDataset:
     def __call__(self, data_config, **kwargs):
-        return VolumeDataset(data_config.dataset, get_transform(data_config.transform), kwargs.get('entries'))
+        return VolumeDataset(data_config.dataset, get_transform(data_config.transform), kwargs.get('entries'),
+                             _slice_categories(data_config.extractor))
 
 
 class BuildIsicDataset:
     def __call__(self, data_config, **kwargs):
-        return IsicDataset(data_config.dataset, get_transform(data_config.transform), kwargs.get('entries'))
+        return IsicDataset(data_config.dataset, get_transform(data_config.transform), kwargs.get('entries'),
+                           kwargs.get('prediction_dir'))
 
 
 class BuildData:

@@ -64,11 +64,13 @@ class UNet(nn.Module):
         super().__init__()
         if residual:
             raise NotImplementedError('residual blocks are outside the MI355X hot path (no shipped config uses them)')
-        if provide_features:
-            raise NotImplementedError('provide_features (auxiliary_feat runs) is outside the MI355X hot path')
         self.nb_classes, self.in_channels, self.depth = nb_classes, in_channels, depth
         self.start_filters, self.dropout, self.dropout_center = start_filters, dropout, dropout_center
         self.sigma_out, self.bn = sigma_out, bn
+        # unet.py:135-136, 178-179: when set, ``features`` is the input of conv_cls after every forward --
+        # here a [N, C, H, W] VIEW of the handle's channels-last workspace tensor (no copy), valid until the
+        # next forward; rcu_amd.model.PostNet consumes it in place
+        self.provide_features = provide_features
         self.features = None
         self._site_modules = []
 
@@ -223,9 +225,17 @@ class UNet(nn.Module):
         sigma = torch.empty_like(logits) if self.sigma_out else None
         _lib.check(_lib.load().rcu_unet_forward(handle, _lib.ptr(x), n, _lib.ptr(masks), _lib.ptr(logits),
                                                 _lib.ptr(sigma), _lib.current_stream()))
+        if self.provide_features:
+            self.features = self._features_view(handle, n, h, w, x.device)
         if self.sigma_out:
             return logits, sigma
         return logits
+
+    def _features_view(self, handle, n, h, w, device):
+        ptr, ch, pitch = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().rcu_unet_features(handle, ctypes.byref(ptr), ctypes.byref(ch), ctypes.byref(pitch)))
+        nhwc = _lib.device_view(ptr.value, (n, h, w, pitch.value), device, owner=self)
+        return nhwc[..., :ch.value].permute(0, 3, 1, 2)
 
     def forward_accumulate(self, x, stats, masks=None):
         """One pass fused with softmax + accumulation into ``stats`` (rcu_amd.steps.McStatistics):
@@ -280,7 +290,94 @@ class UNet(nn.Module):
         return int(_lib.load().rcu_unet_workspace_bytes(self._handle(h, w, n)))
 
 
-model_registry = {'unet': UNet}  # common/model/factory.py:12-15 (postnet is out of scope)
+class PostNet(nn.Module):
+    """Drop-in for common/model/postnet.py:6-18 (the auxiliary confidence network of the auxiliary_feat runs):
+    ``nb_convs`` x [Conv2d 1x1 + BatchNorm2d + ReLU] + Conv2d 1x1 -> nb_classes, same constructor and state_dict
+    keys, evaluated by ONE fused kernel (csrc/rcu_postnet.hip).  Fed with ``UNet.features`` it reads the U-Net's
+    channels-last workspace tensor in place; any other [N, C, H, W] device tensor is re-laid out first."""
+
+    def __init__(self, in_channels, nb_classes, nb_convs=3, dropout=None):
+        super().__init__()
+        self.in_channels, self.nb_classes, self.nb_convs = in_channels, nb_classes, nb_convs
+        self._dropouts = []
+        for i in range(nb_convs):
+            base = 'convs.{}.conv2d_batch_relu'.format(i)
+            _add(self, base + '.conv', nn.Conv2d(in_channels, in_channels, 1))
+            if dropout is not None:
+                do = nn.Dropout2d(p=dropout)
+                _add(self, base + '.dropout', do)
+                self._dropouts.append(do)
+            _add(self, base + '.bn', nn.BatchNorm2d(in_channels))
+        _add(self, 'conv_logits', nn.Conv2d(in_channels, nb_classes, 1))
+        for p in self.parameters():
+            p.requires_grad = False
+        self._handle_entry = None    # (handle, weights version)
+        self._weights_version = 0
+        self.eval()
+
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        state_dict = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+        result = super().load_state_dict(state_dict, strict=strict, **kwargs)
+        self.weights_changed()
+        return result
+
+    def weights_changed(self):
+        self._weights_version += 1
+
+    def __del__(self):
+        try:
+            if self._handle_entry is not None:
+                _lib.load().rcu_postnet_destroy(self._handle_entry[0])
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def _handle(self):
+        lib = _lib.load()
+        if self._handle_entry is not None and self._handle_entry[1] == self._weights_version:
+            return self._handle_entry[0]
+        if self._handle_entry is not None:
+            lib.rcu_postnet_destroy(self._handle_entry[0])
+            self._handle_entry = None
+        handle = ctypes.c_void_p()
+        _lib.check(lib.rcu_postnet_create(self.in_channels, self.nb_classes, self.nb_convs, 1, ctypes.byref(handle)))
+        try:
+            for key, value in self.state_dict().items():
+                if not torch.is_floating_point(value):
+                    continue
+                host = value.detach().to('cpu', torch.float32).contiguous()
+                _lib.check(lib.rcu_postnet_load_weight(handle, key.encode(), ctypes.c_void_p(host.data_ptr()),
+                                                       host.numel()))
+            _lib.check(lib.rcu_postnet_finalize_weights(handle))
+        except Exception:
+            lib.rcu_postnet_destroy(handle)
+            raise
+        self._handle_entry = (handle, self._weights_version)
+        return handle
+
+    def forward(self, x):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError('expected a [N, {}, H, W] tensor'.format(self.in_channels))
+        if not x.is_cuda:
+            raise RuntimeError('rcu_amd.model.PostNet only runs on the GPU (librcu_hip); got a {} tensor'.format(x.device))
+        if any(m.training for m in self._dropouts):
+            raise NotImplementedError('MC-dropout inside PostNet is not part of the reference test scripts; call .eval()')
+        n, c, h, w = x.shape
+        nhwc = x.permute(0, 2, 3, 1)
+        pitch = nhwc.stride(2)
+        in_place = (x.dtype == torch.float32 and nhwc.stride(3) == 1 and pitch >= 32 and pitch % 4 == 0 and
+                    nhwc.stride(1) == w * pitch and nhwc.stride(0) == h * w * pitch and x.data_ptr() % 16 == 0)
+        if not in_place:      # generic input: channels-last copy padded to the 32-float voxel pitch of the kernel
+            pitch = 32
+            buf = torch.zeros((n, h, w, pitch), device=x.device, dtype=torch.float32)
+            buf[..., :c] = nhwc
+            nhwc = buf
+        logits = torch.empty((n, self.nb_classes, h, w), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.load().rcu_postnet_forward(self._handle(), ctypes.c_void_p(nhwc.data_ptr()), pitch, n, h * w,
+                                                   _lib.ptr(logits), _lib.current_stream()))
+        return logits
+
+
+model_registry = {'unet': UNet, 'postnet': PostNet}  # common/model/factory.py:12-15
 
 
 def get_model(model_type, **params):

@@ -5,6 +5,8 @@ Each function is the ``main`` of the same-named reference script (flags unchange
     bin-dl/brats_test_ensemble.py  -config_file                   (bin-dl/brats_test_ensemble.py:25-69)
     bin-dl/brats_test_aleatoric.py -config_file                   (bin-dl/brats_test_aleatoric.py:24-48)
     bin-dl/isic_test_default.py / isic_test_ensemble.py / isic_test_aleatoric.py
+    bin-dl/{brats,isic}_test_auxiliary_feat.py -config_file       (bin-dl/brats_test_auxiliary_feat.py:23-61)
+    bin-dl/{brats,isic}_test_auxiliary_segm.py -config_file       (bin-dl/brats_test_auxiliary_segm.py:23-47)
     bin-eval/eval_uncertainty.py   --ds --ids --act               (bin-eval/eval_uncertainty.py:13-50, 248-288)
 Config ids map to the same YAML names under ``<project>/config``; paths inside the YAML stay relative to the
 working directory, as in the reference.  Datasets: see rcu_amd.data (volume directories instead of pymia HDF5).
@@ -147,7 +149,173 @@ def test_aleatoric(dataset, config_file=None, device='cuda'):
                 None)
 
 
-test_default.__test__ = test_ensemble.__test__ = test_aleatoric.__test__ = False   # not pytest tests
+# ------------------------------------------------------------------------------- auxiliary networks
+class AuxiliaryFeatPredictStep(steps.BatchStep):
+    """bin-dl/brats_test_auxiliary_feat.py:64-82: segmentation network with provide_features, then the auxiliary
+    PostNet (``context.model``) on its features; the features stay in the U-Net's workspace (no copy)."""
+
+    def __init__(self, test_model):
+        self.test_model = test_model
+
+    def __call__(self, batch_context, task_context, context) -> None:
+        if not isinstance(context, steps.Context):
+            raise ValueError('expected type is "TorchTestContext" but object is of type "{}"'.format(type(context).__name__))
+        batch_context.input['images'] = batch_context.input['images'].float().to(context.device)
+        segm_logits = self.test_model(batch_context.input['images'])
+        batch_context.output['segm_probabilities'] = steps.softmax(segm_logits)
+        logits = context.model(self.test_model.features)
+        batch_context.output['probabilities'] = steps.softmax(logits)
+
+
+class AuxiliarySegmPredictStep(steps.BatchStep):
+    """bin-dl/brats_test_auxiliary_segm.py:50-71: the auxiliary U-Net sees the images plus the segmentation to be
+    judged (labels channel 1) and predicts where that segmentation is wrong."""
+
+    def __init__(self, keep_labels=False):
+        self.keep_labels = keep_labels       # isic_test_auxiliary_segm.py:80-81
+
+    def __call__(self, batch_context, task_context, context) -> None:
+        if not isinstance(context, steps.Context):
+            raise ValueError('expected type is "TorchTestContext" but object is of type "{}"'.format(type(context).__name__))
+        import torch
+        batch_context.input['images'] = batch_context.input['images'].float().to(context.device)
+        batch_context.input['labels'] = batch_context.input['labels'].long().to(context.device)
+        pred = batch_context.input['labels'][:, 1]
+        inpt = torch.cat([batch_context.input['images'], pred.unsqueeze(1).float()], dim=1)
+        logits = context.model(inpt)
+        batch_context.output['logits'] = logits
+        batch_context.output['probabilities'] = steps.softmax(logits)
+        batch_context.output['orig_prediction'] = pred.unsqueeze(1)
+        if self.keep_labels:
+            batch_context.output['labels'] = batch_context.input['labels']
+
+
+class EvalAuxiliaryFeatStep(loops.SubjectStep):
+    """Dice of the SEGMENTATION network's arg-max (brats_test_auxiliary_feat.py:85-99)."""
+
+    def __init__(self, squeeze_labels=False):
+        self.evaluate = ev.ComposeEvaluation([ev.DiceNumpy()])
+        self.squeeze_labels = squeeze_labels
+
+    def __call__(self, subject_context, task_context, context) -> None:
+        probabilities = subject_context.subject_data['segm_probabilities']
+        target = subject_context.subject_data['labels']
+        if self.squeeze_labels:
+            target = target.squeeze(-1)
+        results = {}
+        self.evaluate({'prediction': np.argmax(probabilities, axis=-1), 'probabilities': probabilities, 'target': target},
+                      results)
+        subject_context.metrics.update(results)
+
+
+class EvalAuxiliarySegmStep(loops.SubjectStep):
+    """Dice of "predicted wrong" against "is wrong" (brats_test_auxiliary_segm.py:74-91)."""
+
+    def __init__(self, set_score=False):
+        self.evaluate = ev.ComposeEvaluation([ev.DiceNumpy()])
+        self.set_score = set_score
+
+    def __call__(self, subject_context, task_context, context) -> None:
+        probabilities = subject_context.subject_data['probabilities']
+        labels = subject_context.subject_data['labels']
+        results = {}
+        self.evaluate({'prediction': np.argmax(probabilities, axis=-1), 'probabilities': probabilities,
+                       'target': labels[..., 1] != labels[..., 0]}, results)
+        subject_context.metrics.update(results)
+        if self.set_score:
+            subject_context.score = results['dice']
+
+
+class WriteConfidenceHook(loops.TestLoopHook):
+    """``{subject}_confidence.nii.gz`` (foreground output of the auxiliary network) + ``{subject}_prediction.nii.gz``
+    (brats_test_auxiliary_feat.py:102-135, brats_test_auxiliary_segm.py:94-124; ISIC variants symlink the inputs)."""
+
+    def __init__(self, prediction_entry, link=(), in_background=True):
+        self.prediction_entry, self.link, self.in_background = prediction_entry, tuple(link), in_background
+
+    def on_test_subject_end(self, subject_context, task_context, context):
+        if not isinstance(context, loops.TorchTestContext):
+            raise ValueError('expected type is "TorchTestContext" but object is of type "{}"'.format(type(context).__name__))
+        data = subject_context.subject_data
+        subject = data.get('subject', subject_context.subject_index)
+        confidence = np.ascontiguousarray(data['probabilities'][..., 1], dtype=np.float32)
+        if self.prediction_entry == 'segm_probabilities':
+            prediction = np.argmax(data['segm_probabilities'], axis=-1).astype(np.uint8)
+        else:
+            prediction = np.squeeze(data['orig_prediction']).astype(np.uint8)
+        props, test_dir = data.get('properties'), context.test_dir
+
+        def work():
+            nifti.write(os.path.join(test_dir, '{}_confidence.nii.gz'.format(subject)), confidence, props)
+            nifti.write(os.path.join(test_dir, '{}_prediction.nii.gz'.format(subject)), prediction, props)
+
+        nifti.do_work(work, in_background=self.in_background)
+        if self.link:
+            files = context.test_data.dataset.get_files_by_id(subject_context.subject_index)
+            for key in self.link:
+                src = os.path.abspath(files[key])
+                dst = os.path.join(context.test_dir, os.path.basename(src))
+                if not os.path.lexists(dst):
+                    os.symlink(src, dst)
+
+    def on_termination(self, context):
+        nifti.join_all()
+
+
+def _load_segmentation_model(context):
+    """others.model_dir + others.test_at -> the trained segmentation U-Net with provide_features set
+    (brats_test_auxiliary_feat.py:35-46)."""
+    others = context.config.others
+    if not hasattr(others, 'model_dir') or not hasattr(others, 'test_at'):
+        raise ValueError('missing "model_dir" or "test_at" entry in the configuration (others)')
+    mf = mgt.ModelFiles.from_model_dir(others.model_dir)
+    model = mgt.load_model_from_parameters(mf.model_path())
+    model.provide_features = True
+    mgt.load_checkpoint(mgt.find_checkpoint_file(mf.weight_checkpoint_dir, others.test_at), model)
+    return model.to(context.device).eval()
+
+
+def test_auxiliary_feat(dataset, config_file=None, device='cuda'):
+    context = loops.TorchTestContext(device)
+    context.load_from_config(config_file or os.path.join(CONFIG_DIR, 'test_{}_auxiliary_feat.yaml'.format(dataset)))
+    test_model = _load_segmentation_model(context)
+    if dataset == 'brats':
+        build = data_mod.BuildData(build_dataset=data_mod.BuildVolumeDataset())
+        test = loops.Test([AuxiliaryFeatPredictStep(test_model)], [loops.ExtractSubjectInfoStep(), EvalAuxiliaryFeatStep()],
+                          loops.SubjectAssembler(), entries=('probabilities', 'segm_probabilities'))
+        hook = WriteConfidenceHook('segm_probabilities')
+    else:
+        build = data_mod.BuildData(build_dataset=data_mod.BuildIsicDataset())
+        test = loops.Test([AuxiliaryFeatPredictStep(test_model), PrepareSubjectStep()],
+                          [EvalAuxiliaryFeatStep(squeeze_labels=True)], loops.Subject2dAssembler(),
+                          entries=('probabilities', 'segm_probabilities', 'labels'))
+        hook = WriteConfidenceHook('segm_probabilities', link=('label_paths',))
+    test(context, build, hook=_hooks(hook))
+    return context
+
+
+def test_auxiliary_segm(dataset, config_file=None, device='cuda'):
+    context = loops.TorchTestContext(device)
+    context.load_from_config(config_file or os.path.join(CONFIG_DIR, 'test_{}_auxiliary_segm.yaml'.format(dataset)))
+    if dataset == 'brats':
+        build = data_mod.BuildData(build_dataset=data_mod.BuildVolumeDataset())
+        test = loops.Test([AuxiliarySegmPredictStep()], [loops.ExtractSubjectInfoStep(), EvalAuxiliarySegmStep()],
+                          loops.SubjectAssembler(), entries=('probabilities', 'orig_prediction'))
+        hook = WriteConfidenceHook('orig_prediction')
+    else:
+        if not hasattr(context.config.others, 'prediction_dir'):
+            raise ValueError('"others.prediction_dir" is required in the config')
+        build = data_mod.BuildData(build_dataset=data_mod.BuildIsicDataset(),
+                                   prediction_dir=context.config.others.prediction_dir)
+        test = loops.Test([AuxiliarySegmPredictStep(keep_labels=True)], [EvalAuxiliarySegmStep(set_score=True)],
+                          loops.Subject2dAssembler(), entries=('probabilities', 'labels', 'orig_prediction'))
+        hook = WriteConfidenceHook('orig_prediction', link=('label_paths', 'image_paths'))
+    test(context, build, hook=_hooks(hook))
+    return context
+
+
+for _fn in (test_default, test_ensemble, test_aleatoric, test_auxiliary_feat, test_auxiliary_segm):
+    _fn.__test__ = False   # not pytest tests
 
 
 def eval_uncertainty(dataset, run_dirs: dict, ground_truth_dir, base_dir, actions=('minmax', 'ece_dice', 'calib', 'bnf_ue'),

@@ -562,12 +562,40 @@ def g12_eval_csv():
     save('g12_eval_csv', **out)
 
 
+def g13_postnet():
+    """auxiliary_feat: reference UNet(provide_features=True) -> features -> reference PostNet (postnet.py:6-18),
+    the way bin-dl/brats_test_auxiliary_feat.py:67-77 chains them; a second PostNet with non-default depth/classes."""
+    import common.model.postnet as ref_postnet
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=4, dropout=0.05, provide_features=True)
+    model = make_unet(13, **params)
+    gen = torch.Generator().manual_seed(131)
+    x = torch.randn(2, 4, 32, 48, generator=gen)
+    torch.manual_seed(14)
+    post = ref_postnet.PostNet(4, 2)
+    randomise_bn(post, gen)
+    post.eval()
+    post5 = ref_postnet.PostNet(4, 3, nb_convs=5)
+    randomise_bn(post5, gen)
+    post5.eval()
+    with torch.no_grad():
+        segm_logits = model(x)
+        feats = model.features
+        logits = post(feats)
+        logits5 = post5(feats)
+    arrays = dict(params=np.array(repr(params)), x=x.numpy(), segm_logits=segm_logits.numpy(), features=feats.numpy(),
+                  logits=logits.numpy(), logits5=logits5.numpy())
+    arrays.update(state_to_npz(model, 'unet::'))
+    arrays.update(state_to_npz(post, 'post::'))
+    arrays.update(state_to_npz(post5, 'post5::'))
+    save('g13_postnet', **arrays)
+
+
 def main():
     install_reference()
     torch.set_num_threads(4)
     torch.set_grad_enabled(False)
     for fn in (g1_unet_eval, g2_unet_mc, g3_unet_center, g4_unet_sigma, g5_unet_isic, g6_mc_summary,
-               g7_mc_step_end2end, g8_ece, g9_uncertainty, g10_prep, g11_fullsize_digest, g12_eval_csv):
+               g7_mc_step_end2end, g8_ece, g9_uncertainty, g10_prep, g11_fullsize_digest, g12_eval_csv, g13_postnet):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

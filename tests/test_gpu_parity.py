@@ -255,6 +255,49 @@ def test_aggregation_properties_full_size(dev):
     assert float((sa.blob - sb.blob).abs().max()) < 1e-12
 
 
+# ---------------------------------------------------------------------------------- auxiliary_feat: features + PostNet
+def test_postnet_golden_and_features_view(golden, dev):
+    """bin-dl/brats_test_auxiliary_feat.py:67-77: segmentation forward with provide_features, PostNet on the
+    features -- against the reference's own outputs (G13)."""
+    from rcu_amd.model import PostNet, UNet
+    g = golden('g13_postnet')
+    params = golden_params(g)
+    model = UNet(**params).to(dev)
+    model.load_state_dict({k[len('unet::'):]: torch.as_tensor(g[k]) for k in g if k.startswith('unet::')})
+    x = torch.as_tensor(g['x']).to(dev)
+    logits = model(x)
+    assert _maxdiff(logits.cpu(), g['segm_logits']) < LOGIT_TOL
+    feats = model.features
+    assert tuple(feats.shape) == g['features'].shape
+    assert _maxdiff(feats.cpu(), g['features']) < LOGIT_TOL
+    for tag, nb_convs, classes in (('post', 3, 2), ('post5', 5, 3)):
+        post = PostNet(params['start_filters'], classes, nb_convs=nb_convs).to(dev)
+        post.load_state_dict({k[len(tag) + 2:]: torch.as_tensor(g[k]) for k in g if k.startswith(tag + '::')})
+        ref = g['logits' if tag == 'post' else 'logits5']
+        assert _maxdiff(post(model.features).cpu(), ref) < LOGIT_TOL                         # in place on the workspace tensor
+        assert _maxdiff(post(torch.as_tensor(g['features']).to(dev)).cpu(), ref) < LOGIT_TOL  # generic NCHW input
+    with pytest.raises(RuntimeError):
+        post(torch.zeros(1, params['start_filters'], 8, 8))
+    with pytest.raises(ValueError):
+        post(torch.zeros(1, 7, 8, 8, device=dev))
+
+
+def test_postnet_full_width_vs_oracle(dev):
+    """32 feature channels (start_filters 32, config/train_brats_auxiliary_feat.yaml:7-9) on a BraTS slice batch;
+    ragged voxel count (not a multiple of 32) and a single voxel."""
+    from oracle import unet_oracle as uo
+    from rcu_amd.model import PostNet
+    for (n, h, w), classes, nb_convs in (((3, 192, 128), 2, 3), ((1, 5, 7), 2, 3), ((1, 1, 1), 4, 1), ((2, 16, 16), 32, 0)):
+        state = uo.postnet_synthetic_state(5 + n, 32, classes, nb_convs)
+        post = PostNet(32, classes, nb_convs=nb_convs).to(dev)
+        post.load_state_dict(state)
+        x = torch.randn(n, 32, h, w, generator=torch.Generator().manual_seed(h))
+        ref = uo.postnet_forward(state, x, nb_convs)
+        assert _maxdiff(post(x.to(dev)).cpu(), ref) < 2e-5
+    with pytest.raises(Exception):
+        PostNet(64, 2).to(dev)(torch.zeros(1, 64, 8, 8, device=dev))      # wider than the kernel handles: loud
+
+
 # ---------------------------------------------------------------------------------- calibration
 def test_ece_golden_bit_exact_bins(golden, dev):
     from rcu_amd import evaluation as ev

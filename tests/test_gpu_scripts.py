@@ -202,3 +202,143 @@ def test_isic_default_script_mc2(tmp_path):
         assert np.array_equal(pred, (p > 0.5).astype(np.uint8)) or np.mean(pred == (p > 0.5)) > 0.9999
         assert os.path.islink(os.path.join(ctx.test_dir, id_ + '.jpg'))
         assert os.path.islink(os.path.join(ctx.test_dir, id_ + '_segmentation.png'))
+
+
+def _confidence(ctx, name):
+    from rcu_amd import nifti
+    return (nifti.read(os.path.join(ctx.test_dir, name + '_confidence.nii.gz'))[0],
+            nifti.read(os.path.join(ctx.test_dir, name + '_prediction.nii.gz'))[0])
+
+
+def test_brats_auxiliary_feat_and_segm_scripts(tmp_path):
+    """bin-dl/brats_test_auxiliary_feat.py (PostNet on the segmentation U-Net's features) and
+    bin-dl/brats_test_auxiliary_segm.py (5-channel U-Net on images + segmentation) against the oracle chain."""
+    from oracle import unet_oracle as uo
+    from rcu_amd import data as data_mod
+    from rcu_amd import management as mgt
+    from rcu_amd import scripts
+    cfg_path, vols, states, params = _setup(tmp_path)
+    # ---- auxiliary_feat: model_dir = PostNet, others.model_dir = the segmentation network
+    post_state = uo.postnet_synthetic_state(31, 32, 2)
+    mf = mgt.ModelFiles(str(tmp_path / 'train_post'), 'post')
+    mgt.save_model(mf, 'postnet', dict(in_channels=32, nb_classes=2), post_state, epoch=3)
+    text = open(cfg_path).read()
+    seg_dir = [ln.split('model_dir: ')[1] for ln in text.splitlines() if ln.startswith('  model_dir: ')][0]
+    text_feat = text.replace('model_dir: ' + seg_dir, 'model_dir: ' + mf.model_dir) \
+                    .replace('  others: {}\n', '  others:\n    model_dir: {}\n    test_at: best\n'.format(seg_dir)) \
+                    .replace('brats_test_baseline_mc', 'brats_test_axuiliary_feat')
+    cfg_feat = str(tmp_path / 'test_feat.yaml')
+    open(cfg_feat, 'w').write(text_feat)
+    ctx = scripts.test_auxiliary_feat('brats', cfg_feat)
+    rows = {r['subject']: r for r in csv.DictReader(open(os.path.join(ctx.test_dir, 'metrics.csv')))}
+    for name, (images, labels, props) in vols.items():
+        x = torch.from_numpy(images).permute(0, 3, 1, 2)
+        logits, feats = uo.unet_forward(states[0], x, None, return_features=True, **params)
+        ref_conf = torch.softmax(uo.postnet_forward(post_state, feats), 1)[:, 1].numpy()
+        conf, pred = _confidence(ctx, name)
+        assert conf.dtype == np.float32 and pred.dtype == np.uint8
+        assert np.max(np.abs(conf - ref_conf)) < 1e-4
+        assert np.mean(pred == logits.argmax(1).numpy()) > 0.999
+        assert 0 <= float(rows[name]['dice']) <= 1
+    # ---- auxiliary_segm: dataset with labels [D,H,W,2] = (ground truth, segmentation to be judged), 5-channel U-Net
+    params5 = dict(params, in_channels=5)
+    st5 = uo.synthetic_state(41, **params5)
+    mf5 = mgt.ModelFiles(str(tmp_path / 'train_seg5'), 'seg5')
+    mgt.save_model(mf5, 'unet', params5, st5, epoch=1)
+    rng = np.random.RandomState(9)
+    vols5 = {}
+    for name, (images, labels, props) in vols.items():
+        judged = np.where(rng.rand(*labels.shape) < 0.1, 1 - labels, labels).astype(np.uint8)
+        lab2 = np.stack([labels, judged], -1)
+        data_mod.write_volume(str(tmp_path / 'ds_wpred'), name, images, lab2, props)
+        vols5[name] = (images, lab2, props)
+    text_segm = text.replace('model_dir: ' + seg_dir, 'model_dir: ' + mf5.model_dir) \
+                    .replace(str(tmp_path / 'ds'), str(tmp_path / 'ds_wpred')) \
+                    .replace('    - data\n', '    - data:\n        categories:\n        - images\n        - labels\n') \
+                    .replace('        entries:\n        - images\n        permutation', '        permutation') \
+                    .replace('brats_test_baseline_mc', 'brats_test_auxiliary_segm')
+    assert 'categories:\n        - images\n        - labels' in text_segm
+    cfg_segm = str(tmp_path / 'test_segm.yaml')
+    open(cfg_segm, 'w').write(text_segm)
+    ctx5 = scripts.test_auxiliary_segm('brats', cfg_segm)
+    rows5 = {r['subject']: r for r in csv.DictReader(open(os.path.join(ctx5.test_dir, 'metrics.csv')))}
+    from oracle import calib_oracle as co
+    for name, (images, lab2, props) in vols5.items():
+        x = torch.cat([torch.from_numpy(images).permute(0, 3, 1, 2), torch.from_numpy(lab2[..., 1:2]).permute(0, 3, 1, 2).float()], 1)
+        ref = torch.softmax(uo.unet_forward(st5, x, None, **params5), 1).numpy()
+        conf, pred = _confidence(ctx5, name)
+        assert np.max(np.abs(conf - ref[:, 1])) < 1e-4
+        assert np.array_equal(pred, lab2[..., 1])                  # the judged segmentation is passed through
+        tp, tn, fp, fn, n = co.confusion_counts((conf > 0.5).astype(np.uint8), (lab2[..., 1] != lab2[..., 0]).astype(np.uint8))
+        assert abs(float(rows5[name]['dice']) - co.dice_from_counts(tp, fp, fn)) < 0.02   # ties at 0.5 aside
+
+
+def test_isic_auxiliary_scripts(tmp_path):
+    """isic_test_auxiliary_feat.py and isic_test_auxiliary_segm.py; the latter reads the `<id>_prediction.nii.gz`
+    files of an earlier isic_test_default run through others.prediction_dir (customdatasets.py:104-109)."""
+    from PIL import Image
+    from oracle import unet_oracle as uo
+    from rcu_amd import management as mgt
+    from rcu_amd import nifti, scripts
+    params = dict(nb_classes=2, in_channels=3, depth=4, start_filters=32, dropout=0.05)
+    prefix = tmp_path / 'isic_small' / 'ISIC-2017_Test_v2'
+    img_dir, lab_dir = str(prefix) + '_Data', str(prefix) + '_Part1_GroundTruth'
+    os.makedirs(img_dir)
+    os.makedirs(lab_dir)
+    rng = np.random.RandomState(6)
+    ids = ['ISIC_0000020', 'ISIC_0000021']
+    for id_ in ids:
+        Image.fromarray(rng.randint(0, 255, (64, 96, 3)).astype(np.uint8)).save(os.path.join(img_dir, id_ + '.jpg'))
+        Image.fromarray(((rng.rand(64, 96) > 0.6) * 255).astype(np.uint8)).save(os.path.join(lab_dir, id_ + '_segmentation.png'))
+    st = uo.synthetic_state(20, **params)
+    mf = mgt.ModelFiles(str(tmp_path / 'train'), 'isic')
+    mgt.save_model(mf, 'unet', params, st)
+    base = ISIC_MC_YAML.replace('  others:\n    mc: 2\n', '  others: {{}}\n')
+    cfg0 = str(tmp_path / 'test_isic_baseline.yaml')
+    open(cfg0, 'w').write(base.format(test_dir=str(tmp_path / 'out'), model_dir=mf.model_dir, dataset=str(prefix)))
+    ctx0 = scripts.test_default('isic', cfg0, None)
+    # ---- auxiliary_feat
+    post_state = uo.postnet_synthetic_state(33, 32, 2)
+    mfp = mgt.ModelFiles(str(tmp_path / 'train_post'), 'post')
+    mgt.save_model(mfp, 'postnet', dict(in_channels=32, nb_classes=2), post_state)
+    text = base.replace('  others: {{}}\n', '  others:\n    model_dir: {seg_dir}\n    test_at: best\n') \
+               .replace('isic_test_baseline_mc', 'isic_test_auxiliary_feat')
+    cfg1 = str(tmp_path / 'test_isic_auxiliary_feat.yaml')
+    open(cfg1, 'w').write(text.format(test_dir=str(tmp_path / 'out'), model_dir=mfp.model_dir, dataset=str(prefix),
+                                      seg_dir=mf.model_dir))
+    ctx1 = scripts.test_auxiliary_feat('isic', cfg1)
+    for id_ in ids:
+        img = np.asarray(Image.open(os.path.join(img_dir, id_ + '.jpg'))).astype(np.float32)
+        x = torch.from_numpy((img - img.min()) / (img.max() - img.min())).permute(2, 0, 1)[None]
+        logits, feats = uo.unet_forward(st, x, None, return_features=True, **params)
+        ref = torch.softmax(uo.postnet_forward(post_state, feats), 1)[0, 1].numpy()
+        conf, pred = _confidence(ctx1, id_)
+        assert np.max(np.abs(conf - ref)) < 1e-4
+        assert np.mean(pred == logits.argmax(1)[0].numpy()) > 0.999
+        assert os.path.islink(os.path.join(ctx1.test_dir, id_ + '_segmentation.png'))
+    # ---- auxiliary_segm on the predictions of the first run
+    params4 = dict(params, in_channels=4)
+    st4 = uo.synthetic_state(44, **params4)
+    mf4 = mgt.ModelFiles(str(tmp_path / 'train_aux'), 'aux')
+    mgt.save_model(mf4, 'unet', params4, st4)
+    text = base.replace('  others: {{}}\n', '  others:\n    prediction_dir: {pred_dir}\n') \
+               .replace('isic_test_baseline_mc', 'isic_test_auxiliary_segm')
+    cfg2 = str(tmp_path / 'test_isic_auxiliary_segm.yaml')
+    open(cfg2, 'w').write(text.format(test_dir=str(tmp_path / 'out'), model_dir=mf4.model_dir, dataset=str(prefix),
+                                      pred_dir=ctx0.test_dir))
+    ctx2 = scripts.test_auxiliary_segm('isic', cfg2)
+    rows = {r['subject']: r for r in csv.DictReader(open(os.path.join(ctx2.test_dir, 'metrics.csv')))}
+    for id_ in ids:
+        img = np.asarray(Image.open(os.path.join(img_dir, id_ + '.jpg'))).astype(np.float32)
+        judged = nifti.read(os.path.join(ctx0.test_dir, id_ + '_prediction.nii.gz'))[0]
+        x = torch.cat([torch.from_numpy((img - img.min()) / (img.max() - img.min())).permute(2, 0, 1),
+                       torch.from_numpy(judged.astype(np.float32))[None]])[None]
+        ref = torch.softmax(uo.unet_forward(st4, x, None, **params4), 1)[0, 1].numpy()
+        conf, pred = _confidence(ctx2, id_)
+        assert np.max(np.abs(conf - ref)) < 1e-4
+        assert np.array_equal(pred, judged)
+        assert 0 <= float(rows[id_]['dice']) <= 1
+        for link in (id_ + '_segmentation.png', id_ + '.jpg'):
+            assert os.path.islink(os.path.join(ctx2.test_dir, link))
+    with pytest.raises(ValueError):
+        scripts.test_auxiliary_segm('isic', cfg0)      # others.prediction_dir is required

@@ -229,3 +229,19 @@ def test_g11_fullsize_digest(golden):
     st2 = uo.synthetic_state(20, **p)
     assert sorted(st2.keys()) == sorted(st.keys())
     assert all(tuple(st2[k].shape) == tuple(st[k].shape) for k in st)
+
+
+def test_g13_postnet_and_features(golden):
+    """auxiliary_feat chain: U-Net features (input of conv_cls) and PostNet logits of the reference."""
+    from oracle import unet_oracle as uo
+    g = golden('g13_postnet')
+    params = golden_params(g)
+    params.pop('provide_features')
+    unet_state = {k[len('unet::'):]: g[k] for k in g if k.startswith('unet::')}
+    logits, feats = uo.unet_forward(unet_state, g['x'], None, return_features=True, **params)
+    assert np.max(np.abs(logits.numpy() - g['segm_logits'])) < 1e-5
+    assert np.max(np.abs(feats.numpy() - g['features'])) < 1e-5
+    for tag, nb_convs in (('post', 3), ('post5', 5)):
+        state = {k[len(tag) + 2:]: g[k] for k in g if k.startswith(tag + '::')}
+        out = uo.postnet_forward(state, g['features'], nb_convs)
+        assert np.max(np.abs(out.numpy() - g['logits' if tag == 'post' else 'logits5'])) < 1e-5

@@ -225,3 +225,58 @@ def test_hook_composition_and_metrics_csv(tmp_path):
         w.on_test_subject_end(sc, tc, ctx)
     w.on_test_end(tc, ctx)
     assert open(str(tmp_path / 'metrics.csv')).read().splitlines() == ['subject,acc,dice', 's1,1.0,0.5', 's2,1.0,0.75']
+
+
+def test_auxiliary_dataset_variants_and_wrappers(tmp_path):
+    """Data side of the auxiliary runs: per-slice labels when the `data` extractor lists them
+    (config/test_brats_auxiliary_segm.yaml:25-29), ISIC labels extended by the earlier prediction
+    (rechun/dl/customdatasets.py:64-69); every reference test script has a same-named wrapper; the
+    model registry knows 'postnet' (common/model/factory.py:12-15)."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from rcu_amd import model as model_mod
+    from rcu_amd import nifti
+    rng = np.random.RandomState(2)
+    images = rng.randn(3, 8, 8, 4).astype(np.float32)
+    labels = (rng.rand(3, 8, 8, 2) < 0.5).astype(np.uint8)
+    data_mod.write_volume(str(tmp_path / 'ds2'), 'S1', images, labels)
+    c = cfg.load(_write_cfg(tmp_path))
+    c.test_data.dataset = str(tmp_path / 'ds2')
+    assert len(data_mod.BuildVolumeDataset()(c.test_data)[0]) and 'labels' not in data_mod.BuildVolumeDataset()(c.test_data)[0]
+    c.test_data.extractor = [cfg.Parameter('shape'), cfg.Parameter('data', categories=['images', 'labels'])]
+    c.test_data.transform = [cfg.Parameter('permute', permutation=[2, 0, 1])]
+    sample = data_mod.BuildVolumeDataset()(c.test_data)[1]
+    assert sample['images'].shape == (4, 8, 8) and sample['labels'].shape == (2, 8, 8)
+    assert np.array_equal(sample['labels'], labels[1].transpose(2, 0, 1))
+    # ISIC + prediction_dir
+    prefix = tmp_path / 'ISIC-2017_Test_v2'
+    os.makedirs(str(prefix) + '_Data')
+    os.makedirs(str(prefix) + '_Part1_GroundTruth')
+    os.makedirs(str(tmp_path / 'pred'))
+    Image.fromarray(rng.randint(0, 255, (6, 9, 3)).astype(np.uint8)).save(str(prefix) + '_Data/ISIC_0000001.jpg')
+    Image.fromarray(((rng.rand(6, 9) > 0.5) * 255).astype(np.uint8)).save(
+        str(prefix) + '_Part1_GroundTruth/ISIC_0000001_segmentation.png')
+    with pytest.raises(ValueError):
+        data_mod.IsicDataset(str(prefix), prediction_dir=str(tmp_path / 'pred'))      # prediction missing
+    judged = (rng.rand(6, 9) > 0.5).astype(np.uint8)
+    nifti.write(str(tmp_path / 'pred' / 'ISIC_0000001_prediction.nii.gz'), judged)
+    ds = data_mod.IsicDataset(str(prefix), prediction_dir=str(tmp_path / 'pred'))
+    s = ds[0]
+    assert s['labels'].shape == (6, 9, 2) and s['labels'].dtype == np.uint8
+    assert np.array_equal(s['labels'][..., 1], judged * 255)
+    # wrappers and registry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for ds_name in ('brats', 'isic'):
+        for kind in ('default', 'ensemble', 'aleatoric', 'auxiliary_feat', 'auxiliary_segm'):
+            path = os.path.join(root, 'bin-dl', '{}_test_{}.py'.format(ds_name, kind))
+            assert os.path.exists(path), path
+    r = subprocess.run([sys.executable, os.path.join(root, 'bin-dl', 'brats_test_auxiliary_feat.py'), '-h'],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and '-config_file' in r.stdout
+    assert set(model_mod.model_registry) == {'unet', 'postnet'}
+    post = model_mod.PostNet(32, 2)
+    assert sorted(k for k in post.state_dict() if not k.endswith('num_batches_tracked'))[:3] == [
+        'conv_logits.bias', 'conv_logits.weight', 'convs.0.conv2d_batch_relu.bn.bias']
+    with pytest.raises(RuntimeError):
+        post(torch.zeros(1, 32, 4, 4))          # CPU tensor: no fallback
