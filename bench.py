@@ -158,6 +158,8 @@ def main():
     ap.add_argument('--mc', type=int, default=20, help='T: stochastic passes per volume')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-ws', action='store_true', help='skip the deterministic weight-scaling pass')
+    ap.add_argument('--ensemble', type=int, default=0, metavar='K',
+                    help='K ensemble members (seeds 20..20+K-1) instead of T MC passes (BASELINE config "BraTS ensemble")')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -180,7 +182,13 @@ def main():
     x_cpu, mask_cpu, target_cpu = make_volume(seed)
     x = x_cpu.to(device)
     ctx = steps.TorchTestContext(str(device), model)
-    runner = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world)
+    if args.ensemble:
+        T = args.ensemble
+        members = [model] + [make_model(seed + k, device) for k in range(1, T)]
+        runner = rdist.ShardedEnsembleRunner(members, rank=rank, world=world)
+    else:
+        members = [model]
+        runner = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world)
     torch.manual_seed(seed + rank)              # dropout masks: independent streams per rank
 
     def one_step(k):
@@ -190,9 +198,11 @@ def main():
 
     for k in range(args.warmup):
         one_step(k).result()
-    # per-kernel HIP events for this rank's forwards inside the timed region
-    my_forwards = sum(len(runner.jobs_of(k, rank)) for k in range(args.warmup, args.warmup + args.steps))
-    model.profile_begin(HEIGHT, WIDTH, SLICES, my_forwards)
+    # per-kernel HIP events for this rank's forwards inside the timed region (per member in ensemble mode)
+    my_jobs = [j for k in range(args.warmup, args.warmup + args.steps) for j in runner.jobs_of(k, rank)]
+    for i, m in enumerate(members):
+        count = sum(1 for j in my_jobs if j - 1 == i) if args.ensemble else len(my_jobs)
+        m.profile_begin(HEIGHT, WIDTH, SLICES, max(count, 1))
 
     torch.cuda.synchronize()
     if world > 1:
@@ -212,7 +222,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    forwards, slot_ms = model.profile_collect(HEIGHT, WIDTH, SLICES)
+    forwards, slot_ms = 0, None
+    for m in members:
+        cnt, ms = m.profile_collect(HEIGHT, WIDTH, SLICES)
+        forwards += cnt
+        slot_ms = ms if slot_ms is None else [a + b for a, b in zip(slot_ms, ms)]
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -275,6 +289,7 @@ def main():
         ece_oracle = co.ece_binary(np.stack([1 - p_np, p_np], -1), target_cpu.numpy(), mask=mask_cpu.numpy())
         parity['ece_delta_same_maps'] = abs(ece_gpu - ece_oracle)
         parity['bin_ids_equal'] = bool(np.array_equal(ev.bin_ids(p_np), co.bin_ids(p_np.reshape(-1))))
+    if not args.no_cpu_baseline and world == 1 and not args.ensemble:     # the CPU leg: rank 0 at N=1 only
         cpu, mask_sets, ref = cpu_baseline(model, x_cpu, T, seed)
         n = ref['probabilities'].shape[0]
         bc = steps.BatchContext({'images': x[:n].contiguous()}, 0)
@@ -288,9 +303,10 @@ def main():
         parity['ece_delta_vs_cpu'] = abs(ev.ece_binary(pg, tg, mask=mk) - co.ece_binary(np.stack([1 - pc, pc], -1), tg, mask=mk))
 
     result = {
-        'metric': 'MC-sample-volumes/sec (4x160x192x128, T=20)',
+        'metric': 'ensemble-member-volumes/sec (4x160x192x128, K={})'.format(T) if args.ensemble
+                  else 'MC-sample-volumes/sec (4x160x192x128, T=20)',
         'value': T * args.steps / elapsed,
-        'unit': 'MC-sample-volumes/s',
+        'unit': 'member-volumes/s' if args.ensemble else 'MC-sample-volumes/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True,
@@ -298,10 +314,12 @@ def main():
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': 'BraTS baseline_mc: 2D U-Net(2,4,depth 4,start_filters 32,dropout 0.05) over 160 slices '
-                               'of 4x192x128, T={} MC-dropout passes{} + mean/entropy aggregation per step'
-                               .format(T, '' if args.no_ws else ' + weight-scaling pass'),
-                   'T': T, 'ws_pass': not args.no_ws, 'slices': SLICES, 'height': HEIGHT, 'width': WIDTH,
+        'config': {'workload': ('BraTS ensemble: {} U-Net(2,4,depth 4,start_filters 32) members over 160 slices of 4x192x128 '
+                                '+ mean/entropy aggregation per step'.format(T)) if args.ensemble else
+                               ('BraTS baseline_mc: 2D U-Net(2,4,depth 4,start_filters 32,dropout 0.05) over 160 slices '
+                                'of 4x192x128, T={} MC-dropout passes{} + mean/entropy aggregation per step'
+                                .format(T, '' if args.no_ws else ' + weight-scaling pass')),
+                   'T': T, 'ws_pass': not (args.no_ws or args.ensemble), 'slices': SLICES, 'height': HEIGHT, 'width': WIDTH,
                    'sharding': 'passes over ranks, one RCCL sum-reduce of the statistics per step' if world > 1 else 'none',
                    'gflop_per_sample_volume': conv_flops / max(forwards, 1) / 1e9},
         'roofline': roofline,

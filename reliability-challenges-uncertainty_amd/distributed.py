@@ -58,6 +58,10 @@ class HipEngine:
         finally:
             steps_mod.set_dropout_mode(self.model, False)
 
+    def member_pass(self, member, x, stats):
+        steps_mod.set_dropout_mode(member, False)
+        member.forward_accumulate(x, stats)
+
     def finalize(self, stats, count):
         return stats.finalize(self.do_mi, self.do_var, count=count)
 
@@ -80,13 +84,16 @@ class ShardedMcRunner:
         jobs = self.job_list()
         return [j for i, j in enumerate(jobs) if (i + step * len(jobs)) % self.world == rank]
 
+    def _run_job(self, job, x, stats, ws, mask_sets):
+        if job == 0:
+            self.engine.ws_pass(x, ws)
+        else:
+            self.engine.mc_pass(x, stats, None if mask_sets is None else mask_sets[job - 1])
+
     def _run_jobs(self, x, step_index, mask_sets):
         flat, stats, ws, ws_apart = self.engine.buffers(x, self.ws_pass)
         for job in self.jobs_of(step_index, self.rank):
-            if job == 0:
-                self.engine.ws_pass(x, ws)
-            else:
-                self.engine.mc_pass(x, stats, None if mask_sets is None else mask_sets[job - 1])
+            self._run_job(job, x, stats, ws, mask_sets)
         return flat, stats, ws, ws_apart
 
     def step(self, x, step_index=0, mask_sets=None):
@@ -148,6 +155,23 @@ class ShardedMcRunner:
         """Retire every reduce still in flight (call before destroying the process group)."""
         while getattr(self, '_inflight', None):
             self._inflight.popleft().retire()
+
+
+class ShardedEnsembleRunner(ShardedMcRunner):
+    """K ensemble members instead of T MC passes (bin-dl/brats_test_ensemble.py:78-94; BASELINE config
+    "K=10 checkpoints, members sharded over 8 MI355X with RCCL reduce").  Job j = member j-1 in eval mode, no
+    weight-scaling pass, divisor K.  A member's packed weights are 35 MB, so every rank holds all K members and
+    the job rotation of the base class applies (K = 10 on 8 GPUs: 10 forwards per rank per 8 volumes instead of
+    a static 2,2,1,1,1,1,1,1 split)."""
+
+    def __init__(self, members, rank=0, world=1, engine=None, do_mi=False, do_var=False, root=0):
+        members = list(members)
+        super().__init__(members[0] if members else None, len(members), ws_pass=False, rank=rank, world=world,
+                         engine=engine, do_mi=do_mi, do_var=do_var, root=root)
+        self.members = members
+
+    def _run_job(self, job, x, stats, ws, mask_sets):
+        self.engine.member_pass(self.members[job - 1], x, stats)
 
 
 class PendingSummary:

@@ -38,6 +38,9 @@ class OracleEngine:
     def mc_pass(self, x, stats, masks=None):
         stats += torch.softmax(self.uo.unet_forward(self.state, x, masks, **PARAMS), 1)
 
+    def member_pass(self, member_state, x, stats):
+        stats += torch.softmax(self.uo.unet_forward(member_state, x, None, **PARAMS), 1)
+
     def finalize(self, stats, count):
         from oracle import summary_oracle as so
         p = stats / count
@@ -77,6 +80,19 @@ def _worker(rank, world, port, out_dir):
         else:
             assert out is None
     runner.drain()
+    # ensemble members instead of MC passes: 3 members on 2 ranks, rotation over the steps
+    from oracle import unet_oracle as uo
+    from rcu_amd.distributed import ShardedEnsembleRunner
+    members = [uo.synthetic_state(100 + k, **PARAMS) for k in range(3)]
+    ens = ShardedEnsembleRunner(members, rank=rank, world=world, engine=OracleEngine(state))
+    assert sorted(j for r in range(world) for j in ens.jobs_of(1, r)) == [1, 2, 3]
+    pend = [ens.step_async(x, step) for step in range(2)]
+    for step, p in enumerate(pend):
+        out = p.result()
+        if rank == 0:
+            assert 'ws_probabilities' not in out
+            np.savez(os.path.join(out_dir, 'ens{}.npz'.format(step)), **{k: v.numpy() for k, v in out.items()})
+    ens.drain()
     dist.destroy_process_group()
 
 
@@ -114,5 +130,12 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     for name in ['step{}.npz'.format(k) for k in range(3)] + ['async{}.npz'.format(k) for k in range(3)]:
         got = np.load(os.path.join(str(tmp_path), name))
         assert np.max(np.abs(got['ws_probabilities'] - ws.numpy())) < 1e-6
+        assert np.max(np.abs(got['probabilities'] - ref['probabilities'].numpy())) < 1e-6
+        assert np.max(np.abs(got['entropy'] - ref['entropy'].numpy())) < 2e-6
+    members = [uo.synthetic_state(100 + k, **PARAMS) for k in range(3)]
+    multi = so.ensemble_probabilities([lambda xx, m, st=st: uo.unet_forward(st, xx, m, **PARAMS) for st in members], x)
+    ref = so.multi_prediction_summary(multi)
+    for step in range(2):
+        got = np.load(os.path.join(str(tmp_path), 'ens{}.npz'.format(step)))
         assert np.max(np.abs(got['probabilities'] - ref['probabilities'].numpy())) < 1e-6
         assert np.max(np.abs(got['entropy'] - ref['entropy'].numpy())) < 2e-6
