@@ -99,7 +99,7 @@ static bool unit_has_dropout(const rcu_unet_desc& d, int level, bool is_down, in
 // floats of one packed [TAPS][BN][KC+4] weight tile, rounded up to 256 threads x float4
 static size_t conv_tile_floats(const ConvConfigInfo& ci)
 {
-    const size_t units = (size_t)ci.TAPS * ci.BN * (ci.KC + 4) / 4;
+    const size_t units = (size_t)ci.TAPS * ci.BN * ci.KCP / 4;
     return (units + 255) / 256 * 256 * 4;
 }
 
@@ -321,7 +321,7 @@ static int fold_conv(rcu_unet* h, const ConvLayer& L, const std::string& conv, c
                      std::vector<float>& beta)
 {
     const ConvConfigInfo& ci = conv_config_info(L.cfg);
-    const int KC = ci.KC, KCP = KC + 4, BN = ci.BN;
+    const int KC = ci.KC, KCP = ci.KCP, BN = ci.BN;
     const int cin = L.cin1 + L.cin2;
     const std::vector<float>*w, *b;
     int rc = get_weight(h, conv + ".weight", (size_t)L.cout * cin * 9, &w);
@@ -371,7 +371,9 @@ static int fold_conv(rcu_unet* h, const ConvLayer& L, const std::string& conv, c
                             for (int dx = 0; dx < 3; ++dx)
                                 if (fold_set(a, ty, dy) && fold_set(b, tx, dx)) v += w9[dy * 3 + dx];
                     }
-                    wpack[tile0 + ((size_t)tap * BN + nn) * KCP + kq] = v;
+                    // swizzled layout: the two 16-byte units of a row swap places for channels 16..31 (mod 32)
+                    const int kdst = ci.SWZ ? ((((kq >> 2) ^ ((nn >> 4) & 1)) << 2) | (kq & 3)) : kq;
+                    wpack[tile0 + ((size_t)tap * BN + nn) * KCP + kdst] = v;
                 }
             }
         }
@@ -385,10 +387,8 @@ extern "C" int rcu_unet_finalize_weights(rcu_unet* h)
     if (h->finalized) return RCU_OK;
     for (ConvLayer& L : h->layers) {
         const ConvConfigInfo& ci = conv_config_info(L.cfg);
-        const int KCP = ci.KC + 4;
         const int nchunks = (L.c1p + L.c2p) / ci.KC;
         L.wpack_floats = (size_t)nchunks * L.NT * (L.upsample ? 4 : 1) * conv_tile_floats(ci);
-        (void)KCP;
         std::vector<float> wpack(L.wpack_floats, 0.f);
         const int cpad = L.NT * ci.BN;
         std::vector<float> alpha(cpad, 0.f), betab(cpad, 0.f), beta(cpad, 0.f);

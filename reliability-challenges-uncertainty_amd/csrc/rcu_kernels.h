@@ -49,6 +49,8 @@ enum ConvConfig {
 struct ConvConfigInfo {
     int TS, TH, TW, BN, KC, TAPS;
     const char* kernel_name;
+    int KCP;   // floats per [tap][channel] row of a packed weight tile (KC, or KC + 4 in the padded layout)
+    int SWZ;   // 1: the two 16-byte units of a row are swapped for output channels 16..31 (mod 32), see ConvTile
 };
 const ConvConfigInfo& conv_config_info(int cfg);
 hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream);

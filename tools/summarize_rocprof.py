@@ -20,7 +20,7 @@ import sys
 
 def short(name):
     """Demangled rocprof kernel name -> the kernel_name string of rcu_unet_layer_info / bench.py."""
-    m = re.search(r'conv_igemm(?:_stream)?<rcu::ConvTile<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', name)
+    m = re.search(r'conv_igemm(?:_stream)?<rcu::ConvTile<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, \d+)?>', name)
     if m:
         ts, th, tw, bn, kc, _wm, _wn, taps, db = m.groups()
         tile = ('S{}'.format(ts) if ts != '1' else '') + 'T{}x{}'.format(th, tw)
