@@ -103,7 +103,7 @@ static size_t conv_tile_floats(const ConvConfigInfo& ci)
     return (units + 255) / 256 * 256 * 4;
 }
 
-static int pick_config(const ConvLayer& L)
+static int pick_config(const ConvLayer& L, int n_slices)
 {
     if (L.upsample) {   // sub-pixel form; L.H x L.W is the OUTPUT grid, tiles run over the low-res input grid
         if (L.coutp <= 32) return ((L.H / 2) % 16 == 0 && (L.W / 2) % 16 == 0) ? CONV_CFG_UP_T16x16_N32 : CONV_CFG_UP_T8x16_N32;
@@ -113,6 +113,17 @@ static int pick_config(const ConvLayer& L)
     if (L.c1p + L.c2p == 8) return CONV_CFG_T8x16_N32_FIRST;
     if (L.coutp > 32) {
         if (L.H == 12 && L.W == 8) return CONV_CFG_S2T12x8_N64;
+        // 128-pixel tiles run 3 workgroups per CU (768 slots), 256-pixel tiles 2 (512 slots) with half the staging,
+        // barriers and fragment reads per MFMA.  Measured on the BraTS levels (tools/layer_report.py): the big tile
+        // wins where every work item stages its own input tile (one channel tile) and where the small tile's last
+        // round of work items is badly filled (24x16: 2.5 rounds); it loses 3 % at 48x32 (5 full rounds).
+        const int nt = (L.coutp + 63) / 64;
+        const long items = (long)((L.H + 7) / 8) * ((L.W + 15) / 16) * n_slices * nt;
+        const double fill = (double)items / (double)((items + 767) / 768 * 768);
+        if (nt == 1 || fill < 0.9) {
+            if (L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_T16x16_N64;
+            if (L.H % 8 == 0 && L.W % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_S2T8x16_N64;
+        }
         return CONV_CFG_T8x16_N64;
     }
     return (L.H % 16 == 0 && L.W % 16 == 0) ? CONV_CFG_T16x16_N32 : CONV_CFG_T8x16_N32;
@@ -209,7 +220,7 @@ static int build_plan(rcu_unet* h)
     for (size_t s = 0; s < h->sites.size(); ++s) h->site_offset[s + 1] = h->site_offset[s] + h->sites[s].second;
     h->mask_floats = h->site_offset.back();
     for (ConvLayer& L : h->layers) {
-        L.cfg = pick_config(L);
+        L.cfg = pick_config(L, h->d.max_batch);
         const ConvConfigInfo& ci = conv_config_info(L.cfg);
         if ((L.c1p % ci.KC) != 0 || (L.c2p % ci.KC) != 0)
             return fail(RCU_ERR_INVALID, "internal: channel chunking does not divide for layer " + L.name);

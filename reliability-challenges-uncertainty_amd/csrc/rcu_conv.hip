@@ -598,6 +598,8 @@ using Cfg5 = ConvTile<1, 8, 16, 32, 8, 4, 1, 4, 1, 1>;
 using Cfg6 = ConvTile<2, 12, 8, 64, 8, 2, 2, 4, 1, 1>;
 using Cfg7 = ConvTile<1, 16, 16, 32, 8, 4, 1, 9, 1, 1>;
 using Cfg8 = ConvTile<1, 16, 16, 32, 8, 4, 1, 4, 1, 1>;
+using Cfg9 = ConvTile<1, 16, 16, 64, 8, 2, 2, 9, 1, 1>;
+using Cfg10 = ConvTile<2, 8, 16, 64, 8, 2, 2, 9, 1, 1>;
 
 static const ConvConfigInfo kInfo[CONV_CFG_COUNT] = {
     {Cfg0::TS, Cfg0::TH, Cfg0::TW, Cfg0::BN, Cfg0::KC, Cfg0::TAPS, "conv3x3_igemm<T8x16,N64,K8,db>", Cfg0::KCP, Cfg0::SWZ ? 1 : 0},
@@ -609,6 +611,8 @@ static const ConvConfigInfo kInfo[CONV_CFG_COUNT] = {
     {Cfg6::TS, Cfg6::TH, Cfg6::TW, Cfg6::BN, Cfg6::KC, Cfg6::TAPS, "upconv_subpixel_igemm<S2T12x8,N64,K8,db>", Cfg6::KCP, Cfg6::SWZ ? 1 : 0},
     {Cfg7::TS, Cfg7::TH, Cfg7::TW, Cfg7::BN, Cfg7::KC, Cfg7::TAPS, "conv3x3_igemm<T16x16,N32,K8,db>", Cfg7::KCP, Cfg7::SWZ ? 1 : 0},
     {Cfg8::TS, Cfg8::TH, Cfg8::TW, Cfg8::BN, Cfg8::KC, Cfg8::TAPS, "upconv_subpixel_igemm<T16x16,N32,K8,db>", Cfg8::KCP, Cfg8::SWZ ? 1 : 0},
+    {Cfg9::TS, Cfg9::TH, Cfg9::TW, Cfg9::BN, Cfg9::KC, Cfg9::TAPS, "conv3x3_igemm<T16x16,N64,K8,db>", Cfg9::KCP, Cfg9::SWZ ? 1 : 0},
+    {Cfg10::TS, Cfg10::TH, Cfg10::TW, Cfg10::BN, Cfg10::KC, Cfg10::TAPS, "conv3x3_igemm<S2T8x16,N64,K8,db>", Cfg10::KCP, Cfg10::SWZ ? 1 : 0},
 };
 
 const ConvConfigInfo& conv_config_info(int cfg) { return kInfo[cfg]; }
@@ -659,6 +663,8 @@ hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream)
         case CONV_CFG_UP_S2T12x8_N64: return launch_cfg<Cfg6>(a, stream);
         case CONV_CFG_T16x16_N32: return launch_cfg<Cfg7>(a, stream);
         case CONV_CFG_UP_T16x16_N32: return launch_cfg<Cfg8>(a, stream);
+        case CONV_CFG_T16x16_N64: return launch_cfg<Cfg9>(a, stream);
+        case CONV_CFG_S2T8x16_N64: return launch_cfg<Cfg10>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }

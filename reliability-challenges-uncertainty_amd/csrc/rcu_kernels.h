@@ -37,12 +37,14 @@ enum ConvConfig {
     CONV_CFG_T8x16_N64 = 0,          // 8x16-pixel tile, 64 couts, Cin chunks of 8, LDS double-buffered (workhorse)
     CONV_CFG_T8x16_N32 = 1,          // 8x16-pixel tile, 32 couts, Cin chunks of 8, double-buffered (32-channel layers)
     CONV_CFG_T8x16_N32_FIRST = 2,    // first layer: Cin padded to 8 = a single chunk
-    CONV_CFG_S2T12x8_N64 = 3,        // two whole 12x8 slices per workgroup, chunks of 16 (BraTS bottom level)
-    CONV_CFG_UP_T8x16_N64 = 4,       // sub-pixel up-conv (2x2 taps on the low-res grid), 64 couts, chunks of 16
+    CONV_CFG_S2T12x8_N64 = 3,        // two whole 12x8 slices per workgroup (BraTS bottom level)
+    CONV_CFG_UP_T8x16_N64 = 4,       // sub-pixel up-conv (2x2 taps on the low-res grid), 64 couts
     CONV_CFG_UP_T8x16_N32 = 5,       // sub-pixel up-conv, 32 couts
     CONV_CFG_UP_S2T12x8_N64 = 6,     // sub-pixel up-conv out of the 12x8 bottom level, chunks of 8
     CONV_CFG_T16x16_N32 = 7,         // 16x16-pixel tile, 32 couts: halves the weight staging per MFMA of the 32-channel layers
     CONV_CFG_UP_T16x16_N32 = 8,      // sub-pixel up-conv, 32 couts, 16x16 low-res tile
+    CONV_CFG_T16x16_N64 = 9,         // 256 pixels x 64 couts: half the staging / barriers / fragment reads per MFMA
+    CONV_CFG_S2T8x16_N64 = 10,       // the same tile as two 8x16 pieces of consecutive slices (heights not divisible by 16)
     CONV_CFG_COUNT
 };
 
