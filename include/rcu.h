@@ -101,6 +101,13 @@ int rcu_unet_forward(rcu_unet* h, const float* x_dev, int n, const float* masks_
  * ensemble member, brats_test_ensemble.py:85-92).  stats_dev / flags as for rcu_mc_accumulate. */
 int rcu_unet_forward_accumulate(rcu_unet* h, const float* x_dev, int n, const float* masks_dev, void* stats_dev,
                                 int flags, void* stream);
+/* The same for `passes` stochastic passes at once: the n images run as one batch of n * passes samples (sample
+ * t*n + i = image i under mask rows [site][t*n + i][C_site], masks_dev holds n * passes rows per site) and all passes
+ * are added to the n statistics entries in pass order -- bit-identical to `passes` calls of
+ * rcu_unet_forward_accumulate, but a small batch (the reference's batch_size 32, customsteps.py:30-34) fills the GPU.
+ * n * passes <= max_batch. */
+int rcu_unet_forward_accumulate_passes(rcu_unet* h, const float* x_dev, int n, int passes, const float* masks_dev,
+                                       void* stats_dev, int flags, void* stream);
 
 /* Per-layer introspection for benchmarks: canonical FLOPs (2*Cin*Cout*9*H*W per slice, real
  * channel counts) and the kernel configuration chosen. */

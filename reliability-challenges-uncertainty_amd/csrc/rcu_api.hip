@@ -460,19 +460,25 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     return RCU_OK;
 }
 
+// `passes` > 1 (statistics only): the n images run as ONE batch of n * passes samples -- sample t * n + i is image i
+// under the mask rows [site][t * n + i] -- and the head adds all passes into the n statistics entries.
 static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, float* logits, float* sigma, void* stats,
-                        int flags, hipStream_t stream)
+                        int flags, hipStream_t stream, int passes = 1)
 {
     if (!h || !x) return fail(RCU_ERR_INVALID, "rcu_unet_forward: null argument");
     if (!h->finalized) return fail(RCU_ERR_STATE, "rcu_unet_forward before rcu_unet_finalize_weights");
-    if (n < 1 || n > h->d.max_batch) return fail(RCU_ERR_INVALID, "batch size outside 1..max_batch");
+    if (n < 1 || passes < 1 || (long)n * passes > h->d.max_batch)
+        return fail(RCU_ERR_INVALID, "batch size (times passes) outside 1..max_batch");
+    if (passes > 1 && (!stats || logits || sigma)) return fail(RCU_ERR_INVALID, "pass groups only feed the statistics");
+    const int n_one = n;
+    n *= passes;
     if (sigma && !h->d.sigma_out) return fail(RCU_ERR_INVALID, "sigma output requested from a model without sigma_out");
     hipEvent_t* ev = nullptr;
     if (h->prof_capacity > 0 && h->prof_used < h->prof_capacity)
         ev = h->prof_events.data() + (size_t)(h->prof_used++) * prof_slots(h);
     if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
-    RCU_HIP(launch_pack_input(x, h->tensors[h->t_input].dev, n, h->d.in_channels, h->in_cp, h->d.height, h->d.width,
-                              stream));
+    RCU_HIP(launch_pack_input(x, h->tensors[h->t_input].dev, n_one, h->d.in_channels, h->in_cp, h->d.height, h->d.width,
+                              passes, stream));
     if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
     for (const ConvLayer& L : h->layers) {
         int rc = run_layer(h, L, n, masks, stream);
@@ -485,7 +491,8 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
     a.logits = logits; a.sigma = sigma; a.stats = stats;
     a.C = h->d.nb_classes; a.CP = h->head_cp; a.CPh = h->head_cph; a.stats_flags = flags;
     a.HW = (size_t)h->d.height * h->d.width;
-    a.V = a.HW * n;
+    a.V = a.HW * n_one;
+    a.passes = passes;
     RCU_HIP(launch_head(a, stream));
     if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
     return RCU_OK;
@@ -670,6 +677,14 @@ extern "C" int rcu_postnet_forward(rcu_postnet* h, const float* features_dev, in
     RCU_HIP(launch_postnet(features_dev, channel_pitch, (size_t)n * hw, hw, h->packed, h->nb_convs + 1, h->nb_classes,
                            logits_dev, static_cast<hipStream_t>(stream)));
     return RCU_OK;
+}
+
+extern "C" int rcu_unet_forward_accumulate_passes(rcu_unet* h, const float* x_dev, int n, int passes, const float* masks_dev,
+                                                  void* stats_dev, int flags, void* stream)
+{
+    if (!stats_dev) return fail(RCU_ERR_INVALID, "rcu_unet_forward_accumulate_passes: null stats");
+    return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR),
+                        static_cast<hipStream_t>(stream), passes);
 }
 
 extern "C" int rcu_unet_num_layers(const rcu_unet* h) { return h ? (int)h->layers.size() : 0; }

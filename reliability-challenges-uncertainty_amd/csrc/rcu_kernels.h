@@ -60,7 +60,7 @@ hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream);
 // ---------------------------------------------------------------------------------------------
 // layout / head / aggregation kernels (rcu_pointwise.hip)
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_pack_input(const float* x_nchw, float* out_nhwc, int N, int C, int CP, int H, int W,
+hipError_t launch_pack_input(const float* x_nchw, float* out_nhwc, int N, int C, int CP, int H, int W, int replicas,
                              hipStream_t stream);
 
 // MC statistics blob: planes over the voxel index v = n*HW + hw.
@@ -81,7 +81,9 @@ struct HeadArgs {
     float* sigma;         // NCHW or null
     void* stats;          // MC stats blob or null
     int C, CP, CPh, stats_flags;
-    size_t V, HW;
+    size_t V, HW;         // V = voxels of ONE pass (n * HW)
+    int passes;           // > 1 (statistics only): act holds `passes` consecutive groups of V voxels, all accumulated
+                          // into the same V statistics entries, in pass order
 };
 hipError_t launch_head(const HeadArgs& a, hipStream_t stream);
 

@@ -20,12 +20,13 @@ static constexpr int PW_THREADS = 256;
 static inline unsigned grid_for(size_t n) { return (unsigned)((n + PW_THREADS - 1) / PW_THREADS); }
 
 // ------------------------------------------------------------------------------- NCHW -> padded NHWC
+// `replicas` > 1: the N input images are written `replicas` times one after the other (pass groups).
 __global__ __launch_bounds__(PW_THREADS) void pack_input_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                                 int C, int CP, size_t HW, size_t V)
+                                                                 int C, int CP, size_t HW, size_t V, size_t N)
 {
     const size_t v = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;
     if (v >= V) return;
-    const size_t n = v / HW, hw = v % HW;
+    const size_t n = (v / HW) % N, hw = v % HW;
     for (int c = 0; c < CP; c += 4) {
         float4 q;
         q.x = (c + 0 < C) ? x[(n * C + c + 0) * HW + hw] : 0.f;
@@ -36,10 +37,10 @@ __global__ __launch_bounds__(PW_THREADS) void pack_input_kernel(const float* __r
     }
 }
 
-hipError_t launch_pack_input(const float* x, float* out, int N, int C, int CP, int H, int W, hipStream_t stream)
+hipError_t launch_pack_input(const float* x, float* out, int N, int C, int CP, int H, int W, int replicas, hipStream_t stream)
 {
-    const size_t HW = (size_t)H * W, V = HW * N;
-    hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(V)), dim3(PW_THREADS), 0, stream, x, out, C, CP, HW, V);
+    const size_t HW = (size_t)H * W, V = HW * N * (size_t)replicas;
+    hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(V)), dim3(PW_THREADS), 0, stream, x, out, C, CP, HW, V, (size_t)N);
     return hipGetLastError();
 }
 
@@ -68,6 +69,58 @@ __device__ __forceinline__ float entropy_of(const float (&p)[C])
     for (int c = 0; c < C; ++c) h += (p[c] > 0.f) ? p[c] * logf(p[c]) : 0.f;
     return -h;
 }
+
+// The statistics entries of one voxel held in registers across the passes of a group: load, add pass after pass in
+// the same order and with the same operations as accumulate_voxel, store -- bit-identical to one launch per pass.
+template <int C>
+struct VoxelStats {
+    double d[2 * C + 1];
+    float f[C + 1];
+    __device__ __forceinline__ void load(const void* stats, size_t v, size_t V, int flags)
+    {
+        if (flags & MC_VAR) {
+            const double* sd = reinterpret_cast<const double*>(stats);
+#pragma unroll
+            for (int k = 0; k < 2 * C; ++k) d[k] = sd[(size_t)k * V + v];
+            d[2 * C] = (flags & MC_MI) ? sd[(size_t)(2 * C) * V + v] : 0.0;
+        } else {
+            const float* sf = reinterpret_cast<const float*>(stats);
+#pragma unroll
+            for (int k = 0; k < C; ++k) f[k] = sf[(size_t)k * V + v];
+            f[C] = (flags & MC_MI) ? sf[(size_t)C * V + v] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void add(int flags, const float (&p)[C])
+    {
+        if (flags & MC_VAR) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double pc = (double)p[c];
+                d[c] += pc;
+                d[C + c] += pc * pc;
+            }
+            if (flags & MC_MI) d[2 * C] += (double)entropy_of<C>(p);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) f[c] += p[c];
+            if (flags & MC_MI) f[C] += entropy_of<C>(p);
+        }
+    }
+    __device__ __forceinline__ void store(void* stats, size_t v, size_t V, int flags) const
+    {
+        if (flags & MC_VAR) {
+            double* sd = reinterpret_cast<double*>(stats);
+#pragma unroll
+            for (int k = 0; k < 2 * C; ++k) sd[(size_t)k * V + v] = d[k];
+            if (flags & MC_MI) sd[(size_t)(2 * C) * V + v] = d[2 * C];
+        } else {
+            float* sf = reinterpret_cast<float*>(stats);
+#pragma unroll
+            for (int k = 0; k < C; ++k) sf[(size_t)k * V + v] = f[k];
+            if (flags & MC_MI) sf[(size_t)C * V + v] = f[C];
+        }
+    }
+};
 
 template <int C>
 __device__ __forceinline__ void accumulate_voxel(void* stats, size_t v, size_t V, int flags, const float (&p)[C])
@@ -116,15 +169,12 @@ __device__ __forceinline__ void head_dot8(const float* __restrict__ row, const f
     }
 }
 
+// logits (and raw sigma) of voxel v0 + lane out of the activations starting at `act` (bias not yet added)
 template <int C>
-__global__ __launch_bounds__(PW_THREADS) void head_kernel(const HeadArgs a)
+__device__ __forceinline__ void head_logits(const HeadArgs& a, const float* __restrict__ act, size_t v0, int lane,
+                                            float (&l)[C], float (&s)[C])
 {
-    const int lane = threadIdx.x & 63;
     const int sub = lane & 7, grp = lane >> 3;
-    const size_t wave_id = ((size_t)blockIdx.x * PW_THREADS + threadIdx.x) >> 6;
-    const size_t v0 = wave_id * 64;
-    if (v0 >= a.V) return;
-    float l[C], s[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) l[c] = s[c] = 0.f;
 #pragma unroll
@@ -134,7 +184,7 @@ __global__ __launch_bounds__(PW_THREADS) void head_kernel(const HeadArgs a)
 #pragma unroll
         for (int c = 0; c < C; ++c) pl[c] = ps[c] = 0.f;
         if (v < a.V) {
-            const float* row = a.act + v * a.CP;
+            const float* row = act + v * a.CP;
             head_dot8<C>(row, a.w_cls, a.CPh, sub, pl);
             if (a.sigma != nullptr) head_dot8<C>(row + a.CPh, a.w_sig, a.CPh, sub, ps);
         }
@@ -154,7 +204,31 @@ __global__ __launch_bounds__(PW_THREADS) void head_kernel(const HeadArgs a)
             }
         }
     }
+}
+
+template <int C>
+__global__ __launch_bounds__(PW_THREADS) void head_kernel(const HeadArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave_id = ((size_t)blockIdx.x * PW_THREADS + threadIdx.x) >> 6;
+    const size_t v0 = wave_id * 64;
+    if (v0 >= a.V) return;
     const size_t v = v0 + lane;
+    float l[C], s[C];
+    if (a.passes > 1) {   // pass group: statistics only; one read-modify-write for all passes of the group
+        VoxelStats<C> st;
+        if (v < a.V) st.load(a.stats, v, a.V, a.stats_flags);
+        for (int t = 0; t < a.passes; ++t) {
+            head_logits<C>(a, a.act + (size_t)t * a.V * a.CP, v0, lane, l, s);
+#pragma unroll
+            for (int c = 0; c < C; ++c) l[c] += a.b_cls[c];
+            softmax_inplace<C>(l);
+            st.add(a.stats_flags, l);
+        }
+        if (v < a.V) st.store(a.stats, v, a.V, a.stats_flags);
+        return;
+    }
+    head_logits<C>(a, a.act, v0, lane, l, s);
     if (v >= a.V) return;
     const size_t n = v / a.HW, hw = v % a.HW;
 #pragma unroll

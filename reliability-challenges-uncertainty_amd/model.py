@@ -237,21 +237,46 @@ class UNet(nn.Module):
         nhwc = _lib.device_view(ptr.value, (n, h, w, pitch.value), device, owner=self)
         return nhwc[..., :ch.value].permute(0, 3, 1, 2)
 
-    def forward_accumulate(self, x, stats, masks=None):
-        """One pass fused with softmax + accumulation into ``stats`` (rcu_amd.steps.McStatistics):
-        neither logits nor probabilities reach HBM."""
+    def forward_accumulate(self, x, stats, masks=None, passes=1):
+        """One pass -- or ``passes`` stochastic passes as ONE batch of N * passes samples -- fused with softmax +
+        accumulation into ``stats`` (rcu_amd.steps.McStatistics): neither logits nor probabilities reach HBM.
+        ``masks`` for a pass group: a concatenated device tensor with N * passes rows per site, or a list of
+        ``passes`` mask sets (each a concatenated tensor or a list of per-site ``[N, C_site]`` arrays)."""
         x = self._check_input(x)
         n, _, h, w = x.shape
         if (n, self.nb_classes, h * w) != (stats.n, stats.nb_classes, stats.hw):
             raise ValueError('statistics blob shape does not match the batch')
-        handle = self._handle(h, w, n)
-        if masks is None and self.mc_active():
-            masks = self.sample_masks(n, x.device)
-        elif isinstance(masks, (list, tuple)):
-            masks = self.pack_masks(masks, n, x.device)
-        _lib.check(_lib.load().rcu_unet_forward_accumulate(handle, _lib.ptr(x), n, _lib.ptr(masks),
-                                                           _lib.ptr(stats.blob), stats.flags, _lib.current_stream()))
-        stats.count += 1
+        if passes < 1:
+            raise ValueError('passes must be >= 1')
+        handle = self._handle(h, w, n * passes)
+        if passes == 1:
+            if masks is None and self.mc_active():
+                masks = self.sample_masks(n, x.device)
+            elif isinstance(masks, (list, tuple)):
+                masks = self.pack_masks(masks, n, x.device)
+            _lib.check(_lib.load().rcu_unet_forward_accumulate(handle, _lib.ptr(x), n, _lib.ptr(masks),
+                                                               _lib.ptr(stats.blob), stats.flags, _lib.current_stream()))
+        else:
+            if masks is None:
+                if not self.mc_active():
+                    raise ValueError('a pass group needs stochastic passes: set_dropout_mode(model, True) or inject masks')
+                masks = self.sample_masks(n * passes, x.device)
+            elif isinstance(masks, (list, tuple)):
+                masks = self.group_masks(masks, n, x.device)
+            _lib.check(_lib.load().rcu_unet_forward_accumulate_passes(handle, _lib.ptr(x), n, passes, _lib.ptr(masks),
+                                                                      _lib.ptr(stats.blob), stats.flags,
+                                                                      _lib.current_stream()))
+        stats.count += passes
+
+    def group_masks(self, mask_sets, n, device):
+        """``passes`` mask sets (each [site][n][C_site]) -> the [site][passes * n][C_site] layout of a pass group."""
+        sites = self.dropout_sites()
+        per_set = []
+        for ms in mask_sets:
+            flat = self.pack_masks(ms, n, device) if isinstance(ms, (list, tuple)) else ms.to(device)
+            per_set.append(torch.split(flat, [n * c for _, c in sites]) if sites else [])
+        chunks = [torch.cat([ps[i] for ps in per_set]) for i in range(len(sites))]
+        return torch.cat(chunks).contiguous() if chunks else None
 
     # ------------------------------------------------------------------ introspection (bench)
     def layer_table(self, h, w, n=1):

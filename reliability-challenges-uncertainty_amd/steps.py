@@ -190,13 +190,21 @@ class McPredictStep(BatchStep):
     """T stochastic passes (plus the deterministic 'weight scaling' pass the reference always runs
     first, customsteps.py:22-25)."""
 
-    def __init__(self, mc_steps, do_mi=False, do_var=False, materialize=False, masks=None, ws_pass=True) -> None:
+    # A forward pass fills the GPU from about 160 BraTS slices (3.9 M pixels) on; the shipped configs use
+    # batch_size 32.  The T passes of a batch are independent, so the fused path runs them in groups of
+    # g = GROUP_PIXELS // (N*H*W) as one batch of N * g samples (include/rcu.h: rcu_unet_forward_accumulate_passes)
+    # -- same statistics bit for bit; the workspace grows to that of a 160-slice batch (6 GB), not beyond.
+    GROUP_PIXELS = 160 * 192 * 128
+
+    def __init__(self, mc_steps, do_mi=False, do_var=False, materialize=False, masks=None, ws_pass=True,
+                 group_pixels=None) -> None:
         super().__init__()
         self.mc_steps = mc_steps
         self.do_mi, self.do_var = do_mi, do_var
         self.materialize = materialize
         self.masks = masks          # optional: list (one per pass) of mask sets to inject instead of sampling
         self.ws_pass = ws_pass
+        self.group_pixels = self.GROUP_PIXELS if group_pixels is None else group_pixels
 
     def __call__(self, batch_context, task_context, context) -> None:
         _check_context(context)
@@ -217,8 +225,16 @@ class McPredictStep(BatchStep):
             else:
                 n, _, h, w = images.shape
                 stats = McStatistics(n, model.nb_classes, h, w, images.device, self.do_mi, self.do_var)
-                for i in range(self.mc_steps):
-                    model.forward_accumulate(images, stats, None if self.masks is None else self.masks[i])
+                group = max(1, self.group_pixels // (n * h * w))
+                i = 0
+                while i < self.mc_steps:
+                    g = min(group, self.mc_steps - i)
+                    if g == 1:
+                        model.forward_accumulate(images, stats, None if self.masks is None else self.masks[i])
+                    else:
+                        model.forward_accumulate(images, stats, None if self.masks is None else self.masks[i:i + g],
+                                                 passes=g)
+                    i += g
                 batch_context.output['multi_probabilities'] = stats
         finally:
             set_dropout_mode(model, is_train=False)   # reset to eval for the next batch (customsteps.py:39)

@@ -553,3 +553,51 @@ def test_eval_driver_csvs_against_oracle(dev, tmp_path):
             for k in ('tpu', 'tnu', 'fpu', 'fnu'):
                 assert abs(int(r[k]) - ref[k]) <= near
             assert set(r) >= {'corrected_dice', 'corrected_accuracy', 'corrected_add_dice', 'dice_benefit_correct'}
+
+
+def test_pass_groups_bit_identical_to_single_passes(dev):
+    """rcu_unet_forward_accumulate_passes: T passes of a small batch run as one batch of N*T samples and must
+    give exactly the statistics of T single-pass launches (same masks), float32 and float64 blobs, also through
+    McPredictStep with injected masks and with sampled masks (statistically)."""
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    from rcu_amd.model import UNet
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=8, dropout=0.3)
+    model = UNet(**params)
+    model.load_state_dict(uo.synthetic_state(3, **params))
+    model = model.to(dev)
+    n, h, w, T = 3, 48, 32, 7
+    x = torch.randn(n, 4, h, w, generator=torch.Generator().manual_seed(1)).to(dev)
+    _, sites = uo.unet_plan(**params)
+    g = torch.Generator().manual_seed(2)
+    mask_sets = [uo.sample_masks(sites, n, 0.3, g) for _ in range(T)]
+    for do_mi, do_var in ((False, False), (True, True)):
+        a = steps.McStatistics(n, 2, h, w, dev, do_mi, do_var)
+        for ms in mask_sets:
+            model.forward_accumulate(x, a, ms)
+        b = steps.McStatistics(n, 2, h, w, dev, do_mi, do_var)
+        model.forward_accumulate(x, b, mask_sets[:4], passes=4)
+        model.forward_accumulate(x, b, mask_sets[4:], passes=3)
+        assert a.count == b.count == T
+        assert torch.equal(a.blob, b.blob)
+    ctx = steps.TorchTestContext('cuda', model)
+    outs = []
+    for group_pixels in (0, 160 * 192 * 128):
+        bc = steps.BatchContext({'images': x}, 0)
+        steps.McPredictStep(T, do_mi=True, do_var=True, masks=mask_sets, group_pixels=group_pixels)(bc, None, ctx)
+        steps.MultiPredictionSummary(do_mi=True, do_var=True)(bc, None, ctx)
+        outs.append(bc.output)
+    for key in ('probabilities', 'entropy', 'mutual_info', 'variance', 'ws_probabilities'):
+        assert torch.equal(outs[0][key], outs[1][key]), key
+    # sampled masks: the grouped draw is a different random stream; the mean over many passes must agree
+    torch.manual_seed(0)
+    bc = steps.BatchContext({'images': x}, 0)
+    steps.McPredictStep(200)(bc, None, ctx)
+    steps.MultiPredictionSummary()(bc, None, ctx)
+    torch.manual_seed(1)
+    bc2 = steps.BatchContext({'images': x}, 0)
+    steps.McPredictStep(200, group_pixels=0)(bc2, None, ctx)
+    steps.MultiPredictionSummary()(bc2, None, ctx)
+    assert float((bc.output['probabilities'] - bc2.output['probabilities']).abs().mean()) < 0.02
+    with pytest.raises(Exception):
+        model.forward_accumulate(x, steps.McStatistics(n, 2, h, w, dev), passes=0)
