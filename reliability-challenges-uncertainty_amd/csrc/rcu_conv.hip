@@ -112,12 +112,74 @@ __device__ __forceinline__ int xcd_virtual_block(int group)
     return ((slot / group) * 8 + xcd) * group + slot % group;
 }
 
+// Epilogue shared by both kernels: lane = output channel (lane & 31), 4x4 pixel patch per lane and pixel block.
+//   out = relu(acc * alpha * mask + betab * mask + beta); optional 2x2 max-pool (lane-local).
+// Output grid: (H, W), or (2H, 2W) with the lane's pixels at (2y+a, 2x+b) in sub-pixel mode.
+template <class T>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&acc)[T::MT][T::NTW], int ntile, int pa, int pb,
+                                              int n0, int y0, int x0, int wm, int wn, int m, int half)
+{
+    constexpr int MT = T::MT, NTW = T::NTW;
+    constexpr bool SUBPIXEL = (T::TAPS == 4);
+    constexpr int OS = SUBPIXEL ? 2 : 1;
+    const int OH = a.H * OS, OW = a.W * OS;
+    const bool full_tile = (y0 + T::TH <= a.H) && (x0 + T::TW <= a.W) && (n0 + T::TS <= a.N);
+    const size_t row_stride = (size_t)OW * a.CoutP * OS, col_stride = (size_t)a.CoutP * OS;
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) {
+        const int co = ntile * T::BN + (wn * NTW + ni) * 32 + m;
+        if (co >= a.CoutP) continue;
+        const float al = a.alpha[co], bb = a.betab[co], be = a.beta[co];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int blk = wm * MT + mi;
+            const int s = blk / T::BPS, rb = blk % T::BPS;
+            const int by = rb / (T::TW / 8), bx = rb % (T::TW / 8);
+            const int n = n0 + s;
+            if (n >= a.N) continue;
+            float mk = 1.f;
+            if (a.mask != nullptr && co < a.Cmask) mk = a.mask[(size_t)n * a.Cmask + co];
+            if (a.mask2 != nullptr && co >= a.Csplit && co - a.Csplit < a.Cmask2)
+                mk = a.mask2[(size_t)n * a.Cmask2 + (co - a.Csplit)];
+            const float scale = al * mk, shift = bb * mk + be;
+            const int yb = y0 + 4 * by, xb = x0 + 8 * bx + 4 * half;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float t = acc[mi][ni][i] * scale + shift;
+                v[i] = a.relu ? fmaxf(t, 0.f) : t;
+            }
+            float* const obase = a.out + ((size_t)(n * OH + yb * OS + pa) * OW + xb * OS + pb) * a.CoutP + co;
+            if (full_tile) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (yb + (i >> 2) < a.H && xb + (i & 3) < a.W)
+                        obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];
+            }
+            if (!SUBPIXEL && a.pooled != nullptr) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const int i0 = (2 * pr) * 4 + 2 * pc;
+                        const float mx = fmaxf(fmaxf(v[i0], v[i0 + 1]), fmaxf(v[i0 + 4], v[i0 + 5]));
+                        const int py = (yb >> 1) + pr, px = (xb >> 1) + pc;
+                        if (py < Hp && px < Wp) a.pooled[((size_t)(n * Hp + py) * Wp + px) * a.CoutP + co] = mx;
+                    }
+            }
+        }
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KC = T::KC, KCP = T::KCP, MT = T::MT, NTW = T::NTW;
-    constexpr bool SUBPIXEL = (T::TAPS == 4);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -275,60 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvArgs a)
 #undef RCU_PREFETCH
 #undef RCU_STAGE
 
-    // ---- epilogue: lane = output channel (lane & 31), 4x4 pixel patch per lane.
-    // Output grid: (H, W), or (2H, 2W) with the lane's pixels at (2y+a, 2x+b) in sub-pixel mode.
-    constexpr int OS = SUBPIXEL ? 2 : 1;
-    const int OH = a.H * OS, OW = a.W * OS;
-    const bool full_tile = (y0 + T::TH <= a.H) && (x0 + T::TW <= a.W) && (n0 + T::TS <= a.N);
-    const size_t row_stride = (size_t)OW * a.CoutP * OS, col_stride = (size_t)a.CoutP * OS;
-    const int Hp = a.H >> 1, Wp = a.W >> 1;
-#pragma unroll
-    for (int ni = 0; ni < NTW; ++ni) {
-        const int co = ntile * T::BN + (wn * NTW + ni) * 32 + m;
-        if (co >= a.CoutP) continue;
-        const float al = a.alpha[co], bb = a.betab[co], be = a.beta[co];
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int blk = wm * MT + mi;
-            const int s = blk / T::BPS, rb = blk % T::BPS;
-            const int by = rb / (T::TW / 8), bx = rb % (T::TW / 8);
-            const int n = n0 + s;
-            if (n >= a.N) continue;
-            float mk = 1.f;
-            if (a.mask != nullptr && co < a.Cmask) mk = a.mask[(size_t)n * a.Cmask + co];
-            if (a.mask2 != nullptr && co >= a.Csplit && co - a.Csplit < a.Cmask2)
-                mk = a.mask2[(size_t)n * a.Cmask2 + (co - a.Csplit)];
-            const float scale = al * mk, shift = bb * mk + be;
-            const int yb = y0 + 4 * by, xb = x0 + 8 * bx + 4 * half;
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float t = acc[mi][ni][i] * scale + shift;
-                v[i] = a.relu ? fmaxf(t, 0.f) : t;
-            }
-            float* const obase = a.out + ((size_t)(n * OH + yb * OS + pa) * OW + xb * OS + pb) * a.CoutP + co;
-            if (full_tile) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (yb + (i >> 2) < a.H && xb + (i & 3) < a.W)
-                        obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];
-            }
-            if (!SUBPIXEL && a.pooled != nullptr) {
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-                    for (int pc = 0; pc < 2; ++pc) {
-                        const int i0 = (2 * pr) * 4 + 2 * pc;
-                        const float mx = fmaxf(fmaxf(v[i0], v[i0 + 1]), fmaxf(v[i0 + 4], v[i0 + 5]));
-                        const int py = (yb >> 1) + pr, px = (xb >> 1) + pc;
-                        if (py < Hp && px < Wp) a.pooled[((size_t)(n * Hp + py) * Wp + px) * a.CoutP + co] = mx;
-                    }
-            }
-        }
-    }
+    conv_epilogue<T>(a, acc, ntile, pa, pb, n0, y0, x0, wm, wn, m, half);
 }
 
 
@@ -385,7 +394,6 @@ __global__ __launch_bounds__(256, T::WGS_PER_CU) void conv_igemm_stream(const Co
     static_assert(T::DB, "streaming kernel needs the double-buffered LDS layout");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KC = T::KC, KCP = T::KCP, MT = T::MT, NTW = T::NTW;
-    constexpr bool SUBPIXEL = (T::TAPS == 4);
     constexpr int STEPS = T::TAPS * (KC / 8);
 
     const int tid = threadIdx.x;
@@ -514,62 +522,7 @@ __global__ __launch_bounds__(256, T::WGS_PER_CU) void conv_igemm_stream(const Co
         }
 
         // ---- epilogue of the finished tile (registers only; the next tile's first chunk is already in LDS)
-        {
-            constexpr int OS = SUBPIXEL ? 2 : 1;
-            const int OH = a.H * OS, OW = a.W * OS;
-            const bool full_tile = (cur.y0 + T::TH <= a.H) && (cur.x0 + T::TW <= a.W) && (cur.n0 + T::TS <= a.N);
-            const size_t row_stride = (size_t)OW * a.CoutP * OS, col_stride = (size_t)a.CoutP * OS;
-            const int Hp = a.H >> 1, Wp = a.W >> 1;
-#pragma unroll
-            for (int ni = 0; ni < NTW; ++ni) {
-                const int co = cur.ntile * T::BN + (wn * NTW + ni) * 32 + m;
-                if (co >= a.CoutP) continue;
-                const float al = a.alpha[co], bb = a.betab[co], be = a.beta[co];
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi) {
-                    const int blk = wm * MT + mi;
-                    const int s = blk / T::BPS, rb = blk % T::BPS;
-                    const int by = rb / (T::TW / 8), bx = rb % (T::TW / 8);
-                    const int n = cur.n0 + s;
-                    if (n >= a.N) continue;
-                    float mk = 1.f;
-                    if (a.mask != nullptr && co < a.Cmask) mk = a.mask[(size_t)n * a.Cmask + co];
-                    if (a.mask2 != nullptr && co >= a.Csplit && co - a.Csplit < a.Cmask2)
-                        mk = a.mask2[(size_t)n * a.Cmask2 + (co - a.Csplit)];
-                    const float scale = al * mk, shift = bb * mk + be;
-                    const int yb = cur.y0 + 4 * by, xb = cur.x0 + 8 * bx + 4 * half;
-                    float v[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float t = acc[mi][ni][i] * scale + shift;
-                        v[i] = a.relu ? fmaxf(t, 0.f) : t;
-                    }
-                    float* const obase =
-                        a.out + ((size_t)(n * OH + yb * OS + cur.pa) * OW + xb * OS + cur.pb) * a.CoutP + co;
-                    if (full_tile) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            if (yb + (i >> 2) < a.H && xb + (i & 3) < a.W)
-                                obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];
-                    }
-                    if (!SUBPIXEL && a.pooled != nullptr) {
-#pragma unroll
-                        for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-                            for (int pc = 0; pc < 2; ++pc) {
-                                const int i0 = (2 * pr) * 4 + 2 * pc;
-                                const float mx = fmaxf(fmaxf(v[i0], v[i0 + 1]), fmaxf(v[i0 + 4], v[i0 + 5]));
-                                const int py = (yb >> 1) + pr, px = (xb >> 1) + pc;
-                                if (py < Hp && px < Wp)
-                                    a.pooled[((size_t)(n * Hp + py) * Wp + px) * a.CoutP + co] = mx;
-                            }
-                    }
-                }
-            }
-        }
+        conv_epilogue<T>(a, acc, cur.ntile, cur.pa, cur.pb, cur.n0, cur.y0, cur.x0, wm, wn, m, half);
 
         if (!has_next) break;
         // advance: next tile becomes current; plan the one after it
