@@ -10,7 +10,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from oracle import unet_oracle as uo  # noqa: E402  (weights only: deterministic synthetic state)
 from rcu_amd import model as model_mod  # noqa: E402
 from rcu_amd import steps  # noqa: E402
 
@@ -21,8 +20,14 @@ def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     dev = torch.device('cuda')
-    model = model_mod.UNet(**PARAMS)
-    model.load_state_dict(uo.synthetic_state(20, **PARAMS))
+    torch.manual_seed(20)
+    model = model_mod.UNet(**PARAMS)        # torch's default init; BatchNorm statistics randomised as in bench.py
+    gen = torch.Generator().manual_seed(1020)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+    model.weights_changed()
     model = model.to(dev)
     x = torch.rand(batch, 3, 256, 256, generator=torch.Generator().manual_seed(20)).to(dev)
     ctx = steps.TorchTestContext('cuda', model)
