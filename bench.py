@@ -167,10 +167,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('--gpus {} but WORLD_SIZE={}: launch N>1 through torch.distributed.run'.format(args.gpus, world))
+    # Test-only switches for a box with ONE GPU (RCCL refuses two ranks per device): all ranks on device 0 over gloo.
+    single_device = os.environ.get('RCU_BENCH_SINGLE_DEVICE') == '1'
+    backend = os.environ.get('RCU_BENCH_BACKEND', 'nccl')
+    if single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)   # "nccl" is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from rcu_amd import distributed as rdist
     from rcu_amd import evaluation as ev

@@ -21,3 +21,23 @@ def test_two_ranks_one_gpu_pipelined_matches_single_rank():
     line = [ln for ln in r.stdout.splitlines() if 'max |pipelined' in ln][-1]
     worst = float(line.rsplit('=', 1)[1])
     assert worst < 1e-5      # float32 sums in a different order across ranks
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_through_torch_distributed_run():
+    """The driver's N>1 launch line (python -m torch.distributed.run ... bench.py --gpus N) with both ranks on the one
+    GPU of the test box over gloo (test-only switches of bench.py): rank 0 prints the one JSON line."""
+    import json
+    env = dict(os.environ, RCU_BENCH_SINGLE_DEVICE='1', RCU_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29541', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
+           '--warmup', '1', '--mc', '4']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['value'] > 0 and d['scaling'] == 'strong'
+    assert d['roofline']['launches'] > 0 and d['cpu_baseline'] is None
+    assert d['parity']['bin_ids_equal'] and d['parity']['ece_delta_same_maps'] < 1e-9

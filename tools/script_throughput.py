@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""End-to-end wall time of the drop-in brats_test_default script (YAML -> dataset -> Test loop -> NIfTI + metrics) on
+full-size synthetic subjects, with a cProfile breakdown of the host side: python tools/script_throughput.py [subjects] [mc]"""
+import cProfile
+import json
+import os
+import pstats
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from rcu_amd import data as data_mod  # noqa: E402
+from rcu_amd import management as mgt  # noqa: E402
+from rcu_amd import nifti, scripts  # noqa: E402
+from test_script_surface_cpu import BRATS_MC_YAML  # noqa: E402  (the reference's YAML layout)
+
+
+def main():
+    n_subjects = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    mc = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    tmp = tempfile.mkdtemp(prefix='rcu_e2e_')
+    x, mask, target = bench.make_volume(20)
+    names = []
+    for i in range(n_subjects):
+        name = 'Brats18_SYN_{:03d}_1'.format(i)
+        images = (x + 0.01 * i).permute(0, 2, 3, 1).numpy()            # [D, H, W, C]
+        props = nifti.ImageProperties((bench.WIDTH, bench.HEIGHT, bench.SLICES), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+        data_mod.write_volume(os.path.join(tmp, 'ds'), name, images, target.numpy(), props)
+        names.append(name)
+    model = bench.make_model(20, torch.device('cuda'))
+    mf = mgt.ModelFiles(os.path.join(tmp, 'train'), 'syn')
+    mgt.save_model(mf, 'unet', bench.MODEL_PARAMS, {k: v.cpu() for k, v in model.state_dict().items()})
+    split = os.path.join(tmp, 'split.json')
+    with open(split, 'w') as f:
+        json.dump({'train': [], 'valid': [], 'test': names}, f)
+    text = BRATS_MC_YAML.format(test_dir=os.path.join(tmp, 'out'), model_dir=mf.model_dir, split=split,
+                                dataset=os.path.join(tmp, 'ds'))
+    text = text.replace('mc: 20', 'mc: {}'.format(mc)).replace('batch_size: 32', 'batch_size: {}'.format(batch))
+    cfg = os.path.join(tmp, 'test_brats_baseline_mc.yaml')
+    with open(cfg, 'w') as f:
+        f.write(text)
+    prof = cProfile.Profile()
+    t0 = time.perf_counter()
+    prof.enable()
+    scripts.test_default('brats', cfg, None)
+    prof.disable()
+    dt = time.perf_counter() - t0
+    print('{} subjects, T={}, batch_size {}: {:.2f} s total, {:.2f} s per subject ({:.1f} MC-sample-volumes/s end to end)'
+          .format(n_subjects, mc, batch, dt, dt / n_subjects, mc * n_subjects / dt))
+    pstats.Stats(prof).sort_stats('cumulative').print_stats(22)
+
+
+if __name__ == '__main__':
+    main()
