@@ -312,7 +312,7 @@ def main():
 
     result = {
         'metric': 'ensemble-member-volumes/sec (4x160x192x128, K={})'.format(T) if args.ensemble
-                  else 'MC-sample-volumes/sec (4x160x192x128, T=20)',
+                  else 'MC-sample-volumes/sec (4x160x192x128, T={})'.format(T),
         'value': T * args.steps / elapsed,
         'unit': 'member-volumes/s' if args.ensemble else 'MC-sample-volumes/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
