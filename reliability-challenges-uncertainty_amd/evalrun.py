@@ -183,6 +183,31 @@ def collect_brats_ground_truth(root_dir):
     return out
 
 
+def collect_isic_ground_truth(root_dir_with_prefix):
+    """``<prefix>_Data/<id>.jpg`` + ``<prefix>_Part1_GroundTruth/<id>_segmentation.png`` (collector.py:75-120);
+    subject = the first 12 characters of the file name."""
+    by_id = {}
+    for path in glob.glob(root_dir_with_prefix + '_Data/*') + glob.glob(root_dir_with_prefix + '_Part1_GroundTruth/*'):
+        name = os.path.basename(path)
+        if name.endswith('_segmentation.png'):
+            by_id.setdefault(name[:12], {})['gt'] = path
+        elif name.endswith('.jpg'):
+            by_id.setdefault(name[:12], {})['image'] = path
+    out = []
+    for id_, files in sorted(by_id.items()):
+        if 'gt' in files and 'image' in files:
+            out.append(SubjectFiles(id_, images={'image': files['image']}, labels={'gt': files['gt']}))
+    return out
+
+
+def read_label_image(path, dtype=np.uint8):
+    """NIfTI, or the png masks of ISIC (the reference reads both through ``sitk.ReadImage(path, sitkUInt8)``)."""
+    if str(path).endswith(('.png', '.jpg')):
+        from PIL import Image
+        return np.array(Image.open(path).convert('L')).astype(dtype)
+    return nifti.read(path, dtype)[0]
+
+
 def combine(files_from, files_to):
     """collector.py:164-174: add the categories of ``files_from`` to the same subject in ``files_to``."""
     by_id = {sf.subject: sf for sf in files_from}
@@ -238,7 +263,7 @@ class Loader:
         to_eval = {params.misc_entry: self._get(params.misc_entry,
                                                 lambda: nifti.read(sf.categories['misc'][params.misc_entry])[0])}
         if params.need_target:   # labels 0..4 are binarised (analysis.py:88-89)
-            to_eval['target'] = self._get('target', lambda: (nifti.read(sf.categories['labels']['gt'])[0] > 0)
+            to_eval['target'] = self._get('target', lambda: (read_label_image(sf.categories['labels']['gt']) > 0)
                                           .astype(np.uint8))
         if params.need_prediction:
             to_eval['prediction'] = self._get('prediction', lambda: nifti.read(sf.categories['labels']['prediction'],

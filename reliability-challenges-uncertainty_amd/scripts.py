@@ -321,14 +321,17 @@ for _fn in (test_default, test_ensemble, test_aleatoric, test_auxiliary_feat, te
 def eval_uncertainty(dataset, run_dirs: dict, ground_truth_dir, base_dir, actions=('minmax', 'ece_dice', 'calib', 'bnf_ue'),
                      expected_subjects=None):
     """``run_dirs``: run id (baseline, baseline_mc, ..., aleatoric) -> prediction directory.  BraTS evaluates
-    inside the T2 brain mask (``ece_details='foreground'``), ISIC on all pixels (eval_uncertainty.py:19-26)."""
+    inside the T2 brain mask (``ece_details='foreground'``), ISIC on all pixels (eval_uncertainty.py:19-26).
+    ``ground_truth_dir``: the BraTS tree of ``<subject>/<subject>_{t2,seg,...}.nii.gz`` or, for ISIC, the dataset
+    prefix (``.../ISIC-2017_Test_v2``) whose ``_Data`` / ``_Part1_GroundTruth`` folders hold the jpg / png files."""
     if dataset not in ('brats', 'isic'):
         raise ValueError('chose "brats" or "isic" as dataset')
     if dataset == 'brats':
         gts = evalrun.collect_brats_ground_truth(ground_truth_dir)
         details = 'foreground'
     else:
-        raise NotImplementedError('ISIC evaluation reads png ground truth; only the BraTS NIfTI tree is wired up')
+        gts = evalrun.collect_isic_ground_truth(ground_truth_dir)
+        details = ''
     entries = [evalrun.get_eval_data(run_id, path, gts, expected_subjects) for run_id, path in run_dirs.items()]
     evalrun.evaluate_runs(entries, list(actions), base_dir, details)
     return entries

@@ -342,3 +342,19 @@ def test_isic_auxiliary_scripts(tmp_path):
             assert os.path.islink(os.path.join(ctx2.test_dir, link))
     with pytest.raises(ValueError):
         scripts.test_auxiliary_segm('isic', cfg0)      # others.prediction_dir is required
+    # ---- evaluation driver on the ISIC outputs: png ground truth, all pixels (no mask), confidence entries
+    from oracle import calib_oracle as co
+    runs = {'baseline': ctx0.test_dir, 'auxiliary_feat': ctx1.test_dir, 'auxiliary_segm': ctx2.test_dir}
+    scripts.eval_uncertainty('isic', runs, str(prefix), str(tmp_path / 'eval'), expected_subjects=ids)
+    rows = list(csv.DictReader(open(str(tmp_path / 'eval' / 'ece' / 'eval_ece_baseline.csv'))))
+    assert [r['subject_name'] for r in rows] == ids
+    for r in rows:
+        p = nifti.read(os.path.join(ctx0.test_dir, r['subject_name'] + '_probabilities.nii.gz'))[0]
+        gt = (np.array(Image.open(os.path.join(lab_dir, r['subject_name'] + '_segmentation.png')).convert('L')) > 0)
+        ref = co.ece_binary(np.stack([1 - p, p], -1), gt.astype(np.uint8))
+        assert abs(float(r['ece']) - ref) < 1e-9
+    for run in ('auxiliary_feat', 'auxiliary_segm'):
+        files = glob.glob(str(tmp_path / 'eval' / 'ece' / 'eval_ece_{}*.csv'.format(run)))
+        assert files, run
+        assert all(0 <= float(r['ece']) <= 1 for f in files for r in csv.DictReader(open(f)))
+    assert len(glob.glob(str(tmp_path / 'eval' / 'uncertainty' / 'eval_uncertainty_baseline_th*.csv'))) == 11
