@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Evaluation driver -- flags of the reference's bin-eval/eval_uncertainty.py (--ds --ids --act) plus the
 directories the reference hard-codes in rechun/directories.py (--pred_dir <root with one sub-directory per
-run id>, --gt_dir <BraTS training tree>, --out_dir)."""
+run id>, --gt_dir <BraTS training tree, or the ISIC dataset prefix .../ISIC-2017_Test_v2>, --out_dir)."""
 import argparse
 import os
 import sys

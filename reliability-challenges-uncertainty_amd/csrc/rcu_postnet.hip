@@ -19,8 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // LDS image per layer: weights [j = 0..3][lane][4] (float4 = W[lane % 32][8 j + 4 (lane / 32) .. + 3]), then
 // bias [j][h][4] (bias[8 j + 4 h .. + 3]) -- what postnet_pack_layer (rcu_api.hip) writes.
-static constexpr int PN_W_FLOATS = 4 * 64 * 4;
-static constexpr int PN_B_FLOATS = 4 * 2 * 4;
+static constexpr int PN_W_FLOATS = 4 * 64 * 4;   // followed by 4 * 2 * 4 bias floats: PN_LAYER_FLOATS in rcu_kernels.h
 
 __global__ __launch_bounds__(256) void postnet_kernel(const float* __restrict__ x, int channel_pitch, size_t nvox, int hw,
                                                       const float* __restrict__ packed, int n_layers, int nb_classes,
