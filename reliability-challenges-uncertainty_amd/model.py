@@ -57,6 +57,7 @@ class UNet(nn.Module):
     DEFAULT_DEPTH = 4
     DEFAULT_START_FILTERS = 16
     DEFAULT_DROPOUT = 0.2
+    MAX_HANDLES = 4          # cached (height, width) plans incl. their workspaces
 
     def __init__(self, nb_classes, in_channels, depth=DEFAULT_DEPTH, start_filters=DEFAULT_START_FILTERS,
                  dropout=DEFAULT_DROPOUT, dropout_center: int = None, residual=False, sigma_out=False,
@@ -136,6 +137,7 @@ class UNet(nn.Module):
         lib = _lib.load()
         entry = self._handles.get((h, w))
         if entry is not None and entry[1] >= n and entry[2] == self._weights_version:
+            self._handles[(h, w)] = self._handles.pop((h, w))     # most recently used last
             return entry[0]
         max_batch = n if entry is None else max(n, entry[1])
         if entry is not None:
@@ -159,6 +161,9 @@ class UNet(nn.Module):
             lib.rcu_unet_destroy(handle)
             raise
         self._handles[(h, w)] = (handle, max_batch, self._weights_version)
+        while len(self._handles) > self.MAX_HANDLES:    # images of many different sizes: drop the least recently used plan
+            old = next(iter(self._handles))
+            lib.rcu_unet_destroy(self._handles.pop(old)[0])
         return handle
 
     # ------------------------------------------------------------------ dropout

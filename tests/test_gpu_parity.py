@@ -120,6 +120,24 @@ def test_unet_g11_reference_digest(golden, dev):
     assert _maxdiff(y[::int(g['stride'])], g['logits_strided']) < LOGIT_TOL
 
 
+def test_unet_plan_cache_is_bounded(dev):
+    from oracle import unet_oracle as uo
+    from rcu_amd.model import UNet
+    params = dict(nb_classes=2, in_channels=3, depth=2, start_filters=4, dropout=None)
+    state = uo.synthetic_state(1, **params)
+    m = UNet(**params)
+    m.load_state_dict(state)
+    m = m.to(dev)
+    first = None
+    for k in range(UNet.MAX_HANDLES + 3):
+        x = torch.randn(1, 3, 16 + 4 * k, 32, generator=torch.Generator().manual_seed(k))
+        y = m(x.to(dev)).cpu()
+        assert _maxdiff(y, uo.unet_forward(state, x, None, **params)) < LOGIT_TOL
+        first = first if first is not None else (x, y)
+        assert len(m._handles) <= UNet.MAX_HANDLES
+    assert torch.equal(m(first[0].to(dev)).cpu(), first[1])      # an evicted plan is rebuilt transparently
+
+
 def test_unet_batch_split_invariance_and_errors(dev):
     from oracle import unet_oracle as uo
     from rcu_amd import _lib
