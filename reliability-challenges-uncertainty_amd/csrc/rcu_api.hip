@@ -3,7 +3,9 @@
 #include "../../include/rcu.h"
 #include "rcu_kernels.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -111,6 +113,18 @@ static int pick_config(const ConvLayer& L, int n_slices)
         return CONV_CFG_UP_T8x16_N64;
     }
     if (L.c1p + L.c2p == 8) return CONV_CFG_T8x16_N32_FIRST;
+    // Winograd F(2x2,3x3) kernels (rcu_wino.hip): 16/36 of the multiplications.  They address activations through
+    // 32-bit byte offsets of a buffer resource (tensors < 2 GB) and take whole tiles only.
+    static const bool wino_on = [] {
+        const char* e = getenv("RCU_CONV_WINO");
+        return !(e && atoi(e) == 0);
+    }();
+    const size_t max_bytes = (size_t)n_slices * L.H * L.W * (size_t)std::max(std::max(L.c1p, L.c2p), L.coutp) * 4;
+    if (wino_on && (L.c1p + L.c2p) % 32 == 0 && max_bytes < ((size_t)1 << 31)) {
+        if (L.coutp == 32 && L.H % 32 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T32x16_N32;
+        if (L.coutp > 32 && L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T16x16_N64;
+        if (L.coutp > 32 && L.H % 8 == 0 && L.W % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_WINO_S2T8x16_N64;
+    }
     if (L.coutp > 32) {
         if (L.H == 12 && L.W == 8) return CONV_CFG_S2T12x8_N64;
         // 128-pixel tiles run 3 workgroups per CU (768 slots), 256-pixel tiles 2 (512 slots) with half the staging,
@@ -357,6 +371,30 @@ static int fold_conv(rcu_unet* h, const ConvLayer& L, const std::string& conv, c
         beta[co0 + co] = B;
     }
     const size_t tile_floats = conv_tile_floats(ci);   // padded to a whole number of float4 per thread
+    if (ci.WINO) {
+        // U = G g G^T per (cout, cin), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; packed per Cin chunk and cout tile as
+        // [position p][channel pair q][cout][2] (rcu_wino.hip).  Computed in double, rounded once.
+        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        for (int co = 0; co < L.cout; ++co) {
+            const int cop = co0 + co;
+            const int ntile = cop / BN, nn = cop % BN;
+            for (int ci_ = 0; ci_ < cin; ++ci_) {
+                const int kp = ci_ < L.cin1 ? ci_ : L.c1p + (ci_ - L.cin1);
+                const int chunk = kp / KC, kq = kp % KC;
+                const float* w9 = w->data() + ((size_t)co * cin + ci_) * 9;
+                const size_t tile0 = ((size_t)chunk * L.NT + ntile) * tile_floats;
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) {
+                        double u = 0.0;
+                        for (int r = 0; r < 3; ++r)
+                            for (int c = 0; c < 3; ++c) u += G[i][r] * (double)w9[r * 3 + c] * G[j][c];
+                        const int p = 4 * i + j;
+                        wpack[tile0 + (((size_t)p * 4 + (kq >> 1)) * BN + nn) * 2 + (kq & 1)] = (float)u;
+                    }
+            }
+        }
+        return RCU_OK;
+    }
     const int ncls = L.upsample ? 4 : 1;
     // Sub-pixel up-conv: output parity a (rows) folds the 3 kernel rows onto 2 low-res rows,
     //   a = 0: low-res row y-1 <- {dy 0},   row y   <- {dy 1, 2}
@@ -456,6 +494,9 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     a.slice_groups = (n + ci.TS - 1) / ci.TS;
     a.NT = L.NT;
     a.NTW_total = L.NT * (L.upsample ? 4 : 1);
+    a.src1_bytes = (uint32_t)std::min<size_t>(h->tensors[L.t_src1].floats_per_slice * (size_t)n * 4, 0xFFFFFFFFu);
+    a.src2_bytes = L.t_src2 >= 0 ? (uint32_t)std::min<size_t>(h->tensors[L.t_src2].floats_per_slice * (size_t)n * 4, 0xFFFFFFFFu) : 0u;
+    a.wpack_bytes = (uint32_t)std::min<size_t>(L.wpack_floats * 4, 0xFFFFFFFFu);
     RCU_HIP(launch_conv3x3(L.cfg, a, stream));
     return RCU_OK;
 }
@@ -708,7 +749,8 @@ extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info*
         const double tiles = (double)((lh + ci.TH - 1) / ci.TH) * ((lw + ci.TW - 1) / ci.TW);
         const double px = tiles * ci.TH * ci.TW * (L.upsample ? 4.0 : 1.0);
         const double ncols = (double)L.NT * ci.BN;
-        out->mfma_flops_per_slice = 2.0 * (L.c1p + L.c2p) * ncols * ci.TAPS * px;
+        // Winograd: 16 multiplications per 2x2 output tile instead of 9 per pixel
+        out->mfma_flops_per_slice = 2.0 * (L.c1p + L.c2p) * ncols * (ci.WINO ? 4.0 : (double)ci.TAPS) * px;
     }
     return RCU_OK;
 }

@@ -31,6 +31,7 @@ struct ConvArgs {
     int tiles_y, tiles_x, slice_groups;
     int NT;              // output-channel tiles
     int NTW_total;       // weight tiles per Cin chunk = NT (3x3) or 4 * NT (sub-pixel: one set per parity class)
+    uint32_t src1_bytes, src2_bytes, wpack_bytes;   // buffer-resource ranges (Winograd kernels)
 };
 
 enum ConvConfig {
@@ -45,7 +46,12 @@ enum ConvConfig {
     CONV_CFG_UP_T16x16_N32 = 8,      // sub-pixel up-conv, 32 couts, 16x16 low-res tile
     CONV_CFG_T16x16_N64 = 9,         // 256 pixels x 64 couts: half the staging / barriers / fragment reads per MFMA
     CONV_CFG_S2T8x16_N64 = 10,       // the same tile as two 8x16 pieces of consecutive slices (heights not divisible by 16)
-    CONV_CFG_COUNT
+    CONV_CFG_COUNT,
+    // Winograd F(2x2,3x3) kernels (rcu_wino.hip): 16 positions instead of 9 taps, weights host-transformed
+    CONV_CFG_WINO_T16x16_N64 = CONV_CFG_COUNT,   // 16x16-pixel tile (64 Winograd tiles) x 64 couts
+    CONV_CFG_WINO_T32x16_N32,                    // 32x16-pixel tile x 32 couts (32-channel layers)
+    CONV_CFG_WINO_S2T8x16_N64,                   // two 8x16 pieces of consecutive slices x 64 couts
+    CONV_CFG_END
 };
 
 struct ConvConfigInfo {
@@ -53,9 +59,12 @@ struct ConvConfigInfo {
     const char* kernel_name;
     int KCP;   // floats per [tap][channel] row of a packed weight tile (KC, or KC + 4 in the padded layout)
     int SWZ;   // 1: the two 16-byte units of a row are swapped for output channels 16..31 (mod 32), see ConvTile
+    int WINO;  // 1: Winograd kernel; TAPS = 16 positions, packed tile = [p][channel pair][cout][2] (rcu_wino.hip)
 };
 const ConvConfigInfo& conv_config_info(int cfg);
+const ConvConfigInfo& wino_config_info(int cfg);
 hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream);
+hipError_t launch_conv_wino(int cfg, const ConvArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // layout / head / aggregation kernels (rcu_pointwise.hip)

@@ -1,0 +1,405 @@
+// conv3x3 (pad 1) conv unit in Winograd F(2x2, 3x3) form on the fp32 matrix cores of gfx950.
+//
+//     Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        per 2x2 output tile, 4x4 input patch d
+//
+// 16 multiplications per 4 output pixels and (cin, cout) pair instead of 36: the channel contraction -- the only dense
+// part -- is 2.25x smaller than in rcu_conv.hip, and it is what runs on the MFMA pipe: one GEMM
+// [tiles x Cin] * [Cin x Cout] per Winograd position p = 0..15.  Everything else of the reference's conv unit
+// (common/model/unet.py:8-23: bias, Dropout2d factor, folded BatchNorm, ReLU, optional 2x2 max-pool of DownConv,
+// unet.py:85-95, cat-free two-source K loop of UpConv, unet.py:118) is fused exactly as in rcu_conv.hip.
+// fp32 throughout: measured against float64 the Winograd form is as accurate as the direct fp32 form here (the
+// transforms only add/subtract; G's halves are exact), see DESIGN.md.
+//
+// Mapping (v_mfma_f32_16x16x4_f32):
+//   * a wave owns 16 tiles (2 tile rows x 8 tile columns = 4 x 16 pixels) x 32 output channels x 16 positions
+//     = 128 accumulator registers; a workgroup of 8 waves (2 per SIMD) owns WM tile blocks x WN channel blocks.
+//   * A operand: lane (tile m = lane & 15, channel group kq = lane >> 4) reads its tile's 4x4 input patch for the
+//     channel pair (2kq, 2kq+1) of the 8-channel chunk straight from the RAW input tile in LDS (16 ds_read_b64),
+//     applies B^T d B in registers (64 adds) and feeds the 16 results per channel to the 16 positions' MFMAs: the
+//     transformed input never exists in memory.
+//   * B operand: host-transformed weights U = G g G^T, packed [chunk][cout tile][p][channel pair][cout][2] so that
+//     one ds_read_b128 per position serves both 16-channel MFMA blocks of the wave (couts 2n, 2n+1 per lane).
+//   * D: lane (n = lane & 15, g = lane >> 4) holds, for couts (2n, 2n+1), the four horizontally adjacent tiles
+//     4(g & 1) .. +3 of tile row g >> 1: the output transform A^T M A, the epilogue and the 2x2 max-pool (= one tile)
+//     are lane-local and every store writes float2, 16 lanes x 8 B = one 128-B line per pixel.
+//   * staging by LDS-DMA only (`buffer_load_dwordx4 ... lds`, no staging registers, no ds_write): the LDS images are
+//     lane-linear per wave instruction.  Input image: [channel half hh][halo row R][position][4 channels] where
+//     position = x ^ ((R >> 1) & 1) -- the swizzle is applied on the SOURCE address -- with a row pitch of 8k positions:
+//     the 32 lanes a ds_read_b64 serves per cycle (2 channel pairs x 2 tile rows x 8 tile columns) then fall on 64
+//     distinct banks.  Zero padding comes from the buffer resource: halo pixels outside the image carry an
+//     out-of-range offset and the DMA writes zeros (tools/microbench/glds_oob_probe.hip).
+//   * streaming: a workgroup walks over several output tiles and runs one double-buffered pipeline across all their
+//     Cin chunks (chunk k+1 streams into the other LDS buffer while chunk k is multiplied).
+#include "rcu_kernels.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace rcu {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ int wino_xcd_virtual_block(int group)
+{
+    const int g = (int)gridDim.x, b = (int)blockIdx.x;
+    if ((g & 7) != 0 || ((g >> 3) % group) != 0) return b;
+    const int xcd = b & 7, slot = b >> 3;
+    return ((slot / group) * 8 + xcd) * group + slot % group;
+}
+
+}  // namespace
+
+template <int TS_, int TH_, int TW_, int BN_, int WM_, int WN_>
+struct WinoTile {
+    static constexpr int TS = TS_, TH = TH_, TW = TW_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int KC = 8, THREADS = 512, WAVES = 8;
+    static constexpr int TILES = TS * (TH / 2) * (TW / 2);
+    static constexpr int BPS = (TH / 4) * (TW / 16);          // 16-tile blocks (4 x 16 pixels) per slice tile
+    static constexpr int ROWS = TS * (TH + 2);
+    static constexpr int PITCH = (TW + 2 + 7) / 8 * 8;        // positions per halo row; a multiple of 8 (bank analysis)
+    static constexpr int HALF_POS = ROWS * PITCH;             // positions of one channel-half image
+    static constexpr int A_POS = 2 * HALF_POS;                // 16-byte positions of the input image
+    static constexpr int A_PIECES = (A_POS + 63) / 64;        // 1-KB LDS-DMA pieces (one wave instruction each)
+    static constexpr int NA = (A_PIECES + WAVES - 1) / WAVES; // pieces per wave
+    static constexpr int A_DW = A_PIECES * 256;
+    static constexpr int W_DW = 16 * 4 * BN * 2;              // [p][q][n][2]
+    static constexpr int W_PIECES = W_DW / 256;
+    static constexpr int NW = W_PIECES / WAVES;               // consecutive pieces per wave
+    static constexpr int BUF_DW = A_DW + W_DW;
+    static constexpr int LDS_BYTES = 2 * BUF_DW * 4;
+    static_assert(WM * WN == 8, "8 waves per workgroup");
+    static_assert(TILES == 16 * WM && BN == 32 * WN, "wave tiling");
+    static_assert(TH % 4 == 0 && TW % 16 == 0, "block geometry");
+    static_assert(W_PIECES % WAVES == 0, "weight staging");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+// Output transform + conv-unit epilogue of one finished tile.  acc[b][p][r]: MFMA block b (cout 2n+b), position p,
+// tile r of the lane's four.
+template <class T>
+__device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&acc)[2][16], int ntile, int n0, int y0, int x0,
+                                              int wm, int wn, int lane)
+{
+    const int n16 = lane & 15, g = lane >> 4;
+    const int co = ntile * T::BN + wn * 32 + 2 * n16;
+    if (co >= a.CoutP) return;
+    const int s = wm / T::BPS, rb = wm % T::BPS;
+    const int by = rb / (T::TW / 16), bx = rb % (T::TW / 16);
+    const int n = n0 + s;
+    if (n >= a.N) return;
+    const int yb = y0 + 4 * by + 2 * (g >> 1);          // top pixel row of the lane's tiles
+    const int xb = x0 + 16 * bx + 8 * (g & 1);          // left pixel column of the lane's first tile
+    float scale[2], shift[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int c = co + b;
+        float mk = 1.f;
+        if (a.mask != nullptr && c < a.Cmask) mk = a.mask[(size_t)n * a.Cmask + c];
+        if (a.mask2 != nullptr && c >= a.Csplit && c - a.Csplit < a.Cmask2) mk = a.mask2[(size_t)n * a.Cmask2 + (c - a.Csplit)];
+        scale[b] = a.alpha[c] * mk;
+        shift[b] = a.betab[c] * mk + a.beta[c];
+    }
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    const bool rows_ok = yb + 1 < a.H;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int x = xb + 2 * r;
+        f32x2 y[2][2];   // [row a][col bb], components = the two couts
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float nn[4][2];   // N[i][bb] = sum_j M[i][j] A[j][bb]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float m0 = acc[b][4 * i + 0][r], m1 = acc[b][4 * i + 1][r], m2 = acc[b][4 * i + 2][r],
+                            m3 = acc[b][4 * i + 3][r];
+                nn[i][0] = m0 + m1 + m2;
+                nn[i][1] = m1 - m2 - m3;
+            }
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const float v0 = nn[0][bb] + nn[1][bb] + nn[2][bb];
+                const float v1 = nn[1][bb] - nn[2][bb] - nn[3][bb];
+                const float t0 = v0 * scale[b] + shift[b], t1 = v1 * scale[b] + shift[b];
+                y[0][bb][b] = a.relu ? fmaxf(t0, 0.f) : t0;
+                y[1][bb][b] = a.relu ? fmaxf(t1, 0.f) : t1;
+            }
+        }
+        if (x + 1 < a.W && rows_ok) {
+            float* const o = a.out + ((size_t)(n * a.H + yb) * a.W + x) * a.CoutP + co;
+            *reinterpret_cast<f32x2*>(o) = y[0][0];
+            *reinterpret_cast<f32x2*>(o + a.CoutP) = y[0][1];
+            *reinterpret_cast<f32x2*>(o + (size_t)a.W * a.CoutP) = y[1][0];
+            *reinterpret_cast<f32x2*>(o + (size_t)a.W * a.CoutP + a.CoutP) = y[1][1];
+        } else {
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+                    if (yb + aa < a.H && x + bb < a.W)
+                        *reinterpret_cast<f32x2*>(a.out + ((size_t)(n * a.H + yb + aa) * a.W + x + bb) * a.CoutP + co) = y[aa][bb];
+        }
+        if (a.pooled != nullptr) {
+            const int py = yb >> 1, px = x >> 1;
+            if (py < Hp && px < Wp) {
+                f32x2 mx;
+                mx.x = fmaxf(fmaxf(y[0][0].x, y[0][1].x), fmaxf(y[1][0].x, y[1][1].x));
+                mx.y = fmaxf(fmaxf(y[0][0].y, y[0][1].y), fmaxf(y[1][0].y, y[1][1].y));
+                *reinterpret_cast<f32x2*>(a.pooled + ((size_t)(n * Hp + py) * Wp + px) * a.CoutP + co) = mx;
+            }
+        }
+    }
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// Per-thread staging plan of one output tile: byte offsets (into src1 / src2) of the pixel chunk each of the lane's
+// LDS-DMA slots fetches; slots of zero padding / pitch padding / outside the batch point far out of range, where the
+// buffer load returns zeros.
+template <class T>
+struct WinoPlan {
+    uint32_t off1[T::NA], off2[T::NA];
+    int wtile, n0, y0, x0;
+};
+
+constexpr uint32_t WINO_OOB = 0x80000000u;
+
+template <class T>
+__device__ __forceinline__ void wino_make_plan(WinoPlan<T>& p, const ConvArgs& a, int item, int wave, int lane)
+{
+    p.wtile = item % a.NT;
+    int mtile = item / a.NT;
+    const int tx = mtile % a.tiles_x;
+    mtile /= a.tiles_x;
+    const int ty = mtile % a.tiles_y;
+    const int sg = mtile / a.tiles_y;
+    p.n0 = sg * T::TS;
+    p.y0 = ty * T::TH;
+    p.x0 = tx * T::TW;
+#pragma unroll
+    for (int j = 0; j < T::NA; ++j) {
+        const int f = (j * T::WAVES + wave) * 64 + lane;       // position index in the LDS image
+        const int hh = f / T::HALF_POS, rem = f % T::HALF_POS;
+        const int R = rem / T::PITCH, pos = rem % T::PITCH;
+        const int x = pos ^ ((R >> 1) & 1);                     // pixel column stored at this position
+        const int s = R / (T::TH + 2), yy = R % (T::TH + 2);
+        const int n = p.n0 + s, gy = p.y0 + yy - 1, gx = p.x0 + x - 1;
+        const bool ok = f < T::A_POS && x < T::TW + 2 && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const uint32_t pix = (uint32_t)((n * a.H + gy) * a.W + gx);
+        p.off1[j] = ok ? (pix * (uint32_t)a.C1 + hh * 4) * 4u : WINO_OOB;
+        p.off2[j] = ok ? (pix * (uint32_t)a.C2 + hh * 4) * 4u : WINO_OOB;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, const int total_items)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource types and LDS-DMA builtins exist in the device pass only
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    constexpr int KC = T::KC;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % T::WN;
+    const int wm = wave / T::WN;
+    const int m16 = lane & 15, kq = lane >> 4;
+    const int nchunks = (a.C1 + a.C2) / KC;   // even, >= 4 (checked by the launcher)
+    const uint32_t wchunk_bytes = (uint32_t)a.NT * T::W_DW * 4u;
+
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1), 0, a.src1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src2 ? a.src2 : a.src1), 0, a.src2 ? a.src2_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, a.wpack_bytes, 0x00020000);
+
+    // fragment addresses (dword offsets inside a buffer).  Patch rows 0,1 share one swizzle bit, rows 2,3 the other.
+    int aA[2], aB[2];
+    {
+        const int s = wm / T::BPS, rb = wm % T::BPS;
+        const int by = rb / (T::TW / 16), bx = rb % (T::TW / 16);
+        const int R0 = s * (T::TH + 2) + 4 * by + 2 * (m16 >> 3), x0l = 16 * bx + 2 * (m16 & 7);
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int R = R0 + 2 * i2, swz = (R >> 1) & 1;
+            const int rowbase = (((kq >> 1) * T::ROWS + R) * T::PITCH) * 4 + (kq & 1) * 2;
+            aA[i2] = rowbase + 4 * (x0l + swz);   // even patch columns j: pixel x0l + j sits at position x0l + j + swz
+            aB[i2] = rowbase + 4 * (x0l - swz);   // odd  patch columns j: pixel x0l + j sits at position x0l + j - swz
+        }
+    }
+    const int b_addr = T::A_DW + (kq * T::BN + wn * 32 + 2 * m16) * 2;
+    const uint32_t w_voff = (uint32_t)(wave * T::NW * 1024 + lane * 16);
+
+    WinoPlan<T> cur, nxt;
+    int item = wino_xcd_virtual_block(a.NT < 4 ? 4 : a.NT);
+    wino_make_plan<T>(cur, a, item, wave, lane);
+    bool has_next = item + (int)gridDim.x < total_items;
+    wino_make_plan<T>(nxt, a, has_next ? item + (int)gridDim.x : item, wave, lane);
+
+    // LDS-DMA of Cin chunk kc of the tile `plan_` into buffer buf_: this wave's NW weight pieces and NA input pieces
+#define WINO_DMA(plan_, kc_, buf_)                                                                                    \
+    {                                                                                                                 \
+        const int c0_ = (kc_) * KC;                                                                                   \
+        const bool first_ = c0_ < a.C1;                                                                               \
+        const uint32_t cb_ = (uint32_t)(first_ ? c0_ : c0_ - a.C1) * 4u;                                             \
+        char* const lb_ = reinterpret_cast<char*>(smem) + (buf_) * (T::BUF_DW * 4);                                   \
+        const uint32_t wso_ = (uint32_t)(kc_) * wchunk_bytes + (uint32_t)plan_.wtile * (T::W_DW * 4u);               \
+        static_for<0, T::NW>([&](auto j_c) {                                                                          \
+            constexpr int j = decltype(j_c)::value;                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(lb_ + T::A_DW * 4 + (wave * T::NW + j) * 1024), \
+                                                     16, w_voff, wso_ + j * 1024u, 0, 0);                                  \
+        });                                                                                                           \
+        static_for<0, T::NA>([&](auto j_c) {                                                                          \
+            constexpr int j = decltype(j_c)::value;                                                                   \
+            if ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES) {                             \
+                if (first_)                                                                                           \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(lb_ + (j * T::WAVES + wave) * 1024),    \
+                                                             16, plan_.off1[j], cb_, 0, 0);                           \
+                else                                                                                                  \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr_t)(lb_ + (j * T::WAVES + wave) * 1024),    \
+                                                             16, plan_.off2[j], cb_, 0, 0);                           \
+            }                                                                                                         \
+        });                                                                                                           \
+    }
+
+    WINO_DMA(cur, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __syncthreads();
+
+    f32x4 acc[2][16];
+
+    // One Cin chunk out of LDS buffer BUF; FIRST: the accumulators start from zero (first chunk of a tile).
+    auto chunk = [&](auto buf_c, auto first_c, int kc) {
+        constexpr int BUF = decltype(buf_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
+        const float* const Ab = smem + BUF * T::BUF_DW;
+        // the next chunk (of this tile or of the workgroup's next tile) streams into the other buffer meanwhile
+        if (kc + 1 < nchunks) {
+            WINO_DMA(cur, kc + 1, BUF ^ 1);
+        } else if (has_next) {
+            WINO_DMA(nxt, 0, BUF ^ 1);
+        }
+        // raw 4x4 patch of the lane's tile, channel pair (2kq, 2kq+1)
+        f32x2 d[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[4 * i + j] = *reinterpret_cast<const f32x2*>(Ab + ((j & 1) ? aB[i >> 1] : aA[i >> 1]) + (i & 1) * (T::PITCH * 4) + 4 * j);
+        // B^T d B, in place
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2 d0 = d[j], d1 = d[4 + j], d2 = d[8 + j], d3 = d[12 + j];
+            d[j] = d0 - d2;
+            d[4 + j] = d1 + d2;
+            d[8 + j] = d2 - d1;
+            d[12 + j] = d1 - d3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 t0 = d[4 * i], t1 = d[4 * i + 1], t2 = d[4 * i + 2], t3 = d[4 * i + 3];
+            d[4 * i] = t0 - t2;
+            d[4 * i + 1] = t1 + t2;
+            d[4 * i + 2] = t2 - t1;
+            d[4 * i + 3] = t1 - t3;
+        }
+        // 16 positions x (2 channel steps x 2 cout blocks); the weights of positions p+AHEAD.. are read while p multiplies
+        constexpr int AHEAD = 4;
+        f32x4 bv[16];
+#pragma unroll
+        for (int p = 0; p < AHEAD; ++p) bv[p] = *reinterpret_cast<const f32x4*>(Ab + b_addr + p * (8 * T::BN));
+        static_for<0, 8>([&](auto pp_c) {
+            constexpr int p0 = 2 * decltype(pp_c)::value, p1 = p0 + 1;
+            if constexpr (p0 + AHEAD < 16) {
+                bv[p0 + AHEAD] = *reinterpret_cast<const f32x4*>(Ab + b_addr + (p0 + AHEAD) * (8 * T::BN));
+                bv[p1 + AHEAD] = *reinterpret_cast<const f32x4*>(Ab + b_addr + (p1 + AHEAD) * (8 * T::BN));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            acc[0][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p0].x, bv[p0].x, FIRST ? z : acc[0][p0], 0, 0, 0);
+            acc[1][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p0].x, bv[p0].z, FIRST ? z : acc[1][p0], 0, 0, 0);
+            acc[0][p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p1].x, bv[p1].x, FIRST ? z : acc[0][p1], 0, 0, 0);
+            acc[1][p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p1].x, bv[p1].z, FIRST ? z : acc[1][p1], 0, 0, 0);
+            acc[0][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p0].y, bv[p0].y, acc[0][p0], 0, 0, 0);
+            acc[1][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p0].y, bv[p0].w, acc[1][p0], 0, 0, 0);
+            acc[0][p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p1].y, bv[p1].y, acc[0][p1], 0, 0, 0);
+            acc[1][p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p1].y, bv[p1].w, acc[1][p1], 0, 0, 0);
+        });
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the next chunk have landed
+        __syncthreads();                      // everyone done with buffer BUF and with filling the other one
+    };
+
+    for (;;) {
+        chunk(std::integral_constant<int, 0>{}, std::true_type{}, 0);
+        chunk(std::integral_constant<int, 1>{}, std::false_type{}, 1);
+        for (int kc = 2; kc < nchunks; kc += 2) {
+            chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc);
+            chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1);
+        }
+        wino_epilogue<T>(a, acc, cur.wtile, cur.n0, cur.y0, cur.x0, wm, wn, lane);
+        if (!has_next) break;
+        item += (int)gridDim.x;
+#pragma unroll
+        for (int j = 0; j < T::NA; ++j) {
+            cur.off1[j] = nxt.off1[j];
+            cur.off2[j] = nxt.off2[j];
+        }
+        cur.wtile = nxt.wtile; cur.n0 = nxt.n0; cur.y0 = nxt.y0; cur.x0 = nxt.x0;
+        has_next = item + (int)gridDim.x < total_items;
+        wino_make_plan<T>(nxt, a, has_next ? item + (int)gridDim.x : item, wave, lane);
+    }
+#undef WINO_DMA
+#endif
+}
+
+using WCfg0 = WinoTile<1, 16, 16, 64, 4, 2>;   // 256 pixels x 64 couts
+using WCfg1 = WinoTile<1, 32, 16, 32, 8, 1>;   // 512 pixels x 32 couts (32-channel full-resolution layers)
+using WCfg2 = WinoTile<2, 8, 16, 64, 4, 2>;    // two 8x16 pieces of consecutive slices (heights not divisible by 16)
+
+static const ConvConfigInfo kWinoInfo[3] = {
+    {WCfg0::TS, WCfg0::TH, WCfg0::TW, WCfg0::BN, 8, 16, "conv3x3_winograd<T16x16,N64,K8>", 8, 0, 1},
+    {WCfg1::TS, WCfg1::TH, WCfg1::TW, WCfg1::BN, 8, 16, "conv3x3_winograd<T32x16,N32,K8>", 8, 0, 1},
+    {WCfg2::TS, WCfg2::TH, WCfg2::TW, WCfg2::BN, 8, 16, "conv3x3_winograd<S2T8x16,N64,K8>", 8, 0, 1},
+};
+
+const ConvConfigInfo& wino_config_info(int cfg) { return kWinoInfo[cfg - CONV_CFG_WINO_T16x16_N64]; }
+
+template <class T>
+static hipError_t launch_wino_cfg(const ConvArgs& a, hipStream_t stream)
+{
+    static bool attr_set = false;
+    const int nchunks = (a.C1 + a.C2) / T::KC;
+    if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0) return hipErrorInvalidValue;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_stream<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const unsigned items = (unsigned)a.NT * a.tiles_x * a.tiles_y * a.slice_groups;
+    const unsigned grid = items < 256u ? items : 256u;
+    hipLaunchKernelGGL(conv_wino_stream<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_wino(int cfg, const ConvArgs& a, hipStream_t stream)
+{
+    switch (cfg) {
+        case CONV_CFG_WINO_T16x16_N64: return launch_wino_cfg<WCfg0>(a, stream);
+        case CONV_CFG_WINO_T32x16_N32: return launch_wino_cfg<WCfg1>(a, stream);
+        case CONV_CFG_WINO_S2T8x16_N64: return launch_wino_cfg<WCfg2>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace rcu
