@@ -120,8 +120,8 @@ static int pick_config(const ConvLayer& L, int n_slices)
         return !(e && atoi(e) == 0);
     }();
     const size_t max_bytes = (size_t)n_slices * L.H * L.W * (size_t)std::max(std::max(L.c1p, L.c2p), L.coutp) * 4;
-    if (wino_on && (L.c1p + L.c2p) % 32 == 0 && max_bytes < ((size_t)1 << 31)) {
-        if (L.coutp == 32 && L.H % 32 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T32x16_N32;
+    if (wino_on && (L.c1p + L.c2p) % 32 == 0 && (L.c2p == 0 || L.c2p == L.c1p) && max_bytes < ((size_t)1 << 31)) {
+        if (L.coutp == 32 && L.H % 16 == 0 && L.W % 32 == 0) return CONV_CFG_WINO_T16x32_N32;
         if (L.coutp > 32 && L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T16x16_N64;
         if (L.coutp > 32 && L.H % 8 == 0 && L.W % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_WINO_S2T8x16_N64;
     }

@@ -49,7 +49,7 @@ enum ConvConfig {
     CONV_CFG_COUNT,
     // Winograd F(2x2,3x3) kernels (rcu_wino.hip): 16 positions instead of 9 taps, weights host-transformed
     CONV_CFG_WINO_T16x16_N64 = CONV_CFG_COUNT,   // 16x16-pixel tile (64 Winograd tiles) x 64 couts
-    CONV_CFG_WINO_T32x16_N32,                    // 32x16-pixel tile x 32 couts (32-channel layers)
+    CONV_CFG_WINO_T16x32_N32,                    // 16x32-pixel tile x 32 couts (32-channel layers)
     CONV_CFG_WINO_S2T8x16_N64,                   // two 8x16 pieces of consecutive slices x 64 couts
     CONV_CFG_END
 };

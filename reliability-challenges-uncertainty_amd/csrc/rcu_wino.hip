@@ -86,11 +86,38 @@ struct WinoTile {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
+// Per-lane constants of the conv-unit epilogue (the lane's two couts of the tile's slice): loaded while the tile's last
+// Cin chunk is multiplied, so that the epilogue does not start with a global-memory round trip.
+struct WinoEpi {
+    float al[2], bb[2], be[2], mk[2];
+};
+
+template <class T>
+__device__ __forceinline__ WinoEpi wino_epilogue_load(const ConvArgs& a, int ntile, int n0, int wm, int wn, int lane)
+{
+    WinoEpi e;
+    const int co = ntile * T::BN + wn * 32 + 2 * (lane & 15);
+    const int n = n0 + wm / T::BPS;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int c = co + b;
+        const bool live = c < a.CoutP && n < a.N;
+        e.al[b] = live ? a.alpha[c] : 0.f;
+        e.bb[b] = live ? a.betab[c] : 0.f;
+        e.be[b] = live ? a.beta[c] : 0.f;
+        float mk = 1.f;
+        if (live && a.mask != nullptr && c < a.Cmask) mk = a.mask[(size_t)n * a.Cmask + c];
+        if (live && a.mask2 != nullptr && c >= a.Csplit && c - a.Csplit < a.Cmask2) mk = a.mask2[(size_t)n * a.Cmask2 + (c - a.Csplit)];
+        e.mk[b] = mk;
+    }
+    return e;
+}
+
 // Output transform + conv-unit epilogue of one finished tile.  acc[b][p][r]: MFMA block b (cout 2n+b), position p,
 // tile r of the lane's four.
 template <class T>
-__device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&acc)[2][16], int ntile, int n0, int y0, int x0,
-                                              int wm, int wn, int lane)
+__device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&acc)[2][16], const WinoEpi& ep, int ntile, int n0, int y0,
+                                              int x0, int wm, int wn, int lane)
 {
     const int n16 = lane & 15, g = lane >> 4;
     const int co = ntile * T::BN + wn * 32 + 2 * n16;
@@ -104,12 +131,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
     float scale[2], shift[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int c = co + b;
-        float mk = 1.f;
-        if (a.mask != nullptr && c < a.Cmask) mk = a.mask[(size_t)n * a.Cmask + c];
-        if (a.mask2 != nullptr && c >= a.Csplit && c - a.Csplit < a.Cmask2) mk = a.mask2[(size_t)n * a.Cmask2 + (c - a.Csplit)];
-        scale[b] = a.alpha[c] * mk;
-        shift[b] = a.betab[c] * mk + a.beta[c];
+        scale[b] = ep.al[b] * ep.mk[b];
+        shift[b] = ep.bb[b] * ep.mk[b] + ep.be[b];
     }
     const int Hp = a.H >> 1, Wp = a.W >> 1;
     const bool rows_ok = yb + 1 < a.H;
@@ -164,42 +187,44 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// Per-thread staging plan of one output tile: byte offsets (into src1 / src2) of the pixel chunk each of the lane's
-// LDS-DMA slots fetches; slots of zero padding / pitch padding / outside the batch point far out of range, where the
-// buffer load returns zeros.
-template <class T>
-struct WinoPlan {
-    uint32_t off1[T::NA], off2[T::NA];
+constexpr uint32_t WINO_OOB = 0x80000000u;
+
+// Tile coordinates of a work item (wave-uniform).
+struct WinoTileId {
     int wtile, n0, y0, x0;
 };
 
-constexpr uint32_t WINO_OOB = 0x80000000u;
-
 template <class T>
-__device__ __forceinline__ void wino_make_plan(WinoPlan<T>& p, const ConvArgs& a, int item, int wave, int lane)
+__device__ __forceinline__ WinoTileId wino_tile_id(const ConvArgs& a, int item)
 {
-    p.wtile = item % a.NT;
+    WinoTileId t;
+    t.wtile = item % a.NT;
     int mtile = item / a.NT;
     const int tx = mtile % a.tiles_x;
     mtile /= a.tiles_x;
     const int ty = mtile % a.tiles_y;
     const int sg = mtile / a.tiles_y;
-    p.n0 = sg * T::TS;
-    p.y0 = ty * T::TH;
-    p.x0 = tx * T::TW;
-#pragma unroll
-    for (int j = 0; j < T::NA; ++j) {
-        const int f = (j * T::WAVES + wave) * 64 + lane;       // position index in the LDS image
-        const int hh = f / T::HALF_POS, rem = f % T::HALF_POS;
-        const int R = rem / T::PITCH, pos = rem % T::PITCH;
-        const int x = pos ^ ((R >> 1) & 1);                     // pixel column stored at this position
-        const int s = R / (T::TH + 2), yy = R % (T::TH + 2);
-        const int n = p.n0 + s, gy = p.y0 + yy - 1, gx = p.x0 + x - 1;
-        const bool ok = f < T::A_POS && x < T::TW + 2 && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const uint32_t pix = (uint32_t)((n * a.H + gy) * a.W + gx);
-        p.off1[j] = ok ? (pix * (uint32_t)a.C1 + hh * 4) * 4u : WINO_OOB;
-        p.off2[j] = ok ? (pix * (uint32_t)a.C2 + hh * 4) * 4u : WINO_OOB;
-    }
+    t.n0 = sg * T::TS;
+    t.y0 = ty * T::TH;
+    t.x0 = tx * T::TW;
+    return t;
+}
+
+// Per-lane staging plan of one output tile: byte offset (into src1 and src2 alike) of the pixel chunk that slot j of this lane
+// fetches by LDS-DMA; slots of zero padding / pitch padding / outside the batch point far out of range, where the
+// buffer load returns zeros.
+template <class T>
+__device__ __forceinline__ uint32_t wino_slot_offset(const ConvArgs& a, const WinoTileId& t, int j, int wave, int lane)
+{
+    const int f = (j * T::WAVES + wave) * 64 + lane;       // position index in the LDS image
+    const int hh = f / T::HALF_POS, rem = f % T::HALF_POS;
+    const int R = rem / T::PITCH, pos = rem % T::PITCH;
+    const int x = pos ^ ((R >> 1) & 1);                     // pixel column stored at this position
+    const int s = R / (T::TH + 2), yy = R % (T::TH + 2);
+    const int n = t.n0 + s, gy = t.y0 + yy - 1, gx = t.x0 + x - 1;
+    const bool ok = f < T::A_POS && x < T::TW + 2 && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const uint32_t pix = (uint32_t)((n * a.H + gy) * a.W + gx);
+    return ok ? (pix * (uint32_t)a.C1 + hh * 4) * 4u : WINO_OOB;   // C2 == C1 or 0 (checked by the launcher)
 }
 
 template <class T>
@@ -240,91 +265,116 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
     const int b_addr = T::A_DW + (kq * T::BN + wn * 32 + 2 * m16) * 2;
     const uint32_t w_voff = (uint32_t)(wave * T::NW * 1024 + lane * 16);
 
-    WinoPlan<T> cur, nxt;
+    // dp*: the plan the LDS-DMA works from -- the current tile's until its last chunk is being multiplied, then the
+    // next tile's; tile / ntile: coordinates of the tile being multiplied and of the workgroup's next one
     int item = wino_xcd_virtual_block(a.NT < 4 ? 4 : a.NT);
-    wino_make_plan<T>(cur, a, item, wave, lane);
     bool has_next = item + (int)gridDim.x < total_items;
-    wino_make_plan<T>(nxt, a, has_next ? item + (int)gridDim.x : item, wave, lane);
+    WinoTileId tile = wino_tile_id<T>(a, item), ntile = tile;
+    uint32_t dp[T::NA];
+    int dp_wtile = tile.wtile;
+#pragma unroll
+    for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(a, tile, j, wave, lane);
 
-    // LDS-DMA of Cin chunk kc of the tile `plan_` into buffer buf_: this wave's NW weight pieces and NA input pieces
-#define WINO_DMA(plan_, kc_, buf_)                                                                                    \
-    {                                                                                                                 \
-        const int c0_ = (kc_) * KC;                                                                                   \
-        const bool first_ = c0_ < a.C1;                                                                               \
-        const uint32_t cb_ = (uint32_t)(first_ ? c0_ : c0_ - a.C1) * 4u;                                             \
-        char* const lb_ = reinterpret_cast<char*>(smem) + (buf_) * (T::BUF_DW * 4);                                   \
-        const uint32_t wso_ = (uint32_t)(kc_) * wchunk_bytes + (uint32_t)plan_.wtile * (T::W_DW * 4u);               \
-        static_for<0, T::NW>([&](auto j_c) {                                                                          \
-            constexpr int j = decltype(j_c)::value;                                                                   \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(lb_ + T::A_DW * 4 + (wave * T::NW + j) * 1024), \
-                                                     16, w_voff, wso_ + j * 1024u, 0, 0);                                  \
-        });                                                                                                           \
-        static_for<0, T::NA>([&](auto j_c) {                                                                          \
-            constexpr int j = decltype(j_c)::value;                                                                   \
-            if ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES) {                             \
-                if (first_)                                                                                           \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(lb_ + (j * T::WAVES + wave) * 1024),    \
-                                                             16, plan_.off1[j], cb_, 0, 0);                           \
-                else                                                                                                  \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr_t)(lb_ + (j * T::WAVES + wave) * 1024),    \
-                                                             16, plan_.off2[j], cb_, 0, 0);                           \
-            }                                                                                                         \
-        });                                                                                                           \
+    // LDS-DMA of Cin chunk kc of a tile into LDS buffer `buf`: the wave's NW weight pieces and NA input pieces of 1 KB.
+    // DmaJob holds the wave-uniform part; dma_piece(job, off1, off2, I) issues piece I (weights first).
+    struct DmaJob {
+        bool active, first;
+        uint32_t cb, wso, lb;
+    };
+    auto dma_job = [&](int wtile, int kc, int buf, bool active) {
+        DmaJob j;
+        const int c0 = kc * KC;
+        j.active = active;
+        j.first = c0 < a.C1;
+        j.cb = (uint32_t)__builtin_amdgcn_readfirstlane((j.first ? c0 : c0 - a.C1) * 4);
+        j.wso = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)kc * wchunk_bytes + (uint32_t)wtile * (T::W_DW * 4u)));
+        j.lb = (uint32_t)buf * (T::BUF_DW * 4u);
+        return j;
+    };
+    char* const lds_base = reinterpret_cast<char*>(smem);
+    auto dma_piece = [&](const DmaJob& job, auto i_c) {
+        constexpr int I = decltype(i_c)::value;
+        if constexpr (I < T::NW) {
+            if (job.active)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(lds_base + job.lb + T::A_DW * 4 + (wave * T::NW + I) * 1024),
+                                                         16, w_voff, job.wso + I * 1024u, 0, 0);
+        } else if constexpr (I < T::NW + T::NA) {
+            constexpr int j = I - T::NW;
+            if (job.active && ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES)) {
+                if (job.first)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16,
+                                                             dp[j], job.cb, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16,
+                                                             dp[j], job.cb, 0, 0);
+            }
+        }
+    };
+
+    {
+        const DmaJob job = dma_job(dp_wtile, 0, 0, true);
+        static_for<0, T::NW + T::NA>([&](auto i_c) { dma_piece(job, i_c); });
     }
-
-    WINO_DMA(cur, 0, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
 
     f32x4 acc[2][16];
+    WinoEpi ep;
 
     // One Cin chunk out of LDS buffer BUF; FIRST: the accumulators start from zero (first chunk of a tile).
     auto chunk = [&](auto buf_c, auto first_c, int kc) {
         constexpr int BUF = decltype(buf_c)::value;
         constexpr bool FIRST = decltype(first_c)::value;
         const float* const Ab = smem + BUF * T::BUF_DW;
-        // the next chunk (of this tile or of the workgroup's next tile) streams into the other buffer meanwhile
-        if (kc + 1 < nchunks) {
-            WINO_DMA(cur, kc + 1, BUF ^ 1);
-        } else if (has_next) {
-            WINO_DMA(nxt, 0, BUF ^ 1);
+        // the next chunk (of this tile or of the workgroup's next tile) streams into the other buffer meanwhile; its
+        // LDS-DMA pieces are issued one per MFMA group below
+        const bool more = kc + 1 < nchunks;
+        if (!more && has_next) {   // last chunk of the tile: from here on the DMA works on the workgroup's next tile
+            ntile = wino_tile_id<T>(a, item + (int)gridDim.x);
+            dp_wtile = ntile.wtile;
+#pragma unroll
+            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(a, ntile, j, wave, lane);
         }
-        // raw 4x4 patch of the lane's tile, channel pair (2kq, 2kq+1)
+        if (!more) ep = wino_epilogue_load<T>(a, tile.wtile, tile.n0, wm, wn, lane);
+        __builtin_amdgcn_sched_barrier(0);   // keep the address arithmetic above out of the register-heavy part below
+        const DmaJob job = dma_job(dp_wtile, more ? kc + 1 : 0, BUF ^ 1, more || has_next);
+        // raw 4x4 patch of the lane's tile, channel pair (2kq, 2kq+1): rows 0 and 2 first (position row 0 needs only them)
         f32x2 d[16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = (ii & 1) * 2 + (ii >> 1);   // 0, 2, 1, 3
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                d[4 * i + j] = *reinterpret_cast<const f32x2*>(Ab + ((j & 1) ? aB[i >> 1] : aA[i >> 1]) + (i & 1) * (T::PITCH * 4) + 4 * j);
-        // B^T d B, in place
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x2 d0 = d[j], d1 = d[4 + j], d2 = d[8 + j], d3 = d[12 + j];
-            d[j] = d0 - d2;
-            d[4 + j] = d1 + d2;
-            d[8 + j] = d2 - d1;
-            d[12 + j] = d1 - d3;
+                // volatile: hipcc otherwise fuses pairs of these reads into ds_read2_b64, whose 16-lane groups over 32 banks
+                // conflict 2-way on this image (SQ_LDS_BANK_CONFLICT 33 % of the LDS cycles); ds_read_b64 serves 32
+                // lanes over 64 banks
+                d[4 * i + j] = *(const volatile __attribute__((address_space(3))) f32x2*)(Ab + ((j & 1) ? aB[i >> 1] : aA[i >> 1]) + (i & 1) * (T::PITCH * 4) + 4 * j);
         }
+        constexpr int AHEAD = 2;
+        f32x4 bv[16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int p = 0; p < AHEAD; ++p) bv[p] = *reinterpret_cast<const f32x4*>(Ab + b_addr + p * (8 * T::BN));
+        // B^T d B in place, spread over the MFMA groups: row transform t = B^T d, then per row i the column transform
+        auto col_transform = [&](int i) {
             const f32x2 t0 = d[4 * i], t1 = d[4 * i + 1], t2 = d[4 * i + 2], t3 = d[4 * i + 3];
             d[4 * i] = t0 - t2;
             d[4 * i + 1] = t1 + t2;
             d[4 * i + 2] = t2 - t1;
             d[4 * i + 3] = t1 - t3;
-        }
-        // 16 positions x (2 channel steps x 2 cout blocks); the weights of positions p+AHEAD.. are read while p multiplies
-        constexpr int AHEAD = 4;
-        f32x4 bv[16];
+        };
 #pragma unroll
-        for (int p = 0; p < AHEAD; ++p) bv[p] = *reinterpret_cast<const f32x4*>(Ab + b_addr + p * (8 * T::BN));
+        for (int j = 0; j < 4; ++j) d[j] = d[j] - d[8 + j];
+        col_transform(0);
+        // 16 positions x (2 channel steps x 2 cout blocks); the weights of positions p+AHEAD.. are read while p multiplies
         static_for<0, 8>([&](auto pp_c) {
-            constexpr int p0 = 2 * decltype(pp_c)::value, p1 = p0 + 1;
+            constexpr int G = decltype(pp_c)::value;
+            constexpr int p0 = 2 * G, p1 = p0 + 1;
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (p0 + AHEAD < 16) {
                 bv[p0 + AHEAD] = *reinterpret_cast<const f32x4*>(Ab + b_addr + (p0 + AHEAD) * (8 * T::BN));
                 bv[p1 + AHEAD] = *reinterpret_cast<const f32x4*>(Ab + b_addr + (p1 + AHEAD) * (8 * T::BN));
             }
-            __builtin_amdgcn_sched_barrier(0);
+            dma_piece(job, std::integral_constant<int, G>{});
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             acc[0][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p0].x, bv[p0].x, FIRST ? z : acc[0][p0], 0, 0, 0);
             acc[1][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p0].x, bv[p0].z, FIRST ? z : acc[1][p0], 0, 0, 0);
@@ -334,7 +384,21 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
             acc[1][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p0].y, bv[p0].w, acc[1][p0], 0, 0, 0);
             acc[0][p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p1].y, bv[p1].y, acc[0][p1], 0, 0, 0);
             acc[1][p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p1].y, bv[p1].w, acc[1][p1], 0, 0, 0);
+            // transform work for the coming position rows, in the shadow of this group's MFMAs
+            if constexpr (G == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 x1 = d[4 + j], x2 = d[8 + j];
+                    d[4 + j] = x1 + x2;
+                    d[8 + j] = x2 - x1;
+                    d[12 + j] = x1 - d[12 + j];
+                }
+            }
+            if constexpr (G == 1) col_transform(1);
+            if constexpr (G == 2) col_transform(2);
+            if constexpr (G == 3) col_transform(3);
         });
+        static_for<8, T::NW + T::NA>([&](auto i_c) { dma_piece(job, i_c); });
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the next chunk have landed
         __syncthreads();                      // everyone done with buffer BUF and with filling the other one
     };
@@ -346,29 +410,22 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
             chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc);
             chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1);
         }
-        wino_epilogue<T>(a, acc, cur.wtile, cur.n0, cur.y0, cur.x0, wm, wn, lane);
+        wino_epilogue<T>(a, acc, ep, tile.wtile, tile.n0, tile.y0, tile.x0, wm, wn, lane);
         if (!has_next) break;
         item += (int)gridDim.x;
-#pragma unroll
-        for (int j = 0; j < T::NA; ++j) {
-            cur.off1[j] = nxt.off1[j];
-            cur.off2[j] = nxt.off2[j];
-        }
-        cur.wtile = nxt.wtile; cur.n0 = nxt.n0; cur.y0 = nxt.y0; cur.x0 = nxt.x0;
+        tile = ntile;
         has_next = item + (int)gridDim.x < total_items;
-        wino_make_plan<T>(nxt, a, has_next ? item + (int)gridDim.x : item, wave, lane);
     }
-#undef WINO_DMA
 #endif
 }
 
 using WCfg0 = WinoTile<1, 16, 16, 64, 4, 2>;   // 256 pixels x 64 couts
-using WCfg1 = WinoTile<1, 32, 16, 32, 8, 1>;   // 512 pixels x 32 couts (32-channel full-resolution layers)
+using WCfg1 = WinoTile<1, 16, 32, 32, 8, 1>;   // 512 pixels x 32 couts (32-channel full-resolution layers)
 using WCfg2 = WinoTile<2, 8, 16, 64, 4, 2>;    // two 8x16 pieces of consecutive slices (heights not divisible by 16)
 
 static const ConvConfigInfo kWinoInfo[3] = {
     {WCfg0::TS, WCfg0::TH, WCfg0::TW, WCfg0::BN, 8, 16, "conv3x3_winograd<T16x16,N64,K8>", 8, 0, 1},
-    {WCfg1::TS, WCfg1::TH, WCfg1::TW, WCfg1::BN, 8, 16, "conv3x3_winograd<T32x16,N32,K8>", 8, 0, 1},
+    {WCfg1::TS, WCfg1::TH, WCfg1::TW, WCfg1::BN, 8, 16, "conv3x3_winograd<T16x32,N32,K8>", 8, 0, 1},
     {WCfg2::TS, WCfg2::TH, WCfg2::TW, WCfg2::BN, 8, 16, "conv3x3_winograd<S2T8x16,N64,K8>", 8, 0, 1},
 };
 
@@ -379,7 +436,9 @@ static hipError_t launch_wino_cfg(const ConvArgs& a, hipStream_t stream)
 {
     static bool attr_set = false;
     const int nchunks = (a.C1 + a.C2) / T::KC;
-    if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0) return hipErrorInvalidValue;
+    if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
+        (a.C2 != 0 && a.C2 != a.C1))
+        return hipErrorInvalidValue;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_stream<T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
@@ -396,7 +455,7 @@ hipError_t launch_conv_wino(int cfg, const ConvArgs& a, hipStream_t stream)
 {
     switch (cfg) {
         case CONV_CFG_WINO_T16x16_N64: return launch_wino_cfg<WCfg0>(a, stream);
-        case CONV_CFG_WINO_T32x16_N32: return launch_wino_cfg<WCfg1>(a, stream);
+        case CONV_CFG_WINO_T16x32_N32: return launch_wino_cfg<WCfg1>(a, stream);
         case CONV_CFG_WINO_S2T8x16_N64: return launch_wino_cfg<WCfg2>(a, stream);
         default: return hipErrorInvalidValue;
     }

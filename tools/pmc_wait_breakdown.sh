@@ -25,7 +25,7 @@ for i in (1, 2, 3):
     for k, v in sr.per_kernel(f, names).items():
         tot[k].update(v)
 for k, v in sorted(tot.items()):
-    if 'igemm' not in k: continue
+    if 'igemm' not in k and 'wino' not in k: continue
     wc = v['SQ_WAVE_CYCLES']
     print(k)
     print('   of wave cycles: wait_any {:.3f} wait_inst_any {:.3f} (lds {:.3f}) active_inst_any {:.3f}'.format(
