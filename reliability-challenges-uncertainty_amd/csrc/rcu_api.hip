@@ -124,6 +124,7 @@ static int pick_config(const ConvLayer& L, int n_slices)
         if (L.coutp == 32 && L.H % 16 == 0 && L.W % 32 == 0) return CONV_CFG_WINO_T16x32_N32;
         if (L.coutp > 32 && L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T16x16_N64;
         if (L.coutp > 32 && L.H % 8 == 0 && L.W % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_WINO_S2T8x16_N64;
+        if (L.coutp > 32 && L.H % 4 == 0 && L.W == 8 && n_slices % 8 == 0) return CONV_CFG_WINO_S8T4x8_N64;
     }
     if (L.coutp > 32) {
         if (L.H == 12 && L.W == 8) return CONV_CFG_S2T12x8_N64;

@@ -51,6 +51,7 @@ enum ConvConfig {
     CONV_CFG_WINO_T16x16_N64 = CONV_CFG_COUNT,   // 16x16-pixel tile (64 Winograd tiles) x 64 couts
     CONV_CFG_WINO_T16x32_N32,                    // 16x32-pixel tile x 32 couts (32-channel layers)
     CONV_CFG_WINO_S2T8x16_N64,                   // two 8x16 pieces of consecutive slices x 64 couts
+    CONV_CFG_WINO_S8T4x8_N64,                    // 4x8 strips of eight consecutive slices x 64 couts (8-pixel-wide level)
     CONV_CFG_END
 };
 

@@ -61,15 +61,19 @@ __device__ __forceinline__ int wino_xcd_virtual_block(int group)
 
 }  // namespace
 
-template <int TS_, int TH_, int TW_, int BN_, int WM_, int WN_>
+// A 16-tile MFMA row block is 2 tile rows x 8 tile columns: 4 x 16 pixels of one slice (SW = 1) or, for images only
+// 8 pixels wide, 4 x 8 pixels of each of SW = 2 consecutive slices.
+template <int TS_, int TH_, int TW_, int BN_, int WM_, int WN_, int SW_ = 1>
 struct WinoTile {
-    static constexpr int TS = TS_, TH = TH_, TW = TW_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int TS = TS_, TH = TH_, TW = TW_, BN = BN_, WM = WM_, WN = WN_, SW = SW_;
     static constexpr int KC = 8, THREADS = 512, WAVES = 8;
     static constexpr int TILES = TS * (TH / 2) * (TW / 2);
-    static constexpr int BPS = (TH / 4) * (TW / 16);          // 16-tile blocks (4 x 16 pixels) per slice tile
-    static constexpr int ROWS = TS * (TH + 2);
+    static constexpr int BPS = (TH / 4) * (TW * SW / 16);     // 16-tile blocks per group of SW slices
     static constexpr int PITCH = (TW + 2 + 7) / 8 * 8;        // positions per halo row; a multiple of 8 (bank analysis)
-    static constexpr int HALF_POS = ROWS * PITCH;             // positions of one channel-half image
+    // positions per slice image; with SW = 2 an odd multiple of 8 so that the two slices of a block fall on different
+    // halves of the 64 banks
+    static constexpr int SLICE_POS = (TH + 2) * PITCH + (SW == 2 ? 8 : 0);
+    static constexpr int HALF_POS = TS * SLICE_POS;           // positions of one channel-half image
     static constexpr int A_POS = 2 * HALF_POS;                // 16-byte positions of the input image
     static constexpr int A_PIECES = (A_POS + 63) / 64;        // 1-KB LDS-DMA pieces (one wave instruction each)
     static constexpr int NA = (A_PIECES + WAVES - 1) / WAVES; // pieces per wave
@@ -81,23 +85,48 @@ struct WinoTile {
     static constexpr int LDS_BYTES = 2 * BUF_DW * 4;
     static_assert(WM * WN == 8, "8 waves per workgroup");
     static_assert(TILES == 16 * WM && BN == 32 * WN, "wave tiling");
-    static_assert(TH % 4 == 0 && TW % 16 == 0, "block geometry");
+    static_assert(TH % 4 == 0 && (TW * SW) % 16 == 0 && (SW == 1 || (SW == 2 && TW == 8 && TS % 2 == 0)), "block geometry");
+    static_assert(SW == 1 || SLICE_POS % 16 == 8, "slice stride");
     static_assert(W_PIECES % WAVES == 0, "weight staging");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    // block index -> (first slice of the block inside the tile, pixel origin of the block inside the slice tile)
+    static __device__ __forceinline__ void block_origin(int blk, int& s, int& y, int& x)
+    {
+        const int grp = blk / BPS, rb = blk % BPS;
+        s = grp * SW;
+        y = 4 * (rb / (TW * SW / 16));
+        x = SW == 1 ? 16 * (rb % (TW / 16)) : 0;
+    }
 };
 
-// Per-lane constants of the conv-unit epilogue (the lane's two couts of the tile's slice): loaded while the tile's last
-// Cin chunk is multiplied, so that the epilogue does not start with a global-memory round trip.
-struct WinoEpi {
+// Per-lane constants of the conv-unit epilogue (the lane's two couts of the tile's slice): loaded while the tile's
+// last-but-one Cin chunk is multiplied and folded at the start of the last one, so that the epilogue does not start with
+// a global-memory round trip and the raw values are gone before the register-heavy last chunk.
+struct WinoEpiRaw {
     float al[2], bb[2], be[2], mk[2];
 };
-
-template <class T>
-__device__ __forceinline__ WinoEpi wino_epilogue_load(const ConvArgs& a, int ntile, int n0, int wm, int wn, int lane)
+struct WinoEpi {   // out = relu(acc * scale + shift)
+    float scale[2], shift[2];
+};
+__device__ __forceinline__ WinoEpi wino_epilogue_fold(const WinoEpiRaw& r)
 {
     WinoEpi e;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        e.scale[b] = r.al[b] * r.mk[b];
+        e.shift[b] = r.bb[b] * r.mk[b] + r.be[b];
+    }
+    return e;
+}
+
+template <class T>
+__device__ __forceinline__ WinoEpiRaw wino_epilogue_load(const ConvArgs& a, int ntile, int n0, int wm, int wn, int lane)
+{
+    WinoEpiRaw e;
     const int co = ntile * T::BN + wn * 32 + 2 * (lane & 15);
-    const int n = n0 + wm / T::BPS;
+    int bs, by, bx;
+    T::block_origin(wm, bs, by, bx);
+    const int n = n0 + bs + (T::SW == 2 ? (lane >> 4) & 1 : 0);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int c = co + b;
@@ -122,18 +151,15 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
     const int n16 = lane & 15, g = lane >> 4;
     const int co = ntile * T::BN + wn * 32 + 2 * n16;
     if (co >= a.CoutP) return;
-    const int s = wm / T::BPS, rb = wm % T::BPS;
-    const int by = rb / (T::TW / 16), bx = rb % (T::TW / 16);
-    const int n = n0 + s;
+    int bs, by, bx;
+    T::block_origin(wm, bs, by, bx);
+    // the lane's four tiles 4(g & 1) .. +3 of tile row g >> 1: columns 8(g & 1) .. of one slice, or (SW = 2) the whole
+    // 8-pixel row of slice g & 1
+    const int n = n0 + bs + (T::SW == 2 ? g & 1 : 0);
     if (n >= a.N) return;
-    const int yb = y0 + 4 * by + 2 * (g >> 1);          // top pixel row of the lane's tiles
-    const int xb = x0 + 16 * bx + 8 * (g & 1);          // left pixel column of the lane's first tile
-    float scale[2], shift[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        scale[b] = ep.al[b] * ep.mk[b];
-        shift[b] = ep.bb[b] * ep.mk[b] + ep.be[b];
-    }
+    const int yb = y0 + by + 2 * (g >> 1);                       // top pixel row of the lane's tiles
+    const int xb = x0 + bx + (T::SW == 2 ? 0 : 8 * (g & 1));     // left pixel column of the lane's first tile
+    const float scale[2] = {ep.scale[0], ep.scale[1]}, shift[2] = {ep.shift[0], ep.shift[1]};
     const int Hp = a.H >> 1, Wp = a.W >> 1;
     const bool rows_ok = yb + 1 < a.H;
 #pragma unroll
@@ -212,17 +238,26 @@ __device__ __forceinline__ WinoTileId wino_tile_id(const ConvArgs& a, int item)
 
 // Per-lane staging plan of one output tile: byte offset (into src1 and src2 alike) of the pixel chunk that slot j of this lane
 // fetches by LDS-DMA; slots of zero padding / pitch padding / outside the batch point far out of range, where the
-// buffer load returns zeros.
+// buffer load returns zeros.  The tile-independent part -- which (channel half, slice, halo row, pixel column) the slot
+// holds -- is packed into one register per slot at kernel start (wino_slot_geometry).
 template <class T>
-__device__ __forceinline__ uint32_t wino_slot_offset(const ConvArgs& a, const WinoTileId& t, int j, int wave, int lane)
+__device__ __forceinline__ uint32_t wino_slot_geometry(int j, int wave, int lane)
 {
     const int f = (j * T::WAVES + wave) * 64 + lane;       // position index in the LDS image
     const int hh = f / T::HALF_POS, rem = f % T::HALF_POS;
-    const int R = rem / T::PITCH, pos = rem % T::PITCH;
-    const int x = pos ^ ((R >> 1) & 1);                     // pixel column stored at this position
-    const int s = R / (T::TH + 2), yy = R % (T::TH + 2);
+    const int s = rem / T::SLICE_POS, r2 = rem % T::SLICE_POS;
+    const int yy = r2 / T::PITCH, pos = r2 % T::PITCH;
+    const int x = pos ^ ((yy >> 1) & 1);                    // pixel column stored at this position
+    const bool real = f < T::A_POS && yy < T::TH + 2 && x < T::TW + 2;
+    return real ? (uint32_t)(x | (yy << 8) | (s << 16) | (hh << 24)) : 0xFFFFFFFFu;
+}
+
+template <class T>
+__device__ __forceinline__ uint32_t wino_slot_offset(const ConvArgs& a, const WinoTileId& t, uint32_t geo)
+{
+    const int x = geo & 0xFF, yy = (geo >> 8) & 0xFF, s = (geo >> 16) & 0xFF, hh = (geo >> 24) & 1;
     const int n = t.n0 + s, gy = t.y0 + yy - 1, gx = t.x0 + x - 1;
-    const bool ok = f < T::A_POS && x < T::TW + 2 && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const bool ok = geo != 0xFFFFFFFFu && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     const uint32_t pix = (uint32_t)((n * a.H + gy) * a.W + gx);
     return ok ? (pix * (uint32_t)a.C1 + hh * 4) * 4u : WINO_OOB;   // C2 == C1 or 0 (checked by the launcher)
 }
@@ -251,13 +286,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
     // fragment addresses (dword offsets inside a buffer).  Patch rows 0,1 share one swizzle bit, rows 2,3 the other.
     int aA[2], aB[2];
     {
-        const int s = wm / T::BPS, rb = wm % T::BPS;
-        const int by = rb / (T::TW / 16), bx = rb % (T::TW / 16);
-        const int R0 = s * (T::TH + 2) + 4 * by + 2 * (m16 >> 3), x0l = 16 * bx + 2 * (m16 & 7);
+        int bs, by, bx;
+        T::block_origin(wm, bs, by, bx);
+        const int tr = m16 >> 3, tcg = m16 & 7;
+        const int sl = bs + (T::SW == 2 ? tcg >> 2 : 0);
+        const int yy0 = by + 2 * tr, x0l = bx + 2 * (T::SW == 2 ? tcg & 3 : tcg);
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
-            const int R = R0 + 2 * i2, swz = (R >> 1) & 1;
-            const int rowbase = (((kq >> 1) * T::ROWS + R) * T::PITCH) * 4 + (kq & 1) * 2;
+            const int yy = yy0 + 2 * i2, swz = (yy >> 1) & 1;
+            const int rowbase = ((kq >> 1) * T::HALF_POS + sl * T::SLICE_POS + yy * T::PITCH) * 4 + (kq & 1) * 2;
             aA[i2] = rowbase + 4 * (x0l + swz);   // even patch columns j: pixel x0l + j sits at position x0l + j + swz
             aB[i2] = rowbase + 4 * (x0l - swz);   // odd  patch columns j: pixel x0l + j sits at position x0l + j - swz
         }
@@ -270,10 +307,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
     int item = wino_xcd_virtual_block(a.NT < 4 ? 4 : a.NT);
     bool has_next = item + (int)gridDim.x < total_items;
     WinoTileId tile = wino_tile_id<T>(a, item), ntile = tile;
-    uint32_t dp[T::NA];
+    uint32_t dp[T::NA], geo[T::NA];
     int dp_wtile = tile.wtile;
 #pragma unroll
-    for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(a, tile, j, wave, lane);
+    for (int j = 0; j < T::NA; ++j) {
+        geo[j] = wino_slot_geometry<T>(j, wave, lane);
+        asm volatile("" : "+v"(geo[j]));   // one register per slot; keeps hipcc from carrying the unpacked fields instead
+        dp[j] = wino_slot_offset<T>(a, tile, geo[j]);
+    }
 
     // LDS-DMA of Cin chunk kc of a tile into LDS buffer `buf`: the wave's NW weight pieces and NA input pieces of 1 KB.
     // DmaJob holds the wave-uniform part; dma_piece(job, off1, off2, I) issues piece I (weights first).
@@ -319,6 +360,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
     __syncthreads();
 
     f32x4 acc[2][16];
+    WinoEpiRaw epr;
     WinoEpi ep;
 
     // One Cin chunk out of LDS buffer BUF; FIRST: the accumulators start from zero (first chunk of a tile).
@@ -333,9 +375,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
             ntile = wino_tile_id<T>(a, item + (int)gridDim.x);
             dp_wtile = ntile.wtile;
 #pragma unroll
-            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(a, ntile, j, wave, lane);
+            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(a, ntile, geo[j]);
         }
-        if (!more) ep = wino_epilogue_load<T>(a, tile.wtile, tile.n0, wm, wn, lane);
+        if (kc + 2 == nchunks) epr = wino_epilogue_load<T>(a, tile.wtile, tile.n0, wm, wn, lane);
+        if (!more) ep = wino_epilogue_fold(epr);
         __builtin_amdgcn_sched_barrier(0);   // keep the address arithmetic above out of the register-heavy part below
         const DmaJob job = dma_job(dp_wtile, more ? kc + 1 : 0, BUF ^ 1, more || has_next);
         // raw 4x4 patch of the lane's tile, channel pair (2kq, 2kq+1): rows 0 and 2 first (position row 0 needs only them)
@@ -422,11 +465,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
 using WCfg0 = WinoTile<1, 16, 16, 64, 4, 2>;   // 256 pixels x 64 couts
 using WCfg1 = WinoTile<1, 16, 32, 32, 8, 1>;   // 512 pixels x 32 couts (32-channel full-resolution layers)
 using WCfg2 = WinoTile<2, 8, 16, 64, 4, 2>;    // two 8x16 pieces of consecutive slices (heights not divisible by 16)
+using WCfg3 = WinoTile<8, 4, 8, 64, 4, 2, 2>;  // 4x8 strips of eight slices (8-pixel-wide bottom level)
 
-static const ConvConfigInfo kWinoInfo[3] = {
+static const ConvConfigInfo kWinoInfo[4] = {
     {WCfg0::TS, WCfg0::TH, WCfg0::TW, WCfg0::BN, 8, 16, "conv3x3_winograd<T16x16,N64,K8>", 8, 0, 1},
     {WCfg1::TS, WCfg1::TH, WCfg1::TW, WCfg1::BN, 8, 16, "conv3x3_winograd<T16x32,N32,K8>", 8, 0, 1},
     {WCfg2::TS, WCfg2::TH, WCfg2::TW, WCfg2::BN, 8, 16, "conv3x3_winograd<S2T8x16,N64,K8>", 8, 0, 1},
+    {WCfg3::TS, WCfg3::TH, WCfg3::TW, WCfg3::BN, 8, 16, "conv3x3_winograd<S8T4x8,N64,K8>", 8, 0, 1},
 };
 
 const ConvConfigInfo& wino_config_info(int cfg) { return kWinoInfo[cfg - CONV_CFG_WINO_T16x16_N64]; }
@@ -457,6 +502,7 @@ hipError_t launch_conv_wino(int cfg, const ConvArgs& a, hipStream_t stream)
         case CONV_CFG_WINO_T16x16_N64: return launch_wino_cfg<WCfg0>(a, stream);
         case CONV_CFG_WINO_T16x32_N32: return launch_wino_cfg<WCfg1>(a, stream);
         case CONV_CFG_WINO_S2T8x16_N64: return launch_wino_cfg<WCfg2>(a, stream);
+        case CONV_CFG_WINO_S8T4x8_N64: return launch_wino_cfg<WCfg3>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }
