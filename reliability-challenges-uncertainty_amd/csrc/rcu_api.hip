@@ -101,25 +101,34 @@ static bool unit_has_dropout(const rcu_unet_desc& d, int level, bool is_down, in
 // floats of one packed [TAPS][BN][KC+4] weight tile, rounded up to 256 threads x float4
 static size_t conv_tile_floats(const ConvConfigInfo& ci)
 {
+    if (ci.WINO) return (size_t)ci.TAPS * ci.BN * ci.KCP;   // the LDS image, piece by piece (LDS-DMA)
     const size_t units = (size_t)ci.TAPS * ci.BN * ci.KCP / 4;
     return (units + 255) / 256 * 256 * 4;
 }
 
 static int pick_config(const ConvLayer& L, int n_slices)
 {
+    // Winograd kernels (rcu_wino.hip, rcu_wino_up.hip): 16/36 (conv units) and 9/36 (up-convolutions) of the
+    // multiplications.  They address activations through 32-bit byte offsets of a buffer resource (tensors < 2 GB)
+    // and take whole tiles only.
+    static const bool wino_on = [] {
+        const char* e = getenv("RCU_CONV_WINO");
+        return !(e && atoi(e) == 0);
+    }();
+    const size_t max_bytes = (size_t)n_slices * L.H * L.W * (size_t)std::max(std::max(L.c1p, L.c2p), L.coutp) * 4;
+    if (L.upsample && wino_on && L.c1p % 32 == 0 && L.c2p == 0 && max_bytes < ((size_t)1 << 31)) {
+        const int lh = L.H / 2, lw = L.W / 2;
+        if (L.coutp == 32 && lh % 16 == 0 && lw % 32 == 0) return CONV_CFG_UPW_T16x32_N32;
+        if (L.coutp > 32 && lh % 16 == 0 && lw % 16 == 0) return CONV_CFG_UPW_T16x16_N64;
+        if (L.coutp > 32 && lh % 8 == 0 && lw % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_UPW_S2T8x16_N64;
+        if (L.coutp > 32 && lh % 4 == 0 && lw == 8 && n_slices % 8 == 0) return CONV_CFG_UPW_S8T4x8_N64;
+    }
     if (L.upsample) {   // sub-pixel form; L.H x L.W is the OUTPUT grid, tiles run over the low-res input grid
         if (L.coutp <= 32) return ((L.H / 2) % 16 == 0 && (L.W / 2) % 16 == 0) ? CONV_CFG_UP_T16x16_N32 : CONV_CFG_UP_T8x16_N32;
         if (L.H == 24 && L.W == 16) return CONV_CFG_UP_S2T12x8_N64;
         return CONV_CFG_UP_T8x16_N64;
     }
     if (L.c1p + L.c2p == 8) return CONV_CFG_T8x16_N32_FIRST;
-    // Winograd F(2x2,3x3) kernels (rcu_wino.hip): 16/36 of the multiplications.  They address activations through
-    // 32-bit byte offsets of a buffer resource (tensors < 2 GB) and take whole tiles only.
-    static const bool wino_on = [] {
-        const char* e = getenv("RCU_CONV_WINO");
-        return !(e && atoi(e) == 0);
-    }();
-    const size_t max_bytes = (size_t)n_slices * L.H * L.W * (size_t)std::max(std::max(L.c1p, L.c2p), L.coutp) * 4;
     if (wino_on && (L.c1p + L.c2p) % 32 == 0 && (L.c2p == 0 || L.c2p == L.c1p) && max_bytes < ((size_t)1 << 31)) {
         if (L.coutp == 32 && L.H % 16 == 0 && L.W % 32 == 0) return CONV_CFG_WINO_T16x32_N32;
         if (L.coutp > 32 && L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T16x16_N64;
@@ -372,6 +381,48 @@ static int fold_conv(rcu_unet* h, const ConvLayer& L, const std::string& conv, c
         beta[co0 + co] = B;
     }
     const size_t tile_floats = conv_tile_floats(ci);   // padded to a whole number of float4 per thread
+    // Sub-pixel up-conv: output parity a (rows) folds the 3 kernel rows onto 2 low-res rows,
+    //   a = 0: low-res row y-1 <- {dy 0},   row y   <- {dy 1, 2}
+    //   a = 1: low-res row y   <- {dy 0, 1}, row y+1 <- {dy 2}            (same for columns with b)
+    auto fold_set = [](int parity, int t, int d) { return parity == 0 ? (t == 0 ? d == 0 : d >= 1) : (t == 0 ? d <= 1 : d == 2); };
+    if (ci.WINO == 2) {
+        // F(2x2,2x2) per parity class: U^{ab} = G w^{ab} G^T, G = [[1,0],[1,1],[0,1]], w^{ab} the 2x2 folded taps.  Packed
+        // per Cin chunk as tiles (a, cout tile) of [p = 6 i + 3 b + j][channel pair][cout][2]; column j = 0 of class b = 1
+        // is negated because the kernel feeds P.2 - P.1 where F(2,2) wants P.1 - P.2 (rcu_wino_up.hip).
+        static const double G2[3][2] = {{1, 0}, {1, 1}, {0, 1}};
+        for (int co = 0; co < L.cout; ++co) {
+            const int cop = co0 + co;
+            const int ntile = cop / BN, nn = cop % BN;
+            for (int ci_ = 0; ci_ < cin; ++ci_) {
+                const int chunk = ci_ / KC, kq = ci_ % KC;
+                const float* w9 = w->data() + ((size_t)co * cin + ci_) * 9;
+                for (int pa = 0; pa < 2; ++pa) {
+                    const size_t tile0 = (((size_t)chunk * 2 + pa) * L.NT + ntile) * tile_floats;
+                    for (int pb = 0; pb < 2; ++pb) {
+                        double wc[2][2];
+                        for (int ty = 0; ty < 2; ++ty)
+                            for (int tx = 0; tx < 2; ++tx) {
+                                double v = 0.0;
+                                for (int dy = 0; dy < 3; ++dy)
+                                    for (int dx = 0; dx < 3; ++dx)
+                                        if (fold_set(pa, ty, dy) && fold_set(pb, tx, dx)) v += (double)w9[dy * 3 + dx];
+                                wc[ty][tx] = v;
+                            }
+                        for (int i = 0; i < 3; ++i)
+                            for (int j = 0; j < 3; ++j) {
+                                double u = 0.0;
+                                for (int ty = 0; ty < 2; ++ty)
+                                    for (int tx = 0; tx < 2; ++tx) u += G2[i][ty] * wc[ty][tx] * G2[j][tx];
+                                if (pb == 1 && j == 0) u = -u;
+                                const int p = 6 * i + 3 * pb + j;
+                                wpack[tile0 + (((size_t)p * 4 + (kq >> 1)) * BN + nn) * 2 + (kq & 1)] = (float)u;
+                            }
+                    }
+                }
+            }
+        }
+        return RCU_OK;
+    }
     if (ci.WINO) {
         // U = G g G^T per (cout, cin), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; packed per Cin chunk and cout tile as
         // [position p][channel pair q][cout][2] (rcu_wino.hip).  Computed in double, rounded once.
@@ -397,10 +448,6 @@ static int fold_conv(rcu_unet* h, const ConvLayer& L, const std::string& conv, c
         return RCU_OK;
     }
     const int ncls = L.upsample ? 4 : 1;
-    // Sub-pixel up-conv: output parity a (rows) folds the 3 kernel rows onto 2 low-res rows,
-    //   a = 0: low-res row y-1 <- {dy 0},   row y   <- {dy 1, 2}
-    //   a = 1: low-res row y   <- {dy 0, 1}, row y+1 <- {dy 2}            (same for columns with b)
-    auto fold_set = [](int parity, int t, int d) { return parity == 0 ? (t == 0 ? d == 0 : d >= 1) : (t == 0 ? d <= 1 : d == 2); };
     for (int co = 0; co < L.cout; ++co) {
         const int cop = co0 + co;
         const int ntile = cop / BN, nn = cop % BN;
@@ -438,7 +485,7 @@ extern "C" int rcu_unet_finalize_weights(rcu_unet* h)
     for (ConvLayer& L : h->layers) {
         const ConvConfigInfo& ci = conv_config_info(L.cfg);
         const int nchunks = (L.c1p + L.c2p) / ci.KC;
-        L.wpack_floats = (size_t)nchunks * L.NT * (L.upsample ? 4 : 1) * conv_tile_floats(ci);
+        L.wpack_floats = (size_t)nchunks * L.NT * (ci.WINO == 2 ? 2 : L.upsample ? 4 : 1) * conv_tile_floats(ci);
         std::vector<float> wpack(L.wpack_floats, 0.f);
         const int cpad = L.NT * ci.BN;
         std::vector<float> alpha(cpad, 0.f), betab(cpad, 0.f), beta(cpad, 0.f);
@@ -494,7 +541,7 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     a.tiles_x = (gw + ci.TW - 1) / ci.TW;
     a.slice_groups = (n + ci.TS - 1) / ci.TS;
     a.NT = L.NT;
-    a.NTW_total = L.NT * (L.upsample ? 4 : 1);
+    a.NTW_total = L.NT * (ci.WINO == 2 ? 2 : L.upsample ? 4 : 1);
     a.src1_bytes = (uint32_t)std::min<size_t>(h->tensors[L.t_src1].floats_per_slice * (size_t)n * 4, 0xFFFFFFFFu);
     a.src2_bytes = L.t_src2 >= 0 ? (uint32_t)std::min<size_t>(h->tensors[L.t_src2].floats_per_slice * (size_t)n * 4, 0xFFFFFFFFu) : 0u;
     a.wpack_bytes = (uint32_t)std::min<size_t>(L.wpack_floats * 4, 0xFFFFFFFFu);
@@ -751,7 +798,9 @@ extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info*
         const double px = tiles * ci.TH * ci.TW * (L.upsample ? 4.0 : 1.0);
         const double ncols = (double)L.NT * ci.BN;
         // Winograd: 16 multiplications per 2x2 output tile instead of 9 per pixel
-        out->mfma_flops_per_slice = 2.0 * (L.c1p + L.c2p) * ncols * (ci.WINO ? 4.0 : (double)ci.TAPS) * px;
+        // and 9 per 2x2 low-resolution tile and parity class (= 9 per low-resolution pixel) for the up-convolutions
+        out->mfma_flops_per_slice = ci.WINO == 2 ? 2.0 * L.c1p * ncols * 9.0 * (px / 4.0)
+                                                 : 2.0 * (L.c1p + L.c2p) * ncols * (ci.WINO ? 4.0 : (double)ci.TAPS) * px;
     }
     return RCU_OK;
 }

@@ -568,7 +568,11 @@ static const ConvConfigInfo kInfo[CONV_CFG_COUNT] = {
     {Cfg10::TS, Cfg10::TH, Cfg10::TW, Cfg10::BN, Cfg10::KC, Cfg10::TAPS, "conv3x3_igemm<S2T8x16,N64,K8,db>", Cfg10::KCP, Cfg10::SWZ ? 1 : 0},
 };
 
-const ConvConfigInfo& conv_config_info(int cfg) { return cfg >= CONV_CFG_COUNT ? wino_config_info(cfg) : kInfo[cfg]; }
+const ConvConfigInfo& conv_config_info(int cfg)
+{
+    if (cfg >= CONV_CFG_UPW_T16x16_N64) return wino_up_config_info(cfg);
+    return cfg >= CONV_CFG_COUNT ? wino_config_info(cfg) : kInfo[cfg];
+}
 
 template <class T>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t stream)
@@ -606,6 +610,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t stream)
 
 hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream)
 {
+    if (cfg >= CONV_CFG_UPW_T16x16_N64) return launch_upconv_wino(cfg, a, stream);
     if (cfg >= CONV_CFG_COUNT) return launch_conv_wino(cfg, a, stream);
     switch (cfg) {
         case CONV_CFG_T8x16_N64: return launch_cfg<Cfg0>(a, stream);

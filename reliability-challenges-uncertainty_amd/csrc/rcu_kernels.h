@@ -52,6 +52,11 @@ enum ConvConfig {
     CONV_CFG_WINO_T16x32_N32,                    // 16x32-pixel tile x 32 couts (32-channel layers)
     CONV_CFG_WINO_S2T8x16_N64,                   // two 8x16 pieces of consecutive slices x 64 couts
     CONV_CFG_WINO_S8T4x8_N64,                    // 4x8 strips of eight consecutive slices x 64 couts (8-pixel-wide level)
+    // Winograd F(2x2,2x2) sub-pixel up-convolutions (rcu_wino_up.hip): 18 positions = two parity classes per work item
+    CONV_CFG_UPW_T16x16_N64,
+    CONV_CFG_UPW_T16x32_N32,
+    CONV_CFG_UPW_S2T8x16_N64,
+    CONV_CFG_UPW_S8T4x8_N64,
     CONV_CFG_END
 };
 
@@ -60,12 +65,15 @@ struct ConvConfigInfo {
     const char* kernel_name;
     int KCP;   // floats per [tap][channel] row of a packed weight tile (KC, or KC + 4 in the padded layout)
     int SWZ;   // 1: the two 16-byte units of a row are swapped for output channels 16..31 (mod 32), see ConvTile
-    int WINO;  // 1: Winograd kernel; TAPS = 16 positions, packed tile = [p][channel pair][cout][2] (rcu_wino.hip)
+    int WINO;  // 1: Winograd F(2x2,3x3) kernel, TAPS = 16 positions; 2: F(2x2,2x2) up-conv, TAPS = 18 (two classes);
+               // packed tile = [p][channel pair][cout][2] (rcu_wino.hip, rcu_wino_up.hip)
 };
 const ConvConfigInfo& conv_config_info(int cfg);
 const ConvConfigInfo& wino_config_info(int cfg);
+const ConvConfigInfo& wino_up_config_info(int cfg);
 hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream);
 hipError_t launch_conv_wino(int cfg, const ConvArgs& a, hipStream_t stream);
+hipError_t launch_upconv_wino(int cfg, const ConvArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // layout / head / aggregation kernels (rcu_pointwise.hip)

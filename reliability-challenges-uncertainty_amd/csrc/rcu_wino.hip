@@ -30,117 +30,11 @@
 //     out-of-range offset and the DMA writes zeros (tools/microbench/glds_oob_probe.hip).
 //   * streaming: a workgroup walks over several output tiles and runs one double-buffered pipeline across all their
 //     Cin chunks (chunk k+1 streams into the other LDS buffer while chunk k is multiplied).
-#include "rcu_kernels.h"
+#include "rcu_wino_common.h"
 
 #include <cstdlib>
-#include <type_traits>
 
 namespace rcu {
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-namespace {
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-__device__ __forceinline__ int wino_xcd_virtual_block(int group)
-{
-    const int g = (int)gridDim.x, b = (int)blockIdx.x;
-    if ((g & 7) != 0 || ((g >> 3) % group) != 0) return b;
-    const int xcd = b & 7, slot = b >> 3;
-    return ((slot / group) * 8 + xcd) * group + slot % group;
-}
-
-}  // namespace
-
-// A 16-tile MFMA row block is 2 tile rows x 8 tile columns: 4 x 16 pixels of one slice (SW = 1) or, for images only
-// 8 pixels wide, 4 x 8 pixels of each of SW = 2 consecutive slices.
-template <int TS_, int TH_, int TW_, int BN_, int WM_, int WN_, int SW_ = 1>
-struct WinoTile {
-    static constexpr int TS = TS_, TH = TH_, TW = TW_, BN = BN_, WM = WM_, WN = WN_, SW = SW_;
-    static constexpr int KC = 8, THREADS = 512, WAVES = 8;
-    static constexpr int TILES = TS * (TH / 2) * (TW / 2);
-    static constexpr int BPS = (TH / 4) * (TW * SW / 16);     // 16-tile blocks per group of SW slices
-    static constexpr int PITCH = (TW + 2 + 7) / 8 * 8;        // positions per halo row; a multiple of 8 (bank analysis)
-    // positions per slice image; with SW = 2 an odd multiple of 8 so that the two slices of a block fall on different
-    // halves of the 64 banks
-    static constexpr int SLICE_POS = (TH + 2) * PITCH + (SW == 2 ? 8 : 0);
-    static constexpr int HALF_POS = TS * SLICE_POS;           // positions of one channel-half image
-    static constexpr int A_POS = 2 * HALF_POS;                // 16-byte positions of the input image
-    static constexpr int A_PIECES = (A_POS + 63) / 64;        // 1-KB LDS-DMA pieces (one wave instruction each)
-    static constexpr int NA = (A_PIECES + WAVES - 1) / WAVES; // pieces per wave
-    static constexpr int A_DW = A_PIECES * 256;
-    static constexpr int W_DW = 16 * 4 * BN * 2;              // [p][q][n][2]
-    static constexpr int W_PIECES = W_DW / 256;
-    static constexpr int NW = W_PIECES / WAVES;               // consecutive pieces per wave
-    static constexpr int BUF_DW = A_DW + W_DW;
-    static constexpr int LDS_BYTES = 2 * BUF_DW * 4;
-    static_assert(WM * WN == 8, "8 waves per workgroup");
-    static_assert(TILES == 16 * WM && BN == 32 * WN, "wave tiling");
-    static_assert(TH % 4 == 0 && (TW * SW) % 16 == 0 && (SW == 1 || (SW == 2 && TW == 8 && TS % 2 == 0)), "block geometry");
-    static_assert(SW == 1 || SLICE_POS % 16 == 8, "slice stride");
-    static_assert(W_PIECES % WAVES == 0, "weight staging");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    // block index -> (first slice of the block inside the tile, pixel origin of the block inside the slice tile)
-    static __device__ __forceinline__ void block_origin(int blk, int& s, int& y, int& x)
-    {
-        const int grp = blk / BPS, rb = blk % BPS;
-        s = grp * SW;
-        y = 4 * (rb / (TW * SW / 16));
-        x = SW == 1 ? 16 * (rb % (TW / 16)) : 0;
-    }
-};
-
-// Per-lane constants of the conv-unit epilogue (the lane's two couts of the tile's slice): loaded while the tile's
-// last-but-one Cin chunk is multiplied and folded at the start of the last one, so that the epilogue does not start with
-// a global-memory round trip and the raw values are gone before the register-heavy last chunk.
-struct WinoEpiRaw {
-    float al[2], bb[2], be[2], mk[2];
-};
-struct WinoEpi {   // out = relu(acc * scale + shift)
-    float scale[2], shift[2];
-};
-__device__ __forceinline__ WinoEpi wino_epilogue_fold(const WinoEpiRaw& r)
-{
-    WinoEpi e;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        e.scale[b] = r.al[b] * r.mk[b];
-        e.shift[b] = r.bb[b] * r.mk[b] + r.be[b];
-    }
-    return e;
-}
-
-template <class T>
-__device__ __forceinline__ WinoEpiRaw wino_epilogue_load(const ConvArgs& a, int ntile, int n0, int wm, int wn, int lane)
-{
-    WinoEpiRaw e;
-    const int co = ntile * T::BN + wn * 32 + 2 * (lane & 15);
-    int bs, by, bx;
-    T::block_origin(wm, bs, by, bx);
-    const int n = n0 + bs + (T::SW == 2 ? (lane >> 4) & 1 : 0);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int c = co + b;
-        const bool live = c < a.CoutP && n < a.N;
-        e.al[b] = live ? a.alpha[c] : 0.f;
-        e.bb[b] = live ? a.betab[c] : 0.f;
-        e.be[b] = live ? a.beta[c] : 0.f;
-        float mk = 1.f;
-        if (live && a.mask != nullptr && c < a.Cmask) mk = a.mask[(size_t)n * a.Cmask + c];
-        if (live && a.mask2 != nullptr && c >= a.Csplit && c - a.Csplit < a.Cmask2) mk = a.mask2[(size_t)n * a.Cmask2 + (c - a.Csplit)];
-        e.mk[b] = mk;
-    }
-    return e;
-}
 
 // Output transform + conv-unit epilogue of one finished tile.  acc[b][p][r]: MFMA block b (cout 2n+b), position p,
 // tile r of the lane's four.
@@ -211,57 +105,6 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
     }
 }
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-constexpr uint32_t WINO_OOB = 0x80000000u;
-
-// Tile coordinates of a work item (wave-uniform).
-struct WinoTileId {
-    int wtile, n0, y0, x0;
-};
-
-template <class T>
-__device__ __forceinline__ WinoTileId wino_tile_id(const ConvArgs& a, int item)
-{
-    WinoTileId t;
-    t.wtile = item % a.NT;
-    int mtile = item / a.NT;
-    const int tx = mtile % a.tiles_x;
-    mtile /= a.tiles_x;
-    const int ty = mtile % a.tiles_y;
-    const int sg = mtile / a.tiles_y;
-    t.n0 = sg * T::TS;
-    t.y0 = ty * T::TH;
-    t.x0 = tx * T::TW;
-    return t;
-}
-
-// Per-lane staging plan of one output tile: byte offset (into src1 and src2 alike) of the pixel chunk that slot j of this lane
-// fetches by LDS-DMA; slots of zero padding / pitch padding / outside the batch point far out of range, where the
-// buffer load returns zeros.  The tile-independent part -- which (channel half, slice, halo row, pixel column) the slot
-// holds -- is packed into one register per slot at kernel start (wino_slot_geometry).
-template <class T>
-__device__ __forceinline__ uint32_t wino_slot_geometry(int j, int wave, int lane)
-{
-    const int f = (j * T::WAVES + wave) * 64 + lane;       // position index in the LDS image
-    const int hh = f / T::HALF_POS, rem = f % T::HALF_POS;
-    const int s = rem / T::SLICE_POS, r2 = rem % T::SLICE_POS;
-    const int yy = r2 / T::PITCH, pos = r2 % T::PITCH;
-    const int x = pos ^ ((yy >> 1) & 1);                    // pixel column stored at this position
-    const bool real = f < T::A_POS && yy < T::TH + 2 && x < T::TW + 2;
-    return real ? (uint32_t)(x | (yy << 8) | (s << 16) | (hh << 24)) : 0xFFFFFFFFu;
-}
-
-template <class T>
-__device__ __forceinline__ uint32_t wino_slot_offset(const ConvArgs& a, const WinoTileId& t, uint32_t geo)
-{
-    const int x = geo & 0xFF, yy = (geo >> 8) & 0xFF, s = (geo >> 16) & 0xFF, hh = (geo >> 24) & 1;
-    const int n = t.n0 + s, gy = t.y0 + yy - 1, gx = t.x0 + x - 1;
-    const bool ok = geo != 0xFFFFFFFFu && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    const uint32_t pix = (uint32_t)((n * a.H + gy) * a.W + gx);
-    return ok ? (pix * (uint32_t)a.C1 + hh * 4) * 4u : WINO_OOB;   // C2 == C1 or 0 (checked by the launcher)
-}
-
 template <class T>
 __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, const int total_items)
 {
@@ -300,7 +143,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
         }
     }
     const int b_addr = T::A_DW + (kq * T::BN + wn * 32 + 2 * m16) * 2;
-    const uint32_t w_voff = (uint32_t)(wave * T::NW * 1024 + lane * 16);
+    const uint32_t w_voff = (uint32_t)(lane * 16);
 
     // dp*: the plan the LDS-DMA works from -- the current tile's until its last chunk is being multiplied, then the
     // next tile's; tile / ntile: coordinates of the tile being multiplied and of the workgroup's next one
@@ -336,9 +179,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
     auto dma_piece = [&](const DmaJob& job, auto i_c) {
         constexpr int I = decltype(i_c)::value;
         if constexpr (I < T::NW) {
-            if (job.active)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(lds_base + job.lb + T::A_DW * 4 + (wave * T::NW + I) * 1024),
-                                                         16, w_voff, job.wso + I * 1024u, 0, 0);
+            if (job.active && ((I + 1) * T::WAVES <= T::W_PIECES || I * T::WAVES + wave < T::W_PIECES))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(lds_base + job.lb + T::A_DW * 4 + (I * T::WAVES + wave) * 1024),
+                                                         16, w_voff, job.wso + (uint32_t)(I * T::WAVES + wave) * 1024u, 0, 0);
         } else if constexpr (I < T::NW + T::NA) {
             constexpr int j = I - T::NW;
             if (job.active && ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES)) {
@@ -354,14 +197,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
 
     {
         const DmaJob job = dma_job(dp_wtile, 0, 0, true);
-        static_for<0, T::NW + T::NA>([&](auto i_c) { dma_piece(job, i_c); });
+        wino_static_for<0, T::NW + T::NA>([&](auto i_c) { dma_piece(job, i_c); });
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
 
     f32x4 acc[2][16];
     WinoEpiRaw epr;
-    WinoEpi ep;
 
     // One Cin chunk out of LDS buffer BUF; FIRST: the accumulators start from zero (first chunk of a tile).
     auto chunk = [&](auto buf_c, auto first_c, int kc) {
@@ -377,8 +219,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
 #pragma unroll
             for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(a, ntile, geo[j]);
         }
-        if (kc + 2 == nchunks) epr = wino_epilogue_load<T>(a, tile.wtile, tile.n0, wm, wn, lane);
-        if (!more) ep = wino_epilogue_fold(epr);
+        if (!more) epr = wino_epilogue_load<T>(a, tile.wtile, tile.n0, wm, wn, lane);
         __builtin_amdgcn_sched_barrier(0);   // keep the address arithmetic above out of the register-heavy part below
         const DmaJob job = dma_job(dp_wtile, more ? kc + 1 : 0, BUF ^ 1, more || has_next);
         // raw 4x4 patch of the lane's tile, channel pair (2kq, 2kq+1): rows 0 and 2 first (position row 0 needs only them)
@@ -409,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
         for (int j = 0; j < 4; ++j) d[j] = d[j] - d[8 + j];
         col_transform(0);
         // 16 positions x (2 channel steps x 2 cout blocks); the weights of positions p+AHEAD.. are read while p multiplies
-        static_for<0, 8>([&](auto pp_c) {
+        wino_static_for<0, 8>([&](auto pp_c) {
             constexpr int G = decltype(pp_c)::value;
             constexpr int p0 = 2 * G, p1 = p0 + 1;
             __builtin_amdgcn_sched_barrier(0);
@@ -441,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
             if constexpr (G == 2) col_transform(2);
             if constexpr (G == 3) col_transform(3);
         });
-        static_for<8, T::NW + T::NA>([&](auto i_c) { dma_piece(job, i_c); });
+        wino_static_for<8, T::NW + T::NA>([&](auto i_c) { dma_piece(job, i_c); });
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the next chunk have landed
         __syncthreads();                      // everyone done with buffer BUF and with filling the other one
     };
@@ -453,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
             chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc);
             chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1);
         }
-        wino_epilogue<T>(a, acc, ep, tile.wtile, tile.n0, tile.y0, tile.x0, wm, wn, lane);
+        wino_epilogue<T>(a, acc, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wm, wn, lane);
         if (!has_next) break;
         item += (int)gridDim.x;
         tile = ntile;

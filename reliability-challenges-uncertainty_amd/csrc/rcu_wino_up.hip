@@ -1,0 +1,311 @@
+// UpConv's "nearest x2 -> conv3x3 (+bias)" (common/model/unet.py:105, helpers.py:15) in its sub-pixel form -- output
+// pixel (2y+a, 2x+b) is a 2x2-tap convolution of the LOW-resolution grid with tap weights pre-summed per parity class
+// (a, b), see rcu_conv.hip -- with every class evaluated as Winograd F(2x2, 2x2):
+//
+//     Y^{ab} = A^T [ sum_c (G w^{ab}_c G^T) .* (B^T d^{ab}_c B) ] A,    d^{ab} = 3x3 patch, 9 multiplications per 4 outputs
+//     B^T = [[1,-1,0],[0,1,0],[0,-1,1]]   G = [[1,0],[1,1],[0,1]]   A^T = [[1,1,0],[0,1,1]]
+//
+// i.e. 9 instead of 16 (sub-pixel) or 36 (up-sample, then 3x3) multiplications per (cin, cout) and 2x2 low-resolution
+// tile: the up-convolutions execute 1/4 of their canonical FLOPs on the MFMA pipe.
+//
+// The four classes of a tile read sub-patches of ONE 4x4 low-resolution patch P (the F(2x2,3x3) patch of rcu_wino.hip):
+// class (a, b) takes rows a..a+2 and columns b..b+2.  A work item fixes a; its waves compute both b at once:
+//   rows     rho = (e0 - e1, e1, e2 - e1) of (e0, e1, e2) = P[a .. a+2]
+//   columns  gamma = (P.0 - P.1, P.1, P.2 - P.1, P.2, P.3 - P.2): b = 0 multiplies (gamma0, gamma1, gamma2),
+//            b = 1 multiplies (-gamma2, gamma3, gamma4) -- the sign is folded into the packed weights
+// = 15 transformed values per (tile, channel) feeding 18 positions p = 6 i + 3 b + j: 144 accumulator registers per wave
+// (16 tiles x 32 couts x 18).  Staging (LDS-DMA, swizzled lane-linear images, hardware zero padding), wave / lane
+// mapping and the streaming pipeline are those of rcu_wino.hip; see there.
+#include "rcu_wino_common.h"
+
+#include <cstdlib>
+
+namespace rcu {
+
+// Output transform + epilogue.  acc[blk][p][r]; the lane's tile r of class (pa, b) yields the output pixels
+// (2 (ly + u) + pa, 2 (lx + v) + b), u, v in {0, 1}, of the up-sampled grid.
+template <class T>
+__device__ __forceinline__ void wino_up_epilogue(const ConvArgs& a, const f32x4 (&acc)[2][18], const WinoEpi& ep, int ntile, int pa,
+                                                 int n0, int y0, int x0, int wm, int wn, int lane)
+{
+    const int n16 = lane & 15, g = lane >> 4;
+    const int co = ntile * T::BN + wn * 32 + 2 * n16;
+    if (co >= a.CoutP) return;
+    int bs, by, bx;
+    T::block_origin(wm, bs, by, bx);
+    const int n = n0 + bs + (T::SW == 2 ? g & 1 : 0);
+    if (n >= a.N) return;
+    const int lyb = y0 + by + 2 * (g >> 1);                       // low-res row of the lane's tiles
+    const int lxb = x0 + bx + (T::SW == 2 ? 0 : 8 * (g & 1));     // low-res column of the lane's first tile
+    const int OH = 2 * a.H, OW = 2 * a.W;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int lx = lxb + 2 * r;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x2 y[2][2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                float s[2][3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float m0 = acc[blk][0 * 6 + b * 3 + j][r], m1 = acc[blk][1 * 6 + b * 3 + j][r], m2 = acc[blk][2 * 6 + b * 3 + j][r];
+                    s[0][j] = m0 + m1;
+                    s[1][j] = m1 + m2;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float t0 = (s[u][0] + s[u][1]) * ep.scale[blk] + ep.shift[blk];
+                    const float t1 = (s[u][1] + s[u][2]) * ep.scale[blk] + ep.shift[blk];
+                    y[u][0][blk] = a.relu ? fmaxf(t0, 0.f) : t0;
+                    y[u][1][blk] = a.relu ? fmaxf(t1, 0.f) : t1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v)
+                    if (lyb + u < a.H && lx + v < a.W)
+                        *reinterpret_cast<f32x2*>(a.out + ((size_t)(n * OH + 2 * (lyb + u) + pa) * OW + 2 * (lx + v) + b) * a.CoutP + co) = y[u][v];
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, const int total_items)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource types and LDS-DMA builtins exist in the device pass only
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    constexpr int KC = T::KC;
+    static_assert(T::NPOS == 18, "two F(2x2,2x2) classes per wave");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % T::WN;
+    const int wm = wave / T::WN;
+    const int m16 = lane & 15, kq = lane >> 4;
+    const int nchunks = a.C1 / KC;   // even, >= 4 (checked by the launcher); single source
+    const uint32_t wchunk_bytes = (uint32_t)a.NTW_total * T::W_DW * 4u;
+
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1), 0, a.src1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, a.wpack_bytes, 0x00020000);
+
+    // fragment addresses (dword offsets inside a buffer) of patch rows 0 and 2; rows 1 and 3 follow one pitch later
+    int aA[2], aB[2];
+    {
+        int bs, by, bx;
+        T::block_origin(wm, bs, by, bx);
+        const int tr = m16 >> 3, tcg = m16 & 7;
+        const int sl = bs + (T::SW == 2 ? tcg >> 2 : 0);
+        const int yy0 = by + 2 * tr, x0l = bx + 2 * (T::SW == 2 ? tcg & 3 : tcg);
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int yy = yy0 + 2 * i2, swz = (yy >> 1) & 1;
+            const int rowbase = ((kq >> 1) * T::HALF_POS + sl * T::SLICE_POS + yy * T::PITCH) * 4 + (kq & 1) * 2;
+            aA[i2] = rowbase + 4 * (x0l + swz);
+            aB[i2] = rowbase + 4 * (x0l - swz);
+        }
+    }
+    const int b_addr = T::A_DW + (kq * T::BN + wn * 32 + 2 * m16) * 2;
+    const uint32_t w_voff = (uint32_t)(lane * 16);
+
+    int item = wino_xcd_virtual_block(a.NTW_total < 4 ? 4 : a.NTW_total);
+    bool has_next = item + (int)gridDim.x < total_items;
+    WinoTileId tile = wino_tile_id<T>(a, item), ntile = tile;
+    uint32_t dp[T::NA], geo[T::NA];
+    int dp_wtile = tile.wtile;
+#pragma unroll
+    for (int j = 0; j < T::NA; ++j) {
+        geo[j] = wino_slot_geometry<T>(j, wave, lane);
+        asm volatile("" : "+v"(geo[j]));
+        dp[j] = wino_slot_offset<T>(a, tile, geo[j]);
+    }
+
+    struct DmaJob {
+        bool active;
+        uint32_t cb, wso, lb;
+    };
+    auto dma_job = [&](int wtile, int kc, int buf, bool active) {
+        DmaJob j;
+        j.active = active;
+        j.cb = (uint32_t)__builtin_amdgcn_readfirstlane(kc * KC * 4);
+        j.wso = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)kc * wchunk_bytes + (uint32_t)wtile * (T::W_DW * 4u)));
+        j.lb = (uint32_t)buf * (T::BUF_DW * 4u);
+        return j;
+    };
+    char* const lds_base = reinterpret_cast<char*>(smem);
+    auto dma_piece = [&](const DmaJob& job, auto i_c) {
+        constexpr int I = decltype(i_c)::value;
+        if constexpr (I < T::NW) {
+            if (job.active && ((I + 1) * T::WAVES <= T::W_PIECES || I * T::WAVES + wave < T::W_PIECES))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(lds_base + job.lb + T::A_DW * 4 + (I * T::WAVES + wave) * 1024),
+                                                         16, w_voff, job.wso + (uint32_t)(I * T::WAVES + wave) * 1024u, 0, 0);
+        } else if constexpr (I < T::NW + T::NA) {
+            constexpr int j = I - T::NW;
+            if (job.active && ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16, dp[j],
+                                                         job.cb, 0, 0);
+        }
+    };
+
+    {
+        const DmaJob job = dma_job(dp_wtile, 0, 0, true);
+        wino_static_for<0, T::NW + T::NA>([&](auto i_c) { dma_piece(job, i_c); });
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __syncthreads();
+
+    f32x4 acc[2][18];
+    WinoEpiRaw epr;
+
+    auto chunk = [&](auto buf_c, auto first_c, int kc) {
+        constexpr int BUF = decltype(buf_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
+        const float* const Ab = smem + BUF * T::BUF_DW;
+        const int pa = tile.wtile / a.NT;   // row parity class of this work item
+        const bool more = kc + 1 < nchunks;
+        if (!more && has_next) {   // last chunk of the tile: from here on the DMA works on the workgroup's next tile
+            ntile = wino_tile_id<T>(a, item + (int)gridDim.x);
+            dp_wtile = ntile.wtile;
+#pragma unroll
+            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(a, ntile, geo[j]);
+        }
+        if (!more) epr = wino_epilogue_load<T>(a, tile.wtile % a.NT, tile.n0, wm, wn, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        const DmaJob job = dma_job(dp_wtile, more ? kc + 1 : 0, BUF ^ 1, more || has_next);
+        // rows pa .. pa+2 of the lane's 4x4 patch, channel pair (2kq, 2kq+1): (e0, e1) now, e2 behind the first MFMA group
+        f32x2 e0[4], e1[4], e2[4];
+        auto read_row = [&](f32x2 (&e)[4], auto row_c) {
+            constexpr int ROW = decltype(row_c)::value;   // patch row 0..3
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                e[j] = *(const volatile __attribute__((address_space(3))) f32x2*)(Ab + ((j & 1) ? aB[ROW >> 1] : aA[ROW >> 1]) +
+                                                                                  (ROW & 1) * (T::PITCH * 4) + 4 * j);
+        };
+        if (pa == 0) {
+            read_row(e0, std::integral_constant<int, 0>{});
+            read_row(e1, std::integral_constant<int, 1>{});
+        } else {
+            read_row(e0, std::integral_constant<int, 1>{});
+            read_row(e1, std::integral_constant<int, 2>{});
+        }
+        constexpr int AHEAD = 2;
+        f32x4 bv[18];
+#pragma unroll
+        for (int p = 0; p < AHEAD; ++p) bv[p] = *reinterpret_cast<const f32x4*>(Ab + b_addr + p * (8 * T::BN));
+        // V[5 i + c] = rho_i (x) gamma_c, one position row i at a time, just ahead of the groups that multiply it
+        f32x2 V[15];
+        auto col_transform = [&](int i, const f32x2 (&r)[4]) {
+            V[5 * i + 0] = r[0] - r[1];
+            V[5 * i + 1] = r[1];
+            V[5 * i + 2] = r[2] - r[1];
+            V[5 * i + 3] = r[2];
+            V[5 * i + 4] = r[3] - r[2];
+        };
+        {
+            f32x2 r0[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r0[j] = e0[j] - e1[j];
+            col_transform(0, r0);
+        }
+        // 18 positions p = 6 i + 3 b + j x (2 channel steps x 2 cout blocks)
+        wino_static_for<0, 9>([&](auto pp_c) {
+            constexpr int G = decltype(pp_c)::value;
+            constexpr int p0 = 2 * G, p1 = p0 + 1;
+            constexpr int v0 = 5 * (p0 / 6) + 2 * ((p0 % 6) / 3) + p0 % 3, v1 = 5 * (p1 / 6) + 2 * ((p1 % 6) / 3) + p1 % 3;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (p0 + AHEAD < 18) {
+                bv[p0 + AHEAD] = *reinterpret_cast<const f32x4*>(Ab + b_addr + (p0 + AHEAD) * (8 * T::BN));
+                bv[p1 + AHEAD] = *reinterpret_cast<const f32x4*>(Ab + b_addr + (p1 + AHEAD) * (8 * T::BN));
+            }
+            if constexpr (G == 0) {
+                if (pa == 0)
+                    read_row(e2, std::integral_constant<int, 2>{});
+                else
+                    read_row(e2, std::integral_constant<int, 3>{});
+            }
+            dma_piece(job, std::integral_constant<int, G>{});
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            acc[0][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[v0].x, bv[p0].x, FIRST ? z : acc[0][p0], 0, 0, 0);
+            acc[1][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[v0].x, bv[p0].z, FIRST ? z : acc[1][p0], 0, 0, 0);
+            acc[0][p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[v1].x, bv[p1].x, FIRST ? z : acc[0][p1], 0, 0, 0);
+            acc[1][p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[v1].x, bv[p1].z, FIRST ? z : acc[1][p1], 0, 0, 0);
+            acc[0][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[v0].y, bv[p0].y, acc[0][p0], 0, 0, 0);
+            acc[1][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[v0].y, bv[p0].w, acc[1][p0], 0, 0, 0);
+            acc[0][p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[v1].y, bv[p1].y, acc[0][p1], 0, 0, 0);
+            acc[1][p1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[v1].y, bv[p1].w, acc[1][p1], 0, 0, 0);
+            if constexpr (G == 1) col_transform(1, e1);            // multiplied from group 3 on
+            if constexpr (G == 4) {                                // multiplied from group 6 on
+                f32x2 r2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r2[j] = e2[j] - e1[j];
+                col_transform(2, r2);
+            }
+        });
+        wino_static_for<9, T::NW + T::NA>([&](auto i_c) { dma_piece(job, i_c); });
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the next chunk have landed
+        __syncthreads();                      // everyone done with buffer BUF and with filling the other one
+    };
+
+    for (;;) {
+        chunk(std::integral_constant<int, 0>{}, std::true_type{}, 0);
+        chunk(std::integral_constant<int, 1>{}, std::false_type{}, 1);
+        for (int kc = 2; kc < nchunks; kc += 2) {
+            chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc);
+            chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1);
+        }
+        wino_up_epilogue<T>(a, acc, wino_epilogue_fold(epr), tile.wtile % a.NT, tile.wtile / a.NT, tile.n0, tile.y0, tile.x0, wm, wn, lane);
+        if (!has_next) break;
+        item += (int)gridDim.x;
+        tile = ntile;
+        has_next = item + (int)gridDim.x < total_items;
+    }
+#endif
+}
+
+using UCfg0 = WinoTile<1, 16, 16, 64, 4, 2, 1, 18>;
+using UCfg1 = WinoTile<1, 16, 32, 32, 8, 1, 1, 18>;
+using UCfg2 = WinoTile<2, 8, 16, 64, 4, 2, 1, 18>;
+using UCfg3 = WinoTile<8, 4, 8, 64, 4, 2, 2, 18>;
+
+static const ConvConfigInfo kWinoUpInfo[4] = {
+    {UCfg0::TS, UCfg0::TH, UCfg0::TW, UCfg0::BN, 8, 18, "upconv_winograd<T16x16,N64,K8>", 8, 0, 2},
+    {UCfg1::TS, UCfg1::TH, UCfg1::TW, UCfg1::BN, 8, 18, "upconv_winograd<T16x32,N32,K8>", 8, 0, 2},
+    {UCfg2::TS, UCfg2::TH, UCfg2::TW, UCfg2::BN, 8, 18, "upconv_winograd<S2T8x16,N64,K8>", 8, 0, 2},
+    {UCfg3::TS, UCfg3::TH, UCfg3::TW, UCfg3::BN, 8, 18, "upconv_winograd<S8T4x8,N64,K8>", 8, 0, 2},
+};
+
+const ConvConfigInfo& wino_up_config_info(int cfg) { return kWinoUpInfo[cfg - CONV_CFG_UPW_T16x16_N64]; }
+
+template <class T>
+static hipError_t launch_wino_up_cfg(const ConvArgs& a, hipStream_t stream)
+{
+    static bool attr_set = false;
+    const int nchunks = a.C1 / T::KC;
+    if (nchunks < 4 || (nchunks & 1) != 0 || a.C2 != 0 || a.NTW_total != 2 * a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0)
+        return hipErrorInvalidValue;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_wino_stream<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const unsigned items = (unsigned)a.NTW_total * a.tiles_x * a.tiles_y * a.slice_groups;
+    const unsigned grid = items < 256u ? items : 256u;
+    hipLaunchKernelGGL(upconv_wino_stream<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);
+    return hipGetLastError();
+}
+
+hipError_t launch_upconv_wino(int cfg, const ConvArgs& a, hipStream_t stream)
+{
+    switch (cfg) {
+        case CONV_CFG_UPW_T16x16_N64: return launch_wino_up_cfg<UCfg0>(a, stream);
+        case CONV_CFG_UPW_T16x32_N32: return launch_wino_up_cfg<UCfg1>(a, stream);
+        case CONV_CFG_UPW_S2T8x16_N64: return launch_wino_up_cfg<UCfg2>(a, stream);
+        case CONV_CFG_UPW_S8T4x8_N64: return launch_wino_up_cfg<UCfg3>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace rcu
