@@ -56,6 +56,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
     const float scale[2] = {ep.scale[0], ep.scale[1]}, shift[2] = {ep.shift[0], ep.shift[1]};
     const int Hp = a.H >> 1, Wp = a.W >> 1;
     const bool rows_ok = yb + 1 < a.H;
+    const int odd = n16 & 1;
+    f32x2 mx[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int x = xb + 2 * r;
@@ -79,28 +81,40 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
                 y[1][bb][b] = a.relu ? fmaxf(t1, 0.f) : t1;
             }
         }
-        if (x + 1 < a.W && rows_ok) {
-            float* const o = a.out + ((size_t)(n * a.H + yb) * a.W + x) * a.CoutP + co;
-            *reinterpret_cast<f32x2*>(o) = y[0][0];
-            *reinterpret_cast<f32x2*>(o + a.CoutP) = y[0][1];
-            *reinterpret_cast<f32x2*>(o + (size_t)a.W * a.CoutP) = y[1][0];
-            *reinterpret_cast<f32x2*>(o + (size_t)a.W * a.CoutP + a.CoutP) = y[1][1];
-        } else {
+        // Neighbouring lanes (couts 2n, 2n+1 | 2n+2, 2n+3 of the same pixels) trade one pixel column each, so that the even
+        // lane holds four couts of column x and the odd lane four couts of column x + 1: half as many store instructions
+        // (one 16-byte store per lane and pixel row), which is what the epilogue's time goes into.
+        f32x4 o[2];
 #pragma unroll
-            for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb)
-                    if (yb + aa < a.H && x + bb < a.W)
-                        *reinterpret_cast<f32x2*>(a.out + ((size_t)(n * a.H + yb + aa) * a.W + x + bb) * a.CoutP + co) = y[aa][bb];
+        for (int aa = 0; aa < 2; ++aa) {
+            const f32x2 send = odd ? y[aa][0] : y[aa][1];
+            f32x2 recv;
+            recv.x = wino_swap_adjacent(send.x);
+            recv.y = wino_swap_adjacent(send.y);
+            o[aa] = odd ? f32x4{recv.x, recv.y, y[aa][1].x, y[aa][1].y} : f32x4{y[aa][0].x, y[aa][0].y, recv.x, recv.y};
+        }
+        if (x + odd < a.W) {
+            float* const op = a.out + ((size_t)(n * a.H + yb) * a.W + x + odd) * a.CoutP + (co - 2 * odd);
+            *reinterpret_cast<f32x4*>(op) = o[0];
+            if (rows_ok) *reinterpret_cast<f32x4*>(op + (size_t)a.W * a.CoutP) = o[1];
         }
         if (a.pooled != nullptr) {
-            const int py = yb >> 1, px = x >> 1;
-            if (py < Hp && px < Wp) {
-                f32x2 mx;
-                mx.x = fmaxf(fmaxf(y[0][0].x, y[0][1].x), fmaxf(y[1][0].x, y[1][1].x));
-                mx.y = fmaxf(fmaxf(y[0][0].y, y[0][1].y), fmaxf(y[1][0].y, y[1][1].y));
-                *reinterpret_cast<f32x2*>(a.pooled + ((size_t)(n * Hp + py) * Wp + px) * a.CoutP + co) = mx;
-            }
+            mx[r].x = fmaxf(fmaxf(y[0][0].x, y[0][1].x), fmaxf(y[1][0].x, y[1][1].x));
+            mx[r].y = fmaxf(fmaxf(y[0][0].y, y[0][1].y), fmaxf(y[1][0].y, y[1][1].y));
+        }
+    }
+    if (a.pooled != nullptr) {
+        // same trade for the pooled pixels (one per tile): the even lane stores four couts of tile r, the odd lane of tile r + 1
+        const int py = yb >> 1;
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+            const f32x2 send = odd ? mx[r] : mx[r + 1];
+            f32x2 recv;
+            recv.x = wino_swap_adjacent(send.x);
+            recv.y = wino_swap_adjacent(send.y);
+            const f32x4 o = odd ? f32x4{recv.x, recv.y, mx[r + 1].x, mx[r + 1].y} : f32x4{mx[r].x, mx[r].y, recv.x, recv.y};
+            const int px = (xb >> 1) + r + odd;
+            if (py < Hp && px < Wp) *reinterpret_cast<f32x4*>(a.pooled + ((size_t)(n * Hp + py) * Wp + px) * a.CoutP + (co - 2 * odd)) = o;
         }
     }
 }

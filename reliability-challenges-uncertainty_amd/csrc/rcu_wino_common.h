@@ -11,6 +11,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// Exchange with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2].
+__device__ __forceinline__ float wino_swap_adjacent(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void wino_static_for(F&& f)
 {

@@ -38,6 +38,7 @@ __device__ __forceinline__ void wino_up_epilogue(const ConvArgs& a, const f32x4 
     const int lyb = y0 + by + 2 * (g >> 1);                       // low-res row of the lane's tiles
     const int lxb = x0 + bx + (T::SW == 2 ? 0 : 8 * (g & 1));     // low-res column of the lane's first tile
     const int OH = 2 * a.H, OW = 2 * a.W;
+    const int odd = n16 & 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int lx = lxb + 2 * r;
@@ -61,12 +62,18 @@ __device__ __forceinline__ void wino_up_epilogue(const ConvArgs& a, const f32x4 
                     y[u][1][blk] = a.relu ? fmaxf(t1, 0.f) : t1;
                 }
             }
+            // neighbouring lanes trade one pixel column each: the even lane stores four couts of column v = 0, the odd lane
+            // of v = 1 (one 16-byte store per lane instead of two 8-byte ones, see rcu_wino.hip)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int v = 0; v < 2; ++v)
-                    if (lyb + u < a.H && lx + v < a.W)
-                        *reinterpret_cast<f32x2*>(a.out + ((size_t)(n * OH + 2 * (lyb + u) + pa) * OW + 2 * (lx + v) + b) * a.CoutP + co) = y[u][v];
+            for (int u = 0; u < 2; ++u) {
+                const f32x2 send = odd ? y[u][0] : y[u][1];
+                f32x2 recv;
+                recv.x = wino_swap_adjacent(send.x);
+                recv.y = wino_swap_adjacent(send.y);
+                const f32x4 o = odd ? f32x4{recv.x, recv.y, y[u][1].x, y[u][1].y} : f32x4{y[u][0].x, y[u][0].y, recv.x, recv.y};
+                if (lyb + u < a.H && lx + odd < a.W)
+                    *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * OH + 2 * (lyb + u) + pa) * OW + 2 * (lx + odd) + b) * a.CoutP + (co - 2 * odd)) = o;
+            }
         }
     }
 }
