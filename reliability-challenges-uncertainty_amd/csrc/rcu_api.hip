@@ -111,10 +111,9 @@ static int pick_config(const ConvLayer& L, int n_slices)
     // Winograd kernels (rcu_wino.hip, rcu_wino_up.hip): 16/36 (conv units) and 9/36 (up-convolutions) of the
     // multiplications.  They address activations through 32-bit byte offsets of a buffer resource (tensors < 2 GB)
     // and take whole tiles only.
-    static const bool wino_on = [] {
-        const char* e = getenv("RCU_CONV_WINO");
-        return !(e && atoi(e) == 0);
-    }();
+    // RCU_CONV_WINO=0 keeps every layer on the direct kernels of rcu_conv.hip (read at rcu_unet_create: A/B tests)
+    const char* const wino_env = getenv("RCU_CONV_WINO");
+    const bool wino_on = !(wino_env && atoi(wino_env) == 0);
     const size_t max_bytes = (size_t)n_slices * L.H * L.W * (size_t)std::max(std::max(L.c1p, L.c2p), L.coutp) * 4;
     if (L.upsample && wino_on && L.c1p % 32 == 0 && L.c2p == 0 && max_bytes < ((size_t)1 << 31)) {
         const int lh = L.H / 2, lw = L.W / 2;

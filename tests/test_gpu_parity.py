@@ -109,6 +109,63 @@ def test_unet_full_width_vs_oracle(dev, shape):
         assert _maxdiff(ps, pr) < PROB_TOL
 
 
+def test_winograd_kernels_vs_direct_and_oracle(dev, monkeypatch):
+    """Every Winograd instantiation (csrc/rcu_wino.hip: F(2x2,3x3) conv units, csrc/rcu_wino_up.hip: F(2x2,2x2) sub-pixel
+    up-convolutions) on the BraTS slice size with 8 slices -- enough for the work items that span 2 and 8 slices:
+    against the oracle, against the direct kernels (RCU_CONV_WINO=0), and on ragged batches."""
+    from oracle import unet_oracle as uo
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
+    st = uo.synthetic_state(21, **params)
+    g = torch.Generator().manual_seed(6)
+    n, h, w = 8, 192, 128
+    x = torch.randn(n, 4, h, w, generator=g)
+    _, sites = uo.unet_plan(**params)
+    masks = uo.sample_masks(sites, n, 0.3, g)
+    m_w = _model(params, st, dev)
+    kernels = {row['kernel'] for row in m_w.layer_table(h, w, n)}
+    expected = {'conv3x3_winograd<T16x16,N64,K8>', 'conv3x3_winograd<T16x32,N32,K8>', 'conv3x3_winograd<S2T8x16,N64,K8>',
+                'conv3x3_winograd<S8T4x8,N64,K8>', 'upconv_winograd<T16x16,N64,K8>', 'upconv_winograd<T16x32,N32,K8>',
+                'upconv_winograd<S2T8x16,N64,K8>', 'upconv_winograd<S8T4x8,N64,K8>'}
+    assert expected <= kernels, expected - kernels
+    out_w = m_w(x.to(dev), masks).cpu().numpy()
+    ref = uo.unet_forward(st, x, masks, **params).numpy()
+    assert _maxdiff(out_w, ref) < LOGIT_TOL
+    assert _maxdiff(torch.softmax(torch.from_numpy(out_w), 1).numpy(), torch.softmax(torch.from_numpy(ref), 1).numpy()) < PROB_TOL
+    # ragged batches on the same plan (max_batch 8): slices are independent, so the results are the same bits
+    for k in (3, 5):
+        out_k = m_w(x[:k].to(dev), [mk[:k] for mk in masks]).cpu().numpy()
+        assert np.array_equal(out_k, out_w[:k])
+    # the direct kernels on the same input
+    monkeypatch.setenv('RCU_CONV_WINO', '0')
+    m_d = _model(params, st, dev)
+    assert not any('winograd' in row['kernel'] for row in m_d.layer_table(h, w, n))
+    out_d = m_d(x.to(dev), masks).cpu().numpy()
+    assert _maxdiff(out_d, ref) < LOGIT_TOL
+    assert _maxdiff(out_w, out_d) < 2e-5
+
+
+def test_winograd_sigma_head_and_eval_mode(dev):
+    """conv_cls.0 + conv_sigma.0 as one 64-channel Winograd unit with two dropout sites (mask / mask2), eval mode (no
+    masks) and a deterministic configuration without dropout modules."""
+    from oracle import unet_oracle as uo
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 4, 64, 64, generator=g)
+    for params in (dict(nb_classes=2, in_channels=4, depth=3, start_filters=32, dropout=0.05, sigma_out=True),
+                   dict(nb_classes=3, in_channels=4, depth=3, start_filters=32, dropout=None)):
+        st = uo.synthetic_state(22, **params)
+        m = _model(params, st, dev)
+        assert any('winograd' in row['kernel'] for row in m.layer_table(64, 64, 2))
+        _, sites = uo.unet_plan(**params)
+        for mk in ((None, uo.sample_masks(sites, 2, 0.3, g)) if sites else (None,)):
+            ref = uo.unet_forward(st, x, mk, **params)
+            out = m(x.to(dev), mk)
+            if params.get('sigma_out'):
+                assert _maxdiff(out[0].cpu().numpy(), ref[0].numpy()) < LOGIT_TOL
+                assert _maxdiff(out[1].cpu().numpy(), ref[1].numpy()) < LOGIT_TOL
+            else:
+                assert _maxdiff(out.cpu().numpy(), ref.numpy()) < LOGIT_TOL
+
+
 def test_unet_g11_reference_digest(golden, dev):
     """Full-width weights rebuilt by replaying the reference constructor's draws; the committed strided
     logits came from the reference itself."""
