@@ -26,6 +26,11 @@ def short(name):
         tile = ('S{}'.format(ts) if ts != '1' else '') + 'T{}x{}'.format(th, tw)
         base = 'upconv_subpixel_igemm' if taps == '4' else 'conv3x3_igemm'
         return '{}<{},N{},K{}{}>'.format(base, tile, bn, kc, ',db' if db == '1' else '')
+    m = re.search(r'(conv|upconv)_wino_stream<rcu::WinoTile<(\d+), (\d+), (\d+), (\d+), \d+, \d+(?:, \d+)*>', name)
+    if m:
+        kind, ts, th, tw, bn = m.groups()
+        tile = ('S{}'.format(ts) if ts != '1' else '') + 'T{}x{}'.format(th, tw)
+        return '{}<{},N{},K8>'.format('conv3x3_winograd' if kind == 'conv' else 'upconv_winograd', tile, bn)
     m = re.search(r'rcu::(\w+)', name)
     if m:
         return m.group(1)
