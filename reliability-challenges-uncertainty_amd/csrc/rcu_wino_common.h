@@ -77,7 +77,9 @@ struct WinoTile {
 // last-but-one Cin chunk is multiplied and folded at the start of the last one, so that the epilogue does not start with
 // a global-memory round trip and the raw values are gone before the register-heavy last chunk.
 struct WinoEpiRaw {
-    float al[2], bb[2], be[2], mk[2];
+    f32x2 al, bb, be;   // folded BatchNorm / bias constants of the lane's two couts
+    float mk[2];        // Dropout2d factors as loaded (garbage where no site applies: `site` says which do)
+    int site;           // bit b: cout b of the lane belongs to a dropout site
 };
 struct WinoEpi {   // out = relu(acc * scale + shift)
     float scale[2], shift[2];
@@ -87,31 +89,38 @@ __device__ __forceinline__ WinoEpi wino_epilogue_fold(const WinoEpiRaw& r)
     WinoEpi e;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        e.scale[b] = r.al[b] * r.mk[b];
-        e.shift[b] = r.bb[b] * r.mk[b] + r.be[b];
+        const float mk = (r.site >> b) & 1 ? r.mk[b] : 1.f;
+        e.scale[b] = r.al[b] * mk;
+        e.shift[b] = r.bb[b] * mk + r.be[b];
     }
     return e;
 }
 
+// All loads are unconditional (clamped addresses) and nothing here depends on a loaded value, so the wave does not
+// wait for memory where this is called (the start of a tile's last Cin chunk) but only in the epilogue.
 template <class T>
 __device__ __forceinline__ WinoEpiRaw wino_epilogue_load(const ConvArgs& a, int ntile, int n0, int wm, int wn, int lane)
 {
     WinoEpiRaw e;
-    const int co = ntile * T::BN + wn * 32 + 2 * (lane & 15);
+    const int co = ntile * T::BN + wn * 32 + 2 * (lane & 15);   // < NT * BN, the length of alpha / betab / beta
     int bs, by, bx;
     T::block_origin(wm, bs, by, bx);
-    const int n = n0 + bs + (T::SW == 2 ? (lane >> 4) & 1 : 0);
+    const int n = min(n0 + bs + (T::SW == 2 ? (lane >> 4) & 1 : 0), a.N - 1);
+    e.al = *reinterpret_cast<const f32x2*>(a.alpha + co);
+    e.bb = *reinterpret_cast<const f32x2*>(a.betab + co);
+    e.be = *reinterpret_cast<const f32x2*>(a.beta + co);
+    e.site = 0;
+    e.mk[0] = e.mk[1] = 1.f;
+    if (a.mask != nullptr) {   // wave-uniform
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int c = co + b;
-        const bool live = c < a.CoutP && n < a.N;
-        e.al[b] = live ? a.alpha[c] : 0.f;
-        e.bb[b] = live ? a.betab[c] : 0.f;
-        e.be[b] = live ? a.beta[c] : 0.f;
-        float mk = 1.f;
-        if (live && a.mask != nullptr && c < a.Cmask) mk = a.mask[(size_t)n * a.Cmask + c];
-        if (live && a.mask2 != nullptr && c >= a.Csplit && c - a.Csplit < a.Cmask2) mk = a.mask2[(size_t)n * a.Cmask2 + (c - a.Csplit)];
-        e.mk[b] = mk;
+        for (int b = 0; b < 2; ++b) {
+            const int c = co + b;
+            const bool second = a.mask2 != nullptr && c >= a.Csplit;
+            const int cm = second ? a.Cmask2 : a.Cmask, ci = second ? c - a.Csplit : c;
+            const float* const row = second ? a.mask2 + (size_t)n * a.Cmask2 : a.mask + (size_t)n * a.Cmask;
+            e.mk[b] = row[min(ci, cm - 1)];
+            e.site |= (ci < cm ? 1 : 0) << b;
+        }
     }
     return e;
 }
