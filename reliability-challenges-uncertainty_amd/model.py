@@ -183,17 +183,27 @@ class UNet(nn.Module):
     def sample_masks(self, n, device, generator=None):
         """Concatenated ``[site][n][C_site]`` factors {0, 1/(1-p)} for one pass; sites whose Dropout2d
         is in eval mode get ones.  Same law as torch's feature dropout (Bernoulli(1-p) / (1-p))."""
-        chunks = []
+        # consecutive sites with the same state share one Bernoulli draw (the elements are i.i.d.): for the shipped configs
+        # -- every site active with one p -- a pass costs two small kernels instead of three per site
+        groups = []   # [p or None (inactive), number of factors]
         for m, (_, c) in zip(self._site_modules, self.dropout_sites()):
-            if m.training and m.p > 0:
-                if m.p >= 1:
-                    chunks.append(torch.zeros(n * c, device=device))
-                else:
-                    keep = 1.0 - m.p
-                    chunks.append(torch.empty(n * c, device=device).bernoulli_(keep, generator=generator).div_(keep))
+            state = float(m.p) if (m.training and m.p > 0) else None
+            if groups and groups[-1][0] == state:
+                groups[-1][1] += n * c
             else:
-                chunks.append(torch.ones(n * c, device=device))
-        return torch.cat(chunks) if chunks else None
+                groups.append([state, n * c])
+        chunks = []
+        for state, count in groups:
+            if state is None:
+                chunks.append(torch.ones(count, device=device))
+            elif state >= 1:
+                chunks.append(torch.zeros(count, device=device))
+            else:
+                keep = 1.0 - state
+                chunks.append(torch.empty(count, device=device).bernoulli_(keep, generator=generator).div_(keep))
+        if not chunks:
+            return None
+        return chunks[0] if len(chunks) == 1 else torch.cat(chunks)
 
     def pack_masks(self, masks, n, device):
         """List of per-site ``[n, C_site]`` arrays/tensors -> the concatenated device layout."""
