@@ -272,7 +272,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
                 bv[p0 + AHEAD] = *reinterpret_cast<const f32x4*>(Ab + b_addr + (p0 + AHEAD) * (8 * T::BN));
                 bv[p1 + AHEAD] = *reinterpret_cast<const f32x4*>(Ab + b_addr + (p1 + AHEAD) * (8 * T::BN));
             }
-            dma_piece(job, std::integral_constant<int, G>{});
+            // two LDS-DMA pieces per group from the first group on, so that the last piece has 3/4 of the chunk to land (one per
+            // group: -1.5 %; three per group: -1.4 %)
+            dma_piece(job, std::integral_constant<int, 2 * G>{});
+            dma_piece(job, std::integral_constant<int, 2 * G + 1>{});
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             acc[0][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p0].x, bv[p0].x, FIRST ? z : acc[0][p0], 0, 0, 0);
             acc[1][p0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[p0].x, bv[p0].z, FIRST ? z : acc[1][p0], 0, 0, 0);
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
             if constexpr (G == 2) col_transform(2);
             if constexpr (G == 3) col_transform(3);
         });
-        wino_static_for<8, T::NW + T::NA>([&](auto i_c) { dma_piece(job, i_c); });
+        wino_static_for<16, T::NW + T::NA>([&](auto i_c) { dma_piece(job, i_c); });
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the next chunk have landed
         __syncthreads();                      // everyone done with buffer BUF and with filling the other one
     };
