@@ -21,15 +21,19 @@
 //     one ds_read_b128 per position serves both 16-channel MFMA blocks of the wave (couts 2n, 2n+1 per lane).
 //   * D: lane (n = lane & 15, g = lane >> 4) holds, for couts (2n, 2n+1), the four horizontally adjacent tiles
 //     4(g & 1) .. +3 of tile row g >> 1: the output transform A^T M A, the epilogue and the 2x2 max-pool (= one tile)
-//     are lane-local and every store writes float2, 16 lanes x 8 B = one 128-B line per pixel.
+//     are lane-local; neighbouring lanes then trade one pixel column (DPP), so that every store writes 16 bytes: 8 lanes
+//     = one 128-B line per pixel.  With 8-pixel-wide images a 16-tile block is 2 tile rows x 4 tile columns of TWO
+//     consecutive slices (WinoTile::SW) and the lane's four tiles are a whole row of one of them.
 //   * staging by LDS-DMA only (`buffer_load_dwordx4 ... lds`, no staging registers, no ds_write): the LDS images are
-//     lane-linear per wave instruction.  Input image: [channel half hh][halo row R][position][4 channels] where
+//     lane-linear per wave instruction.  Input image: [channel half hh][slice][halo row R][position][4 channels] where
 //     position = x ^ ((R >> 1) & 1) -- the swizzle is applied on the SOURCE address -- with a row pitch of 8k positions:
 //     the 32 lanes a ds_read_b64 serves per cycle (2 channel pairs x 2 tile rows x 8 tile columns) then fall on 64
 //     distinct banks.  Zero padding comes from the buffer resource: halo pixels outside the image carry an
 //     out-of-range offset and the DMA writes zeros (tools/microbench/glds_oob_probe.hip).
 //   * streaming: a workgroup walks over several output tiles and runs one double-buffered pipeline across all their
-//     Cin chunks (chunk k+1 streams into the other LDS buffer while chunk k is multiplied).
+//     Cin chunks (chunk k+1 streams into the other LDS buffer while chunk k is multiplied, two DMA pieces per MFMA group
+//     from the first group on; s_waitcnt vmcnt(0) + one barrier per chunk).  The per-lane DMA plan -- one packed geometry
+//     register and one offset register per slot -- is recomputed for the next tile during the current tile's last chunk.
 #include "rcu_wino_common.h"
 
 #include <cstdlib>
