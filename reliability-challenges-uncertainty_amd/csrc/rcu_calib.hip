@@ -18,6 +18,9 @@
 // t_k = min{float32 t : t >= edge_k}.
 #include "rcu_kernels.h"
 
+#include <cmath>
+#include <type_traits>
+
 namespace rcu {
 
 static constexpr int CB_THREADS = 256;
@@ -30,6 +33,8 @@ struct BinThresholds {
 };
 struct UncThresholds {
     double t[MAX_THR];
+    // float32 uncertainties: u > t[k] (in float64, as the reference compares) <=> u >= t32[k], t32[k] = the least float above t[k]
+    float t32[MAX_THR];
     int n_thr;
 };
 
@@ -374,7 +379,12 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
     auto add = [&](bool active, double u, bool pr, bool tg) {
         if (active) {
             int m = 0;
-            for (int t = 0; t < th.n_thr; ++t) m += (u > th.t[t]) ? 1 : 0;
+            if constexpr (std::is_same<U, float>::value) {   // full-rate float32 compares instead of float64 ones
+                const float uf = (float)u;                   // exact: u was converted from this float
+                for (int t = 0; t < th.n_thr; ++t) m += (uf >= th.t32[t]) ? 1 : 0;
+            } else {
+                for (int t = 0; t < th.n_thr; ++t) m += (u > th.t[t]) ? 1 : 0;
+            }
             const int cell = tg ? (pr ? 0 : 3) : (pr ? 2 : 1);
             __hip_atomic_fetch_add(col + (m * 2 + (cell >> 1)) * 64, 1u << ((cell & 1) * 16), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -481,7 +491,12 @@ hipError_t launch_unc_counts(const void* unc, int unc_is_f64, const uint8_t* pre
     if (n_thr < 1 || n_thr > MAX_THR || n_volumes < 1) return hipErrorInvalidValue;
     UncThresholds th;
     th.n_thr = n_thr;
-    for (int t = 0; t < MAX_THR; ++t) th.t[t] = (t < n_thr) ? thr_host[t] : 0.0;
+    for (int t = 0; t < MAX_THR; ++t) {
+        th.t[t] = (t < n_thr) ? thr_host[t] : 0.0;
+        float f = (float)th.t[t];                                   // nearest float
+        if (!((double)f > th.t[t])) f = std::nextafter(f, INFINITY);  // the least float strictly above the threshold
+        th.t32[t] = f;
+    }
     const unsigned nb = blocks_per_volume(n);
     if (nb == 0) return hipMemsetAsync(out_dev, 0, sizeof(unsigned long long) * 8 * n_thr * n_volumes, stream);
     unsigned long long* part = reinterpret_cast<unsigned long long*>(workspace);
