@@ -520,7 +520,15 @@ extern "C" int rcu_unet_finalize_weights(rcu_unet* h)
     return RCU_OK;
 }
 
-static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks, hipStream_t stream)
+// `head`: when set (conv_cls.0 on the 32-cout Winograd tile, two classes), the 1x1 classifier + softmax + statistics run in
+// the layer's epilogue and its output tensor is not written (rcu_wino.hip, wino_epilogue_head).
+struct FusedHead {
+    float* logits;
+    void* stats;
+    int flags;
+};
+
+static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks, hipStream_t stream, const FusedHead* head = nullptr)
 {
     const ConvConfigInfo& ci = conv_config_info(L.cfg);
     ConvArgs a{};
@@ -544,7 +552,14 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     a.src1_bytes = (uint32_t)std::min<size_t>(h->tensors[L.t_src1].floats_per_slice * (size_t)n * 4, 0xFFFFFFFFu);
     a.src2_bytes = L.t_src2 >= 0 ? (uint32_t)std::min<size_t>(h->tensors[L.t_src2].floats_per_slice * (size_t)n * 4, 0xFFFFFFFFu) : 0u;
     a.wpack_bytes = (uint32_t)std::min<size_t>(L.wpack_floats * 4, 0xFFFFFFFFu);
-    RCU_HIP(launch_conv3x3(L.cfg, a, stream));
+    int cfg = L.cfg;
+    if (head) {
+        cfg = CONV_CFG_WINO_T16x32_N32_HEAD;
+        a.head_w = h->w_cls; a.head_b = h->b_cls;
+        a.head_logits = head->logits; a.head_stats = head->stats; a.head_flags = head->flags;
+        a.head_V = (size_t)n * L.H * L.W;
+    }
+    RCU_HIP(launch_conv3x3(cfg, a, stream));
     return RCU_OK;
 }
 
@@ -568,10 +583,22 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
     RCU_HIP(launch_pack_input(x, h->tensors[h->t_input].dev, n_one, h->d.in_channels, h->in_cp, h->d.height, h->d.width,
                               passes, stream));
     if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
+    // conv_cls.0 and the classifier as one kernel where the shapes allow (the shipped configurations; RCU_FUSE_HEAD=0
+    // keeps them apart): two classes, no sigma twin, one pass per sample, 32-cout Winograd tile
+    const ConvLayer& last = h->layers.back();
+    const char* const fuse_env = getenv("RCU_FUSE_HEAD");
+    const bool fuse = last.cfg == CONV_CFG_WINO_T16x32_N32 && h->d.nb_classes == 2 && last.name2.empty() && passes == 1 &&
+                      sigma == nullptr && (logits != nullptr || stats != nullptr) && h->head_cph == 32 &&
+                      !(fuse_env && atoi(fuse_env) == 0);
     for (const ConvLayer& L : h->layers) {
-        int rc = run_layer(h, L, n, masks, stream);
+        const FusedHead fh{logits, stats, flags};
+        int rc = run_layer(h, L, n, masks, stream, (fuse && &L == &last) ? &fh : nullptr);
         if (rc) return rc;
         if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
+    }
+    if (fuse) {
+        if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
+        return RCU_OK;
     }
     HeadArgs a{};
     a.act = h->tensors[h->t_head].dev;

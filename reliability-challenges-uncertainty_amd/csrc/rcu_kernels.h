@@ -32,6 +32,13 @@ struct ConvArgs {
     int NT;              // output-channel tiles
     int NTW_total;       // weight tiles per Cin chunk = NT (3x3) or 4 * NT (sub-pixel: one set per parity class)
     uint32_t src1_bytes, src2_bytes, wpack_bytes;   // buffer-resource ranges (Winograd kernels)
+    // fused 1x1 head of conv_cls.0 (rcu_wino.hip, two classes): when head_w is set the conv unit's output stays on chip
+    const float* head_w;   // [2][32] 1x1 weights, head_b[2] bias
+    const float* head_b;
+    float* head_logits;    // NCHW [N][2][H*W] or null
+    void* head_stats;      // MC statistics blob or null
+    int head_flags;        // MC_MI | MC_VAR
+    size_t head_V;         // voxels of the pass = N * H * W
 };
 
 enum ConvConfig {
@@ -52,6 +59,7 @@ enum ConvConfig {
     CONV_CFG_WINO_T16x32_N32,                    // 16x32-pixel tile x 32 couts (32-channel layers)
     CONV_CFG_WINO_S2T8x16_N64,                   // two 8x16 pieces of consecutive slices x 64 couts
     CONV_CFG_WINO_S8T4x8_N64,                    // 4x8 strips of eight consecutive slices x 64 couts (8-pixel-wide level)
+    CONV_CFG_WINO_T16x32_N32_HEAD,               // T16x32_N32 with the 1x1 head + softmax + statistics in the epilogue
     // Winograd F(2x2,2x2) sub-pixel up-convolutions (rcu_wino_up.hip): 18 positions = two parity classes per work item
     CONV_CFG_UPW_T16x16_N64,
     CONV_CFG_UPW_T16x32_N32,

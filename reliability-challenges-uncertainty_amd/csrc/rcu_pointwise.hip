@@ -11,7 +11,7 @@
 //   aleatoric sigma = |raw| or exp(raw)                   bin-dl/brats_test_aleatoric.py:63-73
 // The T probability volumes are never materialised: each pass adds its softmax output into the
 // statistics planes (sum p, optionally sum p^2 in double, optionally sum H).
-#include "rcu_kernels.h"
+#include "rcu_head_common.h"
 
 namespace rcu {
 
@@ -42,32 +42,6 @@ hipError_t launch_pack_input(const float* x, float* out, int N, int C, int CP, i
     const size_t HW = (size_t)H * W, V = HW * N * (size_t)replicas;
     hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(V)), dim3(PW_THREADS), 0, stream, x, out, C, CP, HW, V, (size_t)N);
     return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------- shared device helpers
-template <int C>
-__device__ __forceinline__ void softmax_inplace(float (&l)[C])
-{
-    float mx = l[0];
-#pragma unroll
-    for (int c = 1; c < C; ++c) mx = fmaxf(mx, l[c]);
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        l[c] = expf(l[c] - mx);
-        s += l[c];
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) l[c] = l[c] / s;
-}
-
-template <int C>
-__device__ __forceinline__ float entropy_of(const float (&p)[C])
-{
-    float h = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) h += (p[c] > 0.f) ? p[c] * logf(p[c]) : 0.f;
-    return -h;
 }
 
 // The statistics entries of one voxel held in registers across the passes of a group: load, add pass after pass in
@@ -121,26 +95,6 @@ struct VoxelStats {
         }
     }
 };
-
-template <int C>
-__device__ __forceinline__ void accumulate_voxel(void* stats, size_t v, size_t V, int flags, const float (&p)[C])
-{
-    if (flags & MC_VAR) {
-        double* sd = reinterpret_cast<double*>(stats);
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const double pc = (double)p[c];
-            sd[(size_t)c * V + v] += pc;
-            sd[(size_t)(C + c) * V + v] += pc * pc;
-        }
-        if (flags & MC_MI) sd[(size_t)(2 * C) * V + v] += (double)entropy_of<C>(p);
-    } else {
-        float* sf = reinterpret_cast<float*>(stats);
-#pragma unroll
-        for (int c = 0; c < C; ++c) sf[(size_t)c * V + v] += p[c];
-        if (flags & MC_MI) sf[(size_t)C * V + v] += entropy_of<C>(p);
-    }
-}
 
 // ------------------------------------------------------------------------------- fused head
 // act[v][0..CPh) -> logits (1x1 conv, unet.py:161); optional twin on act[v][CPh..2CPh) -> sigma

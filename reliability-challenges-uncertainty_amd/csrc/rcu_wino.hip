@@ -34,6 +34,7 @@
 //     Cin chunks (chunk k+1 streams into the other LDS buffer while chunk k is multiplied, two DMA pieces per MFMA group
 //     from the first group on; s_waitcnt vmcnt(0) + one barrier per chunk).  The per-lane DMA plan -- one packed geometry
 //     register and one offset register per slot -- is recomputed for the next tile during the current tile's last chunk.
+#include "rcu_head_common.h"
 #include "rcu_wino_common.h"
 
 #include <cstdlib>
@@ -123,7 +124,83 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
     }
 }
 
+// conv_cls.0 with the classifier behind it (common/model/unet.py:160-161, rechun/dl/customsteps.py:24,33): the finished
+// 16x32-pixel x 32-channel tile goes to LDS instead of HBM ([pixel][34 floats]: conflict-free both ways), then every
+// thread takes one pixel: 1x1 conv to two logits, and either the logits (NCHW) or softmax + the MC statistics update.
+// The dot product is summed exactly as head_kernel sums it (eight 4-channel fmaf chains, pairwise tree), so a pass
+// through this epilogue and a pass through head_kernel (pass groups) give the same bits.
+constexpr int WINO_HEAD_PITCH = 34;
 template <class T>
+__device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x4 (&acc)[2][16], const WinoEpi& ep, int n0, int y0,
+                                                   int x0, int wm, int wn, int lane, int tid, float* hl)
+{
+    static_assert(T::TS == 1 && T::TH * T::TW == T::THREADS && T::BN == 32 && T::SW == 1, "one pixel per thread");
+    {
+        const int n16 = lane & 15, g = lane >> 4;
+        int bs, by, bx;
+        T::block_origin(wm, bs, by, bx);
+        const int yrel = by + 2 * (g >> 1), xrel = bx + 8 * (g & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f32x2 y[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float nn[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float m0 = acc[b][4 * i + 0][r], m1 = acc[b][4 * i + 1][r], m2 = acc[b][4 * i + 2][r],
+                                m3 = acc[b][4 * i + 3][r];
+                    nn[i][0] = m0 + m1 + m2;
+                    nn[i][1] = m1 - m2 - m3;
+                }
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const float v0 = nn[0][bb] + nn[1][bb] + nn[2][bb];
+                    const float v1 = nn[1][bb] - nn[2][bb] - nn[3][bb];
+                    const float t0 = v0 * ep.scale[b] + ep.shift[b], t1 = v1 * ep.scale[b] + ep.shift[b];
+                    y[0][bb][b] = a.relu ? fmaxf(t0, 0.f) : t0;
+                    y[1][bb][b] = a.relu ? fmaxf(t1, 0.f) : t1;
+                }
+            }
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+                    *reinterpret_cast<f32x2*>(hl + ((yrel + aa) * T::TW + xrel + 2 * r + bb) * WINO_HEAD_PITCH + 2 * n16) = y[aa][bb];
+        }
+    }
+    __syncthreads();
+    const int gy = y0 + tid / T::TW, gx = x0 + tid % T::TW;
+    if (n0 < a.N && gy < a.H && gx < a.W) {
+        const float* const row = hl + tid * WINO_HEAD_PITCH;
+        float l[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float p[8];
+#pragma unroll
+            for (int sgm = 0; sgm < 8; ++sgm) {
+                const f32x2 xa = *reinterpret_cast<const f32x2*>(row + 4 * sgm), xb = *reinterpret_cast<const f32x2*>(row + 4 * sgm + 2);
+                const float* const w = a.head_w + c * 32 + 4 * sgm;
+                float t = fmaf(w[0], xa.x, 0.f);
+                t = fmaf(w[1], xa.y, t);
+                t = fmaf(w[2], xb.x, t);
+                p[sgm] = fmaf(w[3], xb.y, t);
+            }
+            l[c] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) + a.head_b[c];
+        }
+        const size_t hw = (size_t)gy * a.W + gx, HW = (size_t)a.H * a.W;
+        if (a.head_logits != nullptr) {
+            a.head_logits[((size_t)n0 * 2 + 0) * HW + hw] = l[0];
+            a.head_logits[((size_t)n0 * 2 + 1) * HW + hw] = l[1];
+        }
+        if (a.head_stats != nullptr) {
+            softmax_inplace<2>(l);
+            accumulate_voxel<2>(a.head_stats, (size_t)n0 * HW + hw, a.head_V, a.head_flags, l);
+        }
+    }
+}
+
+template <class T, bool HEAD = false>
 __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, const int total_items)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource types and LDS-DMA builtins exist in the device pass only
@@ -315,7 +392,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
             chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc);
             chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1);
         }
-        wino_epilogue<T>(a, acc, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wm, wn, lane);
+        if constexpr (HEAD)
+            wino_epilogue_head<T>(a, acc, wino_epilogue_fold(epr), tile.n0, tile.y0, tile.x0, wm, wn, lane, tid, smem + 2 * T::BUF_DW);
+        else
+            wino_epilogue<T>(a, acc, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wm, wn, lane);
         if (!has_next) break;
         item += (int)gridDim.x;
         tile = ntile;
@@ -329,32 +409,36 @@ using WCfg1 = WinoTile<1, 16, 32, 32, 8, 1>;   // 512 pixels x 32 couts (32-chan
 using WCfg2 = WinoTile<2, 8, 16, 64, 4, 2>;    // two 8x16 pieces of consecutive slices (heights not divisible by 16)
 using WCfg3 = WinoTile<8, 4, 8, 64, 4, 2, 2>;  // 4x8 strips of eight slices (8-pixel-wide bottom level)
 
-static const ConvConfigInfo kWinoInfo[4] = {
+static const ConvConfigInfo kWinoInfo[5] = {
     {WCfg0::TS, WCfg0::TH, WCfg0::TW, WCfg0::BN, 8, 16, "conv3x3_winograd<T16x16,N64,K8>", 8, 0, 1},
     {WCfg1::TS, WCfg1::TH, WCfg1::TW, WCfg1::BN, 8, 16, "conv3x3_winograd<T16x32,N32,K8>", 8, 0, 1},
     {WCfg2::TS, WCfg2::TH, WCfg2::TW, WCfg2::BN, 8, 16, "conv3x3_winograd<S2T8x16,N64,K8>", 8, 0, 1},
     {WCfg3::TS, WCfg3::TH, WCfg3::TW, WCfg3::BN, 8, 16, "conv3x3_winograd<S8T4x8,N64,K8>", 8, 0, 1},
+    {WCfg1::TS, WCfg1::TH, WCfg1::TW, WCfg1::BN, 8, 16, "conv3x3_winograd<T16x32,N32,K8>+head", 8, 0, 1},
 };
 
 const ConvConfigInfo& wino_config_info(int cfg) { return kWinoInfo[cfg - CONV_CFG_WINO_T16x16_N64]; }
 
-template <class T>
+template <class T, bool HEAD = false>
 static hipError_t launch_wino_cfg(const ConvArgs& a, hipStream_t stream)
 {
+    constexpr int lds_bytes = T::LDS_BYTES + (HEAD ? T::TH * T::TW * WINO_HEAD_PITCH * 4 : 0);
+    static_assert(lds_bytes <= 160 * 1024, "LDS");
+    if (HEAD && (a.head_w == nullptr || a.NT != 1 || a.pooled != nullptr || a.mask2 != nullptr)) return hipErrorInvalidValue;
     static bool attr_set = false;
     const int nchunks = (a.C1 + a.C2) / T::KC;
     if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
         (a.C2 != 0 && a.C2 != a.C1))
         return hipErrorInvalidValue;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_stream<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_stream<T, HEAD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const unsigned items = (unsigned)a.NT * a.tiles_x * a.tiles_y * a.slice_groups;
     const unsigned grid = items < 256u ? items : 256u;
-    hipLaunchKernelGGL(conv_wino_stream<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);
+    hipLaunchKernelGGL((conv_wino_stream<T, HEAD>), dim3(grid), dim3(T::THREADS), lds_bytes, stream, a, (int)items);
     return hipGetLastError();
 }
 
@@ -365,6 +449,7 @@ hipError_t launch_conv_wino(int cfg, const ConvArgs& a, hipStream_t stream)
         case CONV_CFG_WINO_T16x32_N32: return launch_wino_cfg<WCfg1>(a, stream);
         case CONV_CFG_WINO_S2T8x16_N64: return launch_wino_cfg<WCfg2>(a, stream);
         case CONV_CFG_WINO_S8T4x8_N64: return launch_wino_cfg<WCfg3>(a, stream);
+        case CONV_CFG_WINO_T16x32_N32_HEAD: return launch_wino_cfg<WCfg1, true>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -166,6 +166,51 @@ def test_winograd_sigma_head_and_eval_mode(dev):
                 assert _maxdiff(out.cpu().numpy(), ref.numpy()) < LOGIT_TOL
 
 
+def test_fused_head_matches_head_kernel_bitwise(dev, monkeypatch):
+    """conv_cls.0 with the 1x1 classifier + softmax + statistics in its epilogue (csrc/rcu_wino.hip, wino_epilogue_head)
+    against the separate head kernel (RCU_FUSE_HEAD=0): logits, MC statistics (incl. variance / mutual information) and
+    a pass group (always the head kernel) must carry the same bits."""
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    params = dict(nb_classes=2, in_channels=4, depth=3, start_filters=32, dropout=0.05)
+    st = uo.synthetic_state(23, **params)
+    m = _model(params, st, dev)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 4, 64, 64, generator=g)
+    _, sites = uo.unet_plan(**params)
+    T = 4
+    mask_sets = [uo.sample_masks(sites, 3, 0.3, g) for _ in range(T)]
+
+    def run():
+        logits = m(x.to(dev), mask_sets[0]).cpu().numpy()
+        bc = steps.BatchContext({'images': x.clone()}, 0)
+        ctx = steps.TorchTestContext('cuda', m)
+        steps.McPredictStep(T, do_mi=True, do_var=True, masks=mask_sets)(bc, None, ctx)
+        steps.MultiPredictionSummary(do_mi=True, do_var=True)(bc, None, ctx)
+        return logits, {k: v.cpu().numpy() for k, v in bc.output.items()}
+
+    def run_single_passes(do_mi, do_var):   # one forward per pass: the fused epilogue updates the statistics itself
+        stats = steps.McStatistics(3, 2, 64, 64, dev, do_mi=do_mi, do_var=do_var)
+        for ms in mask_sets:
+            m.forward_accumulate(x.to(dev), stats, ms, passes=1)
+        return stats.blob.cpu().numpy()
+
+    monkeypatch.setenv('RCU_FUSE_HEAD', '1')
+    lf, of = run()
+    bf = [run_single_passes(*f) for f in ((False, False), (True, False), (True, True))]
+    monkeypatch.setenv('RCU_FUSE_HEAD', '0')
+    lu, ou = run()
+    bu = [run_single_passes(*f) for f in ((False, False), (True, False), (True, True))]
+    assert np.array_equal(lf, lu)
+    assert set(of) == set(ou)
+    for k in of:
+        assert np.array_equal(of[k], ou[k]), k
+    for a_, b_ in zip(bf, bu):
+        assert np.array_equal(a_, b_)
+    ref = uo.unet_forward(st, x, mask_sets[0], **params).numpy()
+    assert _maxdiff(lf, ref) < LOGIT_TOL
+
+
 def test_unet_g11_reference_digest(golden, dev):
     """Full-width weights rebuilt by replaying the reference constructor's draws; the committed strided
     logits came from the reference itself."""

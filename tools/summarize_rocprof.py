@@ -30,7 +30,8 @@ def short(name):
     if m:
         kind, ts, th, tw, bn = m.groups()
         tile = ('S{}'.format(ts) if ts != '1' else '') + 'T{}x{}'.format(th, tw)
-        return '{}<{},N{},K8>'.format('conv3x3_winograd' if kind == 'conv' else 'upconv_winograd', tile, bn)
+        return '{}<{},N{},K8>{}'.format('conv3x3_winograd' if kind == 'conv' else 'upconv_winograd', tile, bn,
+                                        '+head' if ', true>' in name else '')
     m = re.search(r'rcu::(\w+)', name)
     if m:
         return m.group(1)
