@@ -265,26 +265,27 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
         const int c0 = kc * KC;
         j.active = active;
         j.first = c0 < a.C1;
-        j.cb = (uint32_t)__builtin_amdgcn_readfirstlane((j.first ? c0 : c0 - a.C1) * 4);
-        j.wso = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)kc * wchunk_bytes + (uint32_t)wtile * (T::W_DW * 4u)));
+        j.cb = (uint32_t)((j.first ? c0 : c0 - a.C1) * 4);
+        j.wso = (uint32_t)kc * wchunk_bytes + (uint32_t)wtile * (T::W_DW * 4u);
         j.lb = (uint32_t)buf * (T::BUF_DW * 4u);
         return j;
     };
-    char* const lds_base = reinterpret_cast<char*>(smem);
+    // LDS byte address of the dynamic shared memory as an integer: no generic-to-LDS pointer conversion (null check) per piece
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
     auto dma_piece = [&](const DmaJob& job, auto i_c) {
         constexpr int I = decltype(i_c)::value;
         if constexpr (I < T::NW) {
             if (job.active && ((I + 1) * T::WAVES <= T::W_PIECES || I * T::WAVES + wave < T::W_PIECES))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(lds_base + job.lb + T::A_DW * 4 + (I * T::WAVES + wave) * 1024),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + T::A_DW * 4 + (I * T::WAVES + wave) * 1024),
                                                          16, w_voff, job.wso + (uint32_t)(I * T::WAVES + wave) * 1024u, 0, 0);
         } else if constexpr (I < T::NW + T::NA) {
             constexpr int j = I - T::NW;
             if (job.active && ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES)) {
                 if (job.first)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16,
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16,
                                                              dp[j], job.cb, 0, 0);
                 else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16,
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16,
                                                              dp[j], job.cb, 0, 0);
             }
         }
