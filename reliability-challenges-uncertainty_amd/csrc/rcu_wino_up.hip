@@ -165,7 +165,6 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
     __syncthreads();
 
     f32x4 acc[2][18];
-    WinoEpiRaw epr;
 
     auto chunk = [&](auto buf_c, auto first_c, int kc) {
         constexpr int BUF = decltype(buf_c)::value;
@@ -179,7 +178,6 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
 #pragma unroll
             for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(a, ntile, geo[j]);
         }
-        if (!more) epr = wino_epilogue_load<T>(a, tile.wtile % a.NT, tile.n0, wm, wn, lane);
         __builtin_amdgcn_sched_barrier(0);
         const DmaJob job = dma_job(dp_wtile, more ? kc + 1 : 0, BUF ^ 1, more || has_next);
         // rows pa .. pa+2 of the lane's 4x4 patch, channel pair (2kq, 2kq+1): (e0, e1) now, e2 behind the first MFMA group
@@ -198,7 +196,7 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
             read_row(e0, std::integral_constant<int, 1>{});
             read_row(e1, std::integral_constant<int, 2>{});
         }
-        constexpr int AHEAD = 2;
+        constexpr int AHEAD = 1;   // 144 accumulators leave room for a three-position weight window only (no spills)
         f32x4 bv[18];
 #pragma unroll
         for (int p = 0; p < AHEAD; ++p) bv[p] = *reinterpret_cast<const f32x4*>(Ab + b_addr + p * (8 * T::BN));
@@ -266,7 +264,7 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
             chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc);
             chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1);
         }
-        wino_up_epilogue<T>(a, acc, wino_epilogue_fold(epr), tile.wtile % a.NT, tile.wtile / a.NT, tile.n0, tile.y0, tile.x0, wm, wn, lane);
+        wino_up_epilogue<T>(a, acc, wino_epilogue_fold(wino_epilogue_load<T>(a, tile.wtile % a.NT, tile.n0, wm, wn, lane)), tile.wtile % a.NT, tile.wtile / a.NT, tile.n0, tile.y0, tile.x0, wm, wn, lane);
         if (!has_next) break;
         item += (int)gridDim.x;
         tile = ntile;
