@@ -31,11 +31,27 @@ struct BinThresholds {
     float t[MAX_BINS - 1];
     int n_bins;
 };
+static constexpr int UNC_CELLS = 64;
+
+__host__ __device__ inline int unc_cell_of(float u, float lo, float scale)
+{
+    const float x = (u - lo) * scale;            // float32, the same two roundings on host and device
+    int c = (x > 0.f) ? (int)x : 0;              // NaN and negatives -> cell 0
+    return c < UNC_CELLS - 1 ? c : UNC_CELLS - 1;
+}
+
 struct UncThresholds {
     double t[MAX_THR];
     // float32 uncertainties: u > t[k] (in float64, as the reference compares) <=> u >= t32[k], t32[k] = the least float above t[k]
     float t32[MAX_THR];
     int n_thr;
+    // float32 maps, ascending thresholds: cell table over f(u) = clamp(int((u - cell_lo) * cell_scale), 0, UNC_CELLS - 1).  f is monotone,
+    // so with at most one threshold per cell  m = cell_base[f(u)] + (u >= cell_thr[f(u)])  counts exactly the thresholds u exceeds:
+    // those in lower cells are below u, those in higher cells above it, the cell's own one is compared (n_cells = 0: no table).
+    int n_cells;
+    float cell_lo, cell_scale;
+    float cell_thr[UNC_CELLS];
+    unsigned char cell_base[UNC_CELLS];
 };
 
 struct EcePartial {
@@ -366,6 +382,13 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
 {
     extern __shared__ unsigned unc_smem[];           // [wave][(n_thr + 1) * 2][lane], two 16-bit cell counters per word
     __shared__ unsigned s_w[CB_WAVES][UNC_SLOTS];    // per wave: [m][cell] totals
+    __shared__ float s_cell_thr[UNC_CELLS];
+    __shared__ unsigned s_cell_base[UNC_CELLS];
+    if (threadIdx.x < UNC_CELLS) {
+        s_cell_thr[threadIdx.x] = th.cell_thr[threadIdx.x];
+        s_cell_base[threadIdx.x] = th.cell_base[threadIdx.x];
+    }
+    __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ncol = (th.n_thr + 1) * 2;
     unsigned* const col = unc_smem + (size_t)wave * ncol * 64 + lane;
@@ -381,7 +404,12 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
             int m = 0;
             if constexpr (std::is_same<U, float>::value) {   // full-rate float32 compares instead of float64 ones
                 const float uf = (float)u;                   // exact: u was converted from this float
-                for (int t = 0; t < th.n_thr; ++t) m += (uf >= th.t32[t]) ? 1 : 0;
+                if (th.n_cells > 0) {
+                    const int c = unc_cell_of(uf, th.cell_lo, th.cell_scale);
+                    m = (int)s_cell_base[c] + ((uf >= s_cell_thr[c]) ? 1 : 0);
+                } else {
+                    for (int t = 0; t < th.n_thr; ++t) m += (uf >= th.t32[t]) ? 1 : 0;
+                }
             } else {
                 for (int t = 0; t < th.n_thr; ++t) m += (u > th.t[t]) ? 1 : 0;
             }
@@ -496,6 +524,42 @@ hipError_t launch_unc_counts(const void* unc, int unc_is_f64, const uint8_t* pre
         float f = (float)th.t[t];                                   // nearest float
         if (!((double)f > th.t[t])) f = std::nextafter(f, INFINITY);  // the least float strictly above the threshold
         th.t32[t] = f;
+    }
+    th.n_cells = 0;
+    th.cell_lo = 0.f;
+    th.cell_scale = 0.f;
+    for (int c = 0; c < UNC_CELLS; ++c) {
+        th.cell_thr[c] = INFINITY;
+        th.cell_base[c] = 0;
+    }
+    {
+        bool asc = true;
+        for (int t = 1; t < n_thr; ++t) asc = asc && (thr_host[t - 1] < thr_host[t]);
+        const float lo = th.t32[0], hi = th.t32[n_thr - 1];
+        if (asc && n_thr >= 2 && std::isfinite(lo) && std::isfinite(hi) && hi > lo) {
+            const float scale = (float)(UNC_CELLS - 1) / (hi - lo);
+            bool one_per_cell = std::isfinite(scale);
+            int prev = -1;
+            for (int t = 0; t < n_thr && one_per_cell; ++t) {
+                const int c = unc_cell_of(th.t32[t], lo, scale);
+                one_per_cell = c > prev;
+                prev = c;
+            }
+            if (one_per_cell) {
+                th.n_cells = UNC_CELLS;
+                th.cell_lo = lo;
+                th.cell_scale = scale;
+                int below = 0;   // thresholds in lower cells
+                for (int c = 0, t = 0; c < UNC_CELLS; ++c) {
+                    th.cell_base[c] = (unsigned char)below;
+                    if (t < n_thr && unc_cell_of(th.t32[t], lo, scale) == c) {
+                        th.cell_thr[c] = th.t32[t];
+                        ++t;
+                        ++below;
+                    }
+                }
+            }
+        }
     }
     const unsigned nb = blocks_per_volume(n);
     if (nb == 0) return hipMemsetAsync(out_dev, 0, sizeof(unsigned long long) * 8 * n_thr * n_volumes, stream);

@@ -587,6 +587,42 @@ def test_uncertainty_counts_threshold_order_and_dtypes(dev):
                     assert np.array_equal(got, ref.astype(np.int64)), (n, thr, u.dtype, mask is None)
 
 
+def test_uncertainty_counts_at_threshold_neighbours(dev):
+    """float32 uncertainty maps are compared through exact float32 thresholds and a monotone cell table (csrc/rcu_calib.hip):
+    values on, next to and between every threshold and every cell boundary, outside the threshold range, NaN; threshold
+    sets the table takes (one threshold per cell) and sets it must refuse (two thresholds in one cell, a single one)."""
+    from oracle import c_oracle
+    from rcu_amd import evaluation as ev
+    sets = (ev.UE_THRESHOLDS, tuple(np.linspace(0.01, 0.99, 16)), (0.1, 0.1000001, 0.9), (0.3, 0.300001), (-0.5, 0.25, 1.5),
+            (0.5,), (1e-30, 0.5, 0.999999))
+    for thr in sets:
+        t64 = np.asarray(thr, dtype=np.float64)
+        vals = [np.float32(0), np.float32(1), np.float32(-1), np.float32(2), np.float32(np.nan), np.float32(np.inf)]
+        for t in t64:
+            f = np.float32(t)
+            for _ in range(3):
+                vals.append(f)
+                f = np.nextafter(f, np.float32(np.inf), dtype=np.float32)
+            f = np.float32(t)
+            for _ in range(3):
+                f = np.nextafter(f, np.float32(-np.inf), dtype=np.float32)
+                vals.append(f)
+        lo, hi = np.float32(t64.min()), np.float32(t64.max())
+        if hi > lo:   # the cell boundaries of the table: lo + k * (hi - lo) / 63 and their float neighbours
+            for k in range(0, 65):
+                b = np.float32(lo + np.float32(k) * (hi - lo) / np.float32(63))
+                vals += [b, np.nextafter(b, np.float32(np.inf), dtype=np.float32), np.nextafter(b, np.float32(-np.inf), dtype=np.float32)]
+        u = np.asarray(vals, dtype=np.float32)
+        u = np.tile(u, 40)[:16384 + 7]            # long enough for the vectorised path, ragged tail
+        rng = np.random.RandomState(len(thr))
+        pr = (rng.rand(u.size) < 0.5).astype(np.uint8)
+        tg = (rng.rand(u.size) < 0.5).astype(np.uint8)
+        with np.errstate(invalid='ignore'):
+            got = ev.uncertainty_counts(pr, tg, u, thr)[0]
+            ref = c_oracle.unc_counts(u.astype(np.float64), pr, tg, None, thr)
+        assert np.array_equal(got, ref.astype(np.int64)), thr
+
+
 def test_preparation_golden(golden, dev):
     from rcu_amd import evaluation as ev
     g = golden('g10_prep')
