@@ -310,12 +310,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
         // LDS-DMA pieces are issued one per MFMA group below
         const bool more = kc + 1 < nchunks;
         if (!more && has_next) {   // last chunk of the tile: from here on the DMA works on the workgroup's next tile
-            ntile = wino_tile_id<T>(a, item + (int)gridDim.x);
+            const ConvArgs& ca = wino_cold_args();   // tile counts and image extents are not kept in SGPRs either
+            ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
             dp_wtile = ntile.wtile;
 #pragma unroll
-            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(a, ntile, geo[j]);
+            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(ca, ntile, geo[j]);
         }
-        if (!more) epr = wino_epilogue_load<T>(a, tile.wtile, tile.n0, wm, wn, lane);
+        if (!more) epr = wino_epilogue_load<T>(wino_cold_args(), tile.wtile, tile.n0, wm, wn, lane);
         __builtin_amdgcn_sched_barrier(0);   // keep the address arithmetic above out of the register-heavy part below
         const DmaJob job = dma_job(dp_wtile, more ? kc + 1 : 0, BUF ^ 1, more || has_next);
         // raw 4x4 patch of the lane's tile, channel pair (2kq, 2kq+1): rows 0 and 2 first (position row 0 needs only them)
@@ -394,9 +395,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
             chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1);
         }
         if constexpr (HEAD)
-            wino_epilogue_head<T>(a, acc, wino_epilogue_fold(epr), tile.n0, tile.y0, tile.x0, wm, wn, lane, tid, smem + 2 * T::BUF_DW);
+            wino_epilogue_head<T>(wino_cold_args(), acc, wino_epilogue_fold(epr), tile.n0, tile.y0, tile.x0, wm, wn, lane, tid, smem + 2 * T::BUF_DW);
         else
-            wino_epilogue<T>(a, acc, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wm, wn, lane);
+            wino_epilogue<T>(wino_cold_args(), acc, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wm, wn, lane);
         if (!has_next) break;
         item += (int)gridDim.x;
         tile = ntile;

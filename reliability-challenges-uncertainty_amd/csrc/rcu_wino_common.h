@@ -17,6 +17,17 @@ __device__ __forceinline__ float wino_swap_adjacent(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
 }
 
+// The kernel's arguments as they sit in the kernarg segment (ConvArgs is the first argument), re-read where the rarely used
+// fields are needed -- epilogue constants, output pointers, next-tile arithmetic -- instead of living in SGPRs through the chunk
+// loop (the kernels need ~150 SGPRs otherwise; the spills to VGPR lanes come back as v_readlane in the loop).  The empty
+// assembly keeps hipcc from hoisting the loads back to the kernel entry.
+__device__ __forceinline__ const ConvArgs& wino_cold_args()
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const ConvArgs*)p;
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void wino_static_for(F&& f)
 {

@@ -173,10 +173,11 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
         const int pa = tile.wtile / a.NT;   // row parity class of this work item
         const bool more = kc + 1 < nchunks;
         if (!more && has_next) {   // last chunk of the tile: from here on the DMA works on the workgroup's next tile
-            ntile = wino_tile_id<T>(a, item + (int)gridDim.x);
+            const ConvArgs& ca = wino_cold_args();   // tile counts and image extents are not kept in SGPRs either
+            ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
             dp_wtile = ntile.wtile;
 #pragma unroll
-            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(a, ntile, geo[j]);
+            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(ca, ntile, geo[j]);
         }
         __builtin_amdgcn_sched_barrier(0);
         const DmaJob job = dma_job(dp_wtile, more ? kc + 1 : 0, BUF ^ 1, more || has_next);
@@ -264,7 +265,11 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
             chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc);
             chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1);
         }
-        wino_up_epilogue<T>(a, acc, wino_epilogue_fold(wino_epilogue_load<T>(a, tile.wtile % a.NT, tile.n0, wm, wn, lane)), tile.wtile % a.NT, tile.wtile / a.NT, tile.n0, tile.y0, tile.x0, wm, wn, lane);
+        {
+            const ConvArgs& ca = wino_cold_args();
+            wino_up_epilogue<T>(ca, acc, wino_epilogue_fold(wino_epilogue_load<T>(ca, tile.wtile % a.NT, tile.n0, wm, wn, lane)), tile.wtile % a.NT,
+                                tile.wtile / a.NT, tile.n0, tile.y0, tile.x0, wm, wn, lane);
+        }
         if (!has_next) break;
         item += (int)gridDim.x;
         tile = ntile;
