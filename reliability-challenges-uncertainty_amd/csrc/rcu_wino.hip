@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
                 // lanes over 64 banks
                 d[4 * i + j] = *(const volatile __attribute__((address_space(3))) f32x2*)(Ab + ((j & 1) ? aB[i >> 1] : aA[i >> 1]) + (i & 1) * (T::PITCH * 4) + 4 * j);
         }
-        constexpr int AHEAD = 2;
+        constexpr int AHEAD = 4;
         f32x4 bv[16];
 #pragma unroll
         for (int p = 0; p < AHEAD; ++p) bv[p] = *reinterpret_cast<const f32x4*>(Ab + b_addr + p * (8 * T::BN));

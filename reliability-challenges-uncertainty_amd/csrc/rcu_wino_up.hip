@@ -197,7 +197,7 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
             read_row(e0, std::integral_constant<int, 1>{});
             read_row(e1, std::integral_constant<int, 2>{});
         }
-        constexpr int AHEAD = 1;   // 144 accumulators leave room for a three-position weight window only (no spills)
+        constexpr int AHEAD = 2;   // the weights of positions p + 2, p + 3 are read while p, p + 1 multiply
         f32x4 bv[18];
 #pragma unroll
         for (int p = 0; p < AHEAD; ++p) bv[p] = *reinterpret_cast<const f32x4*>(Ab + b_addr + p * (8 * T::BN));
