@@ -59,6 +59,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
     const int yb = y0 + by + 2 * (g >> 1);                       // top pixel row of the lane's tiles
     const int xb = x0 + bx + (T::SW == 2 ? 0 : 8 * (g & 1));     // left pixel column of the lane's first tile
     const float scale[2] = {ep.scale[0], ep.scale[1]}, shift[2] = {ep.shift[0], ep.shift[1]};
+    const float relu_floor = a.relu ? 0.f : -__builtin_inff();   // one v_max either way (a select per value otherwise)
     const int Hp = a.H >> 1, Wp = a.W >> 1;
     const bool rows_ok = yb + 1 < a.H;
     const int odd = n16 & 1;
@@ -82,8 +83,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
                 const float v0 = nn[0][bb] + nn[1][bb] + nn[2][bb];
                 const float v1 = nn[1][bb] - nn[2][bb] - nn[3][bb];
                 const float t0 = v0 * scale[b] + shift[b], t1 = v1 * scale[b] + shift[b];
-                y[0][bb][b] = a.relu ? fmaxf(t0, 0.f) : t0;
-                y[1][bb][b] = a.relu ? fmaxf(t1, 0.f) : t1;
+                y[0][bb][b] = fmaxf(t0, relu_floor);
+                y[1][bb][b] = fmaxf(t1, relu_floor);
             }
         }
         // Neighbouring lanes (couts 2n, 2n+1 | 2n+2, 2n+3 of the same pixels) trade one pixel column each, so that the even
@@ -140,6 +141,7 @@ __device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x
         int bs, by, bx;
         T::block_origin(wm, bs, by, bx);
         const int yrel = by + 2 * (g >> 1), xrel = bx + 8 * (g & 1);
+        const float relu_floor = a.relu ? 0.f : -__builtin_inff();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             f32x2 y[2][2];
@@ -158,8 +160,8 @@ __device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x
                     const float v0 = nn[0][bb] + nn[1][bb] + nn[2][bb];
                     const float v1 = nn[1][bb] - nn[2][bb] - nn[3][bb];
                     const float t0 = v0 * ep.scale[b] + ep.shift[b], t1 = v1 * ep.scale[b] + ep.shift[b];
-                    y[0][bb][b] = a.relu ? fmaxf(t0, 0.f) : t0;
-                    y[1][bb][b] = a.relu ? fmaxf(t1, 0.f) : t1;
+                    y[0][bb][b] = fmaxf(t0, relu_floor);
+                    y[1][bb][b] = fmaxf(t1, relu_floor);
                 }
             }
 #pragma unroll

@@ -39,6 +39,7 @@ __device__ __forceinline__ void wino_up_epilogue(const ConvArgs& a, const f32x4 
     const int lxb = x0 + bx + (T::SW == 2 ? 0 : 8 * (g & 1));     // low-res column of the lane's first tile
     const int OH = 2 * a.H, OW = 2 * a.W;
     const int odd = n16 & 1;
+    const float relu_floor = a.relu ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int lx = lxb + 2 * r;
@@ -58,8 +59,8 @@ __device__ __forceinline__ void wino_up_epilogue(const ConvArgs& a, const f32x4 
                 for (int u = 0; u < 2; ++u) {
                     const float t0 = (s[u][0] + s[u][1]) * ep.scale[blk] + ep.shift[blk];
                     const float t1 = (s[u][1] + s[u][2]) * ep.scale[blk] + ep.shift[blk];
-                    y[u][0][blk] = a.relu ? fmaxf(t0, 0.f) : t0;
-                    y[u][1][blk] = a.relu ? fmaxf(t1, 0.f) : t1;
+                    y[u][0][blk] = fmaxf(t0, relu_floor);
+                    y[u][1][blk] = fmaxf(t1, relu_floor);
                 }
             }
             // neighbouring lanes trade one pixel column each: the even lane stores four couts of column v = 0, the odd lane
