@@ -60,13 +60,16 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
     const int xb = x0 + bx + (T::SW == 2 ? 0 : 8 * (g & 1));     // left pixel column of the lane's first tile
     const float scale[2] = {ep.scale[0], ep.scale[1]}, shift[2] = {ep.shift[0], ep.shift[1]};
     const float relu_floor = a.relu ? 0.f : -__builtin_inff();   // one v_max either way (a select per value otherwise)
-    const int Hp = a.H >> 1, Wp = a.W >> 1;
-    const bool rows_ok = yb + 1 < a.H;
     const int odd = n16 & 1;
+    // Whole tiles only (checked by the launcher) and tensors below 2 GB: stores through a buffer resource, one per-lane byte offset
+    // per tile, the steps between a lane's pixels in SGPRs -- no 64-bit address arithmetic, no per-store predicates.
+    const uint32_t row_bytes = (uint32_t)(a.W * a.CoutP) * 4u;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (uint32_t)(a.N * a.H) * row_bytes, 0x00020000);
+    const uint32_t vo = ((uint32_t)((n * a.H + yb) * a.W + xb + odd) * (uint32_t)a.CoutP + (uint32_t)(co - 2 * odd)) * 4u;
+    const uint32_t px_step = (uint32_t)a.CoutP * 8u;   // two pixels to the right
     f32x2 mx[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int x = xb + 2 * r;
         f32x2 y[2][2];   // [row a][col bb], components = the two couts
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -99,11 +102,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
             recv.y = wino_swap_adjacent(send.y);
             o[aa] = odd ? f32x4{recv.x, recv.y, y[aa][1].x, y[aa][1].y} : f32x4{y[aa][0].x, y[aa][0].y, recv.x, recv.y};
         }
-        if (x + odd < a.W) {
-            float* const op = a.out + ((size_t)(n * a.H + yb) * a.W + x + odd) * a.CoutP + (co - 2 * odd);
-            *reinterpret_cast<f32x4*>(op) = o[0];
-            if (rows_ok) *reinterpret_cast<f32x4*>(op + (size_t)a.W * a.CoutP) = o[1];
-        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[0]), ro, vo, r * px_step, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[1]), ro, vo, r * px_step + row_bytes, 0);
         if (a.pooled != nullptr) {
             mx[r].x = fmaxf(fmaxf(y[0][0].x, y[0][1].x), fmaxf(y[1][0].x, y[1][1].x));
             mx[r].y = fmaxf(fmaxf(y[0][0].y, y[0][1].y), fmaxf(y[1][0].y, y[1][1].y));
@@ -111,7 +111,10 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
     }
     if (a.pooled != nullptr) {
         // same trade for the pooled pixels (one per tile): the even lane stores four couts of tile r, the odd lane of tile r + 1
-        const int py = yb >> 1;
+        const int Hp = a.H >> 1, Wp = a.W >> 1;
+        const __amdgpu_buffer_rsrc_t rp =
+            __builtin_amdgcn_make_buffer_rsrc(a.pooled, 0, (uint32_t)(a.N * Hp * Wp * a.CoutP) * 4u, 0x00020000);
+        const uint32_t vp = ((uint32_t)((n * Hp + (yb >> 1)) * Wp + (xb >> 1) + odd) * (uint32_t)a.CoutP + (uint32_t)(co - 2 * odd)) * 4u;
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
             const f32x2 send = odd ? mx[r] : mx[r + 1];
@@ -119,8 +122,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
             recv.x = wino_swap_adjacent(send.x);
             recv.y = wino_swap_adjacent(send.y);
             const f32x4 o = odd ? f32x4{recv.x, recv.y, mx[r + 1].x, mx[r + 1].y} : f32x4{mx[r].x, mx[r].y, recv.x, recv.y};
-            const int px = (xb >> 1) + r + odd;
-            if (py < Hp && px < Wp) *reinterpret_cast<f32x4*>(a.pooled + ((size_t)(n * Hp + py) * Wp + px) * a.CoutP + (co - 2 * odd)) = o;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rp, vp, (r >> 1) * px_step, 0);
         }
     }
 }
@@ -432,7 +434,8 @@ static hipError_t launch_wino_cfg(const ConvArgs& a, hipStream_t stream)
     static bool attr_set = false;
     const int nchunks = (a.C1 + a.C2) / T::KC;
     if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
-        (a.C2 != 0 && a.C2 != a.C1))
+        (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 ||
+        (size_t)a.N * a.H * a.W * a.CoutP * 4 >= ((size_t)1 << 31))
         return hipErrorInvalidValue;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_stream<T, HEAD>),

@@ -9,6 +9,7 @@ namespace rcu {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // Exchange with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2].
