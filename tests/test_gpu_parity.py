@@ -9,7 +9,7 @@ from conftest import golden_params, golden_state
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = 2e-4      # |logit| ~ 1..10 after 24 stacked fp32 convs in a different summation order
+LOGIT_TOL = 2e-6      # |logit| ~ 0.1..1 after 24 stacked fp32 convs in a different summation order: measured <= 1e-7
 PROB_TOL = 1e-4       # north_star: uncertainty maps within 1e-4 of the CPU reference
 
 
