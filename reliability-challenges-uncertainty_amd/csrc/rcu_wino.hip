@@ -102,8 +102,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
             recv.y = wino_swap_adjacent(send.y);
             o[aa] = odd ? f32x4{recv.x, recv.y, y[aa][1].x, y[aa][1].y} : f32x4{y[aa][0].x, y[aa][0].y, recv.x, recv.y};
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[0]), ro, vo, r * px_step, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[1]), ro, vo, r * px_step + row_bytes, 0);
+        wino_store16(o[0], ro, vo, r * px_step);
+        wino_store16(o[1], ro, vo, r * px_step + row_bytes);
         if (a.pooled != nullptr) {
             mx[r].x = fmaxf(fmaxf(y[0][0].x, y[0][1].x), fmaxf(y[1][0].x, y[1][1].x));
             mx[r].y = fmaxf(fmaxf(y[0][0].y, y[0][1].y), fmaxf(y[1][0].y, y[1][1].y));
@@ -122,7 +122,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
             recv.x = wino_swap_adjacent(send.x);
             recv.y = wino_swap_adjacent(send.y);
             const f32x4 o = odd ? f32x4{recv.x, recv.y, mx[r + 1].x, mx[r + 1].y} : f32x4{mx[r].x, mx[r].y, recv.x, recv.y};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rp, vp, (r >> 1) * px_step, 0);
+            wino_store16(o, rp, vp, (r >> 1) * px_step);
         }
     }
 }

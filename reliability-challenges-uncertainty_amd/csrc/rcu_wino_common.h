@@ -29,6 +29,18 @@ __device__ __forceinline__ const ConvArgs& wino_cold_args()
     return *(const ConvArgs*)p;
 }
 
+// 16-byte buffer store at rsrc[voff + soff].  hipcc lets a VALU write to the data registers follow such a store at once when
+// the offset sits in an SGPR (the store-data hazard it knows is the immediate-offset one); on gfx950 that loses data now and
+// then (measured: an up-conv epilogue whose selects overwrote v[8:11] two instructions after the store gave a few wrong
+// pixels, different ones per run).  Two wait states, pinned right behind the store.
+__device__ __forceinline__ void wino_store16(const f32x4& v, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff, soff, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void wino_static_for(F&& f)
 {

@@ -40,9 +40,12 @@ __device__ __forceinline__ void wino_up_epilogue(const ConvArgs& a, const f32x4 
     const int OH = 2 * a.H, OW = 2 * a.W;
     const int odd = n16 & 1;
     const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+    // whole tiles only (checked by the launcher), output below 2 GB: buffer stores, one per-lane byte offset per tile, scalar steps
+    const uint32_t px_bytes = (uint32_t)a.CoutP * 4u, row_bytes = (uint32_t)OW * px_bytes;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (uint32_t)(a.N * OH) * row_bytes, 0x00020000);
+    const uint32_t vo = ((uint32_t)((n * OH + 2 * lyb + pa) * OW + 2 * (lxb + odd)) * (uint32_t)a.CoutP + (uint32_t)(co - 2 * odd)) * 4u;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int lx = lxb + 2 * r;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             f32x2 y[2][2];
@@ -72,8 +75,7 @@ __device__ __forceinline__ void wino_up_epilogue(const ConvArgs& a, const f32x4 
                 recv.x = wino_swap_adjacent(send.x);
                 recv.y = wino_swap_adjacent(send.y);
                 const f32x4 o = odd ? f32x4{recv.x, recv.y, y[u][1].x, y[u][1].y} : f32x4{y[u][0].x, y[u][0].y, recv.x, recv.y};
-                if (lyb + u < a.H && lx + odd < a.W)
-                    *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * OH + 2 * (lyb + u) + pa) * OW + 2 * (lx + odd) + b) * a.CoutP + (co - 2 * odd)) = o;
+                wino_store16(o, ro, vo, (4 * r + b) * px_bytes + u * 2 * row_bytes);
             }
         }
     }
@@ -298,7 +300,8 @@ static hipError_t launch_wino_up_cfg(const ConvArgs& a, hipStream_t stream)
 {
     static bool attr_set = false;
     const int nchunks = a.C1 / T::KC;
-    if (nchunks < 4 || (nchunks & 1) != 0 || a.C2 != 0 || a.NTW_total != 2 * a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0)
+    if (nchunks < 4 || (nchunks & 1) != 0 || a.C2 != 0 || a.NTW_total != 2 * a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
+        a.H % T::TH != 0 || a.W % T::TW != 0 || (size_t)a.N * a.H * a.W * a.CoutP * 16 >= ((size_t)1 << 31))
         return hipErrorInvalidValue;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_wino_stream<T>),
