@@ -127,7 +127,16 @@ static int pick_config(const ConvLayer& L, int n_slices)
         if (L.H == 24 && L.W == 16) return CONV_CFG_UP_S2T12x8_N64;
         return CONV_CFG_UP_T8x16_N64;
     }
-    if (L.c1p + L.c2p == 8) return CONV_CFG_T8x16_N32_FIRST;
+    if (L.c1p + L.c2p == 8) {
+        // the network's first conv unit: unpadded K = 9 x 4 (8) on whole 8x32 tiles (rcu_first.hip); RCU_CONV_FIRST=0 keeps the
+        // tiled kernel (A/B tests)
+        const char* const first_env = getenv("RCU_CONV_FIRST");
+        const bool first_on = !(first_env && atoi(first_env) == 0);
+        if (first_on && L.c2p == 0 && L.H % 8 == 0 && L.W % 32 == 0 && (L.coutp == 32 || L.coutp == 64) && L.t_pool < 0 &&
+            L.name2.empty())
+            return CONV_CFG_FIRST_T8x32;
+        return CONV_CFG_T8x16_N32_FIRST;
+    }
     if (wino_on && (L.c1p + L.c2p) % 32 == 0 && (L.c2p == 0 || L.c2p == L.c1p) && max_bytes < ((size_t)1 << 31)) {
         if (L.coutp == 32 && L.H % 16 == 0 && L.W % 32 == 0) return CONV_CFG_WINO_T16x32_N32;
         if (L.coutp > 32 && L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T16x16_N64;
@@ -542,6 +551,7 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     const int gh = L.upsample ? L.H / 2 : L.H, gw = L.upsample ? L.W / 2 : L.W;   // tile grid = input grid
     a.N = n; a.H = gh; a.W = gw;
     a.C1 = L.c1p; a.C2 = L.c2p; a.CoutP = L.coutp;
+    a.cin_real = L.cin1;
     a.Cmask = L.cout; a.Csplit = L.csplit; a.Cmask2 = L.cout;
     a.relu = L.relu;
     a.tiles_y = (gh + ci.TH - 1) / ci.TH;
@@ -827,6 +837,8 @@ extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info*
         // and 9 per 2x2 low-resolution tile and parity class (= 9 per low-resolution pixel) for the up-convolutions
         out->mfma_flops_per_slice = ci.WINO == 2 ? 2.0 * L.c1p * ncols * 9.0 * (px / 4.0)
                                                  : 2.0 * (L.c1p + L.c2p) * ncols * (ci.WINO ? 4.0 : (double)ci.TAPS) * px;
+        if (L.cfg == CONV_CFG_FIRST_T8x32)   // K = 4 channels per tap unless more than four are real
+            out->mfma_flops_per_slice = 2.0 * (L.cin1 > 4 ? 8 : 4) * ncols * 9.0 * px;
     }
     return RCU_OK;
 }

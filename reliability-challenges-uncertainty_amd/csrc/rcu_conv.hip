@@ -570,6 +570,7 @@ static const ConvConfigInfo kInfo[CONV_CFG_COUNT] = {
 
 const ConvConfigInfo& conv_config_info(int cfg)
 {
+    if (cfg == CONV_CFG_FIRST_T8x32) return first_config_info();
     if (cfg >= CONV_CFG_UPW_T16x16_N64) return wino_up_config_info(cfg);
     return cfg >= CONV_CFG_COUNT ? wino_config_info(cfg) : kInfo[cfg];
 }
@@ -610,6 +611,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t stream)
 
 hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream)
 {
+    if (cfg == CONV_CFG_FIRST_T8x32) return launch_conv_first(a, stream);
     if (cfg >= CONV_CFG_UPW_T16x16_N64) return launch_upconv_wino(cfg, a, stream);
     if (cfg >= CONV_CFG_COUNT) return launch_conv_wino(cfg, a, stream);
     switch (cfg) {

@@ -24,6 +24,7 @@ struct ConvArgs {
     float* pooled;       // [N][H/2][W/2][CoutP] or null
     int N, H, W;         // input grid = pixel-tile grid
     int C1, C2;          // padded channel counts of the two sources
+    int cin_real;        // first-layer kernel (rcu_first.hip): input channels that are not padding
     int CoutP;           // padded output channels (multiple of 32)
     int Cmask;           // real channel count of the dropout site (mask row length)
     int Csplit, Cmask2;  // mask2 row = [N][Cmask2], applies to channel co - Csplit
@@ -65,6 +66,8 @@ enum ConvConfig {
     CONV_CFG_UPW_T16x32_N32,
     CONV_CFG_UPW_S2T8x16_N64,
     CONV_CFG_UPW_S8T4x8_N64,
+    // first conv unit of the network, K = 9 taps x 4 (8) channels unpadded (rcu_first.hip)
+    CONV_CFG_FIRST_T8x32,
     CONV_CFG_END
 };
 
@@ -79,9 +82,11 @@ struct ConvConfigInfo {
 const ConvConfigInfo& conv_config_info(int cfg);
 const ConvConfigInfo& wino_config_info(int cfg);
 const ConvConfigInfo& wino_up_config_info(int cfg);
+const ConvConfigInfo& first_config_info();
 hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream);
 hipError_t launch_conv_wino(int cfg, const ConvArgs& a, hipStream_t stream);
 hipError_t launch_upconv_wino(int cfg, const ConvArgs& a, hipStream_t stream);
+hipError_t launch_conv_first(const ConvArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // layout / head / aggregation kernels (rcu_pointwise.hip)
