@@ -122,7 +122,9 @@ typedef struct rcu_layer_info {
 } rcu_layer_info;
 int rcu_unet_num_layers(const rcu_unet* h);
 int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info* out);
-/* Runs only conv layer `layer` on the handle's current workspace contents (benchmark aid). */
+/* Runs only conv layer `layer` on the handle's current workspace contents (benchmark aid; layer 0 then reads the
+   workspace's channels-last input copy, which a forward pass only fills when its first-layer kernel does not read the
+   caller's NCHW input directly -- timing only). */
 int rcu_unet_run_layer(rcu_unet* h, int layer, int n, const float* masks_dev, void* stream);
 
 /* Per-kernel timing of the next `max_forwards` forward calls with HIP events recorded on the caller's

@@ -537,7 +537,8 @@ struct FusedHead {
     int flags;
 };
 
-static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks, hipStream_t stream, const FusedHead* head = nullptr)
+static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks, hipStream_t stream, const FusedHead* head = nullptr,
+                     const float* x_nchw = nullptr, int n_images = 0)
 {
     const ConvConfigInfo& ci = conv_config_info(L.cfg);
     ConvArgs a{};
@@ -552,6 +553,8 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     a.N = n; a.H = gh; a.W = gw;
     a.C1 = L.c1p; a.C2 = L.c2p; a.CoutP = L.coutp;
     a.cin_real = L.cin1;
+    a.x_nchw = L.cfg == CONV_CFG_FIRST_T8x32 ? x_nchw : nullptr;
+    a.n_images = n_images;
     a.Cmask = L.cout; a.Csplit = L.csplit; a.Cmask2 = L.cout;
     a.relu = L.relu;
     a.tiles_y = (gh + ci.TH - 1) / ci.TH;
@@ -590,8 +593,11 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
     if (h->prof_capacity > 0 && h->prof_used < h->prof_capacity)
         ev = h->prof_events.data() + (size_t)(h->prof_used++) * prof_slots(h);
     if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
-    RCU_HIP(launch_pack_input(x, h->tensors[h->t_input].dev, n_one, h->d.in_channels, h->in_cp, h->d.height, h->d.width,
-                              passes, stream));
+    // the first-layer kernel reads the caller's NCHW input itself; every other first layer wants the channels-last copy
+    const bool direct_input = h->layers.front().cfg == CONV_CFG_FIRST_T8x32;
+    if (!direct_input)
+        RCU_HIP(launch_pack_input(x, h->tensors[h->t_input].dev, n_one, h->d.in_channels, h->in_cp, h->d.height, h->d.width,
+                                  passes, stream));
     if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
     // conv_cls.0 and the classifier as one kernel where the shapes allow (the shipped configurations; RCU_FUSE_HEAD=0
     // keeps them apart): two classes, no sigma twin, one pass per sample, 32-cout Winograd tile
@@ -602,7 +608,7 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
                       !(fuse_env && atoi(fuse_env) == 0);
     for (const ConvLayer& L : h->layers) {
         const FusedHead fh{logits, stats, flags};
-        int rc = run_layer(h, L, n, masks, stream, (fuse && &L == &last) ? &fh : nullptr);
+        int rc = run_layer(h, L, n, masks, stream, (fuse && &L == &last) ? &fh : nullptr, direct_input ? x : nullptr, n_one);
         if (rc) return rc;
         if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
     }

@@ -11,7 +11,8 @@
 //   * workgroup = 4 waves = an 8 x 32 pixel tile (wave w: rows 2w, 2w+1), input halo tile 10 x 34 pixels x 4 (8) channels
 //     = 5.4 (10.9) KB of LDS in [channel group][row][column][4] order: the 64 lanes of a B read (16 pixels x 4 channels) hit
 //     64 consecutive banks.  Workgroups walk over the tiles (grid = a few per CU), weights and per-channel constants
-//     are loaded once.
+//     are loaded once.  In a forward pass the tile is filled straight from the caller's NCHW input (ConvArgs::x_nchw): the
+//     channels-last copy of the input (pack_input_kernel) is only made for the layer-by-layer API.
 // fp32 throughout; the MFMA is an fmaf chain over (tap, channel) -- a different summation order than the tiled kernel's,
 // the same as far as the parity tests (|dlogit| <= 1e-7 against the oracle) can tell.
 #include "rcu_kernels.h"
@@ -64,8 +65,17 @@ __global__ __launch_bounds__(FIRST_THREADS) void conv3x3_first_kernel(const Conv
             const int r = rem / FIRST_HC, c = rem % FIRST_HC;
             const int gy = y0 + r - 1, gx = x0 + c - 1;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                v = *reinterpret_cast<const f32x4*>(a.src1 + ((size_t)(n * a.H + gy) * a.W + gx) * a.C1 + ks * 4);
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                if (a.x_nchw != nullptr) {   // the caller's NCHW planes: consecutive threads read consecutive columns of a plane
+                    const size_t HW = (size_t)a.H * a.W;
+                    const float* const px = a.x_nchw + (size_t)(n % a.n_images) * a.cin_real * HW + (size_t)gy * a.W + gx;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (ks * 4 + k < a.cin_real) v[k] = px[(size_t)(ks * 4 + k) * HW];
+                } else {
+                    v = *reinterpret_cast<const f32x4*>(a.src1 + ((size_t)(n * a.H + gy) * a.W + gx) * a.C1 + ks * 4);
+                }
+            }
             *reinterpret_cast<f32x4*>(&tile[ks][r][c][0]) = v;
         }
         // Dropout2d factors of (sample n, the lane's channels); channels beyond the site's width are padding

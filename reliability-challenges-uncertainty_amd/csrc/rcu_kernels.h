@@ -25,6 +25,8 @@ struct ConvArgs {
     int N, H, W;         // input grid = pixel-tile grid
     int C1, C2;          // padded channel counts of the two sources
     int cin_real;        // first-layer kernel (rcu_first.hip): input channels that are not padding
+    const float* x_nchw; // first-layer kernel: when set, the caller's [n_images][cin_real][H][W] input is read in place of src1
+    int n_images;        //   (sample n is image n % n_images: pass groups replicate the images)
     int CoutP;           // padded output channels (multiple of 32)
     int Cmask;           // real channel count of the dropout site (mask row length)
     int Csplit, Cmask2;  // mask2 row = [N][Cmask2], applies to channel co - Csplit
