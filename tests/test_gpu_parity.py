@@ -144,6 +144,44 @@ def test_winograd_kernels_vs_direct_and_oracle(dev, monkeypatch):
     assert _maxdiff(out_w, out_d) < 2e-5
 
 
+@pytest.mark.parametrize('in_channels,start_filters', [(3, 32), (4, 32), (6, 32), (4, 64), (1, 16)])
+def test_first_layer_kernel_vs_tiled_kernel_and_oracle(dev, monkeypatch, in_channels, start_filters):
+    """csrc/rcu_first.hip (unpadded K = 9 taps x 4 or 8 channels, NCHW input read in place, 32 or 64 output channels) against
+    the oracle, against the tiled first-layer kernel + channels-last copy (RCU_CONV_FIRST=0), on a ragged batch and through a
+    pass group (sample t * N + i reads image i)."""
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    params = dict(nb_classes=2, in_channels=in_channels, depth=2, start_filters=start_filters, dropout=0.1)
+    st = uo.synthetic_state(23, **params)
+    g = torch.Generator().manual_seed(8)
+    n, h, w = 3, 24, 64
+    x = torch.randn(n, in_channels, h, w, generator=g)
+    _, sites = uo.unet_plan(**params)
+    masks = uo.sample_masks(sites, n, 0.3, g)
+    m = _model(params, st, dev)
+    # one plan for everything below (the kernel choice of the other layers depends on the plan's batch size)
+    assert m.layer_table(h, w, 2 * n)[0]['kernel'] == 'conv3x3_first<T8x32,K36>'
+    ref = uo.unet_forward(st, x, masks, **params).numpy()
+    out = m(x.to(dev), masks).cpu().numpy()
+    assert _maxdiff(out, ref) < LOGIT_TOL
+    assert _maxdiff(m(x.to(dev)).cpu().numpy(), uo.unet_forward(st, x, None, **params).numpy()) < LOGIT_TOL
+    assert np.array_equal(m(x[:2].to(dev), [mk[:2] for mk in masks]).cpu().numpy(), out[:2])
+    # two passes as one batch of 2 n samples = the same statistics as two single passes, bit for bit
+    masks2 = uo.sample_masks(sites, n, 0.3, g)
+    s1 = steps.McStatistics(n, 2, h, w, dev)
+    m.forward_accumulate(x.to(dev), s1, masks)
+    m.forward_accumulate(x.to(dev), s1, masks2)
+    s2 = steps.McStatistics(n, 2, h, w, dev)
+    m.forward_accumulate(x.to(dev), s2, [masks, masks2], passes=2)
+    assert torch.equal(s1.blob, s2.blob)
+    monkeypatch.setenv('RCU_CONV_FIRST', '0')
+    m_t = _model(params, st, dev)
+    assert m_t.layer_table(h, w, 2 * n)[0]['kernel'].startswith('conv3x3_igemm')
+    out_t = m_t(x.to(dev), masks).cpu().numpy()
+    assert _maxdiff(out_t, ref) < LOGIT_TOL
+    assert _maxdiff(out, out_t) < LOGIT_TOL
+
+
 def test_winograd_sigma_head_and_eval_mode(dev):
     """conv_cls.0 + conv_sigma.0 as one 64-channel Winograd unit with two dropout sites (mask / mask2), eval mode (no
     masks) and a deterministic configuration without dropout modules."""
