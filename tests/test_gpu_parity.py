@@ -182,6 +182,24 @@ def test_first_layer_kernel_vs_tiled_kernel_and_oracle(dev, monkeypatch, in_chan
     assert _maxdiff(out, out_t) < LOGIT_TOL
 
 
+def test_forward_is_bitwise_repeatable(dev):
+    """Ten forwards of the BraTS-sized network on the same input and masks give the same bits (no atomics, no races: the
+    store-data hazard behind csrc/rcu_wino_common.h: wino_store16 showed up as a few voxels differing from run to run)."""
+    from oracle import unet_oracle as uo
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
+    st = uo.synthetic_state(24, **params)
+    g = torch.Generator().manual_seed(9)
+    n, h, w = 8, 192, 128
+    x = torch.randn(n, 4, h, w, generator=g).to(dev)
+    _, sites = uo.unet_plan(**params)
+    masks = uo.sample_masks(sites, n, 0.3, g)
+    m = _model(params, st, dev)
+    packed = m.pack_masks(masks, n, dev)
+    first = m(x, packed).clone()
+    for _ in range(9):
+        assert torch.equal(m(x, packed), first)
+
+
 def test_winograd_sigma_head_and_eval_mode(dev):
     """conv_cls.0 + conv_sigma.0 as one 64-channel Winograd unit with two dropout sites (mask / mask2), eval mode (no
     masks) and a deterministic configuration without dropout modules."""
