@@ -200,6 +200,28 @@ def test_forward_is_bitwise_repeatable(dev):
         assert torch.equal(m(x, packed), first)
 
 
+def test_tensors_beyond_2gb_take_the_64bit_kernels(dev):
+    """272 ISIC-sized images in one batch: the full-resolution activations (272 x 256 x 256 x 32 floats = 2.3 GB) are beyond the
+    32-bit buffer offsets of the Winograd kernels, so those layers must run on the direct kernels (64-bit addressing) -- and the
+    last images of the batch, whose pixels sit above 2 GB, must come out like in a small batch."""
+    from oracle import unet_oracle as uo
+    params = dict(nb_classes=2, in_channels=3, depth=4, start_filters=32, dropout=0.05)
+    st = uo.synthetic_state(25, **params)
+    g = torch.Generator().manual_seed(10)
+    n = 272
+    x = torch.rand(n, 3, 256, 256, generator=g).to(dev)
+    m_small = _model(params, st, dev)
+    m_big = _model(params, st, dev)
+    big = {row['name']: row['kernel'] for row in m_big.layer_table(256, 256, n)}
+    small = {row['name']: row['kernel'] for row in m_small.layer_table(256, 256, 8)}
+    name = 'down_convs.0.block.block.1.conv2d_batch_relu.conv'
+    assert 'winograd' in small[name] and 'igemm' in big[name]
+    assert any('winograd' in k for k in big.values())            # the low-resolution levels stay below 2 GB
+    out = m_big(x)
+    for sl in (slice(0, 8), slice(n - 8, n)):
+        assert _maxdiff(out[sl].cpu().numpy(), m_small(x[sl]).cpu().numpy()) < LOGIT_TOL
+
+
 def test_winograd_sigma_head_and_eval_mode(dev):
     """conv_cls.0 + conv_sigma.0 as one 64-channel Winograd unit with two dropout sites (mask / mask2), eval mode (no
     masks) and a deterministic configuration without dropout modules."""
