@@ -87,7 +87,7 @@ def test_unet_sigma_head_golden(golden, dev):
     assert _maxdiff(sp.cpu().numpy(), g['sigma_pred']) < 1e-6
 
 
-@pytest.mark.parametrize('shape', [(2, 192, 128), (3, 48, 32), (1, 32, 48)])
+@pytest.mark.parametrize('shape', [(2, 192, 128), (3, 48, 32), (1, 32, 48), (1, 192, 128), (5, 96, 64), (8, 16, 16)])
 def test_unet_full_width_vs_oracle(dev, shape):
     """start_filters=32 (the shipped width; no channel padding anywhere) incl. the BraTS slice size whose
     bottom level (12x8) uses the two-slices-per-workgroup kernel; dropout masks sampled and injected."""
