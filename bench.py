@@ -34,12 +34,12 @@ SLICES, CHANNELS, HEIGHT, WIDTH = 160, 4, 192, 128
 MODEL_PARAMS = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)  # config/train_brats_baseline.yaml:7-12
 
 
-def make_model(seed, device):
+def make_model(seed, device, sigma_out=False):
     """UNet(2, 4, 4, 32, 0.05) with torch's default init under the seed and randomised BatchNorm statistics
      -- random-init weights of the named architecture; there are no checkpoints offline."""
     from rcu_amd.model import UNet
     torch.manual_seed(seed)
-    model = UNet(**MODEL_PARAMS)
+    model = UNet(**MODEL_PARAMS, sigma_out=sigma_out)
     gen = torch.Generator().manual_seed(seed + 1000)
     for m in model.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
@@ -160,7 +160,11 @@ def main():
     ap.add_argument('--no-ws', action='store_true', help='skip the deterministic weight-scaling pass')
     ap.add_argument('--ensemble', type=int, default=0, metavar='K',
                     help='K ensemble members (seeds 20..20+K-1) instead of T MC passes (BASELINE config "BraTS ensemble")')
+    ap.add_argument('--aleatoric', action='store_true',
+                    help='sigma-head U-Net, per-pass sigma averaged next to the MC statistics (BASELINE config "BraTS aleatoric + MC", use --mc 50)')
     args = ap.parse_args()
+    if args.aleatoric and args.ensemble:
+        raise SystemExit('--aleatoric and --ensemble exclude each other')
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -186,7 +190,7 @@ def main():
 
     T = args.mc
     seed = 20                                   # config seed (config/test_brats_baseline_mc.yaml:6)
-    model = make_model(seed, device)
+    model = make_model(seed, device, sigma_out=args.aleatoric)
     x_cpu, mask_cpu, target_cpu = make_volume(seed)
     x = x_cpu.to(device)
     ctx = steps.TorchTestContext(str(device), model)
@@ -194,6 +198,9 @@ def main():
         T = args.ensemble
         members = [model] + [make_model(seed + k, device) for k in range(1, T)]
         runner = rdist.ShardedEnsembleRunner(members, rank=rank, world=world)
+    elif args.aleatoric:
+        members = [model]
+        runner = rdist.ShardedAleatoricMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world)
     else:
         members = [model]
         runner = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world)
@@ -321,7 +328,7 @@ def main():
         ece_oracle = co.ece_binary(np.stack([1 - p_np, p_np], -1), target_cpu.numpy(), mask=mask_cpu.numpy())
         parity['ece_delta_same_maps'] = abs(ece_gpu - ece_oracle)
         parity['bin_ids_equal'] = bool(np.array_equal(ev.bin_ids(p_np), co.bin_ids(p_np.reshape(-1))))
-    if not args.no_cpu_baseline and world == 1 and not args.ensemble:     # the CPU leg: rank 0 at N=1 only
+    if not args.no_cpu_baseline and world == 1 and not args.ensemble and not args.aleatoric:     # the CPU leg: rank 0 at N=1 only
         cpu, mask_sets, ref = cpu_baseline(model, x_cpu, T, seed)
         n = ref['probabilities'].shape[0]
         bc = steps.BatchContext({'images': x[:n].contiguous()}, 0)
@@ -336,7 +343,7 @@ def main():
 
     result = {
         'metric': 'ensemble-member-volumes/sec (4x160x192x128, K={})'.format(T) if args.ensemble
-                  else 'MC-sample-volumes/sec (4x160x192x128, T={})'.format(T),
+                  else 'MC-sample-volumes/sec (4x160x192x128, T={}{})'.format(T, ', sigma head' if args.aleatoric else ''),
         'value': T * args.steps / elapsed,
         'unit': 'member-volumes/s' if args.ensemble else 'MC-sample-volumes/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -348,9 +355,10 @@ def main():
         'data': 'synthetic',
         'config': {'workload': ('BraTS ensemble: {} U-Net(2,4,depth 4,start_filters 32) members over 160 slices of 4x192x128 '
                                 '+ mean/entropy aggregation per step'.format(T)) if args.ensemble else
-                               ('BraTS baseline_mc: 2D U-Net(2,4,depth 4,start_filters 32,dropout 0.05) over 160 slices '
+                               ('BraTS {}: 2D U-Net(2,4,depth 4,start_filters 32,dropout 0.05{}) over 160 slices '
                                 'of 4x192x128, T={} MC-dropout passes{} + mean/entropy aggregation per step'
-                                .format(T, '' if args.no_ws else ' + weight-scaling pass')),
+                                .format('aleatoric + MC' if args.aleatoric else 'baseline_mc', ', sigma_out' if args.aleatoric else '',
+                                        T, '' if args.no_ws else ' + weight-scaling pass')),
                    'T': T, 'ws_pass': not (args.no_ws or args.ensemble), 'slices': SLICES, 'height': HEIGHT, 'width': WIDTH,
                    'sharding': 'passes over ranks, one RCCL sum-reduce of the statistics per step' if world > 1 else 'none',
                    'gflop_per_sample_volume': conv_flops / max(forwards, 1) / 1e9},

@@ -109,6 +109,14 @@ int rcu_unet_forward_accumulate(rcu_unet* h, const float* x_dev, int n, const fl
 int rcu_unet_forward_accumulate_passes(rcu_unet* h, const float* x_dev, int n, int passes, const float* masks_dev,
                                        void* stats_dev, int flags, void* stream);
 
+/* EXTENSION (BASELINE.json config "BraTS aleatoric + MC"; the reference has no such path: its McPredictStep cannot take the
+ * (logits, sigma) tuple of a sigma_out model, customsteps.py:32-33, and bin-dl/brats_test_aleatoric.py:57-73 does ONE forward).
+ * One stochastic pass of a sigma_out model: softmax(logits) goes into the MC statistics exactly as in
+ * rcu_unet_forward_accumulate, and the pass's sigma = |raw| (exp(raw) with is_log_sigma, as brats_test_aleatoric.py:66-69)
+ * is ADDED to sigma_sum_dev [n][nb_classes][H][W] (float32; zero it before the first pass, divide by T after the last). */
+int rcu_unet_forward_accumulate_sigma(rcu_unet* h, const float* x_dev, int n, const float* masks_dev, void* stats_dev,
+                                      int flags, float* sigma_sum_dev, int is_log_sigma, void* stream);
+
 /* Per-layer introspection for benchmarks: canonical FLOPs (2*Cin*Cout*9*H*W per slice, real
  * channel counts) and the kernel configuration chosen. */
 typedef struct rcu_layer_info {

@@ -579,7 +579,7 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
 // `passes` > 1 (statistics only): the n images run as ONE batch of n * passes samples -- sample t * n + i is image i
 // under the mask rows [site][t * n + i] -- and the head adds all passes into the n statistics entries.
 static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, float* logits, float* sigma, void* stats,
-                        int flags, hipStream_t stream, int passes = 1)
+                        int flags, hipStream_t stream, int passes = 1, float* sigma_sum = nullptr, int sigma_log = 0)
 {
     if (!h || !x) return fail(RCU_ERR_INVALID, "rcu_unet_forward: null argument");
     if (!h->finalized) return fail(RCU_ERR_STATE, "rcu_unet_forward before rcu_unet_finalize_weights");
@@ -588,7 +588,7 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
     if (passes > 1 && (!stats || logits || sigma)) return fail(RCU_ERR_INVALID, "pass groups only feed the statistics");
     const int n_one = n;
     n *= passes;
-    if (sigma && !h->d.sigma_out) return fail(RCU_ERR_INVALID, "sigma output requested from a model without sigma_out");
+    if ((sigma || sigma_sum) && !h->d.sigma_out) return fail(RCU_ERR_INVALID, "sigma output requested from a model without sigma_out");
     hipEvent_t* ev = nullptr;
     if (h->prof_capacity > 0 && h->prof_used < h->prof_capacity)
         ev = h->prof_events.data() + (size_t)(h->prof_used++) * prof_slots(h);
@@ -620,6 +620,7 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
     a.act = h->tensors[h->t_head].dev;
     a.w_cls = h->w_cls; a.b_cls = h->b_cls; a.w_sig = h->w_sig; a.b_sig = h->b_sig;
     a.logits = logits; a.sigma = sigma; a.stats = stats;
+    a.sigma_sum = sigma_sum; a.sigma_log = sigma_log;
     a.C = h->d.nb_classes; a.CP = h->head_cp; a.CPh = h->head_cph; a.stats_flags = flags;
     a.HW = (size_t)h->d.height * h->d.width;
     a.V = a.HW * n_one;
@@ -679,6 +680,14 @@ extern "C" int rcu_unet_forward_accumulate(rcu_unet* h, const float* x_dev, int 
     if (!stats_dev) return fail(RCU_ERR_INVALID, "rcu_unet_forward_accumulate: null stats");
     return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR),
                         static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rcu_unet_forward_accumulate_sigma(rcu_unet* h, const float* x_dev, int n, const float* masks_dev, void* stats_dev,
+                                                 int flags, float* sigma_sum_dev, int is_log_sigma, void* stream)
+{
+    if (!stats_dev || !sigma_sum_dev) return fail(RCU_ERR_INVALID, "rcu_unet_forward_accumulate_sigma: null stats / sigma sum");
+    return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR),
+                        static_cast<hipStream_t>(stream), 1, sigma_sum_dev, is_log_sigma ? 1 : 0);
 }
 
 extern "C" int rcu_unet_features(const rcu_unet* h, const float** features_dev, int* channels, int* channel_pitch)

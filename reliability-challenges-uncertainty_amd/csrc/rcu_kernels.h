@@ -112,6 +112,8 @@ struct HeadArgs {
     const float* b_sig;
     float* logits;        // NCHW [N][C][HW] or null
     float* sigma;         // NCHW or null
+    float* sigma_sum;     // NCHW or null: += |sigma| (or exp(sigma), sigma_log) of this pass (aleatoric + MC extension)
+    int sigma_log;
     void* stats;          // MC stats blob or null
     int C, CP, CPh, stats_flags;
     size_t V, HW;         // V = voxels of ONE pass (n * HW)

@@ -140,19 +140,19 @@ __device__ __forceinline__ void head_logits(const HeadArgs& a, const float* __re
         if (v < a.V) {
             const float* row = act + v * a.CP;
             head_dot8<C>(row, a.w_cls, a.CPh, sub, pl);
-            if (a.sigma != nullptr) head_dot8<C>(row + a.CPh, a.w_sig, a.CPh, sub, ps);
+            if ((a.sigma != nullptr || a.sigma_sum != nullptr)) head_dot8<C>(row + a.CPh, a.w_sig, a.CPh, sub, ps);
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
 #pragma unroll
             for (int off = 1; off < 8; off <<= 1) {
                 pl[c] += __shfl_xor(pl[c], off, 64);
-                if (a.sigma != nullptr) ps[c] += __shfl_xor(ps[c], off, 64);
+                if ((a.sigma != nullptr || a.sigma_sum != nullptr)) ps[c] += __shfl_xor(ps[c], off, 64);
             }
             // voxel (round*8 + j) lives in lanes 8j..8j+7; lane i wants voxel i = 8*(i>>3) + (i&7)
             const float tl = __shfl(pl[c], (lane & 7) * 8, 64);
             l[c] = (grp == round) ? tl : l[c];
-            if (a.sigma != nullptr) {
+            if ((a.sigma != nullptr || a.sigma_sum != nullptr)) {
                 const float ts = __shfl(ps[c], (lane & 7) * 8, 64);
                 s[c] = (grp == round) ? ts : s[c];
             }
@@ -194,6 +194,13 @@ __global__ __launch_bounds__(PW_THREADS) void head_kernel(const HeadArgs a)
     if (a.sigma != nullptr) {
 #pragma unroll
         for (int c = 0; c < C; ++c) a.sigma[(n * C + c) * a.HW + hw] = s[c] + a.b_sig[c];
+    }
+    if (a.sigma_sum != nullptr) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float raw = s[c] + a.b_sig[c];
+            a.sigma_sum[(n * C + c) * a.HW + hw] += a.sigma_log ? expf(raw) : fabsf(raw);
+        }
     }
     if (a.stats != nullptr) {
         softmax_inplace<C>(l);

@@ -65,6 +65,56 @@ class HipEngine:
     def finalize(self, stats, count):
         return stats.finalize(self.do_mi, self.do_var, count=count)
 
+    def ws_outputs(self, ws):
+        return {'ws_probabilities': ws}
+
+
+class AleatoricHipEngine(HipEngine):
+    """EXTENSION (BASELINE config "aleatoric + MC", see rcu_amd.steps.AleatoricMcPredictStep): passes of a sigma-head U-Net.  The
+    per-pass sigmas are plain sums like the statistics, so they ride in the same reduce buffer:
+    flat = [statistics | sigma sum [n,C,H,W] | ws probabilities | ws sigma]."""
+
+    def __init__(self, model, is_log_sigma=False, do_mi=False):
+        super().__init__(model, do_mi, False)
+        if not getattr(model, 'sigma_out', False):
+            raise ValueError('AleatoricHipEngine needs a model built with sigma_out=True')
+        self.is_log_sigma = is_log_sigma
+
+    def buffers(self, x, with_ws):
+        n, _, h, w = x.shape
+        c = self.model.nb_classes
+        n_stats = steps_mod.McStatistics.blob_elements(n, c, h * w, self.do_mi, False)
+        n_vol = n * c * h * w
+        flat = torch.empty(n_stats + n_vol * (3 if with_ws else 1), device=x.device, dtype=torch.float32)
+        stats = steps_mod.McStatistics(n, c, h, w, x.device, self.do_mi, False, blob=flat[:n_stats])
+        flat[n_stats:].zero_()
+        stats.sigma_sum = flat[n_stats:n_stats + n_vol].view(n, c, h, w)
+        ws = flat[n_stats + n_vol:].view(2, n, c, h, w) if with_ws else None
+        return flat, stats, ws, False
+
+    def ws_pass(self, x, ws_out):
+        steps_mod.set_dropout_mode(self.model, False)
+        logits, raw = self.model(x)
+        n, c, h, w = logits.shape
+        lib = steps_mod._lib
+        lib.check(lib.load().rcu_aleatoric(lib.ptr(logits), lib.ptr(raw.contiguous()), n, h * w, c, int(self.is_log_sigma),
+                                           lib.ptr(ws_out[0]), lib.ptr(ws_out[1]), None, None, lib.current_stream()))
+
+    def mc_pass(self, x, stats, masks=None):
+        steps_mod.set_dropout_mode(self.model, True)
+        try:
+            self.model.forward_accumulate_sigma(x, stats, stats.sigma_sum, masks, self.is_log_sigma)
+        finally:
+            steps_mod.set_dropout_mode(self.model, False)
+
+    def finalize(self, stats, count):
+        out = stats.finalize(self.do_mi, False, count=count)
+        out['sigma'] = stats.sigma_sum / float(max(count, 1))
+        return out
+
+    def ws_outputs(self, ws):
+        return {'ws_probabilities': ws[0], 'ws_sigma': ws[1]}
+
 
 class ShardedMcRunner:
 
@@ -75,6 +125,10 @@ class ShardedMcRunner:
         self.ws_pass = ws_pass
         self.rank, self.world, self.root = rank, world, root
         self.jobs_per_step = mc_steps + (1 if ws_pass else 0)
+
+    def _ws_outputs(self, ws):
+        hook = getattr(self.engine, 'ws_outputs', None)
+        return hook(ws) if hook is not None else {'ws_probabilities': ws}
 
     def job_list(self):
         """Job ids of one step: 0 = weight-scaling pass (when enabled), 1..T = MC passes."""
@@ -109,7 +163,7 @@ class ShardedMcRunner:
             return None
         out = self.engine.finalize(stats, self.mc_steps)
         if ws is not None:
-            out['ws_probabilities'] = ws
+            out.update(self._ws_outputs(ws))
         return out
 
     def step_async(self, x, step_index=0, mask_sets=None, depth=2):
@@ -146,7 +200,7 @@ class ShardedMcRunner:
                 out = self.engine.finalize(stats, self.mc_steps)
                 pending.works = []
             if ws is not None:
-                out['ws_probabilities'] = ws
+                out.update(self._ws_outputs(ws))
             pending.value = out
         self._inflight.append(pending)
         return pending
@@ -155,6 +209,15 @@ class ShardedMcRunner:
         """Retire every reduce still in flight (call before destroying the process group)."""
         while getattr(self, '_inflight', None):
             self._inflight.popleft().retire()
+
+
+class ShardedAleatoricMcRunner(ShardedMcRunner):
+    """ShardedMcRunner over AleatoricHipEngine (BASELINE config "BraTS aleatoric + MC: sigma-head U-Net, T = 50, samples sharded
+    over 8 MI355X"): the summary gains ``sigma`` (mean over the passes) and ``ws_sigma``."""
+
+    def __init__(self, model, mc_steps, is_log_sigma=False, ws_pass=True, rank=0, world=1, do_mi=False, root=0):
+        super().__init__(model, mc_steps, ws_pass=ws_pass, rank=rank, world=world,
+                         engine=AleatoricHipEngine(model, is_log_sigma, do_mi), do_mi=do_mi, root=root)
 
 
 class ShardedEnsembleRunner(ShardedMcRunner):

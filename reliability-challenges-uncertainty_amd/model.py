@@ -283,6 +283,29 @@ class UNet(nn.Module):
                                                                       _lib.current_stream()))
         stats.count += passes
 
+    def forward_accumulate_sigma(self, x, stats, sigma_sum, masks=None, is_log_sigma=False):
+        """EXTENSION (BASELINE config "aleatoric + MC", not in the reference): one stochastic pass of a ``sigma_out`` model --
+        softmax(logits) into ``stats`` as in ``forward_accumulate`` and this pass's sigma (|raw|, or exp(raw)) added to the
+        float32 ``[N, C, H, W]`` tensor ``sigma_sum``; neither logits nor sigma reach HBM as volumes of their own."""
+        if not self.sigma_out:
+            raise ValueError('forward_accumulate_sigma needs a model built with sigma_out=True')
+        x = self._check_input(x)
+        n, _, h, w = x.shape
+        if (n, self.nb_classes, h * w) != (stats.n, stats.nb_classes, stats.hw):
+            raise ValueError('statistics blob shape does not match the batch')
+        if (tuple(sigma_sum.shape) != (n, self.nb_classes, h, w) or sigma_sum.dtype != torch.float32 or
+                not sigma_sum.is_contiguous() or sigma_sum.device != x.device):
+            raise ValueError('sigma_sum must be a contiguous float32 [N, C, H, W] tensor on the input device')
+        handle = self._handle(h, w, n)
+        if masks is None and self.mc_active():
+            masks = self.sample_masks(n, x.device)
+        elif isinstance(masks, (list, tuple)):
+            masks = self.pack_masks(masks, n, x.device)
+        _lib.check(_lib.load().rcu_unet_forward_accumulate_sigma(handle, _lib.ptr(x), n, _lib.ptr(masks), _lib.ptr(stats.blob),
+                                                                 stats.flags, _lib.ptr(sigma_sum), int(bool(is_log_sigma)),
+                                                                 _lib.current_stream()))
+        stats.count += 1
+
     def group_masks(self, mask_sets, n, device):
         """``passes`` mask sets (each [site][n][C_site]) -> the [site][passes * n][C_site] layout of a pass group."""
         sites = self.dropout_sites()

@@ -7,6 +7,7 @@ Mirrors (names, arguments, output keys, error behaviour):
   MultiPredictionSummary        rechun/dl/customsteps.py:42-71
   EnsemblePredictionStep        bin-dl/brats_test_ensemble.py:72-94
   AleatoricPredictStep          bin-dl/brats_test_aleatoric.py:51-73
+  AleatoricMcPredictStep        extension (BASELINE config 'aleatoric + MC'): composition of the two above
   BatchContext / TaskContext    common/trainloop/context.py:334-355
 A step is called as ``step(batch_context, task_context, context)``, reads
 ``batch_context.input['images']`` and writes torch tensors with the channel dim at 1 into
@@ -312,6 +313,52 @@ class AleatoricPredictStep(BatchStep):
                                              _lib.current_stream()))
         batch_context.output['sigma'] = sigma
         batch_context.output['probabilities'] = probs
+
+
+class AleatoricMcPredictStep(BatchStep):
+    """EXTENSION -- BASELINE config "aleatoric + MC" (sigma-head U-Net, T stochastic passes); the reference has no such step
+    (McPredictStep cannot take the (logits, sigma) tuple, customsteps.py:32-33).  It is the composition of the reference's
+    pieces: per pass t, with dropout on, ``logits_t, raw_t = model(x)``; ``p_t = softmax(logits_t)`` goes into the MC statistics
+    (-> ``multi_probabilities`` for MultiPredictionSummary, as McPredictStep); ``sigma_t = |raw_t|`` or ``exp(raw_t)``
+    (AleatoricPredictStep, brats_test_aleatoric.py:66-69) is averaged over the passes -> ``sigma`` [N, C, H, W].  The
+    deterministic pass that McPredictStep runs first gives ``ws_probabilities`` and ``ws_sigma``."""
+
+    def __init__(self, mc_steps, is_log_sigma=False, do_mi=False, do_var=False, masks=None, ws_pass=True) -> None:
+        super().__init__()
+        self.mc_steps = mc_steps
+        self.is_log_sigma = is_log_sigma
+        self.do_mi, self.do_var = do_mi, do_var
+        self.masks = masks
+        self.ws_pass = ws_pass
+
+    def __call__(self, batch_context, task_context, context) -> None:
+        _check_context(context)
+        images = _images_to_device(batch_context, context)
+        model = context.model
+        if not isinstance(model, model_mod.UNet) or not model.sigma_out:
+            raise ValueError('AleatoricMcPredictStep needs a rcu_amd.model.UNet built with sigma_out=True')
+        n, _, h, w = images.shape
+        c = model.nb_classes
+        if self.ws_pass:
+            logits, sigma_raw = model(images)
+            probs = torch.empty_like(logits)
+            sigma = torch.empty_like(logits)
+            _lib.check(_lib.load().rcu_aleatoric(_lib.ptr(logits), _lib.ptr(sigma_raw.contiguous()), n, h * w, c,
+                                                 int(self.is_log_sigma), _lib.ptr(probs), _lib.ptr(sigma), None, None,
+                                                 _lib.current_stream()))
+            batch_context.output['ws_probabilities'] = probs
+            batch_context.output['ws_sigma'] = sigma
+        set_dropout_mode(model, is_train=True)
+        try:
+            stats = McStatistics(n, c, h, w, images.device, self.do_mi, self.do_var)
+            sigma_sum = torch.zeros((n, c, h, w), device=images.device, dtype=torch.float32)
+            for i in range(self.mc_steps):
+                model.forward_accumulate_sigma(images, stats, sigma_sum, None if self.masks is None else self.masks[i],
+                                               self.is_log_sigma)
+            batch_context.output['multi_probabilities'] = stats
+            batch_context.output['sigma'] = sigma_sum.div_(float(max(self.mc_steps, 1)))
+        finally:
+            set_dropout_mode(model, is_train=False)
 
 
 def prediction_and_foreground(probabilities):

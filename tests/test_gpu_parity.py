@@ -200,6 +200,60 @@ def test_forward_is_bitwise_repeatable(dev):
         assert torch.equal(m(x, packed), first)
 
 
+@pytest.mark.parametrize('is_log_sigma', [False, True])
+def test_aleatoric_mc_step_is_the_composition_of_the_reference_pieces(dev, is_log_sigma):
+    """Extension step for BASELINE's "aleatoric + MC" config (csrc: rcu_unet_forward_accumulate_sigma): T stochastic passes of
+    a sigma-head U-Net.  Oracle = the pieces the reference has, composed on the CPU: per pass softmax(logits_t) and
+    |raw_t| / exp(raw_t) (brats_test_aleatoric.py:66-69), then MultiPredictionSummary's mean / entropy over the passes
+    (customsteps.py:50-71) and the mean of the sigmas."""
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    params = dict(nb_classes=2, in_channels=4, depth=3, start_filters=32, dropout=0.05, sigma_out=True)
+    st = uo.synthetic_state(26, **params)
+    g = torch.Generator().manual_seed(11)
+    n, h, w, T = 2, 64, 64, 4
+    x = torch.randn(n, 4, h, w, generator=g)
+    _, sites = uo.unet_plan(**params)
+    mask_sets = [uo.sample_masks(sites, n, 0.3, g) for _ in range(T)]
+    m = _model(params, st, dev)
+    ctx = steps.TorchTestContext('cuda', m)
+    bc = steps.BatchContext({'images': x}, 0)
+    steps.AleatoricMcPredictStep(T, is_log_sigma=is_log_sigma, do_mi=True, masks=mask_sets)(bc, None, ctx)
+    assert set(bc.output) == {'ws_probabilities', 'ws_sigma', 'multi_probabilities', 'sigma'}
+    steps.MultiPredictionSummary(do_mi=True)(bc, None, ctx)
+    assert set(bc.output) == {'ws_probabilities', 'ws_sigma', 'sigma', 'probabilities', 'entropy', 'mutual_info'}
+    act = (lambda r: r.double().exp()) if is_log_sigma else (lambda r: r.double().abs())
+    ps, sg = [], []
+    for mk in mask_sets:
+        lg, raw = uo.unet_forward(st, x, mk, **params)
+        ps.append(torch.softmax(lg.double(), 1))
+        sg.append(act(raw))
+    p_mean = torch.stack(ps).mean(0)
+    ent = -(torch.where(p_mean > 0, p_mean * p_mean.log(), torch.zeros_like(p_mean))).sum(1, keepdim=True)
+    ent_t = torch.stack([-(torch.where(p > 0, p * p.log(), torch.zeros_like(p))).sum(1, keepdim=True) for p in ps]).mean(0)
+    assert _maxdiff(bc.output['probabilities'].cpu().numpy(), p_mean.numpy()) < 1e-6
+    assert _maxdiff(bc.output['entropy'].cpu().numpy(), ent.numpy()) < 1e-6
+    assert _maxdiff(bc.output['mutual_info'].cpu().numpy(), (ent - ent_t).numpy()) < 1e-6
+    sigma_ref = torch.stack(sg).mean(0).numpy()
+    assert _maxdiff(bc.output['sigma'].cpu().numpy(), sigma_ref) < 1e-6 * max(1.0, float(np.abs(sigma_ref).max()))
+    lg0, raw0 = uo.unet_forward(st, x, None, **params)
+    assert _maxdiff(bc.output['ws_probabilities'].cpu().numpy(), torch.softmax(lg0, 1).numpy()) < 1e-6
+    assert _maxdiff(bc.output['ws_sigma'].cpu().numpy(), act(raw0).numpy()) < 1e-6 * max(1.0, float(act(raw0).max()))
+    # the sharded runner (world size 1 here; the sigma sums ride in the reduce buffer next to the statistics) gives the same maps
+    from rcu_amd import distributed as rdist
+    out = rdist.ShardedAleatoricMcRunner(m, T, is_log_sigma=is_log_sigma, do_mi=True).step(x.to(dev), 0, mask_sets)
+    assert set(out) == {'probabilities', 'entropy', 'mutual_info', 'sigma', 'ws_probabilities', 'ws_sigma'}
+    for key in out:
+        assert torch.equal(out[key], bc.output[key]), key
+    # errors of the boundary
+    with pytest.raises(ValueError):
+        steps.AleatoricMcPredictStep(2)(steps.BatchContext({'images': x}, 0), None, object())
+    plain = dict(params, sigma_out=False)
+    with pytest.raises(ValueError):
+        steps.AleatoricMcPredictStep(2)(steps.BatchContext({'images': x}, 0), None,
+                                        steps.TorchTestContext('cuda', _model(plain, uo.synthetic_state(26, **plain), dev)))
+
+
 def test_tensors_beyond_2gb_take_the_64bit_kernels(dev):
     """272 ISIC-sized images in one batch: the full-resolution activations (272 x 256 x 256 x 32 floats = 2.3 GB) are beyond the
     32-bit buffer offsets of the Winograd kernels, so those layers must run on the direct kernels (64-bit addressing) -- and the
