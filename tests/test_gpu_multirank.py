@@ -25,14 +25,16 @@ def test_two_ranks_one_gpu_pipelined_matches_single_rank():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-def test_bench_two_ranks_through_torch_distributed_run():
+@pytest.mark.parametrize('port,extra', [(29541, ['--mc', '4']), (29542, ['--mc', '4', '--aleatoric']), (29543, ['--ensemble', '3'])])
+def test_bench_two_ranks_through_torch_distributed_run(port, extra):
     """The driver's N>1 launch line (python -m torch.distributed.run ... bench.py --gpus N) with both ranks on the one
-    GPU of the test box over gloo (test-only switches of bench.py): rank 0 prints the one JSON line."""
+    GPU of the test box over gloo (test-only switches of bench.py): rank 0 prints the one JSON line -- for the MC-dropout
+    workload, its sigma-head extension and the ensemble workload."""
     import json
     env = dict(os.environ, RCU_BENCH_SINGLE_DEVICE='1', RCU_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', '29541', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
-           '--warmup', '1', '--mc', '4']
+           '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
+           '--warmup', '1'] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
