@@ -47,6 +47,54 @@ class OracleEngine:
         return {'probabilities': p, 'entropy': so.torch_entropy(p, dim=1, keepdim=True)}
 
 
+class OracleAleatoricEngine:
+    """Same interface as rcu_amd.distributed.AleatoricHipEngine (sigma-head extension): the per-pass sigmas are plain sums
+    in the reduce buffer, [statistics | sigma sum | ws probabilities | ws sigma]."""
+
+    def __init__(self, state):
+        from oracle import unet_oracle as uo
+        self.state, self.uo = state, uo
+        self.params = dict(PARAMS, sigma_out=True)
+
+    def buffers(self, x, with_ws):
+        n, _, h, w = x.shape
+        vol = n * PARAMS['nb_classes'] * h * w
+        shape = (n, PARAMS['nb_classes'], h, w)
+        flat = torch.zeros(vol * (4 if with_ws else 2))
+        stats = flat[:vol].view(shape)
+        stats.sigma_sum = flat[vol:2 * vol].view(shape)
+        ws = flat[2 * vol:].view((2,) + shape) if with_ws else None
+        return flat, stats, ws, False
+
+    def ws_pass(self, x, ws_out):
+        lg, raw = self.uo.unet_forward(self.state, x, None, **self.params)
+        ws_out[0].copy_(torch.softmax(lg, 1))
+        ws_out[1].copy_(raw.abs())
+
+    def mc_pass(self, x, stats, masks=None):
+        lg, raw = self.uo.unet_forward(self.state, x, masks, **self.params)
+        stats += torch.softmax(lg, 1)
+        stats.sigma_sum += raw.abs()
+
+    def finalize(self, stats, count):
+        from oracle import summary_oracle as so
+        p = stats / count
+        return {'probabilities': p, 'entropy': so.torch_entropy(p, dim=1, keepdim=True), 'sigma': stats.sigma_sum / count}
+
+    def ws_outputs(self, ws):
+        return {'ws_probabilities': ws[0], 'ws_sigma': ws[1]}
+
+
+def _sigma_inputs():
+    from oracle import unet_oracle as uo
+    params = dict(PARAMS, sigma_out=True)
+    state = uo.synthetic_state(9, **params)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 4, 32, 32, generator=g)
+    _, sites = uo.unet_plan(**params)
+    return params, state, x, [uo.sample_masks(sites, 2, 0.3, g) for _ in range(T)]
+
+
 def _inputs():
     from oracle import unet_oracle as uo
     state = uo.synthetic_state(7, **PARAMS)
@@ -93,6 +141,15 @@ def _worker(rank, world, port, out_dir):
             assert 'ws_probabilities' not in out
             np.savez(os.path.join(out_dir, 'ens{}.npz'.format(step)), **{k: v.numpy() for k, v in out.items()})
     ens.drain()
+    # sigma-head extension: the sigma sums travel in the same reduce as the statistics
+    _, sstate, sx, smasks = _sigma_inputs()
+    sig = ShardedMcRunner(None, T, ws_pass=True, rank=rank, world=world, engine=OracleAleatoricEngine(sstate))
+    pend = [sig.step_async(sx, step, smasks) for step in range(2)]
+    for step, p in enumerate(pend):
+        out = p.result()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, 'sigma{}.npz'.format(step)), **{k: v.numpy() for k, v in out.items()})
+    sig.drain()
     dist.destroy_process_group()
 
 
@@ -139,3 +196,15 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         got = np.load(os.path.join(str(tmp_path), 'ens{}.npz'.format(step)))
         assert np.max(np.abs(got['probabilities'] - ref['probabilities'].numpy())) < 1e-6
         assert np.max(np.abs(got['entropy'] - ref['entropy'].numpy())) < 2e-6
+    params, sstate, sx, smasks = _sigma_inputs()
+    passes = [uo.unet_forward(sstate, sx, mk, **params) for mk in smasks]
+    p_ref = torch.stack([torch.softmax(lg, 1) for lg, _ in passes]).mean(0)
+    s_ref = torch.stack([raw.abs() for _, raw in passes]).mean(0)
+    lg0, raw0 = uo.unet_forward(sstate, sx, None, **params)
+    for step in range(2):
+        got = np.load(os.path.join(str(tmp_path), 'sigma{}.npz'.format(step)))
+        assert set(got.files) == {'probabilities', 'entropy', 'sigma', 'ws_probabilities', 'ws_sigma'}
+        assert np.max(np.abs(got['probabilities'] - p_ref.numpy())) < 1e-6
+        assert np.max(np.abs(got['sigma'] - s_ref.numpy())) < 1e-5 * max(1.0, float(s_ref.max()))
+        assert np.max(np.abs(got['ws_probabilities'] - torch.softmax(lg0, 1).numpy())) < 1e-6
+        assert np.max(np.abs(got['ws_sigma'] - raw0.abs().numpy())) < 1e-6 * max(1.0, float(raw0.abs().max()))
