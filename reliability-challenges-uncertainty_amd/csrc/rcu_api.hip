@@ -562,6 +562,13 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     a.slice_groups = (n + ci.TS - 1) / ci.TS;
     a.NT = L.NT;
     a.NTW_total = L.NT * (ci.WINO == 2 ? 2 : L.upsample ? 4 : 1);
+    {
+        const unsigned long long items = (unsigned long long)a.NTW_total * a.tiles_x * a.tiles_y * a.slice_groups;
+        auto magic = [&](int d) -> uint32_t {
+            return (d > 1 && items * (unsigned long long)d < (1ull << 32)) ? (uint32_t)(((1ull << 32) + d - 1) / d) : 0u;
+        };
+        a.magic_ntw = magic(a.NTW_total); a.magic_tx = magic(a.tiles_x); a.magic_ty = magic(a.tiles_y);
+    }
     a.src1_bytes = (uint32_t)std::min<size_t>(h->tensors[L.t_src1].floats_per_slice * (size_t)n * 4, 0xFFFFFFFFu);
     a.src2_bytes = L.t_src2 >= 0 ? (uint32_t)std::min<size_t>(h->tensors[L.t_src2].floats_per_slice * (size_t)n * 4, 0xFFFFFFFFu) : 0u;
     a.wpack_bytes = (uint32_t)std::min<size_t>(L.wpack_floats * 4, 0xFFFFFFFFu);

@@ -33,6 +33,8 @@ struct ConvArgs {
     int relu;            // 1: max(0, .) epilogue
     int tiles_y, tiles_x, slice_groups;
     int NT;              // output-channel tiles
+    uint32_t magic_ntw, magic_tx, magic_ty;   // ceil(2^32 / d) for d = NTW_total, tiles_x, tiles_y (0: divide): the Winograd kernels
+                                              // split a work item into tile coordinates with s_mul_hi instead of three divisions
     int NTW_total;       // weight tiles per Cin chunk = NT (3x3) or 4 * NT (sub-pixel: one set per parity class)
     uint32_t src1_bytes, src2_bytes, wpack_bytes;   // buffer-resource ranges (Winograd kernels)
     // fused 1x1 head of conv_cls.0 (rcu_wino.hip, two classes): when head_w is set the conv unit's output stays on chip

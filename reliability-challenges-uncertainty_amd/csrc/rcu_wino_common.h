@@ -160,12 +160,14 @@ template <class T>
 __device__ __forceinline__ WinoTileId wino_tile_id(const ConvArgs& a, int item)
 {
     WinoTileId t;
-    t.wtile = item % a.NTW_total;
-    int mtile = item / a.NTW_total;
-    const int tx = mtile % a.tiles_x;
-    mtile /= a.tiles_x;
-    const int ty = mtile % a.tiles_y;
-    const int sg = mtile / a.tiles_y;
+    // item / d by multiplication with ceil(2^32 / d): exact while item * d < 2^32 (the launcher falls back to magic = 0)
+    auto div = [](int x, int d, uint32_t magic) { return magic ? (int)__umulhi((uint32_t)x, magic) : x / d; };
+    int mtile = div(item, a.NTW_total, a.magic_ntw);
+    t.wtile = item - mtile * a.NTW_total;
+    const int q = div(mtile, a.tiles_x, a.magic_tx);
+    const int tx = mtile - q * a.tiles_x;
+    const int sg = div(q, a.tiles_y, a.magic_ty);
+    const int ty = q - sg * a.tiles_y;
     t.n0 = sg * T::TS;
     t.y0 = ty * T::TH;
     t.x0 = tx * T::TW;
