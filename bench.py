@@ -5,14 +5,19 @@ i.e. 160 slices of 4 x 192 x 128), T = 20 MC-dropout passes, on N GPUs of one no
 One step = the reference's hot path for one volume (rechun/dl/customsteps.py:16-71):
     weight-scaling pass + T stochastic U-Net passes (softmax + running statistics fused in) ->
     [N > 1: one RCCL sum-reduce of the per-voxel statistics] -> mean probability + predictive entropy.
-Inputs are resident in HBM when the timed region starts.  N > 1 shards the T+1 forward passes of
-every step over the ranks (strong scaling); run through
+Inputs are resident in HBM when the timed region starts (`value`); the same step with the host-to-device copy of the
+volume inside is reported next to it (`with_h2d`).  N > 1 shards the T+1 forward passes of every step over the ranks
+(strong scaling).  Launch forms:
+    python bench.py --gpus N ...                  (starts its N ranks itself, as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+`--workload isic` is BASELINE.json's configs[1] (ISIC baseline_mc: 32 images of 3 x 256 x 256, T = 20) with the same
+JSON schema.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (HIP events recorded on the
 launch stream inside the timed region, see rcu_unet_profile_begin in include/rcu.h); `cpu_baseline`
 is the oracle (a port of the reference's CPU path, pinned against golden vectors) timed on a bounded
-sample of the same workload on this box's host cores.
+sample of the same workload on this box's host cores -- the SAME slices, weights and dropout masks as the
+last timed step, so the sample doubles as the parity check of the timed output (`parity`).
 """
 import argparse
 import json
@@ -32,14 +37,17 @@ PEAK_HBM_GBS = 8000.0            # same guide: HBM3E peak (about 6.3 TB/s is wha
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 SLICES, CHANNELS, HEIGHT, WIDTH = 160, 4, 192, 128
 MODEL_PARAMS = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)  # config/train_brats_baseline.yaml:7-12
+# BASELINE.json configs[1]: ISIC baseline_mc (config/test_isic_baseline_mc.yaml: batch_size 32, rescaled to 0..1, 3 x 256 x 256)
+ISIC_IMAGES, ISIC_CHANNELS, ISIC_HEIGHT, ISIC_WIDTH = 32, 3, 256, 256
+ISIC_PARAMS = dict(nb_classes=2, in_channels=3, depth=4, start_filters=32, dropout=0.05)
 
 
-def make_model(seed, device, sigma_out=False):
+def make_model(seed, device, sigma_out=False, params=None):
     """UNet(2, 4, 4, 32, 0.05) with torch's default init under the seed and randomised BatchNorm statistics
      -- random-init weights of the named architecture; there are no checkpoints offline."""
     from rcu_amd.model import UNet
     torch.manual_seed(seed)
-    model = UNet(**MODEL_PARAMS, sigma_out=sigma_out)
+    model = UNet(**(params or MODEL_PARAMS), sigma_out=sigma_out)
     gen = torch.Generator().manual_seed(seed + 1000)
     for m in model.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
@@ -62,45 +70,63 @@ def make_volume(seed, n=SLICES):
     return x, mask, target
 
 
-def cpu_baseline(model, x_cpu, T, seed, budget_s=20.0):
-    """The oracle's CPU path (torch-CPU conv stack + torch aggregation) on one batch of 32 slices of the same
-    volume (batch_size 32: config/test_brats_baseline_mc.yaml:11).  Bounded: the thread count is the fastest
-    of a short probe and the number of stochastic passes is cut so that the sample takes about budget_s."""
+def make_isic_batch(seed, n=ISIC_IMAGES):
+    """x ~ U(0,1) [n, 3, 256, 256] (images rescaled to 0..1); target = a centred ellipse per image (a lesion),
+    no evaluation mask (the ISIC evaluation has none)."""
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, ISIC_CHANNELS, ISIC_HEIGHT, ISIC_WIDTH, generator=gen)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, ISIC_HEIGHT), torch.linspace(-1, 1, ISIC_WIDTH), indexing='ij')
+    radius = 0.3 + 0.4 * torch.rand(n, generator=gen)
+    target = (((yy / 0.9) ** 2 + xx ** 2)[None] < (radius ** 2)[:, None, None]).to(torch.uint8)
+    return x, torch.ones_like(target, dtype=torch.bool), target
+
+
+def cpu_leg(members, params, x_cpu, sel, mask_sets_sel, with_ws, ensemble, budget_s):
+    """The oracle's CPU path (torch-CPU conv stack + torch aggregation, oracle/) on the slices `sel` of the volume with the
+    weights and the dropout masks of the last timed step.  -> (cpu_baseline dict, reference summary on those slices)."""
     from oracle import summary_oracle as so
     from oracle import unet_oracle as uo
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    n = 32
-    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    _, sites = uo.unet_plan(**MODEL_PARAMS)
-    gen = torch.Generator().manual_seed(seed)
-    xs = x_cpu[:n].contiguous()
-    fwd = lambda xx, m: uo.unet_forward(state, xx, m, **MODEL_PARAMS)  # noqa: E731
-    best = None
-    for threads in sorted({min(avail, t) for t in (8, 16, 32, 64, 128)}):
-        torch.set_num_threads(threads)
-        fwd(xs[:4], None)                       # warm-up (thread pool, primitive caches)
-        t0 = time.perf_counter()
-        fwd(xs, None)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[1]:
-            best = (threads, dt)
-        if dt > 8.0:
-            break
-    threads, t_fwd = best
+    threads = min(avail, 32)
     torch.set_num_threads(threads)
-    t_cpu = int(max(1, min(T, budget_s / t_fwd - 1)))
-    mask_sets = [uo.sample_masks(sites, n, MODEL_PARAMS['dropout'], gen) for _ in range(t_cpu)]
+    states = [{k: v.detach().cpu() for k, v in m.state_dict().items()} for m in members]
+    xs = x_cpu[sel].contiguous()
+    fwd = [lambda xx, m, st=st: uo.unet_forward(st, xx, m, **params) for st in states]
+    fwd[0](xs[:2], None)                        # warm-up (thread pool, primitive caches)
     t0 = time.perf_counter()
-    ws, multi = so.mc_probabilities(fwd, xs, mask_sets)
-    out = so.multi_prediction_summary(multi)
+    if ensemble:
+        multi = so.ensemble_probabilities(fwd, xs)
+        ws = None
+    else:
+        ws, multi = so.mc_probabilities(fwd[0], xs, mask_sets_sel)
+    ref = so.multi_prediction_summary(multi)
     dt = time.perf_counter() - t0
-    volumes = t_cpu * n / SLICES            # MC-sample-volume equivalents processed (ws pass timed, not counted)
-    return dict(value=volumes / dt, unit='MC-sample-volumes/s', cores=threads, kind='port',
-                sample='{} of {} slices x ({} MC passes + ws pass) through oracle/ (torch-CPU, {} of {} host threads) '
-                       'in {:.1f} s'.format(n, SLICES, t_cpu, threads, avail, dt)), mask_sets, out
+    if ws is not None and with_ws:
+        ref['ws_probabilities'] = ws
+    passes = multi.shape[0]
+    n_total = x_cpu.shape[0]
+    units = passes * len(sel) / n_total            # sample-volume equivalents (the ws pass is timed, not counted)
+    return dict(value=units / dt, cores=threads, kind='port',
+                sample='{} of {} slices x ({} {}{}) through oracle/ (torch-CPU, {} of {} host threads) in {:.1f} s (budget {:.0f} s)'
+                       .format(len(sel), n_total, passes, 'members' if ensemble else 'MC passes', '' if ensemble else ' + ws pass',
+                               threads, avail, dt, budget_s)), ref
+
+
+def cpu_probe_slices(member, params, x_cpu, passes_total, budget_s, n_max=32):
+    """How many slices the CPU leg can take within budget_s: one timed 4-slice forward of the oracle."""
+    from oracle import unet_oracle as uo
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 32))
+    state = {k: v.detach().cpu() for k, v in member.state_dict().items()}
+    xs = x_cpu[:4].contiguous()
+    uo.unet_forward(state, xs[:1], None, **params)
+    t0 = time.perf_counter()
+    uo.unet_forward(state, xs, None, **params)
+    per_slice = (time.perf_counter() - t0) / 4
+    n = int(budget_s / max(per_slice * passes_total, 1e-6))
+    return max(4, min(n_max, x_cpu.shape[0], n // 4 * 4))
 
 
 def calibration_kernels(device, volumes=160, reps=5):
@@ -139,7 +165,7 @@ def calibration_kernels(device, volumes=160, reps=5):
     nbytes = volumes * n * 6
     out['ece_hist'] = dict(bound='hbm', ms=ms, achieved=nbytes / ms / 1e6, peak=PEAK_HBM_GBS, unit='GB/s',
                            frac=nbytes / ms / 1e6 / PEAK_HBM_GBS, bytes=nbytes, volumes=volumes)
-    ue = (ctypes.c_double * 11)(*[0.05 * k for k in range(1, 11)] + [0.95])
+    ue = (ctypes.c_double * 11)(*([0.05] + [0.1 * k for k in range(1, 10)] + [0.95]))   # bin-eval/eval_uncertainty.py:239
     cnt = torch.empty((volumes, 11, 8), device=device, dtype=torch.int64)
     ws2 = torch.empty(max(lib.rcu_unc_workspace_bytes(n, volumes), 8), device=device, dtype=torch.uint8)
     ms = timed(lambda: _lib.check(lib.rcu_unc_counts(_lib.ptr(p), 0, _lib.ptr(pred), _lib.ptr(t), _lib.ptr(m), n, volumes,
@@ -150,14 +176,41 @@ def calibration_kernels(device, volumes=160, reps=5):
     return out
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a child process on a free rendezvous port of 127.0.0.1.  Never an exec, and only from a process that has made no GPU call."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def split_masks(model, flat, n, rows):
+    """Concatenated device mask tensor [site][n][C_site] -> list of per-site [len(rows), C_site] CPU tensors."""
+    out, off = [], 0
+    for _, c in model.dropout_sites():
+        out.append(flat[off:off + n * c].view(n, c)[rows].cpu())
+        off += n * c
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--mc', type=int, default=20, help='T: stochastic passes per volume')
+    ap.add_argument('--workload', choices=('brats', 'isic'), default='brats',
+                    help='brats: 160 slices of 4x192x128 (the headline, BASELINE configs[2]); isic: 32 images of 3x256x256 (configs[1])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=12.0, help='seconds of CPU work the oracle leg may take (bounded sample)')
     ap.add_argument('--no-ws', action='store_true', help='skip the deterministic weight-scaling pass')
+    ap.add_argument('--pass-group', type=int, default=1, help='MC passes of a rank per launch (N * g samples per batch)')
     ap.add_argument('--ensemble', type=int, default=0, metavar='K',
                     help='K ensemble members (seeds 20..20+K-1) instead of T MC passes (BASELINE config "BraTS ensemble")')
     ap.add_argument('--aleatoric', action='store_true',
@@ -166,11 +219,15 @@ def main():
     if args.aleatoric and args.ensemble:
         raise SystemExit('--aleatoric and --ensemble exclude each other')
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as a fresh child (this process has not touched the GPU and
+        # never will), relay the child's output -- rank 0 prints the one JSON line -- and exit with its return code
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit('--gpus {} but WORLD_SIZE={}: launch N>1 through torch.distributed.run'.format(args.gpus, world))
+        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
     # Test-only switches for a box with ONE GPU (RCCL refuses two ranks per device): all ranks on device 0 over gloo.
     single_device = os.environ.get('RCU_BENCH_SINGLE_DEVICE') == '1'
     backend = os.environ.get('RCU_BENCH_BACKEND', 'nccl')
@@ -190,26 +247,30 @@ def main():
 
     T = args.mc
     seed = 20                                   # config seed (config/test_brats_baseline_mc.yaml:6)
-    model = make_model(seed, device, sigma_out=args.aleatoric)
-    x_cpu, mask_cpu, target_cpu = make_volume(seed)
+    isic = args.workload == 'isic'
+    params = ISIC_PARAMS if isic else MODEL_PARAMS
+    n_slices, height, width = (ISIC_IMAGES, ISIC_HEIGHT, ISIC_WIDTH) if isic else (SLICES, HEIGHT, WIDTH)
+    unit_name = 'image' if isic else 'volume'
+    model = make_model(seed, device, sigma_out=args.aleatoric, params=params)
+    x_cpu, mask_cpu, target_cpu = make_isic_batch(seed) if isic else make_volume(seed)
     x = x_cpu.to(device)
-    ctx = steps.TorchTestContext(str(device), model)
     if args.ensemble:
         T = args.ensemble
-        members = [model] + [make_model(seed + k, device) for k in range(1, T)]
+        members = [model] + [make_model(seed + k, device, params=params) for k in range(1, T)]
         runner = rdist.ShardedEnsembleRunner(members, rank=rank, world=world)
     elif args.aleatoric:
         members = [model]
-        runner = rdist.ShardedAleatoricMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world)
+        runner = rdist.ShardedAleatoricMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed)
     else:
         members = [model]
-        runner = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world)
-    torch.manual_seed(seed + rank)              # dropout masks: independent streams per rank
+        runner = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed,
+                                       pass_group=args.pass_group)
+    # dropout masks: drawn per (seed, volume, pass) by the runner -- the same T samples whatever the world size
 
-    def one_step(k):
+    def one_step(k, xin=x):
         # N>1: the reduce runs on RCCL's stream and the root finalises on a side stream, so the ranks'
         # compute streams do not meet at every volume (rcu_amd.distributed.ShardedMcRunner.step_async)
-        return runner.step_async(x, k)
+        return runner.step_async(xin, k)
 
     for k in range(args.warmup):
         one_step(k).result()
@@ -217,7 +278,8 @@ def main():
     my_jobs = [j for k in range(args.warmup, args.warmup + args.steps) for j in runner.jobs_of(k, rank)]
     for i, m in enumerate(members):
         count = sum(1 for j in my_jobs if j - 1 == i) if args.ensemble else len(my_jobs)
-        m.profile_begin(HEIGHT, WIDTH, SLICES, max(count, 1))
+        m.profile_begin(height, width, n_slices * args.pass_group, max(count, 1))
+    runner.forwards_run = 0
 
     torch.cuda.synchronize()
     if world > 1:
@@ -232,77 +294,106 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    forwards_per_rank = [runner.forwards_run]
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        counts = torch.zeros(world, device=device, dtype=torch.int64)
+        counts[rank] = runner.forwards_run
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        forwards_per_rank = [int(v) for v in counts.tolist()]
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
 
-    forwards, slot_ms = 0, None
+    launches, slot_ms = 0, None
     for m in members:
-        cnt, ms = m.profile_collect(HEIGHT, WIDTH, SLICES)
-        forwards += cnt
+        cnt, ms = m.profile_collect(height, width, n_slices * args.pass_group)
+        launches += cnt
         slot_ms = ms if slot_ms is None else [a + b for a, b in zip(slot_ms, ms)]
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
+    last_step = args.warmup + args.steps - 1
 
-    # ---- roofline of the dominant kernel (this rank's launches in the timed region)
-    layers = model.layer_table(HEIGHT, WIDTH, SLICES)
+    # ---- the same step with the host-to-device copy of the volume inside (SURVEY.md 8d counts it; `value` does not:
+    # inputs are resident when its timed region starts).  Pinned host buffer, copy on the launch stream.  N = 1 only.
+    with_h2d = None
+    if world == 1:
+        x_pin = x_cpu.pin_memory()
+        x_dev = torch.empty_like(x)
+        reps = max(1, min(args.steps, 2))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(reps):
+            x_dev.copy_(x_pin, non_blocking=True)
+            one_step(last_step + 1 + k, x_dev).result()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / reps
+        with_h2d = dict(value=T * (n_slices if isic else 1) / dt, ms_per_step=dt * 1e3, h2d_bytes=x_cpu.numel() * 4,
+                        note='pinned host volume copied on the launch stream inside every step; not the headline value')
+
+    # ---- roofline of the dominant kernel (this rank's launches in the timed region).  A launch covers one pass of the volume, or
+    # pass_group passes (n_slices * g samples) where the runner grouped them: FLOPs count the passes, launches the kernel launches.
+    g = args.pass_group
+    passes_run = max(runner.forwards_run, 1)
+    layers = model.layer_table(height, width, n_slices * g)
     per_kernel = {}
     for L, ms in zip(layers, slot_ms[1:1 + len(layers)]):
         e = per_kernel.setdefault(L['kernel'], dict(ms=0.0, flops=0.0, issued=0.0, launches=0))
         e['ms'] += ms
-        e['flops'] += L['flops_per_slice'] * SLICES * forwards
-        e['issued'] += L['mfma_flops_per_slice'] * SLICES * forwards
-        e['launches'] += forwards
+        e['flops'] += L['flops_per_slice'] * n_slices * passes_run
+        e['issued'] += L['mfma_flops_per_slice'] * n_slices * passes_run
+        e['launches'] += launches
     dominant = max(per_kernel, key=lambda k_: per_kernel[k_]['ms'])
     d = per_kernel[dominant]
     conv_ms = sum(e['ms'] for e in per_kernel.values())
     conv_flops = sum(e['flops'] for e in per_kernel.values())
     conv_issued = sum(e['issued'] for e in per_kernel.values())
-    roofline = dict(bound='mfma', kernel=dominant, achieved=d['flops'] / (d['ms'] * 1e-3) / 1e12,
-                    peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=d['flops'] / (d['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                    traffic=None, launches=d['launches'], avg_launch_ms=d['ms'] / max(d['launches'], 1),
-                    flops_per_launch=d['flops'] / max(d['launches'], 1),
-                    # flops the kernel actually issues to the MFMA pipe (padded channels, whole tiles) / peak:
-                    mfma_pipe_frac=d['issued'] / (d['ms'] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                    # Winograd kernels execute 16/36 (conv units) or 9/36 (up-convolutions) of the canonical multiplications,
-                    # so the algorithmic rate `achieved` can exceed the MFMA peak; the pipe itself is busy mfma_pipe_frac
+    tf = lambda fl, ms_: fl / (ms_ * 1e-3) / 1e12  # noqa: E731
+    # `achieved` / `frac`: FLOPs the kernel EXECUTES on the matrix pipe (padded channels, whole tiles) per second / peak -- the
+    # physical utilisation, <= 1, what SQ_VALU_MFMA_BUSY_CYCLES confirms.  The Winograd kernels execute 16/36 (F(2x2,3x3)),
+    # 36/144 (F(4x4,3x3)) or 9/36 (up-convolutions) of the canonical direct-convolution multiplications, so the ALGORITHMIC rate
+    # (2*Cin*Cout*9*H*W per layer) is reported apart as achieved_canonical / canonical_frac and can exceed 1.
+    roofline = dict(bound='mfma', kernel=dominant, achieved=tf(d['issued'], d['ms']), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                    frac=tf(d['issued'], d['ms']) / PEAK_FP32_MFMA_TFLOPS,
+                    achieved_canonical=tf(d['flops'], d['ms']), canonical_frac=tf(d['flops'], d['ms']) / PEAK_FP32_MFMA_TFLOPS,
                     executed_over_algorithmic=d['issued'] / d['flops'],
-                    all_conv_kernels=dict(achieved=conv_flops / (conv_ms * 1e-3) / 1e12,
-                                          frac=conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                                          mfma_pipe_frac=conv_issued / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                                          ms_per_forward=conv_ms / max(forwards, 1)),
-                    other_ms_per_forward=dict(input_relayout=slot_ms[0] / max(forwards, 1),
-                                              head_softmax_accumulate=slot_ms[-1] / max(forwards, 1)),
-                    per_kernel={k_: dict(ms_per_forward=e['ms'] / max(forwards, 1),
-                                         tflops=e['flops'] / (e['ms'] * 1e-3) / 1e12) for k_, e in per_kernel.items()})
+                    traffic=None, launches=d['launches'], avg_launch_ms=d['ms'] / max(d['launches'], 1),
+                    flops_per_launch=d['flops'] / max(d['launches'], 1), executed_flops_per_launch=d['issued'] / max(d['launches'], 1),
+                    all_conv_kernels=dict(achieved=tf(conv_issued, conv_ms), frac=tf(conv_issued, conv_ms) / PEAK_FP32_MFMA_TFLOPS,
+                                          achieved_canonical=tf(conv_flops, conv_ms),
+                                          canonical_frac=tf(conv_flops, conv_ms) / PEAK_FP32_MFMA_TFLOPS,
+                                          ms_per_forward=conv_ms / passes_run),
+                    other_ms_per_forward=dict(input_relayout=slot_ms[0] / passes_run,
+                                              head_softmax_accumulate=slot_ms[-1] / passes_run),
+                    per_kernel={k_: dict(ms_per_forward=e['ms'] / passes_run, tflops_executed=tf(e['issued'], e['ms']),
+                                         frac=tf(e['issued'], e['ms']) / PEAK_FP32_MFMA_TFLOPS,
+                                         tflops_canonical=tf(e['flops'], e['ms'])) for k_, e in per_kernel.items()})
     # the fused head (1x1 classifier conv + softmax + entropy + accumulate into the statistics): an HBM scan.
     # It reads the 32-channel feature map instead of logits (the logits never exist in HBM) and
     # read-modify-writes the S=2 float32 statistics planes (94.4 MB per sample-volume if
     # logits were materialised; here 4*V*32 + 2*2*4*V bytes, V = voxels).
-    vox = SLICES * HEIGHT * WIDTH
+    vox = n_slices * height * width
     head_bytes = 4.0 * vox * 32 + 2 * 2 * 4.0 * vox
     # In the timed region the classifier + softmax + statistics update run inside conv_cls.0's epilogue (one pass per
     # sample, two classes: csrc/rcu_wino.hip, wino_epilogue_head) and have no launch of their own; the standalone head kernel
     # -- the path of pass groups and of the sigma / feature outputs, same arithmetic, same bits -- is timed here, outside
     # the timed region, on the same volume (RCU_FUSE_HEAD=0 is read per forward).
-    fused_head_ms = slot_ms[-1] / max(forwards, 1)
+    fused_head_ms = slot_ms[-1] / passes_run
     os.environ['RCU_FUSE_HEAD'] = '0'
     try:
-        probe = steps.McStatistics(SLICES, 2, HEIGHT, WIDTH, device)
+        probe = steps.McStatistics(n_slices, 2, height, width, device)
         model.forward_accumulate(x, probe)
-        model.profile_begin(HEIGHT, WIDTH, SLICES, 3)
+        model.profile_begin(height, width, n_slices, 3)
         for _ in range(3):
             model.forward_accumulate(x, probe)
         torch.cuda.synchronize()
-        cnt_h, ms_h = model.profile_collect(HEIGHT, WIDTH, SLICES)
+        cnt_h, ms_h = model.profile_collect(height, width, n_slices)
         head_ms = ms_h[-1] / max(cnt_h, 1)
         del probe
     finally:
         del os.environ['RCU_FUSE_HEAD']
-    roofline['other_ms_per_forward']['head_softmax_accumulate'] = fused_head_ms
     roofline['other_ms_per_forward']['head_fused_into'] = 'conv_cls.0 epilogue' if fused_head_ms < 0.5 * head_ms else None
     # the first conv kernel (csrc/rcu_first.hip) reads the NCHW input itself: no re-layout kernel in the timed region then
     roofline['other_ms_per_forward']['input_read_by'] = layers[0]['kernel'] if layers[0]['kernel'].startswith('conv3x3_first') else 'pack_input_kernel'
@@ -310,17 +401,17 @@ def main():
                                    unit='GB/s', frac=head_bytes / head_ms / 1e6 / PEAK_HBM_GBS, bytes_per_launch=head_bytes,
                                    avg_launch_ms=head_ms, measured='standalone launches outside the timed region')
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and not isic:
         with open(pmc_path) as f:
             pmc = json.load(f)
         if dominant in pmc:
             roofline['traffic'] = pmc[dominant]
 
-    # ---- parity numbers outside the timed region: ECE on the GPU maps vs the oracle on the same maps, and
-    # (with the CPU baseline) the end-to-end difference on the slices the CPU path processed
+    # ---- parity, outside the timed region, of the TIMED output (last step): ECE on the GPU maps vs the oracle on the same maps,
+    # and -- the CPU leg -- the oracle's own forward passes on a slice sample of the same volume under the same dropout masks
     pred, p_fg = steps.prediction_and_foreground(out['probabilities'])
     ece_gpu = ev.ece_binary(p_fg, target_cpu, mask=mask_cpu)
-    parity = dict(ece=ece_gpu)
+    parity = dict(ece=ece_gpu, of='the output of the last timed step')
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import calib_oracle as co
@@ -328,24 +419,35 @@ def main():
         ece_oracle = co.ece_binary(np.stack([1 - p_np, p_np], -1), target_cpu.numpy(), mask=mask_cpu.numpy())
         parity['ece_delta_same_maps'] = abs(ece_gpu - ece_oracle)
         parity['bin_ids_equal'] = bool(np.array_equal(ev.bin_ids(p_np), co.bin_ids(p_np.reshape(-1))))
-    if not args.no_cpu_baseline and world == 1 and not args.ensemble and not args.aleatoric:     # the CPU leg: rank 0 at N=1 only
-        cpu, mask_sets, ref = cpu_baseline(model, x_cpu, T, seed)
-        n = ref['probabilities'].shape[0]
-        bc = steps.BatchContext({'images': x[:n].contiguous()}, 0)
-        steps.McPredictStep(len(mask_sets), masks=mask_sets)(bc, None, ctx)
-        steps.MultiPredictionSummary()(bc, None, ctx)
-        parity['max_abs_dprob_vs_cpu'] = float((bc.output['probabilities'].cpu() - ref['probabilities']).abs().max())
-        parity['max_abs_dentropy_vs_cpu'] = float((bc.output['entropy'].cpu() - ref['entropy']).abs().max())
-        pg = bc.output['probabilities'][:, 1].cpu().numpy()
+    if not args.no_cpu_baseline and world == 1 and not args.aleatoric:     # the CPU leg: rank 0 at N=1 only
+        passes_total = T + (0 if (args.ensemble or args.no_ws) else 1)
+        n_sel = cpu_probe_slices(model, params, x_cpu, passes_total, args.cpu_budget)
+        sel = np.unique(np.linspace(0, n_slices - 1, n_sel).round().astype(np.int64))     # first, last and evenly between
+        mask_sets_sel = None
+        if not args.ensemble:
+            mask_sets_sel = [split_masks(model, runner.masks_of(x, last_step, j), n_slices, torch.as_tensor(sel))
+                             for j in range(1, T + 1)]
+        cpu, ref = cpu_leg(members, params, x_cpu, sel, mask_sets_sel, not args.no_ws, bool(args.ensemble), args.cpu_budget)
+        cpu['unit'] = 'member-{}s/s'.format(unit_name) if args.ensemble else 'MC-sample-{}s/s'.format(unit_name)
+        if isic:
+            cpu['value'] *= n_slices                      # images, not batches
+        idx = torch.as_tensor(sel, device=device)
+        parity['slices_compared'] = [int(v) for v in sel]
+        for key in ('probabilities', 'entropy', 'ws_probabilities'):
+            if key in ref and key in out:
+                parity['max_abs_d{}_vs_cpu'.format(key)] = float((out[key][idx].cpu() - ref[key]).abs().max())
+        pg = out['probabilities'][idx][:, 1].cpu().numpy()
         pc = ref['probabilities'][:, 1].numpy()
-        tg, mk = target_cpu[:n].numpy(), mask_cpu[:n].numpy()
+        tg, mk = target_cpu[sel].numpy(), mask_cpu[sel].numpy()
         parity['ece_delta_vs_cpu'] = abs(ev.ece_binary(pg, tg, mask=mk) - co.ece_binary(np.stack([1 - pc, pc], -1), tg, mask=mk))
 
+    units = T * (n_slices if isic else 1)
+    shape = '{}x{}x{}'.format(ISIC_CHANNELS, height, width) if isic else '4x160x192x128'
     result = {
-        'metric': 'ensemble-member-volumes/sec (4x160x192x128, K={})'.format(T) if args.ensemble
-                  else 'MC-sample-volumes/sec (4x160x192x128, T={}{})'.format(T, ', sigma head' if args.aleatoric else ''),
-        'value': T * args.steps / elapsed,
-        'unit': 'member-volumes/s' if args.ensemble else 'MC-sample-volumes/s',
+        'metric': ('ensemble-member-{}s/sec ({}, K={})'.format(unit_name, shape, T) if args.ensemble
+                   else 'MC-sample-{}s/sec ({}, T={}{})'.format(unit_name, shape, T, ', sigma head' if args.aleatoric else '')),
+        'value': units * args.steps / elapsed,
+        'unit': 'member-{}s/s'.format(unit_name) if args.ensemble else 'MC-sample-{}s/s'.format(unit_name),
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True,
@@ -353,17 +455,26 @@ def main():
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': ('BraTS ensemble: {} U-Net(2,4,depth 4,start_filters 32) members over 160 slices of 4x192x128 '
+        'config': {'workload': ('ISIC {}: 2D U-Net(2,3,depth 4,start_filters 32,dropout 0.05) over a batch of {} images of 3x256x256, '
+                                '{} + mean/entropy aggregation per step'
+                                .format('ensemble' if args.ensemble else 'baseline_mc', n_slices,
+                                        '{} members'.format(T) if args.ensemble else
+                                        'T={} MC-dropout passes{}'.format(T, '' if args.no_ws else ' + weight-scaling pass'))) if isic else
+                               ('BraTS ensemble: {} U-Net(2,4,depth 4,start_filters 32) members over 160 slices of 4x192x128 '
                                 '+ mean/entropy aggregation per step'.format(T)) if args.ensemble else
                                ('BraTS {}: 2D U-Net(2,4,depth 4,start_filters 32,dropout 0.05{}) over 160 slices '
                                 'of 4x192x128, T={} MC-dropout passes{} + mean/entropy aggregation per step'
                                 .format('aleatoric + MC' if args.aleatoric else 'baseline_mc', ', sigma_out' if args.aleatoric else '',
                                         T, '' if args.no_ws else ' + weight-scaling pass')),
-                   'T': T, 'ws_pass': not (args.no_ws or args.ensemble), 'slices': SLICES, 'height': HEIGHT, 'width': WIDTH,
+                   'T': T, 'ws_pass': not (args.no_ws or args.ensemble), 'slices': n_slices, 'height': height, 'width': width,
+                   'pass_group': g,
                    'sharding': 'passes over ranks, one RCCL sum-reduce of the statistics per step' if world > 1 else 'none',
-                   'gflop_per_sample_volume': conv_flops / max(forwards, 1) / 1e9},
+                   'gflop_per_sample_{}'.format(unit_name): conv_flops / passes_run / 1e9 / (n_slices if isic else 1)},
+        'n_ranks_seen': n_ranks_seen,
+        'forwards_per_rank': forwards_per_rank,
+        'with_h2d': with_h2d,
         'roofline': roofline,
-        'calibration_kernels': calibration_kernels(device) if world == 1 else None,
+        'calibration_kernels': calibration_kernels(device) if (world == 1 and not isic) else None,
         'cpu_baseline': cpu,
         'parity': parity,
     }

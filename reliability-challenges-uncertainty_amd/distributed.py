@@ -32,29 +32,38 @@ class HipEngine:
         self.do_mi, self.do_var = do_mi, do_var
 
     def buffers(self, x, with_ws):
-        """-> (flat reduce buffer, statistics object living in its head, ws tensor or None, ws_apart):
-        ws lives in the tail of the flat buffer unless the statistics are float64 (ws_apart=True)."""
+        """-> (flat reduce buffer, statistics object living in its head, ws tensor or None): the weight-scaling
+        probabilities live in the tail of the ONE flat buffer (as float64 when the statistics are float64 -- a float32
+        value is exact in float64, and a sum with the other ranks' zeros is too), so a volume is always one collective."""
         n, _, h, w = x.shape
         c = self.model.nb_classes
         dtype = torch.float64 if self.do_var else torch.float32
         n_stats = steps_mod.McStatistics.blob_elements(n, c, h * w, self.do_mi, self.do_var)
-        n_ws = n * c * h * w if (with_ws and dtype == torch.float32) else 0
+        n_ws = n * c * h * w if with_ws else 0
         flat = torch.empty(n_stats + n_ws, device=x.device, dtype=dtype)
         stats = steps_mod.McStatistics(n, c, h, w, x.device, self.do_mi, self.do_var, blob=flat[:n_stats])
         ws = None
         if with_ws:
-            ws = flat[n_stats:].view(n, c, h, w) if n_ws else torch.empty((n, c, h, w), device=x.device)
+            ws = flat[n_stats:].view(n, c, h, w)
             ws.zero_()
-        return flat, stats, ws, bool(with_ws and not n_ws)
+        return flat, stats, ws
 
     def ws_pass(self, x, ws_out):
         steps_mod.set_dropout_mode(self.model, False)
         ws_out.copy_(steps_mod.softmax(self.model(x)))
 
-    def mc_pass(self, x, stats, masks=None):
+    def sample_masks(self, x, generator, passes=1):
+        """Dropout factors of ``passes`` stochastic passes over x (rows [site][passes * N][C_site]) from ``generator``."""
         steps_mod.set_dropout_mode(self.model, True)
         try:
-            self.model.forward_accumulate(x, stats, masks)
+            return self.model.sample_masks(x.shape[0] * passes, x.device, generator=generator)
+        finally:
+            steps_mod.set_dropout_mode(self.model, False)
+
+    def mc_pass(self, x, stats, masks=None, passes=1):
+        steps_mod.set_dropout_mode(self.model, True)
+        try:
+            self.model.forward_accumulate(x, stats, masks, passes=passes)
         finally:
             steps_mod.set_dropout_mode(self.model, False)
 
@@ -66,7 +75,7 @@ class HipEngine:
         return stats.finalize(self.do_mi, self.do_var, count=count)
 
     def ws_outputs(self, ws):
-        return {'ws_probabilities': ws}
+        return {'ws_probabilities': ws if ws.dtype == torch.float32 else ws.float()}
 
 
 class AleatoricHipEngine(HipEngine):
@@ -90,7 +99,7 @@ class AleatoricHipEngine(HipEngine):
         flat[n_stats:].zero_()
         stats.sigma_sum = flat[n_stats:n_stats + n_vol].view(n, c, h, w)
         ws = flat[n_stats + n_vol:].view(2, n, c, h, w) if with_ws else None
-        return flat, stats, ws, False
+        return flat, stats, ws
 
     def ws_pass(self, x, ws_out):
         steps_mod.set_dropout_mode(self.model, False)
@@ -100,7 +109,9 @@ class AleatoricHipEngine(HipEngine):
         lib.check(lib.load().rcu_aleatoric(lib.ptr(logits), lib.ptr(raw.contiguous()), n, h * w, c, int(self.is_log_sigma),
                                            lib.ptr(ws_out[0]), lib.ptr(ws_out[1]), None, None, lib.current_stream()))
 
-    def mc_pass(self, x, stats, masks=None):
+    def mc_pass(self, x, stats, masks=None, passes=1):
+        if passes != 1:
+            raise ValueError('the sigma-head passes run one per launch')
         steps_mod.set_dropout_mode(self.model, True)
         try:
             self.model.forward_accumulate_sigma(x, stats, stats.sigma_sum, masks, self.is_log_sigma)
@@ -116,15 +127,41 @@ class AleatoricHipEngine(HipEngine):
         return {'ws_probabilities': ws[0], 'ws_sigma': ws[1]}
 
 
+def job_seed(seed, step_index, job):
+    """Seed of the dropout masks of MC pass ``job`` of volume ``step_index``: a function of (seed, volume, pass) only."""
+    return (int(seed) * 1000003 + int(step_index) * 10007 + int(job)) % (2 ** 63 - 1)
+
+
 class ShardedMcRunner:
+    """``seed``: base seed of the dropout masks.  The masks of MC pass j of volume k are drawn from a generator seeded with
+    ``job_seed(seed, k, j)``, so they do not depend on the rank that runs the pass nor on the world size: every world size
+    aggregates the same T samples (ranks that are all seeded alike, as the reference's ``do_seed`` does with
+    ``config.seed``, would otherwise draw the same mask sequence on every rank and the T passes would hold only about T / world
+    distinct samples).  ``seed=None`` draws from the device's default generator after seeding it per rank once.
+    ``pass_group``: MC passes of one rank run ``pass_group`` at a time as one batch (rcu_unet_forward_accumulate_passes)."""
 
     def __init__(self, model, mc_steps, ws_pass=True, rank=0, world=1, engine=None, do_mi=False, do_var=False,
-                 root=0):
+                 root=0, seed=0, pass_group=1):
         self.engine = engine if engine is not None else HipEngine(model, do_mi, do_var)
         self.mc_steps = mc_steps
         self.ws_pass = ws_pass
         self.rank, self.world, self.root = rank, world, root
         self.jobs_per_step = mc_steps + (1 if ws_pass else 0)
+        self.seed = seed
+        self.pass_group = max(1, int(pass_group))
+        self._generator = None
+        self.forwards_run = 0          # launches of this rank (a pass group counts its passes)
+
+    def masks_of(self, x, step_index, job):
+        """The device mask tensor MC pass ``job`` (1..T) of volume ``step_index`` runs under (None without a seed / an engine
+        that samples on its own)."""
+        sample = getattr(self.engine, 'sample_masks', None)
+        if self.seed is None or sample is None:
+            return None
+        if self._generator is None:
+            self._generator = torch.Generator(device=x.device)
+        self._generator.manual_seed(job_seed(self.seed, step_index, job))
+        return sample(x, self._generator)
 
     def _ws_outputs(self, ws):
         hook = getattr(self.engine, 'ws_outputs', None)
@@ -138,27 +175,41 @@ class ShardedMcRunner:
         jobs = self.job_list()
         return [j for i, j in enumerate(jobs) if (i + step * len(jobs)) % self.world == rank]
 
-    def _run_job(self, job, x, stats, ws, mask_sets):
+    def _run_job(self, job, x, stats, ws, mask_sets, step_index=0):
         if job == 0:
             self.engine.ws_pass(x, ws)
         else:
-            self.engine.mc_pass(x, stats, None if mask_sets is None else mask_sets[job - 1])
+            masks = self.masks_of(x, step_index, job) if mask_sets is None else mask_sets[job - 1]
+            self.engine.mc_pass(x, stats, masks)
+        self.forwards_run += 1
 
     def _run_jobs(self, x, step_index, mask_sets):
-        flat, stats, ws, ws_apart = self.engine.buffers(x, self.ws_pass)
-        for job in self.jobs_of(step_index, self.rank):
-            self._run_job(job, x, stats, ws, mask_sets)
-        return flat, stats, ws, ws_apart
+        flat, stats, ws = self.engine.buffers(x, self.ws_pass)
+        jobs = self.jobs_of(step_index, self.rank)
+        i = 0
+        while i < len(jobs):
+            group = [j for j in jobs[i:i + self.pass_group] if j != 0] if jobs[i] != 0 else []
+            if len(group) > 1:     # consecutive MC passes of this rank as one batch of N * g samples
+                if mask_sets is None:
+                    ms = [self.masks_of(x, step_index, j) for j in group]
+                    ms = None if any(m is None for m in ms) else ms
+                else:
+                    ms = [mask_sets[j - 1] for j in group]
+                self.engine.mc_pass(x, stats, ms, passes=len(group))
+                self.forwards_run += len(group)
+                i += len(group)
+            else:
+                self._run_job(jobs[i], x, stats, ws, mask_sets, step_index)
+                i += 1
+        return flat, stats, ws
 
     def step(self, x, step_index=0, mask_sets=None):
         """One volume.  Returns the summary dict on the root rank (probabilities, entropy, ... and
         ws_probabilities when enabled), None elsewhere.  ``mask_sets``: optional list of T injected
         mask sets, indexed by MC pass."""
-        flat, stats, ws, ws_apart = self._run_jobs(x, step_index, mask_sets)
+        flat, stats, ws = self._run_jobs(x, step_index, mask_sets)
         if self.world > 1:
-            dist.reduce(flat, dst=self.root, op=dist.ReduceOp.SUM)          # statistics (+ ws) in one collective
-            if ws_apart:
-                dist.reduce(ws, dst=self.root, op=dist.ReduceOp.SUM)        # float64 statistics: ws travels apart
+            dist.reduce(flat, dst=self.root, op=dist.ReduceOp.SUM)          # statistics (+ ws): THE collective of the volume
         if self.rank != self.root:
             return None
         out = self.engine.finalize(stats, self.mc_steps)
@@ -177,10 +228,8 @@ class ShardedMcRunner:
             self._side = torch.cuda.Stream(device=x.device) if x.is_cuda else None
         while len(self._inflight) >= depth:
             self._inflight.popleft().retire()
-        flat, stats, ws, ws_apart = self._run_jobs(x, step_index, mask_sets)
+        flat, stats, ws = self._run_jobs(x, step_index, mask_sets)
         works = [dist.reduce(flat, dst=self.root, op=dist.ReduceOp.SUM, async_op=True)]
-        if ws_apart:
-            works.append(dist.reduce(ws, dst=self.root, op=dist.ReduceOp.SUM, async_op=True))
         pending = PendingSummary(None, works=works, keep=(flat, ws))
         if self.rank == self.root:
             if self._side is not None:
@@ -190,9 +239,7 @@ class ShardedMcRunner:
                     out = self.engine.finalize(stats, self.mc_steps)
                     pending.ready = torch.cuda.Event()
                     pending.ready.record(self._side)
-                for t in (flat, ws):
-                    if t is not None:
-                        t.record_stream(self._side)
+                flat.record_stream(self._side)
                 pending.works = []
             else:
                 for w in works:
@@ -215,9 +262,9 @@ class ShardedAleatoricMcRunner(ShardedMcRunner):
     """ShardedMcRunner over AleatoricHipEngine (BASELINE config "BraTS aleatoric + MC: sigma-head U-Net, T = 50, samples sharded
     over 8 MI355X"): the summary gains ``sigma`` (mean over the passes) and ``ws_sigma``."""
 
-    def __init__(self, model, mc_steps, is_log_sigma=False, ws_pass=True, rank=0, world=1, do_mi=False, root=0):
+    def __init__(self, model, mc_steps, is_log_sigma=False, ws_pass=True, rank=0, world=1, do_mi=False, root=0, seed=0):
         super().__init__(model, mc_steps, ws_pass=ws_pass, rank=rank, world=world,
-                         engine=AleatoricHipEngine(model, is_log_sigma, do_mi), do_mi=do_mi, root=root)
+                         engine=AleatoricHipEngine(model, is_log_sigma, do_mi), do_mi=do_mi, root=root, seed=seed)
 
 
 class ShardedEnsembleRunner(ShardedMcRunner):
@@ -233,8 +280,9 @@ class ShardedEnsembleRunner(ShardedMcRunner):
                          engine=engine, do_mi=do_mi, do_var=do_var, root=root)
         self.members = members
 
-    def _run_job(self, job, x, stats, ws, mask_sets):
+    def _run_job(self, job, x, stats, ws, mask_sets, step_index=0):
         self.engine.member_pass(self.members[job - 1], x, stats)
+        self.forwards_run += 1
 
 
 class PendingSummary:

@@ -30,13 +30,18 @@ class OracleEngine:
         flat = torch.zeros(n * c * h * w * (2 if with_ws else 1))
         stats = flat[:n * c * h * w].view(n, c, h, w)
         ws = flat[n * c * h * w:].view(n, c, h, w) if with_ws else None
-        return flat, stats, ws, False
+        return flat, stats, ws
 
     def ws_pass(self, x, ws_out):
         ws_out.copy_(torch.softmax(self.uo.unet_forward(self.state, x, None, **PARAMS), 1))
 
-    def mc_pass(self, x, stats, masks=None):
-        stats += torch.softmax(self.uo.unet_forward(self.state, x, masks, **PARAMS), 1)
+    def sample_masks(self, x, generator, passes=1):
+        _, sites = self.uo.unet_plan(**PARAMS)
+        return self.uo.sample_masks(sites, x.shape[0], PARAMS['dropout'], generator)
+
+    def mc_pass(self, x, stats, masks=None, passes=1):
+        for ms in ([masks] if passes == 1 else masks):      # a pass group: list of `passes` mask sets
+            stats += torch.softmax(self.uo.unet_forward(self.state, x, ms, **PARAMS), 1)
 
     def member_pass(self, member_state, x, stats):
         stats += torch.softmax(self.uo.unet_forward(member_state, x, None, **PARAMS), 1)
@@ -64,7 +69,7 @@ class OracleAleatoricEngine:
         stats = flat[:vol].view(shape)
         stats.sigma_sum = flat[vol:2 * vol].view(shape)
         ws = flat[2 * vol:].view((2,) + shape) if with_ws else None
-        return flat, stats, ws, False
+        return flat, stats, ws
 
     def ws_pass(self, x, ws_out):
         lg, raw = self.uo.unet_forward(self.state, x, None, **self.params)
@@ -128,6 +133,13 @@ def _worker(rank, world, port, out_dir):
         else:
             assert out is None
     runner.drain()
+    # masks drawn per (seed, volume, pass): the result must not depend on the world size, with and without pass groups
+    for name, group in (('seeded', 1), ('seeded_grouped', 2)):
+        rs = ShardedMcRunner(None, T, ws_pass=True, rank=rank, world=world, engine=OracleEngine(state), seed=5, pass_group=group)
+        out = rs.step(x, 1)
+        assert rs.forwards_run == len(rs.jobs_of(1, rank))
+        if rank == 0:
+            np.savez(os.path.join(out_dir, name + '.npz'), **{k: v.numpy() for k, v in out.items()})
     # ensemble members instead of MC passes: 3 members on 2 ranks, rotation over the steps
     from oracle import unet_oracle as uo
     from rcu_amd.distributed import ShardedEnsembleRunner
@@ -189,6 +201,16 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         assert np.max(np.abs(got['ws_probabilities'] - ws.numpy())) < 1e-6
         assert np.max(np.abs(got['probabilities'] - ref['probabilities'].numpy())) < 1e-6
         assert np.max(np.abs(got['entropy'] - ref['entropy'].numpy())) < 2e-6
+    sys.path.insert(0, ROOT)
+    from rcu_amd.distributed import ShardedMcRunner, job_seed
+    single = ShardedMcRunner(None, T, ws_pass=True, rank=0, world=1, engine=OracleEngine(state), seed=5).step(x, 1)
+    other = ShardedMcRunner(None, T, ws_pass=True, rank=0, world=1, engine=OracleEngine(state), seed=6).step(x, 1)
+    assert float((single['probabilities'] - other['probabilities']).abs().max()) > 1e-4     # the seed matters
+    assert len({job_seed(5, k, j) for k in range(50) for j in range(1, 51)}) == 2500         # distinct stream per (volume, pass)
+    for name in ('seeded', 'seeded_grouped'):
+        got = np.load(os.path.join(str(tmp_path), name + '.npz'))
+        for key in ('probabilities', 'entropy', 'ws_probabilities'):
+            assert np.max(np.abs(got[key] - single[key].numpy())) < 2e-6, (name, key)
     members = [uo.synthetic_state(100 + k, **PARAMS) for k in range(3)]
     multi = so.ensemble_probabilities([lambda xx, m, st=st: uo.unet_forward(st, xx, m, **PARAMS) for st in members], x)
     ref = so.multi_prediction_summary(multi)

@@ -1,0 +1,114 @@
+"""Parity at BASELINE.json's full sizes and at the shapes real data has (VERDICT r01 weak points 1-2).
+
+* The 160-slice BraTS launch (4 x 160 x 192 x 128): the work-item arithmetic that only triggers at N = 160 (tile ids by
+  reciprocal multiplication, 256-workgroup grids streaming over thousands of tiles).  The first / middle / last slices of the
+  160-slice launch are compared bit for bit with an 8-slice launch of the same slices (slices are independent and every
+  kernel sums in a fixed order) and with the oracle; the fused forward + softmax + accumulate path likewise with injected masks.
+* Native BraTS 240 x 240 slices (levels 240/120/60/30/15: odd sizes -> the direct igemm kernels next to the Winograd ones), the
+  reference's real ISIC size 192 x 256 (scripts/prepare_isic_data.py:29-30) and 3 x 256 x 256, full width, against the
+  oracle, asserting which kernel every layer got.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 2e-6
+PROB_TOL = 1e-4
+PARAMS = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a MI355X'
+    return torch.device('cuda')
+
+
+def _model(params, state, dev):
+    from rcu_amd.model import UNet
+    m = UNet(**params)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in state.items()})
+    return m.to(dev)
+
+
+def _maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+@pytest.mark.timeout(900)
+def test_160_slice_launch_vs_8_slice_launch_and_oracle(dev):
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    st = uo.synthetic_state(31, **PARAMS)
+    g = torch.Generator().manual_seed(9)
+    n, h, w = 160, 192, 128
+    x = torch.randn(n, 4, h, w, generator=g)
+    _, sites = uo.unet_plan(**PARAMS)
+    T = 3
+    mask_sets = [uo.sample_masks(sites, n, 0.3, g) for _ in range(T)]
+    sel = np.r_[0:8, 76:84, 152:160]                           # first, middle and last eight slices
+    groups = [sel[0:8], sel[8:16], sel[16:24]]
+    big = _model(PARAMS, st, dev)
+    small = _model(PARAMS, st, dev)
+    xd = x.to(dev)
+    assert big.layer_table(h, w, n)[1]['kernel'] == small.layer_table(h, w, 8)[1]['kernel']
+
+    # eval pass and one stochastic pass: logits of the 160-slice launch
+    for mk in (None, mask_sets[0]):
+        out = big(xd, mk).cpu().numpy()
+        for rows in groups:
+            mk8 = None if mk is None else [m[rows] for m in mk]
+            out8 = small(xd[rows], mk8).cpu().numpy()
+            assert np.array_equal(out[rows], out8), 'a slice depends on the batch it is launched in'
+            ref = uo.unet_forward(st, x[rows], mk8, **PARAMS).numpy()
+            assert _maxdiff(out[rows], ref) < LOGIT_TOL
+
+    # the fused path of the timed bench: T passes accumulated into the statistics, float32 and float64 (variance) blobs
+    for do_var in (False, True):
+        stats = steps.McStatistics(n, 2, h, w, dev, do_mi=True, do_var=do_var)
+        for mk in mask_sets:
+            big.forward_accumulate(xd, stats, mk)
+        summary = stats.finalize(True, do_var)
+        for rows in groups:
+            s8 = steps.McStatistics(8, 2, h, w, dev, do_mi=True, do_var=do_var)
+            for mk in mask_sets:
+                small.forward_accumulate(xd[rows], s8, [m[rows] for m in mk])
+            sum8 = s8.finalize(True, do_var)
+            for key in summary:
+                assert torch.equal(summary[key][rows], sum8[key]), key
+            multi = torch.stack([torch.softmax(uo.unet_forward(st, x[rows], [m[rows] for m in mk], **PARAMS), 1) for mk in mask_sets])
+            ref = so.multi_prediction_summary(multi, True, do_var)
+            for key in summary:
+                assert _maxdiff(summary[key][rows].cpu().numpy(), ref[key].numpy()) < PROB_TOL, key
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('cin,n,h,w', [(4, 5, 240, 240), (3, 2, 192, 256), (3, 2, 256, 256)])
+def test_real_data_shapes_full_width_vs_oracle(dev, cin, n, h, w):
+    from oracle import unet_oracle as uo
+    params = dict(PARAMS, in_channels=cin)
+    st = uo.synthetic_state(33, **params)
+    g = torch.Generator().manual_seed(10)
+    x = torch.rand(n, cin, h, w, generator=g) if cin == 3 else torch.randn(n, cin, h, w, generator=g)
+    _, sites = uo.unet_plan(**params)
+    masks = uo.sample_masks(sites, n, 0.3, g)
+    m = _model(params, st, dev)
+    rows = m.layer_table(h, w, n)
+    assert len(rows) == 23                                       # 19 conv units (conv_cls.0 last) + 4 up-convolutions
+    # kernel selection (csrc/rcu_api.hip, pick_config): which family every layer got at this shape
+    kernels = [r['kernel'] for r in rows]
+    if (h, w) == (240, 240):
+        # levels 240 / 120 / 60 / 30 / 15: no whole Winograd tile fits below the first level -> the direct igemm kernels carry it
+        assert sum('igemm' in k for k in kernels) >= 16, kernels
+    else:
+        # 192x256 and 256x256: the first unit on its own kernel (whole 8x32 tiles), every other layer on a Winograd kernel
+        assert kernels[0].startswith('conv3x3_first'), kernels
+        # (the 12x16 bottom level of 192x256 has no whole Winograd tile: two units + the up-convolution out of it stay direct)
+        assert sum('winograd' in k for k in kernels[1:]) >= (22 if h == 256 else 19), kernels
+    for mk in (None, masks):
+        ref = uo.unet_forward(st, x, mk, **params).numpy()
+        out = m(x.to(dev), mk).cpu().numpy()
+        assert _maxdiff(out, ref) < LOGIT_TOL
+        assert _maxdiff(torch.softmax(torch.from_numpy(out), 1).numpy(), torch.softmax(torch.from_numpy(ref), 1).numpy()) < PROB_TOL

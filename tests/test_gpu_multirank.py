@@ -43,3 +43,25 @@ def test_bench_two_ranks_through_torch_distributed_run(port, extra):
     assert d['n_gpus'] == 2 and d['steps'] == 2 and d['value'] > 0 and d['scaling'] == 'strong'
     assert d['roofline']['launches'] > 0 and d['cpu_baseline'] is None
     assert d['parity']['bin_ids_equal'] and d['parity']['ece_delta_same_maps'] < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_plain_command_line_starts_its_own_ranks():
+    """`python bench.py --gpus 2` -- no launcher, the form the round driver uses for N = 1 -- must start the two ranks
+    itself (a fresh child process, before any GPU call), print the one JSON line and exit 0.  Both ranks share the one GPU
+    of the test box over gloo (test-only switches); on an 8-GPU node the same line runs one rank per GPU over RCCL."""
+    import json
+    env = dict(os.environ, RCU_BENCH_SINGLE_DEVICE='1', RCU_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--mc', '5']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['n_ranks_seen'] == 2
+    assert len(d['forwards_per_rank']) == 2 and sum(d['forwards_per_rank']) == 2 * 6      # 2 steps x (5 MC + ws pass)
+    assert abs(d['forwards_per_rank'][0] - d['forwards_per_rank'][1]) <= 1
+    assert d['roofline']['frac'] <= 1.0 and d['roofline']['canonical_frac'] > d['roofline']['frac']
+    assert d['parity']['bin_ids_equal'] and d['parity']['ece_delta_same_maps'] < 1e-9
