@@ -106,6 +106,8 @@ static size_t conv_tile_floats(const ConvConfigInfo& ci)
     return (units + 255) / 256 * 256 * 4;
 }
 
+static bool is_head_unit(const ConvLayer& L) { return L.name.rfind("conv_cls.0", 0) == 0; }
+
 static int pick_config(const ConvLayer& L, int n_slices)
 {
     // Winograd kernels (rcu_wino.hip, rcu_wino_up.hip): 16/36 (conv units) and 9/36 (up-convolutions) of the
@@ -138,6 +140,14 @@ static int pick_config(const ConvLayer& L, int n_slices)
         return CONV_CFG_T8x16_N32_FIRST;
     }
     if (wino_on && (L.c1p + L.c2p) % 32 == 0 && (L.c2p == 0 || L.c2p == L.c1p) && max_bytes < ((size_t)1 << 31)) {
+        // F(4x4,3x3) (rcu_wino4.hip) where its 32-pixel-wide tiles fit: 2.25 instead of 4 multiplications per output pixel.
+        // RCU_CONV_WINO4=0 keeps F(2x2,3x3) (A/B tests); the head unit stays on F(2x2,3x3), whose epilogue holds the classifier
+        const char* const w4_env = getenv("RCU_CONV_WINO4");
+        const bool w4_on = !(w4_env && atoi(w4_env) == 0);
+        if (w4_on && L.name2.empty() && !is_head_unit(L) && L.W % 32 == 0) {
+            if (L.H % 32 == 0) return CONV_CFG_WINO4_T32x32_N32;
+            if (L.H % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_WINO4_S2T16x32_N32;
+        }
         if (L.coutp == 32 && L.H % 16 == 0 && L.W % 32 == 0) return CONV_CFG_WINO_T16x32_N32;
         if (L.coutp > 32 && L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T16x16_N64;
         if (L.coutp > 32 && L.H % 8 == 0 && L.W % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_WINO_S2T8x16_N64;
@@ -427,6 +437,31 @@ static int fold_conv(rcu_unet* h, const ConvLayer& L, const std::string& conv, c
                             }
                     }
                 }
+            }
+        }
+        return RCU_OK;
+    }
+    if (ci.WINO == 3) {
+        // F(4x4,3x3): U = G g G^T (6x6) per (cout, cin) with the Lavin-Gray G for the points 0, +-1, +-2, inf; packed per Cin chunk and
+        // cout tile as [position p = 6 i + j][channel pair q][cout][2] (rcu_wino4.hip).  Computed in double, rounded once.
+        static const double G4[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                        {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+        for (int co = 0; co < L.cout; ++co) {
+            const int cop = co0 + co;
+            const int ntile = cop / BN, nn = cop % BN;
+            for (int ci_ = 0; ci_ < cin; ++ci_) {
+                const int kp = ci_ < L.cin1 ? ci_ : L.c1p + (ci_ - L.cin1);
+                const int chunk = kp / KC, kq = kp % KC;
+                const float* w9 = w->data() + ((size_t)co * cin + ci_) * 9;
+                const size_t tile0 = ((size_t)chunk * L.NT + ntile) * tile_floats;
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) {
+                        double u = 0.0;
+                        for (int r = 0; r < 3; ++r)
+                            for (int c = 0; c < 3; ++c) u += G4[i][r] * (double)w9[r * 3 + c] * G4[j][c];
+                        const int p = 6 * i + j;
+                        wpack[tile0 + (((size_t)p * 4 + (kq >> 1)) * BN + nn) * 2 + (kq & 1)] = (float)u;
+                    }
             }
         }
         return RCU_OK;
@@ -857,8 +892,10 @@ extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info*
         const double ncols = (double)L.NT * ci.BN;
         // Winograd: 16 multiplications per 2x2 output tile instead of 9 per pixel
         // and 9 per 2x2 low-resolution tile and parity class (= 9 per low-resolution pixel) for the up-convolutions
+        // F(4x4,3x3): 36 per 4x4 output tile
         out->mfma_flops_per_slice = ci.WINO == 2 ? 2.0 * L.c1p * ncols * 9.0 * (px / 4.0)
-                                                 : 2.0 * (L.c1p + L.c2p) * ncols * (ci.WINO ? 4.0 : (double)ci.TAPS) * px;
+                                    : ci.WINO == 3 ? 2.0 * (L.c1p + L.c2p) * ncols * 36.0 * (px / 16.0)
+                                                   : 2.0 * (L.c1p + L.c2p) * ncols * (ci.WINO ? 4.0 : (double)ci.TAPS) * px;
         if (L.cfg == CONV_CFG_FIRST_T8x32)   // K = 4 channels per tap unless more than four are real
             out->mfma_flops_per_slice = 2.0 * (L.cin1 > 4 ? 8 : 4) * ncols * 9.0 * px;
     }

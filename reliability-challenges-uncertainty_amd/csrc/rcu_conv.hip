@@ -27,7 +27,10 @@
 #include "rcu_kernels.h"
 
 #include <cstdlib>
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 namespace rcu {
 
@@ -568,8 +571,23 @@ static const ConvConfigInfo kInfo[CONV_CFG_COUNT] = {
     {Cfg10::TS, Cfg10::TH, Cfg10::TW, Cfg10::BN, Cfg10::KC, Cfg10::TAPS, "conv3x3_igemm<S2T8x16,N64,K8,db>", Cfg10::KCP, Cfg10::SWZ ? 1 : 0},
 };
 
+hipError_t set_max_dynamic_lds(const void* kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({kernel, dev});
+    return e;
+}
+
 const ConvConfigInfo& conv_config_info(int cfg)
 {
+    if (cfg >= CONV_CFG_WINO4_T32x32_N32) return wino4_config_info(cfg);
     if (cfg == CONV_CFG_FIRST_T8x32) return first_config_info();
     if (cfg >= CONV_CFG_UPW_T16x16_N64) return wino_up_config_info(cfg);
     return cfg >= CONV_CFG_COUNT ? wino_config_info(cfg) : kInfo[cfg];
@@ -578,16 +596,11 @@ const ConvConfigInfo& conv_config_info(int cfg)
 template <class T>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t stream)
 {
-    static bool attr_set = false;
     const unsigned items = (unsigned)a.NTW_total * a.tiles_x * a.tiles_y * a.slice_groups;
     if constexpr (T::DB) {
         if ((a.C1 + a.C2) / T::KC >= 2) {
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_stream<T>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-                if (e != hipSuccess) return e;
-                attr_set = true;
-            }
+            hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_stream<T>), T::LDS_BYTES);
+            if (e != hipSuccess) return e;
             // WGS_PER_CU resident workgroups per CU, each streaming through its share of the tiles
             static const unsigned slots = [] {
                 const char* e = getenv("RCU_CONV_WGS");
@@ -598,19 +611,15 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t stream)
             return hipGetLastError();
         }
     }
-    static bool attr_set_plain = false;
-    if (!attr_set_plain) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set_plain = true;
-    }
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm<T>), T::LDS_BYTES);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(conv_igemm<T>, dim3(items), dim3(T::THREADS), T::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream)
 {
+    if (cfg >= CONV_CFG_WINO4_T32x32_N32) return launch_conv_wino4(cfg, a, stream);
     if (cfg == CONV_CFG_FIRST_T8x32) return launch_conv_first(a, stream);
     if (cfg >= CONV_CFG_UPW_T16x16_N64) return launch_upconv_wino(cfg, a, stream);
     if (cfg >= CONV_CFG_COUNT) return launch_conv_wino(cfg, a, stream);

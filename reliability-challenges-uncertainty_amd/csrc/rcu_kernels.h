@@ -72,6 +72,9 @@ enum ConvConfig {
     CONV_CFG_UPW_S8T4x8_N64,
     // first conv unit of the network, K = 9 taps x 4 (8) channels unpadded (rcu_first.hip)
     CONV_CFG_FIRST_T8x32,
+    // Winograd F(4x4,3x3) kernels (rcu_wino4.hip): 36 positions, one wave per SIMD (288 accumulator registers), 32 couts
+    CONV_CFG_WINO4_T32x32_N32,                   // 32x32-pixel tile (64 Winograd tiles of 4x4)
+    CONV_CFG_WINO4_S2T16x32_N32,                 // 16x32 pixels of two consecutive slices
     CONV_CFG_END
 };
 
@@ -81,16 +84,23 @@ struct ConvConfigInfo {
     int KCP;   // floats per [tap][channel] row of a packed weight tile (KC, or KC + 4 in the padded layout)
     int SWZ;   // 1: the two 16-byte units of a row are swapped for output channels 16..31 (mod 32), see ConvTile
     int WINO;  // 1: Winograd F(2x2,3x3) kernel, TAPS = 16 positions; 2: F(2x2,2x2) up-conv, TAPS = 18 (two classes);
-               // packed tile = [p][channel pair][cout][2] (rcu_wino.hip, rcu_wino_up.hip)
+               // 3: F(4x4,3x3), TAPS = 36 positions; packed tile = [p][channel pair][cout][2] (rcu_wino.hip, rcu_wino_up.hip,
+               // rcu_wino4.hip)
 };
 const ConvConfigInfo& conv_config_info(int cfg);
 const ConvConfigInfo& wino_config_info(int cfg);
 const ConvConfigInfo& wino_up_config_info(int cfg);
+const ConvConfigInfo& wino4_config_info(int cfg);
 const ConvConfigInfo& first_config_info();
 hipError_t launch_conv3x3(int cfg, const ConvArgs& a, hipStream_t stream);
 hipError_t launch_conv_wino(int cfg, const ConvArgs& a, hipStream_t stream);
 hipError_t launch_upconv_wino(int cfg, const ConvArgs& a, hipStream_t stream);
+hipError_t launch_conv_wino4(int cfg, const ConvArgs& a, hipStream_t stream);
 hipError_t launch_conv_first(const ConvArgs& a, hipStream_t stream);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: set once per (kernel, device), so that one
+// process driving several GPUs gets it on every one of them.
+hipError_t set_max_dynamic_lds(const void* kernel, int bytes);
 
 // ---------------------------------------------------------------------------------------------
 // layout / head / aggregation kernels (rcu_pointwise.hip)

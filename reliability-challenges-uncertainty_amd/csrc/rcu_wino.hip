@@ -431,18 +431,13 @@ static hipError_t launch_wino_cfg(const ConvArgs& a, hipStream_t stream)
     constexpr int lds_bytes = T::LDS_BYTES + (HEAD ? T::TH * T::TW * WINO_HEAD_PITCH * 4 : 0);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
     if (HEAD && (a.head_w == nullptr || a.NT != 1 || a.pooled != nullptr || a.mask2 != nullptr)) return hipErrorInvalidValue;
-    static bool attr_set = false;
     const int nchunks = (a.C1 + a.C2) / T::KC;
     if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
         (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 ||
         (size_t)a.N * a.H * a.W * a.CoutP * 4 >= ((size_t)1 << 31))
         return hipErrorInvalidValue;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_stream<T, HEAD>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_stream<T, HEAD>), lds_bytes);
+    if (e != hipSuccess) return e;
     const unsigned items = (unsigned)a.NT * a.tiles_x * a.tiles_y * a.slice_groups;
     const unsigned grid = items < 256u ? items : 256u;
     hipLaunchKernelGGL((conv_wino_stream<T, HEAD>), dim3(grid), dim3(T::THREADS), lds_bytes, stream, a, (int)items);

@@ -1,0 +1,615 @@
+// conv3x3 (pad 1) conv unit in Winograd F(4x4, 3x3) form on the fp32 matrix cores of gfx950.
+//
+//     Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        per 4x4 output tile, 6x6 input patch d
+//
+// 36 multiplications per 16 output pixels and (cin, cout) pair: 2.25 per pixel against 4 in F(2x2,3x3) (rcu_wino.hip) and 9 in
+// the direct form -- the channel contraction, the only dense part and what the MFMA pipe executes, shrinks by another 1.78x.
+// Interpolation points 0, +-1, +-2, inf (Lavin & Gray); in float32 the network stays as close to the float64 network as the
+// direct float32 form does (tools/wino43_numerics.py: max |dlogit| 2.4e-7 against 1.3e-7 direct on the full-width U-Net), far
+// inside the parity gate of the tests (2e-6 on logits).  Everything else of the reference's conv unit (common/model/unet.py:8-23:
+// bias, Dropout2d factor, folded BatchNorm, ReLU; the 2x2 max-pool of DownConv, unet.py:85-95; the cat-free two-source K loop of
+// UpConv, unet.py:118) is fused as in rcu_wino.hip.
+//
+// Mapping (v_mfma_f32_16x16x4_f32), where it differs from rcu_wino.hip:
+//   * a wave owns 16 tiles x 32 output channels x 36 positions = 288 accumulator registers -- the accumulator half of the 512
+//     registers of a lane -- so a workgroup is 4 waves, ONE per SIMD, one workgroup per CU: 64 tiles (1024 pixels) x 32 couts.
+//     With the transform amortised over 32 couts the VALU work per MFMA is that of F(2x2,3x3) (288 operations per 144 MFMAs
+//     and chunk against 64 per 64 there).
+//   * A operand: lane (tile m = lane & 15, channel pair kq = lane >> 4) reads its tile's RAW 6x6 patch (36 ds_read_b64) and
+//     applies B^T d B in registers (scalar operations, per channel), spread over the MFMA groups of the chunk: position rows are
+//     multiplied in the order 0, 5, 1, 2, 3, 4 so that only T0 = 4 d0 - 5 d2 + d4 and its column transform precede the first MFMA.
+//   * B operand: host-transformed weights U = G g G^T packed [chunk][cout tile][p][channel pair][cout][2] as in rcu_wino.hip: one
+//     ds_read_b128 per position serves both 16-channel MFMA blocks of the wave (couts 2n, 2n+1 per lane).
+//   * LDS input image: [slice][halo row R][position][8 channels] -- a pixel's 32 bytes of the chunk stay together, so adjacent lanes
+//     of an LDS-DMA instruction fetch adjacent 16-byte halves (half the L2 requests of a [channel half][position] image, which
+//     is what bounds the staging of these kernels) -- with position = x ^ swz, swz = (((x >> 3) ^ slice) & 1) | (((R >> 2) & 1) << 1),
+//     applied on the SOURCE address of the LDS-DMA; with a row pitch of 4k and a slice stride of 16k positions the 32 lanes a
+//     ds_read_b64 serves per cycle (2 channel pairs x 16 tiles, tiles 4 pixels = 32 dwords apart) fall two by two on the 32
+//     two-dword slots of the 64 banks: 2-way, the minimum for 8-dword positions.
+//   * D: lane (n = lane & 15, g = lane >> 4) holds the four horizontally adjacent tiles 4g .. 4g+3 of one tile row (4 x 16
+//     pixels) for couts (2n, 2n+1): output transform A^T M A (100 operations per tile and cout), epilogue and 2x2 max-pool are
+//     lane-local; neighbouring lanes trade pixel columns by DPP so that every store writes 16 bytes.
+//   * staging by LDS-DMA only, double-buffered chunk pipeline running across the tiles of a workgroup, buffer-resource zero
+//     padding: as rcu_wino.hip.
+#include "rcu_wino_common.h"
+
+#include <cstdlib>
+
+namespace rcu {
+
+// Workgroup tile: WS slice groups x WR block rows of MFMA row blocks; a block = SB slices x BR tile rows x BC tile columns = 16
+// tiles of 4x4 pixels spanning the tile's full width.
+template <int SB_, int BR_, int BC_, int WS_, int WR_>
+struct Wino4Tile {
+    static constexpr int SB = SB_, BR = BR_, BC = BC_, WS = WS_, WR = WR_;
+    static constexpr int TS = SB * WS, TH = 4 * BR * WR, TW = 4 * BC;
+    static constexpr int BN = 32, KC = 8, THREADS = 256, WAVES = 4, NPOS = 36;
+    static constexpr int PITCH = (TW + 2 + 3) / 4 * 4;                       // positions per halo row, a multiple of 4
+    static constexpr int SLICE_POS = ((TH + 2) * PITCH + 15) / 16 * 16;      // positions per slice image, a multiple of 16
+    static constexpr int A_POS = 2 * TS * SLICE_POS;                         // 16-byte units: [slice][halo row][position][channel half]
+    static constexpr int A_PIECES = (A_POS + 63) / 64;
+    static constexpr int NA = (A_PIECES + WAVES - 1) / WAVES;
+    static constexpr int A_DW = A_PIECES * 256;
+    static constexpr int W_DW = NPOS * 4 * BN * 2;                           // [p][channel pair][cout][2]
+    static constexpr int W_PIECES = W_DW / 256;
+    static constexpr int NW = (W_PIECES + WAVES - 1) / WAVES;
+    static constexpr int BUF_DW = A_DW + W_DW;
+    static constexpr int LDS_BYTES = 2 * BUF_DW * 4;
+    static_assert(SB * BR * BC == 16 && WS * WR == WAVES && BC % 4 == 0, "block geometry");
+    static_assert(W_DW % 256 == 0 && LDS_BYTES <= 160 * 1024, "LDS");
+    // wave -> (first slice of its block inside the tile, top pixel row of its block inside the slice tile)
+    static __device__ __forceinline__ void block_origin(int wave, int& s, int& y)
+    {
+        s = (wave / WR) * SB;
+        y = (wave % WR) * (4 * BR);
+    }
+    // tile m of a block -> (slice inside the block, tile row, tile column)
+    static __device__ __forceinline__ void tile_of(int m, int& sb, int& tr, int& tc)
+    {
+        sb = m / (BR * BC);
+        tr = (m / BC) % BR;
+        tc = m % BC;
+    }
+    static __device__ __forceinline__ int swizzle(int x, int s, int R) { return (((x >> 3) ^ s) & 1) | (((R >> 2) & 1) << 1); }
+};
+
+template <class T>
+__device__ __forceinline__ uint32_t wino4_slot_geometry(int j, int wave, int lane)
+{
+    const int f = (j * T::WAVES + wave) * 64 + lane;       // 16-byte unit of the LDS image: adjacent lanes fetch the two halves of a pixel's 32 bytes
+    const int hh = f & 1, rem = f >> 1;
+    const int s = rem / T::SLICE_POS, r2 = rem % T::SLICE_POS;
+    const int yy = r2 / T::PITCH, pos = r2 % T::PITCH;
+    const int x = pos ^ T::swizzle(pos, s, yy);             // the swizzle only moves a position inside its aligned group of four
+    const bool real = f < T::A_POS && yy < T::TH + 2 && x < T::TW + 2;
+    return real ? (uint32_t)(x | (yy << 8) | (s << 16) | (hh << 24)) : 0xFFFFFFFFu;
+}
+
+template <class T>
+__device__ __forceinline__ WinoEpiRaw wino4_epilogue_load(const ConvArgs& a, int ntile, int n0, int wave, int lane)
+{
+    WinoEpiRaw e;
+    const int co = ntile * T::BN + 2 * (lane & 15);   // < NT * BN, the length of alpha / betab / beta
+    int bs, by, sb, tr, tc;
+    T::block_origin(wave, bs, by);
+    T::tile_of(4 * (lane >> 4), sb, tr, tc);
+    const int n = min(n0 + bs + sb, a.N - 1);
+    e.al = *reinterpret_cast<const f32x2*>(a.alpha + co);
+    e.bb = *reinterpret_cast<const f32x2*>(a.betab + co);
+    e.be = *reinterpret_cast<const f32x2*>(a.beta + co);
+    e.site = 0;
+    e.mk[0] = e.mk[1] = 1.f;
+    if (a.mask != nullptr) {   // wave-uniform
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c = co + b;
+            e.mk[b] = a.mask[(size_t)n * a.Cmask + min(c, a.Cmask - 1)];
+            e.site |= (c < a.Cmask ? 1 : 0) << b;
+        }
+    }
+    return e;
+}
+
+// 288 accumulator registers per lane: 64 tuples of 4 in the accumulator file a[0:255], the other 8 in VGPRs.  hipcc gives a kernel
+// ONE form of the MFMA (accumulators in AGPRs), treats all 512 registers as one pool and answers the overflow with
+// v_accvgpr_read / _write pairs around MFMAs inside the loop, so the accumulator file is owned by the inline assembly below: every
+// MFMA names its a[N:N+3] literally and every statement lists the whole file as clobbered (which also makes the kernel descriptor
+// allocate it).  The compiler never holds a value there; the build is audited for that (tests/test_abi_cpu.py: no scratch, no
+// v_accvgpr_* outside the asm statements).  The accumulators of cout block 1 at positions 18..25 are ordinary VGPR variables
+// multiplied by the VGPR form of the instruction.
+//   s_nop 1 (opening the first MFMA of a group): the wait states between a VALU write of an operand and the MFMA reading it, which
+//   hipcc does not add inside asm; the transform writes its operands at least one MFMA group ahead of their use.
+#define WINO4_ALL_AGPRS \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
+    "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
+    "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", \
+    "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", \
+    "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", \
+    "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", \
+    "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
+    "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", \
+    "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", \
+    "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", \
+    "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", \
+    "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", \
+    "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", \
+    "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", \
+    "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", \
+    "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+__host__ __device__ constexpr bool wino4_in_vgpr(int b, int p) { return b == 1 && p >= 18 && p < 26; }
+// first AGPR of the accumulator tuple of (cout block b, position p)
+__host__ __device__ constexpr int wino4_areg(int b, int p) { return 4 * (b == 0 ? p : 36 + (p < 18 ? p : p - 8)); }
+
+template <int B, int P, bool ZERO, bool NOP>
+__device__ __forceinline__ void wino4_mfma(f32x4 (&accv)[8], float av, float wv)
+{
+    if constexpr (wino4_in_vgpr(B, P)) {
+        if constexpr (ZERO)
+            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(accv[P - 18]) : "v"(av), "v"(wv));
+        else
+            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[P - 18]) : "v"(av), "v"(wv));
+    } else {
+        constexpr int R = wino4_areg(B, P);
+        if constexpr (ZERO && NOP)
+            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, 0" ::"v"(av), "v"(wv), "i"(R), "i"(R + 3) : WINO4_ALL_AGPRS);
+        else if constexpr (ZERO)
+            asm volatile("v_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, 0" ::"v"(av), "v"(wv), "i"(R), "i"(R + 3) : WINO4_ALL_AGPRS);
+        else if constexpr (NOP)
+            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(av), "v"(wv), "i"(R), "i"(R + 3) : WINO4_ALL_AGPRS);
+        else
+            asm volatile("v_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(av), "v"(wv), "i"(R), "i"(R + 3) : WINO4_ALL_AGPRS);
+    }
+}
+
+// element r of the accumulator tuple of (b, p)
+template <int B, int P, int R>
+__device__ __forceinline__ float wino4_acc(const f32x4 (&accv)[8])
+{
+    if constexpr (wino4_in_vgpr(B, P)) {
+        return accv[P - 18][R];
+    } else {
+        float v;
+        asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "i"(wino4_areg(B, P) + R));
+        return v;
+    }
+}
+
+// Output transform + conv-unit epilogue of one finished tile.  acc[b][p][r]: MFMA block b (cout 2n+b), position p = 6 i + j,
+// tile r of the lane's four.
+template <class T>
+__device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&accv)[8], const WinoEpi& ep, int ntile, int n0, int y0, int x0,
+                                               int wave, int lane)
+{
+    // every MFMA has long retired: the last chunk's barrier lies between them and this point; the nops cover the asm-to-asm case
+    // (an MFMA's D read by v_accvgpr_read) the compiler cannot see
+    asm volatile("s_nop 15\n\ts_nop 7");
+    const int n16 = lane & 15, g = lane >> 4;
+    const int co = ntile * T::BN + 2 * n16;
+    int bs, by, sb, tr, tc;
+    T::block_origin(wave, bs, by);
+    T::tile_of(4 * g, sb, tr, tc);
+    const int n = n0 + bs + sb;
+    const bool live = co < a.CoutP && n < a.N;   // whole tiles only (launcher): false only for slices beyond the batch
+    const int yb = y0 + by + 4 * tr;      // top pixel row of the lane's tiles
+    const int xb = x0 + 4 * tc;           // left pixel column of the lane's first tile
+    const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+    const int odd = n16 & 1;
+    const uint32_t row_bytes = (uint32_t)(a.W * a.CoutP) * 4u;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (uint32_t)(a.N * a.H) * row_bytes, 0x00020000);
+    // lanes without an output (slices beyond the batch) store out of range: the buffer resource drops the write
+    const uint32_t vo = live ? ((uint32_t)((n * a.H + yb) * a.W + xb + odd) * (uint32_t)a.CoutP + (uint32_t)(co - 2 * odd)) * 4u : WINO_OOB;
+    const uint32_t px_bytes = (uint32_t)a.CoutP * 4u;
+    const bool pool = a.pooled != nullptr;
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(pool ? a.pooled : a.out, 0,
+                                                                       pool ? (uint32_t)(a.N * Hp * Wp * a.CoutP) * 4u : 0u, 0x00020000);
+    const uint32_t vp = live ? ((uint32_t)((n * Hp + (yb >> 1)) * Wp + (xb >> 1) + odd) * (uint32_t)a.CoutP + (uint32_t)(co - 2 * odd)) * 4u : WINO_OOB;
+    const uint32_t prow_bytes = (uint32_t)(Wp * a.CoutP) * 4u;
+    wino_static_for<0, 4>([&](auto r_c) {
+        constexpr int r = decltype(r_c)::value;
+        f32x2 y[4][4];   // [row][col], components = the two couts: packed operations throughout (one instruction costs the same
+                         // matrix time whether it is packed or not, see the chunk pipeline)
+        {
+            const f32x2 scale = {ep.scale[0], ep.scale[1]}, shift = {ep.shift[0], ep.shift[1]}, floor2 = {relu_floor, relu_floor};
+            f32x2 nn[6][4];   // N[i][q] = sum_j M[i][j] A[j][q]
+            wino_static_for<0, 6>([&](auto i_c) {
+                constexpr int i = decltype(i_c)::value;
+                auto m = [&](auto j_c) {
+                    constexpr int j = decltype(j_c)::value;
+                    return f32x2{wino4_acc<0, 6 * i + j, r>(accv), wino4_acc<1, 6 * i + j, r>(accv)};
+                };
+                const f32x2 m0 = m(std::integral_constant<int, 0>{}), m1 = m(std::integral_constant<int, 1>{}), m2 = m(std::integral_constant<int, 2>{}),
+                            m3 = m(std::integral_constant<int, 3>{}), m4 = m(std::integral_constant<int, 4>{}), m5 = m(std::integral_constant<int, 5>{});
+                const f32x2 s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
+                nn[i][0] = (m0 + s1) + s3;
+                nn[i][1] = s2 + 2.f * s4;
+                nn[i][2] = s1 + 4.f * s3;
+                nn[i][3] = (s2 + 8.f * s4) + m5;
+            });
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 s1 = nn[1][q] + nn[2][q], s2 = nn[1][q] - nn[2][q], s3 = nn[3][q] + nn[4][q], s4 = nn[3][q] - nn[4][q];
+                const f32x2 v0 = (nn[0][q] + s1) + s3;
+                const f32x2 v1 = s2 + 2.f * s4;
+                const f32x2 v2 = s1 + 4.f * s3;
+                const f32x2 v3 = (s2 + 8.f * s4) + nn[5][q];
+                y[0][q] = __builtin_elementwise_max(v0 * scale + shift, floor2);
+                y[1][q] = __builtin_elementwise_max(v1 * scale + shift, floor2);
+                y[2][q] = __builtin_elementwise_max(v2 * scale + shift, floor2);
+                y[3][q] = __builtin_elementwise_max(v3 * scale + shift, floor2);
+            }
+        }
+        // Neighbouring lanes (couts 2n, 2n+1 | 2n+2, 2n+3 of the same pixels) trade pixel columns: the even lane ends up with four
+        // couts of columns 0 and 2 of the tile, the odd lane with four couts of columns 1 and 3 -> 16-byte stores.
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f32x2 keep = odd ? y[aa][2 * h2 + 1] : y[aa][2 * h2];
+                const f32x2 send = odd ? y[aa][2 * h2] : y[aa][2 * h2 + 1];
+                f32x2 recv;
+                recv.x = wino_swap_adjacent(send.x);
+                recv.y = wino_swap_adjacent(send.y);
+                const f32x4 o = odd ? f32x4{recv.x, recv.y, keep.x, keep.y} : f32x4{keep.x, keep.y, recv.x, recv.y};
+                wino_store16(o, ro, vo, (uint32_t)(4 * r + 2 * h2) * px_bytes + (uint32_t)aa * row_bytes);
+            }
+        }
+        if (pool) {   // wave-uniform; 2x2 pooled pixels per tile: the even lane stores four couts of pooled column 0, the odd lane of column 1
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2) {
+                f32x2 mx[2];
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+                    mx[b2] = __builtin_elementwise_max(__builtin_elementwise_max(y[2 * a2][2 * b2], y[2 * a2][2 * b2 + 1]),
+                                                       __builtin_elementwise_max(y[2 * a2 + 1][2 * b2], y[2 * a2 + 1][2 * b2 + 1]));
+                const f32x2 keep = odd ? mx[1] : mx[0];
+                const f32x2 send = odd ? mx[0] : mx[1];
+                f32x2 recv;
+                recv.x = wino_swap_adjacent(send.x);
+                recv.y = wino_swap_adjacent(send.y);
+                const f32x4 o = odd ? f32x4{recv.x, recv.y, keep.x, keep.y} : f32x4{keep.x, keep.y, recv.x, recv.y};
+                wino_store16(o, rp, vp, (uint32_t)(2 * r) * px_bytes + (uint32_t)a2 * prow_bytes);
+            }
+        }
+    });
+}
+
+// position rows in the order they are multiplied (see the header), and the position multiplied in slot q of that order
+__host__ __device__ constexpr int wino4_row_of(int k) { return k == 0 ? 0 : k == 1 ? 5 : k - 1; }
+__host__ __device__ constexpr int wino4_pos_of(int q) { return 6 * wino4_row_of(q / 6) + q % 6; }
+
+// VAR: timing ablations for tools/wino4_check.py (wrong results): bit 0 no LDS-DMA inside the chunks, bit 1 no epilogue, bit 2 no
+// input transform, bit 3 no chunk barrier
+template <class T, int VAR = 0>
+__global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, const int total_items)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    constexpr int KC = T::KC;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m16 = lane & 15, kq = lane >> 4;
+    const int nchunks = (a.C1 + a.C2) / KC;   // even, >= 4 (checked by the launcher)
+    const uint32_t wchunk_bytes = (uint32_t)a.NT * T::W_DW * 4u;
+
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1), 0, a.src1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src2 ? a.src2 : a.src1), 0, a.src2 ? a.src2_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, a.wpack_bytes, 0x00020000);
+
+    // fragment addresses (dword offsets inside a buffer) of the lane's patch columns j = 0..5, for patch rows 0..3 ([0]) and 4..5
+    // ([1]: the swizzle's row bit flips); the row itself is an immediate offset
+    int aCol[2][6];
+    {
+        int bs, by, sb, tr, tc;
+        T::block_origin(wave, bs, by);
+        T::tile_of(m16, sb, tr, tc);
+        const int s = bs + sb, R0 = by + 4 * tr;
+        const int base = (s * T::SLICE_POS + R0 * T::PITCH) * 8 + 2 * kq;
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int x = 4 * tc + j;
+                aCol[ip][j] = base + 8 * (x ^ T::swizzle(x, s, R0 + 4 * ip));
+            }
+    }
+    const int b_addr = T::A_DW + (kq * T::BN + 2 * m16) * 2;
+    const uint32_t w_voff = (uint32_t)(lane * 16);
+
+    int item = wino_xcd_virtual_block(a.NT < 4 ? 4 : a.NT);
+    bool has_next = item + (int)gridDim.x < total_items;
+    WinoTileId tile = wino_tile_id<T>(a, item), ntile = tile;
+    uint32_t dp[T::NA], geo[T::NA];
+    int dp_wtile = tile.wtile;
+#pragma unroll
+    for (int j = 0; j < T::NA; ++j) {
+        geo[j] = wino4_slot_geometry<T>(j, wave, lane);
+        asm volatile("" : "+v"(geo[j]));
+        dp[j] = wino_slot_offset<T>(a, tile, geo[j]);
+    }
+
+    struct DmaJob {
+        bool active, first;
+        uint32_t cb, wso, lb;
+    };
+    auto dma_job = [&](int wtile, int kc, int buf, bool active) {
+        DmaJob j;
+        const int c0 = kc * KC;
+        j.active = active;
+        j.first = c0 < a.C1;
+        j.cb = (uint32_t)((j.first ? c0 : c0 - a.C1) * 4);
+        j.wso = (uint32_t)kc * wchunk_bytes + (uint32_t)wtile * (T::W_DW * 4u);
+        j.lb = (uint32_t)buf * (T::BUF_DW * 4u);
+        return j;
+    };
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    auto dma_piece = [&](const DmaJob& job, auto i_c) {
+        constexpr int I = decltype(i_c)::value;
+        if constexpr (I < T::NW) {
+            if (job.active && ((I + 1) * T::WAVES <= T::W_PIECES || I * T::WAVES + wave < T::W_PIECES))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + T::A_DW * 4 + (I * T::WAVES + wave) * 1024),
+                                                         16, w_voff, job.wso + (uint32_t)(I * T::WAVES + wave) * 1024u, 0, 0);
+        } else if constexpr (I < T::NW + T::NA) {
+            constexpr int j = I - T::NW;
+            if (job.active && ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES)) {
+                if (job.first)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16,
+                                                             dp[j], job.cb, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16,
+                                                             dp[j], job.cb, 0, 0);
+            }
+        }
+    };
+
+    {
+        const DmaJob job = dma_job(dp_wtile, 0, 0, true);
+        wino_static_for<0, T::NW + T::NA>([&](auto i_c) { dma_piece(job, i_c); });
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __syncthreads();
+
+    f32x4 accv[8];   // accumulators of (cout block 1, positions 18..25); all others in a[0:255] (wino4_areg)
+    WinoEpiRaw epr;
+
+    // Pipeline of one Cin chunk out of LDS buffer BUF (measured rules of the one-wave-per-SIMD regime, tools/microbench/
+    // gen_mfma_valu_1wave.py: an LDS read between two MFMAs is free, a VALU instruction costs ~5 cycles of matrix time whether packed
+    // or not and less in a clump than spread over the MFMA gaps):
+    //   groups 0..13 of 8 MFMAs (two positions x 2 channel steps x 2 cout blocks), the weight reads of the positions two groups ahead
+    //     and the chunk's LDS-DMA pieces between the MFMAs, the transform of the coming position rows as ONE packed clump per group;
+    //   s_waitcnt vmcnt(0) + barrier: the next chunk (of this tile or of the workgroup's next tile) has landed in the other buffer;
+    //   groups 14..17 -- they only need registers: their weights were read before the barrier -- with the RAW patch of the next
+    //     chunk read between their MFMAs, so that a chunk starts with its transform clump instead of an LDS round trip.
+    // dcur / dnext: the raw patch registers of this chunk and of the next one (the two arrays swap roles from chunk to chunk).
+    constexpr int AHEAD = 4, NPRE = 14;
+    auto load_patch_row = [&](f32x2 (&d)[36], const float* Ab, int i) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            // volatile: keeps hipcc from fusing pairs of these reads into ds_read2_b64
+            d[6 * i + j] = *(const volatile __attribute__((address_space(3))) f32x2*)(Ab + aCol[i >> 2][j] + i * (T::PITCH * 8));
+    };
+    auto load_weights = [&](f32x4 (&bv)[36], const float* Ab, int p) { bv[p] = *reinterpret_cast<const f32x4*>(Ab + b_addr + p * (8 * T::BN)); };
+    // B^T d B in place on channel pairs (packed operations).  One-dimensional transform of (x0..x5):
+    //   t0 = 4 x0 - 5 x2 + x4,  t5 = 4 x1 - 5 x3 + x5,  with a = x4 - 4 x2, b = x3 - 4 x1, c = x4 - x2, e = x3 - x1:
+    //   t1 = a + b, t2 = a - b, t3 = c + 2 e, t4 = c - 2 e.
+    auto row_transform = [&](f32x2 (&d)[36], int i) {   // along the columns of position row i
+        f32x2* const x = d + 6 * i;
+        const f32x2 t0 = 4.f * x[0] + (x[4] - 5.f * x[2]);
+        const f32x2 t5 = 4.f * x[1] + (x[5] - 5.f * x[3]);
+        const f32x2 aa = x[4] - 4.f * x[2], bb = x[3] - 4.f * x[1], cc = x[4] - x[2], ee = x[3] - x[1];
+        x[0] = t0;
+        x[1] = aa + bb;
+        x[2] = aa - bb;
+        x[3] = cc + 2.f * ee;
+        x[4] = cc - 2.f * ee;
+        x[5] = t5;
+    };
+    auto transform_head = [&](f32x2 (&d)[36]) {   // before the first MFMA: T0 of every column, then the columns of position row 0
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[j] = 4.f * d[j] + (d[24 + j] - 5.f * d[12 + j]);
+        row_transform(d, 0);
+    };
+    auto transform_clump = [&](f32x2 (&d)[36], int G) {   // 12 packed operations behind MFMA group G
+        if (G == 0) {          // T5 of every column (rows 1, 3, 5 still raw)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) d[30 + j] = 4.f * d[6 + j] + (d[30 + j] - 5.f * d[18 + j]);
+        }
+        if (G == 1) row_transform(d, 5);
+        if (G == 2 || G == 3) {   // a -> row 2, c -> row 4, b -> row 1, e -> row 3 for three columns each
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const int j = 3 * (G - 2) + jj;
+                const f32x2 x1 = d[6 + j], x2 = d[12 + j], x3 = d[18 + j], x4 = d[24 + j];
+                d[12 + j] = x4 - 4.f * x2;
+                d[24 + j] = x4 - x2;
+                d[6 + j] = x3 - 4.f * x1;
+                d[18 + j] = x3 - x1;
+            }
+        }
+        if (G == 4) {          // t1 = a + b, t2 = a - b
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const f32x2 aa = d[12 + j], bb = d[6 + j];
+                d[6 + j] = aa + bb;
+                d[12 + j] = aa - bb;
+            }
+        }
+        if (G == 5) row_transform(d, 1);
+        if (G == 6) row_transform(d, 2);
+        if (G == 7) {          // t3 = c + 2 e, t4 = c - 2 e
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const f32x2 cc = d[24 + j], ee = d[18 + j];
+                d[18 + j] = cc + 2.f * ee;
+                d[24 + j] = cc - 2.f * ee;
+            }
+        }
+        if (G == 8) row_transform(d, 3);
+        if (G == 9) row_transform(d, 4);
+    };
+
+    auto chunk = [&](auto buf_c, auto first_c, int kc, f32x2 (&d)[36], f32x2 (&dn)[36], f32x4 (&bv)[36], f32x4 (&bvn)[36]) {
+        constexpr int BUF = decltype(buf_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
+        const float* const Ab = smem + BUF * T::BUF_DW;
+        const float* const An = smem + (BUF ^ 1) * T::BUF_DW;
+        const bool more = kc + 1 < nchunks;
+        if (!more && has_next) {   // last chunk of the tile: from here on the DMA works on the workgroup's next tile
+            const ConvArgs& ca = wino_cold_args();
+            ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
+            dp_wtile = ntile.wtile;
+#pragma unroll
+            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(ca, ntile, geo[j]);
+        }
+        if (!more) epr = wino4_epilogue_load<T>(wino_cold_args(), tile.wtile, tile.n0, wave, lane);
+        const bool next_any = more || has_next;
+        const DmaJob job = dma_job(dp_wtile, more ? kc + 1 : 0, BUF ^ 1, next_any);
+        if constexpr ((VAR & 4) == 0) transform_head(d);
+        wino_static_for<0, 18>([&](auto g_c) {
+            constexpr int G = decltype(g_c)::value;
+            constexpr int p0 = wino4_pos_of(2 * G), p1 = wino4_pos_of(2 * G + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (G == NPRE) {
+                if constexpr ((VAR & 8) == 0) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the next chunk have landed
+                    __syncthreads();                      // everyone past the LDS reads of buffer BUF and done filling the other one
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // what goes between the 8 MFMAs of the group: unit u follows MFMA u
+            auto filler = [&](auto u_c) {
+                constexpr int U = decltype(u_c)::value;
+                if constexpr (G < NPRE) {
+                    // weights of the positions two groups ahead; in the last groups before the barrier also those of groups 14..17
+                    if constexpr (U == 0 || U == 4) {
+                        constexpr int q = 2 * G + AHEAD + (U == 4 ? 1 : 0);
+                        if constexpr (q < 2 * NPRE) load_weights(bv, Ab, wino4_pos_of(q));
+                    }
+                    if constexpr (G >= NPRE - 4 && (U == 2 || U == 6)) {
+                        constexpr int q = 2 * NPRE + 2 * (G - (NPRE - 4)) + (U == 6 ? 1 : 0);
+                        load_weights(bv, Ab, wino4_pos_of(q));
+                    }
+                    if constexpr ((VAR & 1) == 0 && G < 10 && (U == 1 || U == 5)) dma_piece(job, std::integral_constant<int, 2 * G + (U == 5 ? 1 : 0)>{});
+                } else {
+                    // behind the barrier: the raw patch of the next chunk (rows 0, 2, 4, 1, 3, 5) and its first weights.  Unconditional
+                    // (a conditional load would keep the old contents of dn alive through the whole chunk); behind a tile's last
+                    // chunk the values are dropped -- the epilogue needs the registers -- and read again after it (load_first)
+                    {
+                        constexpr int slot = 8 * (G - NPRE) + U;           // 0..31
+                        constexpr int order[6] = {0, 2, 4, 1, 3, 5};
+                        if constexpr (slot < 30) {
+                            constexpr int r = order[slot / 5];
+                            if constexpr (slot % 5 == 0) load_patch_row(dn, An, r);   // six reads per slot group of five gaps
+                        }
+                        if constexpr (slot == 30)
+                            wino_static_for<0, AHEAD>([&](auto q_c) { load_weights(bvn, An, wino4_pos_of(decltype(q_c)::value)); });
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            wino4_mfma<0, p0, FIRST, true>(accv, d[p0].x, bv[p0].x);
+            filler(std::integral_constant<int, 0>{});
+            wino4_mfma<1, p0, FIRST, false>(accv, d[p0].x, bv[p0].z);
+            filler(std::integral_constant<int, 1>{});
+            wino4_mfma<0, p1, FIRST, false>(accv, d[p1].x, bv[p1].x);
+            filler(std::integral_constant<int, 2>{});
+            wino4_mfma<1, p1, FIRST, false>(accv, d[p1].x, bv[p1].z);
+            filler(std::integral_constant<int, 3>{});
+            wino4_mfma<0, p0, false, false>(accv, d[p0].y, bv[p0].y);
+            filler(std::integral_constant<int, 4>{});
+            wino4_mfma<1, p0, false, false>(accv, d[p0].y, bv[p0].w);
+            filler(std::integral_constant<int, 5>{});
+            wino4_mfma<0, p1, false, false>(accv, d[p1].y, bv[p1].y);
+            filler(std::integral_constant<int, 6>{});
+            wino4_mfma<1, p1, false, false>(accv, d[p1].y, bv[p1].w);
+            filler(std::integral_constant<int, 7>{});
+            // transform work for the coming position rows: one clump
+            if constexpr ((VAR & 4) == 0) transform_clump(d, G);
+        });
+    };
+
+    f32x2 dA[36], dB[36];
+    f32x4 bvA[36], bvB[36];
+    // a tile's first chunk: nothing to hide the LDS round trip behind
+    auto load_first = [&]() {
+#pragma unroll
+        for (int ii = 0; ii < 6; ++ii) load_patch_row(dA, smem, ii < 3 ? 2 * ii : 2 * (ii - 3) + 1);
+        wino_static_for<0, AHEAD>([&](auto q_c) { load_weights(bvA, smem, wino4_pos_of(decltype(q_c)::value)); });
+    };
+    load_first();
+
+    for (;;) {
+        chunk(std::integral_constant<int, 0>{}, std::true_type{}, 0, dA, dB, bvA, bvB);
+        chunk(std::integral_constant<int, 1>{}, std::false_type{}, 1, dB, dA, bvB, bvA);
+        for (int kc = 2; kc < nchunks; kc += 2) {
+            chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc, dA, dB, bvA, bvB);
+            chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1, dB, dA, bvB, bvA);
+        }
+        if constexpr ((VAR & 2) == 0)
+            wino4_epilogue<T>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wave, lane);
+        if (!has_next) break;
+        load_first();
+        item += (int)gridDim.x;
+        tile = ntile;
+        has_next = item + (int)gridDim.x < total_items;
+    }
+#endif
+}
+
+using W4Cfg0 = Wino4Tile<1, 2, 8, 1, 4>;   // 32x32 pixels of one slice
+using W4Cfg1 = Wino4Tile<1, 2, 8, 2, 2>;   // 16x32 pixels of two consecutive slices (heights not divisible by 32)
+
+static const ConvConfigInfo kWino4Info[2] = {
+    {W4Cfg0::TS, W4Cfg0::TH, W4Cfg0::TW, W4Cfg0::BN, 8, 36, "conv3x3_winograd4<T32x32,N32,K8>", 8, 0, 3},
+    {W4Cfg1::TS, W4Cfg1::TH, W4Cfg1::TW, W4Cfg1::BN, 8, 36, "conv3x3_winograd4<S2T16x32,N32,K8>", 8, 0, 3},
+};
+
+const ConvConfigInfo& wino4_config_info(int cfg) { return kWino4Info[cfg - CONV_CFG_WINO4_T32x32_N32]; }
+
+template <class T, int VAR>
+static hipError_t launch_wino4_var(const ConvArgs& a, hipStream_t stream)
+{
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino4_stream<T, VAR>), T::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const unsigned items = (unsigned)a.NT * a.tiles_x * a.tiles_y * a.slice_groups;
+    const unsigned grid = items < 256u ? items : 256u;
+    hipLaunchKernelGGL((conv_wino4_stream<T, VAR>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);
+    return hipGetLastError();
+}
+
+template <class T>
+static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
+{
+    const int nchunks = (a.C1 + a.C2) / T::KC;
+    if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
+        (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 || a.mask2 != nullptr ||
+        (size_t)a.N * a.H * a.W * a.CoutP * 4 >= ((size_t)1 << 31))
+        return hipErrorInvalidValue;
+#ifdef RCU_WINO4_ABLATIONS   // timing experiments of tools/wino4_check.py (make EXTRA=-DRCU_WINO4_ABLATIONS); results are wrong
+    const char* const v = getenv("RCU_W4_VARIANT");
+    switch (v ? atoi(v) : 0) {
+        case 1: return launch_wino4_var<T, 1>(a, stream);
+        case 2: return launch_wino4_var<T, 2>(a, stream);
+        case 3: return launch_wino4_var<T, 3>(a, stream);
+        case 7: return launch_wino4_var<T, 7>(a, stream);
+        case 11: return launch_wino4_var<T, 11>(a, stream);
+        case 15: return launch_wino4_var<T, 15>(a, stream);
+        default: break;
+    }
+#endif
+    return launch_wino4_var<T, 0>(a, stream);
+}
+
+hipError_t launch_conv_wino4(int cfg, const ConvArgs& a, hipStream_t stream)
+{
+    switch (cfg) {
+        case CONV_CFG_WINO4_T32x32_N32: return launch_wino4_cfg<W4Cfg0>(a, stream);
+        case CONV_CFG_WINO4_S2T16x32_N32: return launch_wino4_cfg<W4Cfg1>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace rcu

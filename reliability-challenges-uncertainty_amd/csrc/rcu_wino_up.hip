@@ -298,17 +298,12 @@ const ConvConfigInfo& wino_up_config_info(int cfg) { return kWinoUpInfo[cfg - CO
 template <class T>
 static hipError_t launch_wino_up_cfg(const ConvArgs& a, hipStream_t stream)
 {
-    static bool attr_set = false;
     const int nchunks = a.C1 / T::KC;
     if (nchunks < 4 || (nchunks & 1) != 0 || a.C2 != 0 || a.NTW_total != 2 * a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
         a.H % T::TH != 0 || a.W % T::TW != 0 || (size_t)a.N * a.H * a.W * a.CoutP * 16 >= ((size_t)1 << 31))
         return hipErrorInvalidValue;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_wino_stream<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&upconv_wino_stream<T>), T::LDS_BYTES);
+    if (e != hipSuccess) return e;
     const unsigned items = (unsigned)a.NTW_total * a.tiles_x * a.tiles_y * a.slice_groups;
     const unsigned grid = items < 256u ? items : 256u;
     hipLaunchKernelGGL(upconv_wino_stream<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);

@@ -101,3 +101,35 @@ def test_host_side_metric_arithmetic_matches_oracle(golden):
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             ev.ece_binary(np.zeros((2, 2), np.float32), np.zeros((2, 2), np.uint8))  # needs the GPU: fails loudly
+
+
+@pytest.mark.timeout(600)
+def test_winograd4_kernel_owns_the_accumulator_file(tmp_path):
+    """csrc/rcu_wino4.hip names its 256 accumulator registers literally in inline assembly (its header says why).  That is only
+    sound while the compiler itself keeps out of the accumulator file and spills nothing: audit the generated code --
+    no scratch, no VGPR spill, no v_accvgpr_* outside the asm statements, 256 AGPRs allocated by the kernel descriptor."""
+    import subprocess
+    csrc = os.path.join(ROOT, 'reliability-challenges-uncertainty_amd', 'csrc')
+    cmd = ['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fno-slp-vectorize', '--cuda-device-only', '-S',
+           os.path.join(csrc, 'rcu_wino4.hip'), '-o', str(tmp_path / 'w4.s')]
+    subprocess.check_call(cmd, cwd=str(tmp_path))
+    text = open(str(tmp_path / 'w4.s')).read()
+    kernels = re.findall(r'\.amdhsa_kernel (\S*conv_wino4_stream\S*)', text)
+    assert len(kernels) >= 2
+    inside, stray = False, []
+    for line in text.splitlines():
+        if ';;#ASMSTART' in line:
+            inside = True
+        elif ';;#ASMEND' in line:
+            inside = False
+        elif 'v_accvgpr' in line and not inside:
+            stray.append(line.strip())
+    assert not stray, stray[:5]
+    assert 'scratch_' not in text
+    meta = text[text.index('amdhsa.kernels'):]
+    for block in meta.split('- .agpr_count:')[1:]:
+        if 'conv_wino4_stream' not in block:
+            continue
+        assert int(block.split()[0]) == 256
+        assert int(re.search(r'\.vgpr_spill_count:\s*(\d+)', block).group(1)) == 0
+        assert int(re.search(r'\.private_segment_fixed_size:\s*(\d+)', block).group(1)) == 0

@@ -31,6 +31,8 @@ def _model_and_input(dev):
 
 
 def worker(rank, world, port, backend, q):
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=True)     # a hung collective shows where instead of timing the caller out
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
