@@ -140,11 +140,15 @@ static int pick_config(const ConvLayer& L, int n_slices)
         return CONV_CFG_T8x16_N32_FIRST;
     }
     if (wino_on && (L.c1p + L.c2p) % 32 == 0 && (L.c2p == 0 || L.c2p == L.c1p) && max_bytes < ((size_t)1 << 31)) {
-        // F(4x4,3x3) (rcu_wino4.hip) where its 32-pixel-wide tiles fit: 2.25 instead of 4 multiplications per output pixel.
-        // RCU_CONV_WINO4=0 keeps F(2x2,3x3) (A/B tests); the head unit stays on F(2x2,3x3), whose epilogue holds the classifier
+        // F(4x4,3x3) (rcu_wino4.hip) where its 32-pixel-wide tiles fit: 2.25 instead of 4 multiplications per output pixel.  Taken for
+        // layers with >= 64 output channels (measured per layer on the BraTS volume, tools/wino4_check.py: 1.1x at 32 -> 64 channels to
+        // 1.4x at 128 -> 128 and 256 -> 128 over F(2x2,3x3)); the 32-channel full-resolution layers are bound by their tile switches --
+        // four Cin chunks per tile, a cold fetch and an epilogue of a chunk's length each -- and stay on F(2x2,3x3), which runs two
+        // waves per SIMD there (0.36-0.64 ms against 0.39-0.69).  RCU_CONV_WINO4=0 keeps F(2x2,3x3) everywhere, =2 takes F(4x4,3x3)
+        // wherever it fits (A/B tests).
         const char* const w4_env = getenv("RCU_CONV_WINO4");
-        const bool w4_on = !(w4_env && atoi(w4_env) == 0);
-        if (w4_on && L.name2.empty() && !is_head_unit(L) && L.W % 32 == 0) {
+        const int w4_mode = w4_env ? atoi(w4_env) : 1;
+        if (w4_mode != 0 && (L.coutp >= 64 || w4_mode == 2) && L.name2.empty() && !is_head_unit(L) && L.W % 32 == 0) {
             if (L.H % 32 == 0) return CONV_CFG_WINO4_T32x32_N32;
             if (L.H % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_WINO4_S2T16x32_N32;
         }

@@ -117,8 +117,9 @@ __device__ __forceinline__ WinoEpiRaw wino4_epilogue_load(const ConvArgs& a, int
 // allocate it).  The compiler never holds a value there; the build is audited for that (tests/test_abi_cpu.py: no scratch, no
 // v_accvgpr_* outside the asm statements).  The accumulators of cout block 1 at positions 18..25 are ordinary VGPR variables
 // multiplied by the VGPR form of the instruction.
-//   s_nop 1 (opening the first MFMA of a group): the wait states between a VALU write of an operand and the MFMA reading it, which
-//   hipcc does not add inside asm; the transform writes its operands at least one MFMA group ahead of their use.
+//   s_nop 1 (opening every MFMA; it costs no matrix time, tools/microbench/gen_mfma_valu_1wave.py): the wait states between a VALU
+//   write of an operand and the MFMA reading it, which hipcc does not add inside asm -- and hipcc is free to sink a transform
+//   operation down to the MFMA that consumes it (a build with the nop on the first MFMA of a group only gave wrong results).
 #define WINO4_ALL_AGPRS \
     "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
     "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
@@ -140,9 +141,10 @@ __host__ __device__ constexpr bool wino4_in_vgpr(int b, int p) { return b == 1 &
 // first AGPR of the accumulator tuple of (cout block b, position p)
 __host__ __device__ constexpr int wino4_areg(int b, int p) { return 4 * (b == 0 ? p : 36 + (p < 18 ? p : p - 8)); }
 
-template <int B, int P, bool ZERO, bool NOP>
+template <int B, int P, bool ZERO, bool NOP, bool PROBE = false>
 __device__ __forceinline__ void wino4_mfma(f32x4 (&accv)[8], float av, float wv)
 {
+    if constexpr (PROBE) asm volatile("s_nop 7\n\ts_nop 7");
     if constexpr (wino4_in_vgpr(B, P)) {
         if constexpr (ZERO)
             asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(accv[P - 18]) : "v"(av), "v"(wv));
@@ -331,17 +333,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         dp[j] = wino_slot_offset<T>(a, tile, geo[j]);
     }
 
+    // LDS-DMA of Cin chunk kc of a tile into LDS buffer `buf`: the wave's NW weight pieces and NA input pieces of 1 KB.  No branch
+    // per piece: a job without work (behind the workgroup's last chunk) points out of range, where the buffer load writes zeros
+    // into a buffer nobody reads; the source tensor's descriptor is picked once per chunk.
     struct DmaJob {
-        bool active, first;
+        __amdgpu_buffer_rsrc_t rs;
         uint32_t cb, wso, lb;
     };
     auto dma_job = [&](int wtile, int kc, int buf, bool active) {
         DmaJob j;
         const int c0 = kc * KC;
-        j.active = active;
-        j.first = c0 < a.C1;
-        j.cb = (uint32_t)((j.first ? c0 : c0 - a.C1) * 4);
-        j.wso = (uint32_t)kc * wchunk_bytes + (uint32_t)wtile * (T::W_DW * 4u);
+        const bool first = c0 < a.C1;
+        j.rs = first ? rs1 : rs2;
+        j.cb = active ? (uint32_t)((first ? c0 : c0 - a.C1) * 4) : WINO_OOB;
+        j.wso = active ? (uint32_t)kc * wchunk_bytes + (uint32_t)wtile * (T::W_DW * 4u) : WINO_OOB;
         j.lb = (uint32_t)buf * (T::BUF_DW * 4u);
         return j;
     };
@@ -349,19 +354,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
     auto dma_piece = [&](const DmaJob& job, auto i_c) {
         constexpr int I = decltype(i_c)::value;
         if constexpr (I < T::NW) {
-            if (job.active && ((I + 1) * T::WAVES <= T::W_PIECES || I * T::WAVES + wave < T::W_PIECES))
+            if ((I + 1) * T::WAVES <= T::W_PIECES || I * T::WAVES + wave < T::W_PIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + T::A_DW * 4 + (I * T::WAVES + wave) * 1024),
                                                          16, w_voff, job.wso + (uint32_t)(I * T::WAVES + wave) * 1024u, 0, 0);
         } else if constexpr (I < T::NW + T::NA) {
             constexpr int j = I - T::NW;
-            if (job.active && ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES)) {
-                if (job.first)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16,
-                                                             dp[j], job.cb, 0, 0);
-                else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16,
-                                                             dp[j], job.cb, 0, 0);
-            }
+            if ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(job.rs, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16, dp[j],
+                                                         job.cb, 0, 0);
         }
     };
 
@@ -464,7 +464,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
 #pragma unroll
             for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(ca, ntile, geo[j]);
         }
-        if (!more) epr = wino4_epilogue_load<T>(wino_cold_args(), tile.wtile, tile.n0, wave, lane);
+        // epilogue constants: loaded a chunk early, so that the barrier wait of the last-but-one chunk covers them and the epilogue
+        // does not wait for memory (the LDS-DMA of the next tile is still in flight then)
+        if (kc == nchunks - 2) epr = wino4_epilogue_load<T>(wino_cold_args(), tile.wtile, tile.n0, wave, lane);
         const bool next_any = more || has_next;
         const DmaJob job = dma_job(dp_wtile, more ? kc + 1 : 0, BUF ^ 1, next_any);
         if constexpr ((VAR & 4) == 0) transform_head(d);
@@ -473,9 +475,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
             constexpr int p0 = wino4_pos_of(2 * G), p1 = wino4_pos_of(2 * G + 1);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (G == NPRE) {
+                // behind a tile's last chunk the wait comes after the epilogue (main loop): the first chunk of the next tile is a
+                // cold fetch, and the epilogue is the work to hide it behind
                 if constexpr ((VAR & 8) == 0) {
-                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the next chunk have landed
-                    __syncthreads();                      // everyone past the LDS reads of buffer BUF and done filling the other one
+                    if (more) {
+                        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the next chunk have landed
+                        __syncthreads();                      // everyone past the LDS reads of buffer BUF and done filling the other one
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -495,8 +501,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
                     if constexpr ((VAR & 1) == 0 && G < 10 && (U == 1 || U == 5)) dma_piece(job, std::integral_constant<int, 2 * G + (U == 5 ? 1 : 0)>{});
                 } else {
                     // behind the barrier: the raw patch of the next chunk (rows 0, 2, 4, 1, 3, 5) and its first weights.  Unconditional
-                    // (a conditional load would keep the old contents of dn alive through the whole chunk); behind a tile's last
-                    // chunk the values are dropped -- the epilogue needs the registers -- and read again after it (load_first)
+                    // (a conditional load would keep the old contents of dn alive through the whole chunk); in a tile's last
+                    // chunk -- no barrier, the other buffer is being filled -- the values are dropped and the next tile's first
+                    // chunk is read behind the epilogue (load_first): the epilogue needs the registers
                     {
                         constexpr int slot = 8 * (G - NPRE) + U;           // 0..31
                         constexpr int order[6] = {0, 2, 4, 1, 3, 5};
@@ -510,25 +517,31 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            wino4_mfma<0, p0, FIRST, true>(accv, d[p0].x, bv[p0].x);
+            wino4_mfma<0, p0, FIRST, true, (VAR & 16) != 0>(accv, d[p0].x, bv[p0].x);
             filler(std::integral_constant<int, 0>{});
-            wino4_mfma<1, p0, FIRST, false>(accv, d[p0].x, bv[p0].z);
+            wino4_mfma<1, p0, FIRST, true, (VAR & 16) != 0>(accv, d[p0].x, bv[p0].z);
             filler(std::integral_constant<int, 1>{});
-            wino4_mfma<0, p1, FIRST, false>(accv, d[p1].x, bv[p1].x);
+            wino4_mfma<0, p1, FIRST, true, (VAR & 16) != 0>(accv, d[p1].x, bv[p1].x);
             filler(std::integral_constant<int, 2>{});
-            wino4_mfma<1, p1, FIRST, false>(accv, d[p1].x, bv[p1].z);
+            wino4_mfma<1, p1, FIRST, true, (VAR & 16) != 0>(accv, d[p1].x, bv[p1].z);
             filler(std::integral_constant<int, 3>{});
-            wino4_mfma<0, p0, false, false>(accv, d[p0].y, bv[p0].y);
+            wino4_mfma<0, p0, false, true, (VAR & 16) != 0>(accv, d[p0].y, bv[p0].y);
             filler(std::integral_constant<int, 4>{});
-            wino4_mfma<1, p0, false, false>(accv, d[p0].y, bv[p0].w);
+            wino4_mfma<1, p0, false, true, (VAR & 16) != 0>(accv, d[p0].y, bv[p0].w);
             filler(std::integral_constant<int, 5>{});
-            wino4_mfma<0, p1, false, false>(accv, d[p1].y, bv[p1].y);
+            wino4_mfma<0, p1, false, true, (VAR & 16) != 0>(accv, d[p1].y, bv[p1].y);
             filler(std::integral_constant<int, 6>{});
-            wino4_mfma<1, p1, false, false>(accv, d[p1].y, bv[p1].w);
+            wino4_mfma<1, p1, false, true, (VAR & 16) != 0>(accv, d[p1].y, bv[p1].w);
             filler(std::integral_constant<int, 7>{});
             // transform work for the coming position rows: one clump
             if constexpr ((VAR & 4) == 0) transform_clump(d, G);
         });
+        if constexpr ((VAR & 64) != 0) {   // probe: read the next chunk's patch and first weights again behind the chunk
+            __syncthreads();
+#pragma unroll
+            for (int ii = 0; ii < 6; ++ii) load_patch_row(dn, An, ii);
+            wino_static_for<0, AHEAD>([&](auto q_c) { load_weights(bvn, An, wino4_pos_of(decltype(q_c)::value)); });
+        }
     };
 
     f32x2 dA[36], dB[36];
@@ -551,6 +564,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         if constexpr ((VAR & 2) == 0)
             wino4_epilogue<T>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wave, lane);
         if (!has_next) break;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's first chunk has landed (and this tile's stores have left)
+        __syncthreads();
         load_first();
         item += (int)gridDim.x;
         tile = ntile;
@@ -597,6 +612,8 @@ static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
         case 7: return launch_wino4_var<T, 7>(a, stream);
         case 11: return launch_wino4_var<T, 11>(a, stream);
         case 15: return launch_wino4_var<T, 15>(a, stream);
+        case 16: return launch_wino4_var<T, 16>(a, stream);
+        case 64: return launch_wino4_var<T, 64>(a, stream);
         default: break;
     }
 #endif

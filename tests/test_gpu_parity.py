@@ -110,9 +110,12 @@ def test_unet_full_width_vs_oracle(dev, shape):
 
 
 def test_winograd_kernels_vs_direct_and_oracle(dev, monkeypatch):
-    """Every Winograd instantiation (csrc/rcu_wino.hip: F(2x2,3x3) conv units, csrc/rcu_wino_up.hip: F(2x2,2x2) sub-pixel
-    up-convolutions) on the BraTS slice size with 8 slices -- enough for the work items that span 2 and 8 slices:
-    against the oracle, against the direct kernels (RCU_CONV_WINO=0), and on ragged batches."""
+    """Every Winograd instantiation (csrc/rcu_wino4.hip: F(4x4,3x3) conv units, csrc/rcu_wino.hip: F(2x2,3x3) conv units,
+    csrc/rcu_wino_up.hip: F(2x2,2x2) sub-pixel up-convolutions) on the BraTS slice size with 8 slices -- enough for the work items
+    that span 2 and 8 slices: against the oracle, against the direct kernels (RCU_CONV_WINO=0), and on ragged batches.  Three
+    plans: the shipped selection (F(4x4,3x3) for the layers with >= 64 output channels), F(4x4,3x3) wherever it fits
+    (RCU_CONV_WINO4=2: also the 32-channel full-resolution layers, the 2x2 max-pool in its epilogue and the two-source K loop at
+    that tile) and F(2x2,3x3) only (RCU_CONV_WINO4=0)."""
     from oracle import unet_oracle as uo
     params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
     st = uo.synthetic_state(21, **params)
@@ -121,27 +124,38 @@ def test_winograd_kernels_vs_direct_and_oracle(dev, monkeypatch):
     x = torch.randn(n, 4, h, w, generator=g)
     _, sites = uo.unet_plan(**params)
     masks = uo.sample_masks(sites, n, 0.3, g)
-    m_w = _model(params, st, dev)
-    kernels = {row['kernel'] for row in m_w.layer_table(h, w, n)}
-    expected = {'conv3x3_winograd<T16x16,N64,K8>', 'conv3x3_winograd<T16x32,N32,K8>', 'conv3x3_winograd<S2T8x16,N64,K8>',
-                'conv3x3_winograd<S8T4x8,N64,K8>', 'upconv_winograd<T16x16,N64,K8>', 'upconv_winograd<T16x32,N32,K8>',
-                'upconv_winograd<S2T8x16,N64,K8>', 'upconv_winograd<S8T4x8,N64,K8>'}
-    assert expected <= kernels, expected - kernels
-    out_w = m_w(x.to(dev), masks).cpu().numpy()
     ref = uo.unet_forward(st, x, masks, **params).numpy()
-    assert _maxdiff(out_w, ref) < LOGIT_TOL
-    assert _maxdiff(torch.softmax(torch.from_numpy(out_w), 1).numpy(), torch.softmax(torch.from_numpy(ref), 1).numpy()) < PROB_TOL
-    # ragged batches on the same plan (max_batch 8): slices are independent, so the results are the same bits
-    for k in (3, 5):
-        out_k = m_w(x[:k].to(dev), [mk[:k] for mk in masks]).cpu().numpy()
-        assert np.array_equal(out_k, out_w[:k])
+    common = {'conv3x3_winograd<T16x32,N32,K8>', 'conv3x3_winograd<S2T8x16,N64,K8>', 'conv3x3_winograd<S8T4x8,N64,K8>',
+              'upconv_winograd<T16x16,N64,K8>', 'upconv_winograd<T16x32,N32,K8>', 'upconv_winograd<S2T8x16,N64,K8>',
+              'upconv_winograd<S8T4x8,N64,K8>'}
+    w4 = {'conv3x3_winograd4<T32x32,N32,K8>', 'conv3x3_winograd4<S2T16x32,N32,K8>'}
+    outs = {}
+    for mode, expected in (('1', common | w4), ('2', common | w4), ('0', common | {'conv3x3_winograd<T16x16,N64,K8>'})):
+        monkeypatch.setenv('RCU_CONV_WINO4', mode)
+        m_w = _model(params, st, dev)
+        rows = m_w.layer_table(h, w, n)
+        kernels = {row['kernel'] for row in rows}
+        assert expected <= kernels, (mode, expected - kernels)
+        n4 = sum('winograd4' in row['kernel'] for row in rows)
+        assert n4 == {'1': 8, '2': 11, '0': 0}[mode], (mode, n4)
+        out_w = m_w(x.to(dev), masks).cpu().numpy()
+        assert _maxdiff(out_w, ref) < LOGIT_TOL, mode
+        assert _maxdiff(torch.softmax(torch.from_numpy(out_w), 1).numpy(), torch.softmax(torch.from_numpy(ref), 1).numpy()) < PROB_TOL
+        assert _maxdiff(m_w(x.to(dev)).cpu().numpy(), uo.unet_forward(st, x, None, **params).numpy()) < LOGIT_TOL, mode
+        # ragged batches on the same plan (max_batch 8): slices are independent, so the results are the same bits
+        for k in (3, 5):
+            out_k = m_w(x[:k].to(dev), [mk[:k] for mk in masks]).cpu().numpy()
+            assert np.array_equal(out_k, out_w[:k]), (mode, k)
+        outs[mode] = out_w
+    monkeypatch.delenv('RCU_CONV_WINO4')
     # the direct kernels on the same input
     monkeypatch.setenv('RCU_CONV_WINO', '0')
     m_d = _model(params, st, dev)
     assert not any('winograd' in row['kernel'] for row in m_d.layer_table(h, w, n))
     out_d = m_d(x.to(dev), masks).cpu().numpy()
     assert _maxdiff(out_d, ref) < LOGIT_TOL
-    assert _maxdiff(out_w, out_d) < 2e-5
+    for mode in outs:
+        assert _maxdiff(outs[mode], out_d) < 2e-5, mode
 
 
 @pytest.mark.parametrize('in_channels,start_filters', [(3, 32), (4, 32), (6, 32), (4, 64), (1, 16)])

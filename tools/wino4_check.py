@@ -36,11 +36,12 @@ def main():
     masks = uo.sample_masks(sites, n, 0.3, g)
     m4, m2 = build(st, dev, True, (h, w, n)), build(st, dev, False, (h, w, n))
     print('kernels F(4,3) build:', sorted({r['kernel'] for r in m4.layer_table(h, w, n)}))
-    for mk in (None, masks):
+    for var, mk in [(v, mk) for v in os.environ.get('RCU_W4_PARITY_VARIANTS', '0').split(',') for mk in (None, masks)]:
+        os.environ['RCU_W4_VARIANT'] = var
         ref = uo.unet_forward(st, x, mk, **bench.MODEL_PARAMS)
         o4 = m4(x.to(dev), mk).cpu()
         o2 = m2(x.to(dev), mk).cpu()
-        print('masks' if mk else 'eval ', 'max|F43 - oracle| {:.3e}   max|F23 - oracle| {:.3e}   max|F43 - F23| {:.3e}   |logit|max {:.3f}'.format(
+        print('variant', var, 'masks' if mk else 'eval ', 'max|F43 - oracle| {:.3e}   max|F23 - oracle| {:.3e}   max|F43 - F23| {:.3e}   |logit|max {:.3f}'.format(
             float((o4 - ref).abs().max()), float((o2 - ref).abs().max()), float((o4 - o2).abs().max()), float(ref.abs().max())))
     torch.cuda.synchronize()
     del m4, m2
