@@ -294,6 +294,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    passes_run = max(runner.forwards_run, 1)        # this rank's forward passes inside the timed region
     forwards_per_rank = [runner.forwards_run]
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -336,7 +337,6 @@ def main():
     # ---- roofline of the dominant kernel (this rank's launches in the timed region).  A launch covers one pass of the volume, or
     # pass_group passes (n_slices * g samples) where the runner grouped them: FLOPs count the passes, launches the kernel launches.
     g = args.pass_group
-    passes_run = max(runner.forwards_run, 1)
     layers = model.layer_table(height, width, n_slices * g)
     per_kernel = {}
     for L, ms in zip(layers, slot_ms[1:1 + len(layers)]):

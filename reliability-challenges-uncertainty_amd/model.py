@@ -70,7 +70,8 @@ class UNet(nn.Module):
         self.sigma_out, self.bn = sigma_out, bn
         # unet.py:135-136, 178-179: when set, ``features`` is the input of conv_cls after every forward --
         # here a [N, C, H, W] VIEW of the handle's channels-last workspace tensor (no copy), valid until the
-        # next forward; rcu_amd.model.PostNet consumes it in place
+        # next forward (``.clone()`` it to keep it; it is reset to None when the plan it points into is rebuilt or
+        # dropped); rcu_amd.model.PostNet consumes it in place
         self.provide_features = provide_features
         self.features = None
         self._site_modules = []
@@ -126,6 +127,7 @@ class UNet(nn.Module):
         for handle, _, _ in self._handles.values():
             lib.rcu_unet_destroy(handle)
         self._handles = {}
+        self.features = None     # a view into a destroyed handle's workspace
 
     def __del__(self):
         try:
@@ -143,6 +145,7 @@ class UNet(nn.Module):
         if entry is not None:
             lib.rcu_unet_destroy(entry[0])
             del self._handles[(h, w)]
+            self.features = None     # ``features`` may be a view into that handle's workspace: valid until the next forward only
         desc = _lib.UnetDesc(nb_classes=self.nb_classes, in_channels=self.in_channels, depth=self.depth,
                              start_filters=self.start_filters, has_dropout=int(self.dropout is not None),
                              dropout_center=-1 if self.dropout_center is None else int(self.dropout_center),
@@ -164,6 +167,7 @@ class UNet(nn.Module):
         while len(self._handles) > self.MAX_HANDLES:    # images of many different sizes: drop the least recently used plan
             old = next(iter(self._handles))
             lib.rcu_unet_destroy(self._handles.pop(old)[0])
+            self.features = None
         return handle
 
     # ------------------------------------------------------------------ dropout

@@ -170,15 +170,33 @@ def read(path, dtype=None):
     count = int(np.prod(sizes))
     arr = np.frombuffer(raw, dtype=np.dtype(_DTYPES[code]).newbyteorder(endian), count=count, offset=vox_offset)
     arr = arr.reshape(sizes[::-1]).astype(_DTYPES[code])
-    if slope not in (0.0, 1.0) or inter != 0.0:
+    if slope != 0.0 and (slope != 1.0 or inter != 0.0):       # NIfTI-1: scl_slope == 0 means "no scaling", whatever scl_inter holds
         arr = arr * slope + inter
-    sform_code = struct.unpack_from(endian + 'h', raw, 254)[0]
+    qform_code, sform_code = struct.unpack_from(endian + '2h', raw, 252)
     n = len(sizes)
     if sform_code > 0:
         aff = np.eye(4)
         aff[0] = struct.unpack_from(endian + '4f', raw, 280)
         aff[1] = struct.unpack_from(endian + '4f', raw, 296)
         aff[2] = struct.unpack_from(endian + '4f', raw, 312)
+    elif qform_code > 0:
+        # method 2 of the NIfTI-1 standard: rotation from the quaternion (b, c, d), a = sqrt(1 - b^2 - c^2 - d^2), columns scaled by
+        # pixdim[1..3] (the third also by qfac = pixdim[0], -1 or 1), translation = the q offsets
+        b, c, d = (float(v) for v in struct.unpack_from(endian + '3f', raw, 256))
+        a2 = 1.0 - (b * b + c * c + d * d)
+        if a2 < 1e-7:                      # |(b, c, d)| >= 1 up to rounding: a 180 degree rotation, renormalise
+            norm = 1.0 / np.sqrt(b * b + c * c + d * d)
+            a, b, c, d = 0.0, b * norm, c * norm, d * norm
+        else:
+            a = float(np.sqrt(a2))
+        rot = np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                        [2 * (b * c + a * d), a * a + c * c - b * b - d * d, 2 * (c * d - a * b)],
+                        [2 * (b * d - a * c), 2 * (c * d + a * b), a * a + d * d - b * b - c * c]])
+        qfac = -1.0 if pixdim[0] < 0 else 1.0
+        scale = [pixdim[1] or 1.0, pixdim[2] or 1.0, (pixdim[3] or 1.0) * qfac]
+        aff = np.eye(4)
+        aff[:3, :3] = rot * np.asarray(scale)[None, :]
+        aff[:3, 3] = struct.unpack_from(endian + '3f', raw, 268)
     else:
         aff = np.diag([pixdim[1], pixdim[2], pixdim[3], 1.0])
     lps = np.diag([-1.0, -1.0, 1.0, 1.0]) @ aff

@@ -99,6 +99,9 @@ class McStatistics:
             raise ValueError('statistics blob must be a contiguous {} tensor of {} elements'.format(dtype, elems))
         self.blob = blob
         self.count = 0
+        # set by the predict steps: recipe(do_mi, do_var, materialize=False) runs the SAME passes again (same inputs, same dropout
+        # masks) into fresh statistics with other flags, or into a real [T, N, C, H, W] tensor
+        self.recipe = None
         _lib.check(_lib.load().rcu_mc_begin(_lib.ptr(self.blob), n, self.hw, nb_classes, self.flags,
                                             _lib.current_stream()))
 
@@ -124,6 +127,14 @@ class McStatistics:
         _lib.check(_lib.load().rcu_mc_accumulate(_lib.ptr(t), _lib.ptr(self.blob), self.n, self.hw, self.nb_classes,
                                                  flags, _lib.current_stream()))
         self.count += 1
+
+    def as_tensor(self):
+        """The stacked ``[T, N, C, H, W]`` probabilities the reference keeps under ``multi_probabilities`` (customsteps.py:36): the
+        statistics do not hold them, so the passes run again, materialised, under the same masks.  For foreign steps that read
+        the key between the predict step and the summary; costs T forward passes and T volumes of HBM."""
+        if self.recipe is None:
+            raise ValueError('these statistics were not produced by a predict step: the passes cannot be replayed')
+        return self.recipe(self.do_mi, self.do_var, materialize=True)
 
     def finalize(self, do_mi=False, do_var=False, count=None):
         """-> dict with the reference's keys: probabilities, entropy[, mutual_info][, variance]."""
@@ -224,21 +235,47 @@ class McPredictStep(BatchStep):
                     probs.append(softmax(logits))
                 batch_context.output['multi_probabilities'] = torch.stack(probs)
             else:
-                n, _, h, w = images.shape
-                stats = McStatistics(n, model.nb_classes, h, w, images.device, self.do_mi, self.do_var)
-                group = max(1, self.group_pixels // (n * h * w))
-                i = 0
-                while i < self.mc_steps:
-                    g = min(group, self.mc_steps - i)
-                    if g == 1:
-                        model.forward_accumulate(images, stats, None if self.masks is None else self.masks[i])
-                    else:
-                        model.forward_accumulate(images, stats, None if self.masks is None else self.masks[i:i + g],
-                                                 passes=g)
-                    i += g
-                batch_context.output['multi_probabilities'] = stats
+                batch_context.output['multi_probabilities'] = self._fused_passes(model, images, self.do_mi, self.do_var)
         finally:
             set_dropout_mode(model, is_train=False)   # reset to eval for the next batch (customsteps.py:39)
+
+    def _fused_passes(self, model, images, do_mi, do_var):
+        """The T passes into per-voxel statistics (dropout mode is on).  The statistics carry a recipe that replays the passes
+        -- same images, same masks: the device generator is put back to where the sampling started -- so that
+        ``MultiPredictionSummary(do_mi / do_var)`` decides alone which outputs exist, as in the reference (customsteps.py:44-48)."""
+        n, _, h, w = images.shape
+        dev = images.device
+        rng_state = torch.cuda.get_rng_state(dev) if (self.masks is None and dev.type == 'cuda') else None
+        stats = McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var)
+        group = max(1, self.group_pixels // (n * h * w))
+        i = 0
+        while i < self.mc_steps:
+            g = min(group, self.mc_steps - i)
+            if g == 1:
+                model.forward_accumulate(images, stats, None if self.masks is None else self.masks[i])
+            else:
+                model.forward_accumulate(images, stats, None if self.masks is None else self.masks[i:i + g], passes=g)
+            i += g
+
+        def recipe(mi, var, materialize=False):
+            now = torch.cuda.get_rng_state(dev) if rng_state is not None else None
+            if rng_state is not None:
+                torch.cuda.set_rng_state(rng_state, dev)
+            set_dropout_mode(model, is_train=True)
+            try:
+                if not materialize:
+                    return self._fused_passes(model, images, mi, var)
+                probs = []
+                for t in range(self.mc_steps):       # the same draws as the fused path makes: one per pass (or per pass group)
+                    probs.append(softmax(model(images) if self.masks is None else model(images, self.masks[t])))
+                return torch.stack(probs)
+            finally:
+                set_dropout_mode(model, is_train=False)
+                if now is not None:
+                    torch.cuda.set_rng_state(now, dev)
+
+        stats.recipe = recipe
+        return stats
 
 
 class EnsemblePredictionStep(BatchStep):
@@ -257,10 +294,15 @@ class EnsemblePredictionStep(BatchStep):
         fused = not self.materialize and all(isinstance(m, model_mod.UNet) for m in members)
         if fused:
             n, _, h, w = images.shape
-            stats = McStatistics(n, members[0].nb_classes, h, w, images.device, self.do_mi, self.do_var)
-            for m in members:
-                m.forward_accumulate(images, stats)
-            batch_context.output['multi_probabilities'] = stats
+            def run(mi, var, materialize=False):
+                if materialize:
+                    return torch.stack([softmax(m(images)) for m in members])
+                st = McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var)
+                for m in members:
+                    m.forward_accumulate(images, st)
+                st.recipe = run
+                return st
+            batch_context.output['multi_probabilities'] = run(self.do_mi, self.do_var)
         else:
             batch_context.output['multi_probabilities'] = torch.stack([softmax(m(images)) for m in members])
 
@@ -280,6 +322,13 @@ class MultiPredictionSummary(BatchStep):
             multi = batch_context.output['multi_probabilities']
         if isinstance(multi, McStatistics):
             stats = multi
+            if (self.do_mi and not stats.do_mi) or (self.do_var and not stats.do_var):
+                # the predict step did not track what this summary asks for (the reference's summary alone decides,
+                # customsteps.py:44-48): replay the passes with the flags of both
+                if stats.recipe is None:
+                    raise ValueError('the statistics lack {} and cannot be replayed'.format(
+                        'the entropy sum (do_mi)' if self.do_mi and not stats.do_mi else 'the squared sums (do_var)'))
+                stats = stats.recipe(self.do_mi or stats.do_mi, self.do_var or stats.do_var)
         else:
             t, n, c, h, w = multi.shape
             stats = McStatistics(n, c, h, w, multi.device, self.do_mi, self.do_var)

@@ -53,6 +53,32 @@ def test_nifti_header_follows_the_spec(tmp_path):
         nifti.write(path, a.astype(np.complex64))
 
 
+def test_nifti_qform_only_header_and_zero_slope(tmp_path):
+    """Files whose geometry lives in the qform only (sform_code 0) and files with scl_slope 0 (= "no scaling" in NIfTI-1, whatever
+    scl_inter holds): the writer of this package stores both forms, so patch its output."""
+    rng = np.random.RandomState(1)
+    a = (rng.rand(5, 7, 9) * 100).astype(np.float32)
+    for direction in ((1, 0, 0, 0, 1, 0, 0, 0, 1), (0, -1, 0, 1, 0, 0, 0, 0, 1), (1, 0, 0, 0, -1, 0, 0, 0, -1), (-1, 0, 0, 0, -1, 0, 0, 0, 1)):
+        props = nifti.ImageProperties((9, 7, 5), origin=(-12.5, 30.0, 4.25), spacing=(0.75, 1.5, 2.0), direction=direction)
+        path = str(tmp_path / 'q.nii')
+        nifti.write(path, a, props)
+        raw = bytearray(open(path, 'rb').read())
+        assert struct.unpack_from('<2h', raw, 252) == (1, 1)
+        struct.pack_into('<h', raw, 254, 0)                       # sform_code = 0: only the quaternion + offsets are left
+        raw[280:328] = bytes(48)
+        struct.pack_into('<2f', raw, 112, 0.0, 7.0)               # scl_slope 0, scl_inter 7: must NOT be applied
+        open(path, 'wb').write(bytes(raw))
+        b, p2 = nifti.read(path)
+        assert np.array_equal(a, b)
+        assert p2.size == props.size
+        assert np.allclose(p2.origin, props.origin, atol=1e-5) and np.allclose(p2.spacing, props.spacing, atol=1e-6)
+        assert np.allclose(p2.direction, props.direction, atol=1e-6), (direction, p2.direction)
+    # a real scaling is still applied
+    struct.pack_into('<2f', raw, 112, 2.0, 1.0)
+    open(path, 'wb').write(bytes(raw))
+    assert np.allclose(nifti.read(path)[0], a * 2.0 + 1.0)
+
+
 def test_write_subject_files(tmp_path):
     rng = np.random.RandomState(1)
     p = rng.rand(4, 8, 8, 2).astype(np.float32)

@@ -280,3 +280,34 @@ def test_auxiliary_dataset_variants_and_wrappers(tmp_path):
         'conv_logits.bias', 'conv_logits.weight', 'convs.0.conv2d_batch_relu.bn.bias']
     with pytest.raises(RuntimeError):
         post(torch.zeros(1, 32, 4, 4))          # CPU tensor: no fallback
+
+
+def test_directories_mirror_and_eval_command_line(tmp_path, monkeypatch):
+    """rcu_amd.directories keeps the reference's names (rechun/directories.py) and takes its "required to be set" entries from the
+    environment; bin-eval/eval_uncertainty.py accepts the reference's command line (--ds --ids --act only)."""
+    import importlib
+    import subprocess
+    import sys
+    monkeypatch.setenv('RCU_BRATS_ORIG_DATA_DIR', str(tmp_path / 'Brats18' / 'Training'))
+    monkeypatch.setenv('RCU_BRATS_BASELINE_MC_PREDICT', '190101-120000_brats_baseline_mc')
+    monkeypatch.setenv('RCU_PROJECT_DIR', str(tmp_path))
+    from rcu_amd import directories as dirs
+    dirs = importlib.reload(dirs)
+    try:
+        assert dirs.BRATS_ORIG_DATA_DIR == str(tmp_path / 'Brats18' / 'Training')
+        assert dirs.prediction_dir('brats', 'baseline_mc') == str(tmp_path / 'out' / 'predictions' / 'brats' / '190101-120000_brats_baseline_mc')
+        assert dirs.prediction_dir('isic', 'auxiliary_feat') == str(tmp_path / 'out' / 'predictions' / 'isic' / 'auxiliary_feat')
+        assert dirs.ground_truth_dir('isic') == str(tmp_path / 'in' / 'datasets' / 'isic_small' / 'ISIC-2017_Test_v2')
+        assert dirs.eval_dir('brats') == str(tmp_path / 'out' / 'eval' / 'brats')
+        assert dirs.UNCERTAINTY_PLACEHOLDER.format('baseline', '005') == 'eval_uncertainty_baseline_th005.csv'
+        assert dirs.SPLITS_DIR == str(tmp_path / 'config' / 'splits')
+    finally:
+        monkeypatch.undo()
+        importlib.reload(dirs)
+    # the reference's command line, with no directory configured: the script names the entry to set and exits non-zero
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith('RCU_')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bin-eval', 'eval_uncertainty.py'), '--ds', 'brats', '--ids', 'baseline_mc',
+                        '--act', 'minmax'], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and 'RCU_BRATS_ORIG_DATA_DIR' in r.stderr
+    assert "to_evaluate: ['baseline_mc']" in r.stdout and "eval_actions: ['minmax']" in r.stdout
