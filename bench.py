@@ -125,7 +125,7 @@ def cpu_probe_slices(member, params, x_cpu, passes_total, budget_s, n_max=32):
     t0 = time.perf_counter()
     uo.unet_forward(state, xs, None, **params)
     per_slice = (time.perf_counter() - t0) / 4
-    n = int(budget_s / max(per_slice * passes_total, 1e-6))
+    n = int(0.5 * budget_s / max(per_slice * passes_total, 1e-6))   # 0.5: a 32-slice forward takes about twice as long per slice as this probe
     return max(4, min(n_max, x_cpu.shape[0], n // 4 * 4))
 
 
@@ -210,7 +210,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=12.0, help='seconds of CPU work the oracle leg may take (bounded sample)')
     ap.add_argument('--no-ws', action='store_true', help='skip the deterministic weight-scaling pass')
-    ap.add_argument('--pass-group', type=int, default=1, help='MC passes of a rank per launch (N * g samples per batch)')
+    ap.add_argument('--pass-group', type=int, default=0,
+                    help='MC passes of a rank per launch (N * g samples per batch); 0 = McPredictStep\'s rule, GROUP_PIXELS // (N*H*W): 2 for the '
+                         '160-slice volume, 3 for the ISIC batch')
     ap.add_argument('--ensemble', type=int, default=0, metavar='K',
                     help='K ensemble members (seeds 20..20+K-1) instead of T MC passes (BASELINE config "BraTS ensemble")')
     ap.add_argument('--aleatoric', action='store_true',
@@ -251,6 +253,10 @@ def main():
     params = ISIC_PARAMS if isic else MODEL_PARAMS
     n_slices, height, width = (ISIC_IMAGES, ISIC_HEIGHT, ISIC_WIDTH) if isic else (SLICES, HEIGHT, WIDTH)
     unit_name = 'image' if isic else 'volume'
+    if args.ensemble or args.aleatoric:
+        args.pass_group = 1                     # members / sigma-head passes run one per launch
+    elif args.pass_group < 1:
+        args.pass_group = max(1, steps.McPredictStep.GROUP_PIXELS // (n_slices * height * width))
     model = make_model(seed, device, sigma_out=args.aleatoric, params=params)
     x_cpu, mask_cpu, target_cpu = make_isic_batch(seed) if isic else make_volume(seed)
     x = x_cpu.to(device)

@@ -202,11 +202,13 @@ class McPredictStep(BatchStep):
     """T stochastic passes (plus the deterministic 'weight scaling' pass the reference always runs
     first, customsteps.py:22-25)."""
 
-    # A forward pass fills the GPU from about 160 BraTS slices (3.9 M pixels) on; the shipped configs use
-    # batch_size 32.  The T passes of a batch are independent, so the fused path runs them in groups of
+    # A forward pass fills the GPU from about 160 BraTS slices (3.9 M pixels) on, and the deep levels of the U-Net -- few, long
+    # work items per launch -- only from twice that (their last round of workgroups is 75-88 % full at 160 slices); the shipped
+    # configs use batch_size 32.  The T passes of a batch are independent, so the fused path runs them in groups of
     # g = GROUP_PIXELS // (N*H*W) as one batch of N * g samples (include/rcu.h: rcu_unet_forward_accumulate_passes)
-    # -- same statistics bit for bit; the workspace grows to that of a 160-slice batch (6 GB), not beyond.
-    GROUP_PIXELS = 160 * 192 * 128
+    # -- same statistics bit for bit; the workspace grows to that of a 320-slice batch (12 GB of the 288), not beyond, and
+    # every tensor stays below the 2 GB the kernels' 32-bit buffer offsets reach.
+    GROUP_PIXELS = 2 * 160 * 192 * 128
 
     def __init__(self, mc_steps, do_mi=False, do_var=False, materialize=False, masks=None, ws_pass=True,
                  group_pixels=None) -> None:
@@ -266,8 +268,20 @@ class McPredictStep(BatchStep):
                 if not materialize:
                     return self._fused_passes(model, images, mi, var)
                 probs = []
-                for t in range(self.mc_steps):       # the same draws as the fused path makes: one per pass (or per pass group)
-                    probs.append(softmax(model(images) if self.masks is None else model(images, self.masks[t])))
+                t = 0
+                while t < self.mc_steps:             # the same draws as the fused path makes: one per pass group
+                    g = min(group, self.mc_steps - t)
+                    if self.masks is not None:
+                        sets = self.masks[t:t + g]
+                    elif g == 1:
+                        sets = [None]
+                    else:                            # rows [site][pass * n + i]: split the group's draw into its passes
+                        flat = model.sample_masks(n * g, dev)
+                        per_site = torch.split(flat, [n * g * c for _, c in model.dropout_sites()])
+                        sets = [[ps.view(g, n, -1)[k] for ps in per_site] for k in range(g)]
+                    for ms in sets:
+                        probs.append(softmax(model(images) if ms is None else model(images, ms)))
+                    t += g
                 return torch.stack(probs)
             finally:
                 set_dropout_mode(model, is_train=False)

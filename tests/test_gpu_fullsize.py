@@ -112,3 +112,36 @@ def test_real_data_shapes_full_width_vs_oracle(dev, cin, n, h, w):
         out = m(x.to(dev), mk).cpu().numpy()
         assert _maxdiff(out, ref) < LOGIT_TOL
         assert _maxdiff(torch.softmax(torch.from_numpy(out), 1).numpy(), torch.softmax(torch.from_numpy(ref), 1).numpy()) < PROB_TOL
+
+
+@pytest.mark.timeout(900)
+def test_pass_pair_of_the_full_volume_is_bit_identical_to_single_passes(dev):
+    """The headline path runs the MC passes of a 160-slice volume two per launch (320 samples: the 48x32 / 24x16 / 12x8 levels
+    then fill their last round of workgroups): rcu_unet_forward_accumulate_passes at N = 160 must give exactly the statistics of
+    two single-pass launches under the same masks, through McPredictStep too (its default GROUP_PIXELS pairs the passes)."""
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    st = uo.synthetic_state(35, **PARAMS)
+    g = torch.Generator().manual_seed(12)
+    n, h, w = 160, 192, 128
+    x = torch.randn(n, 4, h, w, generator=g).to(dev)
+    _, sites = uo.unet_plan(**PARAMS)
+    mask_sets = [uo.sample_masks(sites, n, 0.3, g) for _ in range(4)]
+    model = _model(PARAMS, st, dev)
+    single = steps.McStatistics(n, 2, h, w, dev, do_mi=True)
+    for ms in mask_sets:
+        model.forward_accumulate(x, single, ms)
+    paired = steps.McStatistics(n, 2, h, w, dev, do_mi=True)
+    model.forward_accumulate(x, paired, mask_sets[:2], passes=2)
+    model.forward_accumulate(x, paired, mask_sets[2:], passes=2)
+    assert torch.equal(single.blob, paired.blob)
+    assert steps.McPredictStep.GROUP_PIXELS // (n * h * w) == 2
+    ctx = steps.TorchTestContext('cuda', model)
+    outs = []
+    for group_pixels in (0, None):
+        bc = steps.BatchContext({'images': x}, 0)
+        steps.McPredictStep(4, do_mi=True, masks=mask_sets, group_pixels=group_pixels)(bc, None, ctx)
+        steps.MultiPredictionSummary(do_mi=True)(bc, None, ctx)
+        outs.append(bc.output)
+    for key in ('probabilities', 'entropy', 'mutual_info', 'ws_probabilities'):
+        assert torch.equal(outs[0][key], outs[1][key]), key

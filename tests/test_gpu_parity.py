@@ -450,10 +450,30 @@ def test_mc_step_end_to_end_golden(golden, dev):
             assert _maxdiff(bc.output[k].cpu().numpy(), g['out::' + k]) < PROB_TOL, k
     with pytest.raises(ValueError):
         steps.McPredictStep(1)(steps.BatchContext({'images': torch.from_numpy(g['x'])}, 0), None, object())
+    # In the reference the summary's flags alone decide which outputs exist (customsteps.py:44-48).  A default McPredictStep tracks
+    # mean + entropy only; a summary that asks for more replays the passes under the same masks (injected or sampled: the device
+    # generator is put back), so that every output belongs to the same T samples.
     bc = steps.BatchContext({'images': torch.from_numpy(g['x'])}, 0)
-    steps.McPredictStep(2)(bc, None, ctx)            # sampled masks, default statistics
+    steps.McPredictStep(T, masks=mask_sets)(bc, None, ctx)
+    steps.MultiPredictionSummary(do_mi=True, do_var=True)(bc, None, ctx)
+    assert set(bc.output) == set(g['out_keys'])
+    for k in g['out_keys']:
+        assert _maxdiff(bc.output[k].cpu().numpy(), g['out::' + k]) < PROB_TOL, k
+    torch.manual_seed(11)
+    bc = steps.BatchContext({'images': torch.from_numpy(g['x'])}, 0)
+    steps.McPredictStep(4)(bc, None, ctx)            # sampled masks, default statistics
+    stats = bc.output['multi_probabilities']
+    after = torch.cuda.get_rng_state(dev)
+    stacked = stats.as_tensor()                      # what a foreign step reading the key would want: [T, N, C, H, W]
+    assert tuple(stacked.shape) == (4,) + tuple(g['x'].shape[:1]) + (2,) + tuple(g['x'].shape[2:])
+    assert torch.equal(torch.cuda.get_rng_state(dev), after)       # the replay leaves the generator where it was
+    steps.MultiPredictionSummary(do_var=True)(bc, None, ctx)
+    assert not m.mc_active()
+    assert _maxdiff(bc.output['probabilities'].cpu().numpy(), stacked.mean(0).cpu().numpy()) < 1e-6
+    assert _maxdiff(bc.output['variance'].cpu().numpy(), stacked.var(0).mean(1, keepdim=True).cpu().numpy()) < 1e-6
+    blob = steps.McStatistics(1, 2, 8, 8, dev)       # statistics without a recipe cannot be replayed
     with pytest.raises(ValueError):
-        steps.MultiPredictionSummary(do_var=True)(bc, None, ctx)   # variance was not tracked
+        blob.as_tensor()
 
 
 def test_mc_sampled_dropout_statistics(dev):
