@@ -59,7 +59,8 @@ typedef struct rcu_unet_desc {
     int32_t dropout_center;  /* -1 <=> None (dropout in every conv unit), else unet.py:74-82 */
     int32_t sigma_out;       /* 1: twin head, forward returns (logits, sigma) */
     int32_t bn;              /* 1: BatchNorm2d in every conv unit (folded, eval mode) */
-    int32_t height, width;   /* per-slice size; both divisible by 2^depth */
+    int32_t height, width;   /* per-slice size, each >= 2^depth; sizes not divisible by 2^depth take the reference's centre pad
+                                (common/model/unet.py:110-116) and the direct kernels on the levels with odd sizes */
     int32_t max_batch;       /* largest N a forward call may pass; sizes the workspace */
 } rcu_unet_desc;
 

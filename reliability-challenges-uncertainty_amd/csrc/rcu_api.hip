@@ -57,6 +57,7 @@ struct ConvLayer {
 struct Tensor {
     size_t floats_per_slice = 0;
     float* dev = nullptr;
+    bool zero_fill = false;   // centre-padded up-conv output: the border is never written and must read as zero
 };
 
 struct rcu_unet {
@@ -117,7 +118,8 @@ static int pick_config(const ConvLayer& L, int n_slices)
     const char* const wino_env = getenv("RCU_CONV_WINO");
     const bool wino_on = !(wino_env && atoi(wino_env) == 0);
     const size_t max_bytes = (size_t)n_slices * L.H * L.W * (size_t)std::max(std::max(L.c1p, L.c2p), L.coutp) * 4;
-    if (L.upsample && wino_on && L.c1p % 32 == 0 && L.c2p == 0 && max_bytes < ((size_t)1 << 31)) {
+    const bool center_pad = L.upsample && (2 * (L.H / 2) != L.H || 2 * (L.W / 2) != L.W);   // unet.py:110-116: direct kernel only
+    if (L.upsample && !center_pad && wino_on && L.c1p % 32 == 0 && L.c2p == 0 && max_bytes < ((size_t)1 << 31)) {
         const int lh = L.H / 2, lw = L.W / 2;
         if (L.coutp == 32 && lh % 16 == 0 && lw % 32 == 0) return CONV_CFG_UPW_T16x32_N32;
         if (L.coutp > 32 && lh % 16 == 0 && lw % 16 == 0) return CONV_CFG_UPW_T16x16_N64;
@@ -234,6 +236,7 @@ static int build_plan(rcu_unet* h)
         U.cin1 = cur_c; U.c1p = cur_cp; U.cout = co; U.coutp = cop; U.csplit = cop;
         U.H = H; U.W = W; U.upsample = 1; U.relu = 0;
         U.t_src1 = cur; U.t_out = t_up;
+        if (2 * (H / 2) != H || 2 * (W / 2) != W) h->tensors[t_up].zero_fill = true;   // centre pad (unet.py:110-116)
         h->layers.push_back(U);
         // cat((up, skip), 1) -> block: K split over the two tensors (unet.py:118-119)
         snprintf(buf, sizeof buf, "up_convs.%d.block.block.0", j);
@@ -288,9 +291,8 @@ extern "C" int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out)
     if (d.in_channels > 8 && d.in_channels % 32 != 0)
         return fail(RCU_ERR_INVALID, "in_channels must be <= 8 or a multiple of 32");
     const int div = 1 << d.depth;
-    if (d.height < div || d.width < div || d.height % div != 0 || d.width % div != 0)
-        return fail(RCU_ERR_INVALID, "height and width must be positive multiples of 2^depth (the reference's centre-pad "
-                                     "branch, unet.py:110-116, is not implemented)");
+    if (d.height < div || d.width < div)
+        return fail(RCU_ERR_INVALID, "height and width must be at least 2^depth (one pixel at the bottom level)");
     rcu_unet* h = new rcu_unet();
     h->d = d;
     int rc = build_plan(h);
@@ -313,6 +315,13 @@ extern "C" int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out)
         }
         h->allocs.push_back(t.dev);
         h->workspace_bytes += (int64_t)bytes;
+        if (t.zero_fill) {
+            e = hipMemset(t.dev, 0, bytes);
+            if (e != hipSuccess) {
+                rcu_unet_destroy(h);
+                return hip_fail(e, "hipMemset(centre-pad border)");
+            }
+        }
     }
     *out = h;
     return RCU_OK;
@@ -590,6 +599,10 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     a.pooled = L.t_pool >= 0 ? h->tensors[L.t_pool].dev : nullptr;
     const int gh = L.upsample ? L.H / 2 : L.H, gw = L.upsample ? L.W / 2 : L.W;   // tile grid = input grid
     a.N = n; a.H = gh; a.W = gw;
+    if (L.upsample && (2 * gh != L.H || 2 * gw != L.W)) {   // centre pad: F.pad(up, (dw // 2, dw - dw // 2, dh // 2, dh - dh // 2))
+        a.out_H = L.H; a.out_W = L.W;
+        a.out_y0 = (L.H - 2 * gh) / 2; a.out_x0 = (L.W - 2 * gw) / 2;
+    }
     a.C1 = L.c1p; a.C2 = L.c2p; a.CoutP = L.coutp;
     a.cin_real = L.cin1;
     a.x_nchw = L.cfg == CONV_CFG_FIRST_T8x32 ? x_nchw : nullptr;
@@ -886,7 +899,8 @@ extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info*
     out->cout = L.name2.empty() ? L.cout : 2 * L.cout;
     out->height = L.H; out->width = L.W;
     out->upsample = L.upsample; out->pooled = L.t_pool >= 0; out->dual_source = L.t_src2 >= 0;
-    out->flops_per_slice = 2.0 * out->cin * out->cout * 9.0 * L.H * L.W;
+    // an up-convolution works on the up-sampled grid, which a centre pad leaves smaller than the skip tensor it is padded to
+    out->flops_per_slice = 2.0 * out->cin * out->cout * 9.0 * (L.upsample ? 4.0 * (L.H / 2) * (L.W / 2) : (double)L.H * L.W);
     {
         // executed on the matrix pipe: padded K and N, full tiles, 4 taps per output pixel for the sub-pixel form
         const ConvConfigInfo ci = conv_config_info(L.cfg);

@@ -125,7 +125,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&
     constexpr int MT = T::MT, NTW = T::NTW;
     constexpr bool SUBPIXEL = (T::TAPS == 4);
     constexpr int OS = SUBPIXEL ? 2 : 1;
-    const int OH = a.H * OS, OW = a.W * OS;
+    // the output tensor: the grid itself, or (sub-pixel mode with a centre pad) a larger zero-initialised tensor around it
+    const int OH = (SUBPIXEL && a.out_H > 0) ? a.out_H : a.H * OS, OW = (SUBPIXEL && a.out_W > 0) ? a.out_W : a.W * OS;
+    const int oy0 = SUBPIXEL ? a.out_y0 : 0, ox0 = SUBPIXEL ? a.out_x0 : 0;
     const bool full_tile = (y0 + T::TH <= a.H) && (x0 + T::TW <= a.W) && (n0 + T::TS <= a.N);
     const size_t row_stride = (size_t)OW * a.CoutP * OS, col_stride = (size_t)a.CoutP * OS;
     const int Hp = a.H >> 1, Wp = a.W >> 1;
@@ -153,7 +155,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&
                 float t = acc[mi][ni][i] * scale + shift;
                 v[i] = a.relu ? fmaxf(t, 0.f) : t;
             }
-            float* const obase = a.out + ((size_t)(n * OH + yb * OS + pa) * OW + xb * OS + pb) * a.CoutP + co;
+            float* const obase = a.out + ((size_t)(n * OH + oy0 + yb * OS + pa) * OW + ox0 + xb * OS + pb) * a.CoutP + co;
             if (full_tile) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];

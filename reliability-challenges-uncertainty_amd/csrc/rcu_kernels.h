@@ -22,6 +22,8 @@ struct ConvArgs {
     const float* mask2;  // second site for output channels >= Csplit (fused cls+sigma head unit), or null
     float* out;          // [N][H][W][CoutP]; sub-pixel up-conv kernels: [N][2H][2W][CoutP]
     float* pooled;       // [N][H/2][W/2][CoutP] or null
+    int out_H, out_W;    // sub-pixel up-conv (direct kernels): extent of the output tensor when it is larger than 2H x 2W -- the
+    int out_y0, out_x0;  //   reference's centre pad (common/model/unet.py:110-116) -- and where the 2H x 2W image sits in it; 0: 2H x 2W
     int N, H, W;         // input grid = pixel-tile grid
     int C1, C2;          // padded channel counts of the two sources
     int cin_real;        // first-layer kernel (rcu_first.hip): input channels that are not padding

@@ -44,9 +44,9 @@ def test_thresholds_match_reference_bit_patterns(lib):
 def test_argument_validation_without_gpu(lib):
     so = lib.load()
     desc = lib.UnetDesc(nb_classes=2, in_channels=4, depth=4, start_filters=32, has_dropout=1, dropout_center=-1,
-                        sigma_out=0, bn=1, height=40, width=32, max_batch=1)
+                        sigma_out=0, bn=1, height=8, width=32, max_batch=1)
     handle = ctypes.c_void_p()
-    assert so.rcu_unet_create(ctypes.byref(desc), ctypes.byref(handle)) == -1      # 40 % 16 != 0
+    assert so.rcu_unet_create(ctypes.byref(desc), ctypes.byref(handle)) == -1      # 8 < 2^4: nothing left at the bottom level
     assert b'2^depth' in so.rcu_last_error()
     desc.height, desc.nb_classes = 32, 9
     assert so.rcu_unet_create(ctypes.byref(desc), ctypes.byref(handle)) == -1

@@ -145,3 +145,28 @@ def test_pass_pair_of_the_full_volume_is_bit_identical_to_single_passes(dev):
         outs.append(bc.output)
     for key in ('probabilities', 'entropy', 'mutual_info', 'ws_probabilities'):
         assert torch.equal(outs[0][key], outs[1][key]), key
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('cin,n,h,w', [(4, 3, 100, 100), (3, 2, 150, 200), (4, 2, 40, 32), (3, 1, 77, 51)])
+def test_centre_pad_shapes_full_width_vs_oracle(dev, cin, n, h, w):
+    """Sizes that 2^depth does not divide: max-pool floors (unet.py:94), the up-convolution comes out smaller than the skip tensor and
+    is zero-padded around its centre before the concatenation (unet.py:110-116).  Full width, against the oracle, masks injected;
+    a smaller batch on the same plan gives the same bits (the padded border is written once, at plan creation)."""
+    from oracle import unet_oracle as uo
+    params = dict(PARAMS, in_channels=cin)
+    st = uo.synthetic_state(37, **params)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(n, cin, h, w, generator=g)
+    _, sites = uo.unet_plan(**params)
+    masks = uo.sample_masks(sites, n, 0.3, g)
+    m = _model(params, st, dev)
+    rows = m.layer_table(h, w, n)
+    assert any(r['upsample'] and (r['height'] % 2 or r['width'] % 2) for r in rows)       # at least one padded up-convolution
+    for mk in (None, masks):
+        ref = uo.unet_forward(st, x, mk, **params).numpy()
+        out = m(x.to(dev), mk).cpu().numpy()
+        assert out.shape == ref.shape
+        assert _maxdiff(out, ref) < LOGIT_TOL
+    if n > 1:
+        assert np.array_equal(m(x[:1].to(dev), [mk[:1] for mk in masks]).cpu().numpy(), out[:1])

@@ -399,7 +399,7 @@ def test_unet_batch_split_invariance_and_errors(dev):
     ones = [np.ones((6, c), np.float32) for _, c in m.dropout_sites()]
     assert torch.equal(m(x, ones), full)         # all-ones masks == eval mode, bit for bit
     with pytest.raises(_lib.RcuError):
-        m(torch.zeros(1, 4, 40, 32, device=dev))  # not divisible by 2^depth
+        m(torch.zeros(1, 4, 8, 32, device=dev))   # smaller than 2^depth: nothing left at the bottom level
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 4, 32, 32))              # CPU tensor: no fallback
     with pytest.raises(ValueError):
