@@ -13,9 +13,11 @@ pymia and h5py are not available here and data ingestion is outside the hot path
   * the transform registry entries the shipped YAML files use: permute, squeeze, unsqueeze, rescale.
 A ``.h5`` dataset path raises with a pointer to ``convert`` instead of failing somewhere inside.
 """
+import collections
 import glob
 import json
 import os
+import threading
 
 import numpy as np
 import torch
@@ -111,6 +113,15 @@ def write_volume(dataset_dir, subject, images, labels=None, properties=None):
     np.savez(os.path.join(dataset_dir, subject + '.npz'), **arrays)
 
 
+def _npz_member_shape(path, name):
+    """Shape of array ``name`` of an .npz file from its .npy header alone (np.load(...)[name].shape reads the whole volume)."""
+    import zipfile
+    with zipfile.ZipFile(path) as z, z.open(name + '.npy') as f:
+        version = np.lib.format.read_magic(f)
+        reader = np.lib.format.read_array_header_1_0 if version == (1, 0) else np.lib.format.read_array_header_2_0
+        return tuple(reader(f)[0])
+
+
 class VolumeDataset(torch_data.Dataset):
     """One sample = one slice (axis 0) of one subject; subjects in sorted order, optionally a subset."""
 
@@ -133,17 +144,25 @@ class VolumeDataset(torch_data.Dataset):
         self.index = []          # (subject index, slice index)
         self.shapes = []
         for si, f in enumerate(files):
-            with np.load(f) as z:
-                shape = z['images'].shape
+            shape = _npz_member_shape(f, 'images')
             self.shapes.append(shape)
             self.index.extend((si, k) for k in range(shape[0]))
-        self._cache = (None, None)
+        # the last few subjects read: the loader thread is on subject i + 1 when the test loop asks for the labels of subject i
+        self._cache = collections.OrderedDict()
+        self._cache_lock = threading.Lock()
 
     def _volume(self, si):
-        if self._cache[0] != si:
-            with np.load(self.files[si]) as z:
-                self._cache = (si, {k: z[k] for k in z.files})
-        return self._cache[1]
+        with self._cache_lock:
+            vol = self._cache.get(si)
+            if vol is not None:
+                return vol
+        with np.load(self.files[si]) as z:
+            vol = {k: z[k] for k in z.files}
+        with self._cache_lock:
+            self._cache[si] = vol
+            while len(self._cache) > 3:
+                self._cache.popitem(last=False)
+        return vol
 
     def __len__(self):
         return len(self.index)

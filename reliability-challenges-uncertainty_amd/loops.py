@@ -266,7 +266,7 @@ class Subject2dAssembler:
 
     def add_batch(self, to_assemble: dict, batch: dict, last_batch=False):
         for b, id_ in enumerate(batch[self.id_entry]):
-            self.store[id_] = {key: value[b] for key, value in to_assemble.items()}
+            self.store[id_] = {key: np.array(value[b]) for key, value in to_assemble.items()}   # a copy: the batch arrays may be reused buffers
             self.subjects_ready.add(id_)
 
     def get_assembled_subject(self, subject_index):
@@ -293,6 +293,83 @@ def tensor_to_numpy(tensor):
     return tensor.cpu().numpy()
 
 
+def prefetch(iterable, depth=2, pin=False):
+    """Iterate ``iterable`` from a background thread, ``depth`` items ahead: the loader's work for the next batches (file reads,
+    decompression -- zlib and numpy release the GIL -- transforms, collation) overlaps the GPU work of the current one.  ``pin``:
+    floating-point tensors of a dict batch are moved to pinned host memory there too, so that the step's host-to-device copy is
+    asynchronous and the test loop keeps the GPU's queue filled instead of waiting for each copy."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    done = object()
+
+    # pinned staging buffers, allocated once per (entry, shape) and used in turn: depth queued + one with the consumer + one
+    # whose copy to the device may still be in flight (pinning per batch costs more than the copy it speeds up)
+    ring, turn = {}, [0]
+
+    def staged(key, v):
+        bufs = ring.setdefault((key, tuple(v.shape), v.dtype), [])
+        if len(bufs) < depth + 2:
+            bufs.append(torch.empty(v.shape, dtype=v.dtype, pin_memory=True))
+        buf = bufs[turn[0] % len(bufs)]
+        buf.copy_(v)
+        return buf
+
+    def worker():
+        try:
+            for item in iterable:
+                if pin and isinstance(item, dict):
+                    item = {k: (staged(k, v) if torch.is_tensor(v) and v.is_floating_point() and not v.is_cuda else v)
+                            for k, v in item.items()}
+                    turn[0] += 1
+                q.put((item, None))
+            q.put((done, None))
+        except BaseException as exc:  # noqa: BLE001 - re-raised in the consumer
+            q.put((done, exc))
+
+    threading.Thread(target=worker, daemon=True, name='rcu-loader').start()
+    while True:
+        item, exc = q.get()
+        if item is done:
+            if exc is not None:
+                raise exc
+            return
+        yield item
+
+
+class _Download:
+    """Device -> host copy of a batch's kept output entries on a side stream, into pinned buffers (two sets, used in turn), started
+    right behind the batch's kernels: the copy of batch k runs beside the kernels of batch k + 1 instead of making the host wait for
+    both.  ``wait()`` returns channel-last numpy arrays, as the reference's ``convert_fn`` does (loops.py:214-220)."""
+
+    _buffers = {}
+
+    def __init__(self, tensors: dict, stream, slot):
+        self.done = torch.cuda.Event()
+        self.arrays = {}
+        ready = torch.cuda.Event()
+        ready.record()                                  # behind the batch's kernels on the compute stream
+        with torch.cuda.stream(stream):
+            stream.wait_event(ready)
+            for key, value in tensors.items():
+                value = steps_mod.channel_to_end(value)
+                if not value.is_cuda:                   # an entry a step left on the host (labels kept for the subject steps)
+                    self.arrays[key] = value
+                    continue
+                buf_key = (slot, key, tuple(value.shape), value.dtype)
+                host = self._buffers.get(buf_key)
+                if host is None:
+                    host = self._buffers[buf_key] = torch.empty(value.shape, dtype=value.dtype, pin_memory=True)
+                host.copy_(value, non_blocking=True)
+                value.record_stream(stream)
+                self.arrays[key] = host
+            self.done.record(stream)
+
+    def wait(self):
+        self.done.synchronize()
+        return {k: v.numpy() for k, v in self.arrays.items()}
+
+
 class Test:
     __test__ = False
 
@@ -317,36 +394,66 @@ class Test:
 
         task_context = context.get_task_context()
         hook.on_test_start(task_context, context)
-        for i, batch in enumerate(task_context.data.loader):
+        # Pipelined form of the reference's loop (loops.py:176-235): batch k + 1 is loaded while batch k computes, and the outputs of
+        # batch k come to the host -- and its subjects are assembled, evaluated and written -- while batch k + 1 computes.  Per
+        # batch the order of the callbacks is the reference's (batch start, steps, subject start / steps / end, batch end); only
+        # "batch k + 1 start" now comes before "subjects of batch k".  A custom convert_fn or a CPU device keeps the plain order.
+        pipelined = (self.convert_fn is tensor_to_numpy and self.subject_assembler is not None and
+                     getattr(context.device, 'type', 'cpu') == 'cuda')
+        side = torch.cuda.Stream(device=context.device) if pipelined else None
+        waiting = None
+        for i, batch in enumerate(prefetch(task_context.data.loader, pin=pipelined)):
             batch_context = BatchContext(batch, i)
             hook.on_test_batch_start(batch_context, task_context, context)
-            self._test_batch(batch_context, task_context, context, hook)
-            hook.on_test_batch_end(batch_context, task_context, context)
+            download = self._run_steps(batch_context, task_context, context, side, i & 1)
+            if waiting is not None:
+                self._finish_batch(*waiting, task_context, context, hook)
+            waiting = (batch_context, download)
+            if not pipelined:
+                self._finish_batch(*waiting, task_context, context, hook)
+                waiting = None
+        if waiting is not None:
+            self._finish_batch(*waiting, task_context, context, hook)
         hook.on_test_end(task_context, context)
         hook.on_termination(context)
 
-    def _test_batch(self, batch_context, task_context, context, hook):
+    def _kept(self, batch_context):
+        return {key: value for key, value in batch_context.output.items()
+                if (self.entries is None or key in self.entries) and isinstance(value, torch.Tensor)}
+
+    def _run_steps(self, batch_context, task_context, context, side, slot):
         for batch_step in self.steps:
             batch_step(batch_context, task_context, context)
         if batch_context.metrics:
             task_context.history.add(batch_context.metrics, 'batch_metrics')
-        if self.subject_assembler is None:
-            return
+        if side is None or self.subject_assembler is None:
+            return None
+        return _Download(self._kept(batch_context), side, slot)
 
-        to_assemble = {}
-        for key, value in batch_context.output.items():
-            if (self.entries is None or key in self.entries) and isinstance(value, torch.Tensor):
-                value = steps_mod.channel_to_end(value)
-                to_assemble[key] = self.convert_fn(value) if self.convert_fn else value
-        last = batch_context.batch_index == task_context.data.nb_batches - 1
-        self.subject_assembler.add_batch(to_assemble, batch_context.input, last_batch=last)
+    def _finish_batch(self, batch_context, download, task_context, context, hook):
+        if self.subject_assembler is not None:
+            if download is not None:
+                to_assemble = download.wait()
+            else:
+                to_assemble = {}
+                for key, value in self._kept(batch_context).items():
+                    value = steps_mod.channel_to_end(value)
+                    to_assemble[key] = self.convert_fn(value) if self.convert_fn else value
+            last = batch_context.batch_index == task_context.data.nb_batches - 1
+            self.subject_assembler.add_batch(to_assemble, batch_context.input, last_batch=last)
 
-        for subject_index in sorted(self.subject_assembler.subjects_ready, key=str):
-            subject_data = self.subject_assembler.get_assembled_subject(subject_index)
-            subject_context = SubjectContext(subject_index, subject_data)
-            hook.on_test_subject_start(subject_context, task_context, context)
-            for subject_step in self.subject_steps:
-                subject_step(subject_context, task_context, context)
-            if subject_context.metrics:
-                task_context.history.add(subject_context.metrics, 'subject_metrics')
-            hook.on_test_subject_end(subject_context, task_context, context)
+            for subject_index in sorted(self.subject_assembler.subjects_ready, key=str):
+                subject_data = self.subject_assembler.get_assembled_subject(subject_index)
+                subject_context = SubjectContext(subject_index, subject_data)
+                hook.on_test_subject_start(subject_context, task_context, context)
+                for subject_step in self.subject_steps:
+                    subject_step(subject_context, task_context, context)
+                if subject_context.metrics:
+                    task_context.history.add(subject_context.metrics, 'subject_metrics')
+                hook.on_test_subject_end(subject_context, task_context, context)
+        hook.on_test_batch_end(batch_context, task_context, context)
+
+    def _test_batch(self, batch_context, task_context, context, hook):
+        """One batch in the reference's order (loops.py:196-235), without the pipeline."""
+        self._run_steps(batch_context, task_context, context, None, 0)
+        self._finish_batch(batch_context, None, task_context, context, hook)

@@ -75,6 +75,7 @@ class UNet(nn.Module):
         self.provide_features = provide_features
         self.features = None
         self._site_modules = []
+        self._sites = None
 
         def unit(prefix, cin, cout, with_dropout):
             base = prefix + '.conv2d_batch_relu'
@@ -173,13 +174,12 @@ class UNet(nn.Module):
     # ------------------------------------------------------------------ dropout
     def dropout_sites(self):
         """[(state_dict-style name, channels)] in execution order."""
-        names = {id(m): n for n, m in self.named_modules()}
-        out = []
-        for m in self._site_modules:
-            name = names[id(m)]
-            conv = dict(self.named_modules())[name[:-len('.dropout')] + '.conv']
-            out.append((name, conv.out_channels))
-        return out
+        if self._sites is None:        # the module tree is fixed after construction: walk it once
+            modules = dict(self.named_modules())
+            names = {id(m): n for n, m in modules.items()}
+            self._sites = [(names[id(m)], modules[names[id(m)][:-len('.dropout')] + '.conv'].out_channels)
+                           for m in self._site_modules]
+        return list(self._sites)
 
     def mc_active(self):
         return any(m.training for m in self._site_modules)

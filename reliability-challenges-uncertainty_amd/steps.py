@@ -176,7 +176,8 @@ class BatchStep(abc.ABC):
 
 
 def _images_to_device(batch_context, context):
-    batch_context.input['images'] = batch_context.input['images'].float().to(context.device)
+    # non_blocking: a no-op for pageable host memory, asynchronous when the loader pinned the batch (rcu_amd.loops.prefetch)
+    batch_context.input['images'] = batch_context.input['images'].float().to(context.device, non_blocking=True)
     return batch_context.input['images']
 
 
