@@ -54,10 +54,34 @@ struct UncThresholds {
     unsigned char cell_base[UNC_CELLS];
 };
 
+// One histogram word per voxel: the confidence as a 2^-42 fixed-point integer in bits 0..49, a count of one in bits 50..56 and the
+// positive flag in bits 57..63.  A lane sees at most ELEMS_PER_BLOCK / CB_THREADS = 64 voxels per workgroup, so neither count (<= 64) nor
+// the sum (<= 64 * 2 * 2^42 = 2^49) can carry into its neighbour, and ONE 64-bit LDS add records the voxel.  float32 confidences
+// >= 2^-18 convert exactly (24 mantissa bits above 2^-42), smaller ones are rounded to the nearest 2^-42, so a bin's confidence sum is
+// the exact real sum to within 2^-43 per voxel -- and integer adds commute: the histogram does not depend on the launch geometry.
+// Confidences are clamped to [0, 2): values a probability map cannot hold (the evaluation rejects them, rechun/eval/helper.py:8-12).
+static constexpr int ECE_FIX_BITS = 42, ECE_CNT_SHIFT = 50, ECE_POS_SHIFT = 57;
+
 struct EcePartial {
     unsigned long long count, sum_pos;
-    double sum_conf;
+    unsigned long long sum_fix;   // sum of the fixed-point confidences of one workgroup (<= 16384 * 2^43)
 };
+
+__device__ __forceinline__ unsigned long long ece_fixed_point(float q)
+{
+    q = fminf(fmaxf(q, 0.f), 1.99999988f);                 // NaN -> 0
+    // q + 2^10 in float64 has its unit in the last place at 2^-42: the fraction field IS q * 2^42, rounded to nearest
+    // (float32 values >= 2^-18 exactly); three instructions instead of an exponent / mantissa / shift sequence
+    const double d = (double)q + 1024.0;
+    return (unsigned long long)__double_as_longlong(d) - 0x4090000000000000ull;   // minus the bits of 1024.0
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
 
 __device__ __forceinline__ int bin_of(float p, const BinThresholds& th)
 {
@@ -87,9 +111,8 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned x)
     return x;
 }
 
-// Dynamic LDS of the histogram kernel: [wave][bin][lane] double sums, [wave][bin][lane] packed counts
-// (count | positives << 16; a lane sees at most ELEMS_PER_BLOCK / CB_THREADS = 64 voxels), lookup table.
-static inline size_t ece_lds_bytes(int n_bins) { return (size_t)CB_WAVES * n_bins * 64 * 12 + (size_t)(n_bins + 1) * 4; }
+// Dynamic LDS of the histogram kernel: [wave][bin][lane] histogram words (see EcePartial), lookup table.
+static inline size_t ece_lds_bytes(int n_bins) { return (size_t)CB_WAVES * n_bins * 64 * 8 + (size_t)(n_bins + 1) * 4; }
 
 // bin = #{k : p >= t_k}, computed as a candidate floor(p * n_bins) plus one table lookup.  The edges are
 // k (1 + 1e-8) / n_bins, so p >= t_k implies p * n_bins > k and (k being representable, rounding monotonic)
@@ -106,20 +129,15 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
                                                                const uint8_t* __restrict__ mask, size_t n,
                                                                const BinThresholds th, EcePartial* __restrict__ partial)
 {
-    extern __shared__ double ece_smem[];
+    extern __shared__ unsigned long long ece_smem[];
     __shared__ unsigned s_cnt[CB_WAVES][MAX_BINS];
     __shared__ unsigned s_pos[CB_WAVES][MAX_BINS];
-    __shared__ double s_sum[CB_WAVES][MAX_BINS];
+    __shared__ unsigned long long s_sum[CB_WAVES][MAX_BINS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = th.n_bins;
-    double* const col_sum = ece_smem + (size_t)wave * nb * 64 + lane;                       // + bin * 64
-    unsigned* const col_cp = reinterpret_cast<unsigned*>(ece_smem + (size_t)CB_WAVES * nb * 64) + (size_t)wave * nb * 64 + lane;
-    float* const lut = reinterpret_cast<float*>(reinterpret_cast<unsigned*>(ece_smem + (size_t)CB_WAVES * nb * 64) +
-                                                (size_t)CB_WAVES * nb * 64);
-    for (int b = 0; b < nb; ++b) {
-        col_sum[b * 64] = 0.0;
-        col_cp[b * 64] = 0u;
-    }
+    unsigned long long* const col = ece_smem + (size_t)wave * nb * 64 + lane;                // + bin * 64
+    float* const lut = reinterpret_cast<float*>(ece_smem + (size_t)CB_WAVES * nb * 64);
+    for (int b = 0; b < nb; ++b) col[b * 64] = 0ull;
     if (tid <= nb) lut[tid] = (tid == 0) ? -INFINITY : th.t[min(tid, MAX_BINS - 1) - 1];
     __syncthreads();
     const size_t vol = blockIdx.y;
@@ -130,8 +148,8 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
     auto add = [&](bool active, float q, bool pos) {
         if (active) {
             const int b = bin_lookup(q, nb, lut);
-            __hip_atomic_fetch_add(col_sum + b * 64, (double)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_fetch_add(col_cp + b * 64, pos ? 0x10001u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const unsigned long long word = ece_fixed_point(q) | (1ull << ECE_CNT_SHIFT) | ((unsigned long long)(pos ? 1u : 0u) << ECE_POS_SHIFT);
+            __hip_atomic_fetch_add(col + b * 64, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     };
     constexpr int ROUNDS = ELEMS_PER_BLOCK / (CB_THREADS * 4), BATCH = 4;
@@ -177,9 +195,9 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
         }
     }
     for (int b = 0; b < nb; ++b) {   // wavefront reduction of the 64 columns of this wave
-        const unsigned cp = col_cp[b * 64];
-        const unsigned c = wave_sum_u32(cp & 0xffffu), cpos = wave_sum_u32(cp >> 16);
-        const double sm = wave_sum(col_sum[b * 64]);
+        const unsigned long long word = col[b * 64];
+        const unsigned c = wave_sum_u32((unsigned)(word >> ECE_CNT_SHIFT) & 127u), cpos = wave_sum_u32((unsigned)(word >> ECE_POS_SHIFT));
+        const unsigned long long sm = wave_sum_u64(word & ((1ull << ECE_CNT_SHIFT) - 1));
         if (lane == 0) {
             s_cnt[wave][b] = c;
             s_pos[wave][b] = cpos;
@@ -191,12 +209,12 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
         EcePartial out;
         out.count = 0;
         out.sum_pos = 0;
-        out.sum_conf = 0.0;
+        out.sum_fix = 0;
         if (tid < nb) {
-            for (int w = 0; w < CB_WAVES; ++w) {   // fixed order
+            for (int w = 0; w < CB_WAVES; ++w) {
                 out.count += s_cnt[w][tid];
                 out.sum_pos += s_pos[w][tid];
-                out.sum_conf += s_sum[w][tid];
+                out.sum_fix += s_sum[w][tid];
             }
         }
         partial[((size_t)vol * gridDim.x + blockIdx.x) * MAX_BINS + tid] = out;
@@ -211,32 +229,37 @@ __global__ __launch_bounds__(RED_THREADS) void ece_reduce_kernel(const EcePartia
                                                                   EceResult* __restrict__ result)
 {
     constexpr int ROWS = RED_THREADS / MAX_BINS;
-    __shared__ unsigned long long s_c[ROWS][MAX_BINS], s_p[ROWS][MAX_BINS];
-    __shared__ double s_s[ROWS][MAX_BINS];
+    // the fixed-point sums are added as two 32-bit halves in 64-bit integers (no overflow below 2^32 workgroups per volume) and
+    // turned into ONE double at the end: the exact sum of the confidences, rounded once
+    __shared__ unsigned long long s_c[ROWS][MAX_BINS], s_p[ROWS][MAX_BINS], s_lo[ROWS][MAX_BINS], s_hi[ROWS][MAX_BINS];
     const int b = threadIdx.x % MAX_BINS, row = threadIdx.x / MAX_BINS;
     const size_t vol = blockIdx.x;
-    unsigned long long c = 0, sp = 0;
-    double sc = 0.0;
+    unsigned long long c = 0, sp = 0, lo = 0, hi = 0;
     for (unsigned k = row; k < nblocks; k += ROWS) {
         const EcePartial q = partial[((size_t)vol * nblocks + k) * MAX_BINS + b];
         c += q.count;
         sp += q.sum_pos;
-        sc += q.sum_conf;
+        lo += q.sum_fix & 0xFFFFFFFFull;
+        hi += q.sum_fix >> 32;
     }
     s_c[row][b] = c;
     s_p[row][b] = sp;
-    s_s[row][b] = sc;
+    s_lo[row][b] = lo;
+    s_hi[row][b] = hi;
     __syncthreads();
     if (row == 0) {
-        c = 0, sp = 0, sc = 0.0;
+        c = 0, sp = 0, lo = 0, hi = 0;
         for (int r = 0; r < ROWS; ++r) {
             c += s_c[r][b];
             sp += s_p[r][b];
-            sc += s_s[r][b];
+            lo += s_lo[r][b];
+            hi += s_hi[r][b];
         }
+        hi += lo >> 32;
+        lo &= 0xFFFFFFFFull;
         result[vol].count[b] = c;
         result[vol].sum_pos[b] = sp;
-        result[vol].sum_conf[b] = sc;
+        result[vol].sum_conf[b] = ((double)hi * 4294967296.0 + (double)lo) * (1.0 / (double)(1ull << ECE_FIX_BITS));
     }
 }
 
