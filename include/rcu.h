@@ -62,6 +62,8 @@ typedef struct rcu_unet_desc {
     int32_t height, width;   /* per-slice size, each >= 2^depth; sizes not divisible by 2^depth take the reference's centre pad
                                 (common/model/unet.py:110-116) and the direct kernels on the levels with odd sizes */
     int32_t max_batch;       /* largest N a forward call may pass; sizes the workspace */
+    int32_t residual;        /* 1: ConvResidualBlock (common/model/unet.py:42-60) instead of ConvBlock: a block's second unit has no
+                                ReLU and a 1x1 conv of the block input ("<block>.residual") is added to its output */
 } rcu_unet_desc;
 
 int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out);

@@ -40,21 +40,26 @@ def unet_plan(nb_classes, in_channels, depth=4, start_filters=16, dropout=0.2, d
     """Flat execution plan.  Each entry: dict(kind, key, cin, cout, site) where ``key`` is the
     state_dict prefix of the conv unit and ``site`` the index of its Dropout2d in execution order
     (= torch ``named_modules`` order) or None.  Defaults are the reference's (unet.py:124-130)."""
-    if residual:
-        raise NotImplementedError('ConvResidualBlock is not used by any shipped config (SURVEY 2)')
     plan = []
     sites = []
 
-    def unit(key, cin, cout, has_do):
+    def unit(key, cin, cout, has_do, relu=True):
         site = None
         if has_do:
             site = len(sites)
             sites.append((key + '.conv2d_batch_relu.dropout', cout))
-        plan.append(dict(kind='unit', key=key + '.conv2d_batch_relu', cin=cin, cout=cout, site=site, bn=bn))
+        plan.append(dict(kind='unit', key=key + '.conv2d_batch_relu', cin=cin, cout=cout, site=site, bn=bn, relu=relu))
 
     def block(prefix, cin, cout, rule):
+        # ConvBlock (unet.py:26-39) or, with ``residual``, ConvResidualBlock (unet.py:42-60): the last unit has no ReLU and the
+        # block input goes through a 1x1 conv that is ADDED to the block output (nothing follows the sum)
+        if residual:
+            plan.append(dict(kind='res_begin'))
         for i in range(2):
-            unit('{}.{}'.format(prefix, i), cin if i == 0 else cout, cout, _unit_has_dropout(dropout, rule, i))
+            unit('{}.{}'.format(prefix, i), cin if i == 0 else cout, cout, _unit_has_dropout(dropout, rule, i),
+                 relu=not (residual and i == 1))
+        if residual:
+            plan.append(dict(kind='res_add', key=prefix[:-len('.block')] + '.residual', cin=cin, cout=cout))
 
     cin, cout = in_channels, start_filters
     for lvl in range(depth):
@@ -106,7 +111,12 @@ def unet_forward(state, x, masks=None, return_features=False, **params):
             if op['bn']:
                 x = F.batch_norm(x, state[k + '.bn.running_mean'], state[k + '.bn.running_var'],
                                  state[k + '.bn.weight'], state[k + '.bn.bias'], False, 0.0, BN_EPS)
-            x = F.relu(x)
+            if op.get('relu', True):
+                x = F.relu(x)
+        elif kind == 'res_begin':
+            block_in = x
+        elif kind == 'res_add':
+            x = x + F.conv2d(block_in, state[op['key'] + '.weight'], state[op['key'] + '.bias'])
         elif kind == 'pool':
             skips.append(x)
             x = F.max_pool2d(x, 2)
@@ -131,14 +141,16 @@ def unet_forward(state, x, masks=None, return_features=False, **params):
     return result if len(result) > 1 else result[0]
 
 
-def postnet_forward(state, x, nb_convs=3):
-    """common/model/postnet.py:6-18: nb_convs x [Conv2d 1x1 C->C, BatchNorm2d (eval), ReLU] + Conv2d 1x1 (dropout
-    None as in every shipped config: Conv2dBnRelu gets no dropout module, unet.py:14-15)."""
+def postnet_forward(state, x, nb_convs=3, masks=None):
+    """common/model/postnet.py:6-18: nb_convs x [Conv2d 1x1 C->C, Dropout2d, BatchNorm2d (eval), ReLU] + Conv2d 1x1.  ``masks``:
+    None (dropout None as in every shipped config, or Dropout2d in eval mode) or one [N, C] factor array per conv (MC-dropout)."""
     state = {k: torch.as_tensor(v) for k, v in strip_module_prefix(state).items()}
     x = torch.as_tensor(x, dtype=torch.float32)
     for i in range(nb_convs):
         k = 'convs.{}.conv2d_batch_relu'.format(i)
         x = F.conv2d(x, state[k + '.conv.weight'], state[k + '.conv.bias'])
+        if masks is not None:
+            x = x * torch.as_tensor(masks[i], dtype=torch.float32)[:, :, None, None]
         x = F.batch_norm(x, state[k + '.bn.running_mean'], state[k + '.bn.running_var'], state[k + '.bn.weight'],
                          state[k + '.bn.bias'], False, 0.0, BN_EPS)
         x = F.relu(x)
@@ -199,7 +211,7 @@ def synthetic_state(seed, **params):
                 state[op['key'] + '.bn.num_batches_tracked'] = torch.tensor(1)
         elif op['kind'] == 'up':
             conv(op['key'], op['cout'], op['cin'], 3)
-        elif op['kind'] == 'head':
+        elif op['kind'] in ('head', 'res_add'):
             conv(op['key'], op['cout'], op['cin'], 1)
     return state
 

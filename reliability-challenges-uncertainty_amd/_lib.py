@@ -28,7 +28,7 @@ class RcuError(RuntimeError):
 
 class UnetDesc(Structure):
     _fields_ = [(n, c_int32) for n in ('nb_classes', 'in_channels', 'depth', 'start_filters', 'has_dropout',
-                                       'dropout_center', 'sigma_out', 'bn', 'height', 'width', 'max_batch')]
+                                       'dropout_center', 'sigma_out', 'bn', 'height', 'width', 'max_batch', 'residual')]
 
 
 class LayerInfo(Structure):

@@ -47,6 +47,8 @@ struct ConvLayer {
     int csplit = 0;          // first channel of the twin
     int H = 0, W = 0;
     int upsample = 0, relu = 0;
+    int is_1x1 = 0;          // ConvResidualBlock's residual conv: a 1x1 kernel, run as a 3x3 unit whose centre tap alone is non-zero
+    int accumulate = 0;      // the unit's result is added to what its output tensor holds (the residual conv's output)
     int site = -1, site2 = -1;
     int cfg = 0, NT = 0;
     int t_src1 = -1, t_src2 = -1, t_out = -1, t_pool = -1;
@@ -116,7 +118,8 @@ static int pick_config(const ConvLayer& L, int n_slices)
     // and take whole tiles only.
     // RCU_CONV_WINO=0 keeps every layer on the direct kernels of rcu_conv.hip (read at rcu_unet_create: A/B tests)
     const char* const wino_env = getenv("RCU_CONV_WINO");
-    const bool wino_on = !(wino_env && atoi(wino_env) == 0);
+    // a unit that adds to its output tensor (ConvResidualBlock's second unit) runs on the direct kernels, whose epilogue can
+    const bool wino_on = !(wino_env && atoi(wino_env) == 0) && !L.accumulate;
     const size_t max_bytes = (size_t)n_slices * L.H * L.W * (size_t)std::max(std::max(L.c1p, L.c2p), L.coutp) * 4;
     const bool center_pad = L.upsample && (2 * (L.H / 2) != L.H || 2 * (L.W / 2) != L.W);   // unet.py:110-116: direct kernel only
     if (L.upsample && !center_pad && wino_on && L.c1p % 32 == 0 && L.c2p == 0 && max_bytes < ((size_t)1 << 31)) {
@@ -137,7 +140,7 @@ static int pick_config(const ConvLayer& L, int n_slices)
         const char* const first_env = getenv("RCU_CONV_FIRST");
         const bool first_on = !(first_env && atoi(first_env) == 0);
         if (first_on && L.c2p == 0 && L.H % 8 == 0 && L.W % 32 == 0 && (L.coutp == 32 || L.coutp == 64) && L.t_pool < 0 &&
-            L.name2.empty())
+            L.name2.empty() && !L.accumulate)
             return CONV_CFG_FIRST_T8x32;
         return CONV_CFG_T8x16_N32_FIRST;
     }
@@ -178,19 +181,35 @@ static int pick_config(const ConvLayer& L, int n_slices)
 }
 
 static void add_unit(rcu_unet* h, const std::string& prefix, int cin1, int c1p, int cin2, int c2p, int cout, int H, int W,
-                     bool dropout, int t_src1, int t_src2, int t_out, int t_pool)
+                     bool dropout, int t_src1, int t_src2, int t_out, int t_pool, bool residual_tail = false)
 {
     ConvLayer L;
     L.name = prefix + ".conv2d_batch_relu.conv";
     if (h->d.bn) L.bn = prefix + ".conv2d_batch_relu.bn";
     L.cin1 = cin1; L.c1p = c1p; L.cin2 = cin2; L.c2p = c2p;
     L.cout = cout; L.coutp = round_up(cout, 32); L.csplit = L.coutp;
-    L.H = H; L.W = W; L.relu = 1;
+    L.H = H; L.W = W; L.relu = residual_tail ? 0 : 1;
+    L.accumulate = residual_tail ? 1 : 0;
     if (dropout) {
         L.site = (int)h->sites.size();
         h->sites.push_back({prefix + ".conv2d_batch_relu.dropout", cout});
     }
     L.t_src1 = t_src1; L.t_src2 = t_src2; L.t_out = t_out; L.t_pool = t_pool;
+    h->layers.push_back(L);
+}
+
+// ConvResidualBlock (common/model/unet.py:42-60): conv1x1(block input) + bias into the block's output tensor; the block's second
+// unit (no ReLU) then adds its result to it.  `prefix`: the block's module path ("down_convs.0.block", "bottom_convs", ...).
+static void add_residual_conv(rcu_unet* h, const std::string& prefix, int cin1, int c1p, int cin2, int c2p, int cout, int H, int W,
+                              int t_src1, int t_src2, int t_out)
+{
+    ConvLayer L;
+    L.name = prefix + ".residual";
+    L.is_1x1 = 1;
+    L.cin1 = cin1; L.c1p = c1p; L.cin2 = cin2; L.c2p = c2p;
+    L.cout = cout; L.coutp = round_up(cout, 32); L.csplit = L.coutp;
+    L.H = H; L.W = W; L.relu = 0;
+    L.t_src1 = t_src1; L.t_src2 = t_src2; L.t_out = t_out;
     h->layers.push_back(L);
 }
 
@@ -210,8 +229,12 @@ static int build_plan(rcu_unet* h)
         const int t_pool = new_tensor(h, H / 2, W / 2, cp);
         snprintf(buf, sizeof buf, "down_convs.%d.block.block.0", l);
         add_unit(h, buf, cur_c, cur_cp, 0, 0, c, H, W, unit_has_dropout(d, l, true, 0), cur, -1, t_tmp, -1);
+        if (d.residual) {
+            snprintf(buf, sizeof buf, "down_convs.%d.block", l);
+            add_residual_conv(h, buf, cur_c, cur_cp, 0, 0, c, H, W, cur, -1, t_skip);
+        }
         snprintf(buf, sizeof buf, "down_convs.%d.block.block.1", l);
-        add_unit(h, buf, c, cp, 0, 0, c, H, W, unit_has_dropout(d, l, true, 1), t_tmp, -1, t_skip, t_pool);
+        add_unit(h, buf, c, cp, 0, 0, c, H, W, unit_has_dropout(d, l, true, 1), t_tmp, -1, t_skip, t_pool, d.residual != 0);
         skip[l] = t_skip; skip_c[l] = c;
         cur = t_pool; cur_c = c; cur_cp = cp;
         c *= 2;
@@ -221,8 +244,9 @@ static int build_plan(rcu_unet* h)
         const int t_tmp = new_tensor(h, H, W, cp), t_out = new_tensor(h, H, W, cp);
         add_unit(h, "bottom_convs.block.0", cur_c, cur_cp, 0, 0, c, H, W, unit_has_dropout(d, depth, true, 0), cur, -1,
                  t_tmp, -1);
+        if (d.residual) add_residual_conv(h, "bottom_convs", cur_c, cur_cp, 0, 0, c, H, W, cur, -1, t_out);
         add_unit(h, "bottom_convs.block.1", c, cp, 0, 0, c, H, W, unit_has_dropout(d, depth, true, 1), t_tmp, -1, t_out,
-                 -1);
+                 -1, d.residual != 0);
         cur = t_out; cur_c = c; cur_cp = cp;
     }
     for (int j = 0; j < depth; ++j) {
@@ -242,8 +266,12 @@ static int build_plan(rcu_unet* h)
         snprintf(buf, sizeof buf, "up_convs.%d.block.block.0", j);
         add_unit(h, buf, co, cop, skip_c[l], round_up(skip_c[l], 32), co, H, W, unit_has_dropout(d, l, false, 0), t_up,
                  skip[l], t_tmp, -1);
+        if (d.residual) {
+            snprintf(buf, sizeof buf, "up_convs.%d.block", j);
+            add_residual_conv(h, buf, co, cop, skip_c[l], round_up(skip_c[l], 32), co, H, W, t_up, skip[l], t_out);
+        }
         snprintf(buf, sizeof buf, "up_convs.%d.block.block.1", j);
-        add_unit(h, buf, co, cop, 0, 0, co, H, W, unit_has_dropout(d, l, false, 1), t_tmp, -1, t_out, -1);
+        add_unit(h, buf, co, cop, 0, 0, co, H, W, unit_has_dropout(d, l, false, 1), t_tmp, -1, t_out, -1, d.residual != 0);
         cur = t_out; cur_c = co; cur_cp = cop;
     }
     {   // head unit(s): conv_cls.0 [+ conv_sigma.0 stacked on the output channels] (unet.py:161-164)
@@ -390,7 +418,16 @@ static int fold_conv(rcu_unet* h, const ConvLayer& L, const std::string& conv, c
     const int KC = ci.KC, KCP = ci.KCP, BN = ci.BN;
     const int cin = L.cin1 + L.cin2;
     const std::vector<float>*w, *b;
-    int rc = get_weight(h, conv + ".weight", (size_t)L.cout * cin * 9, &w);
+    std::vector<float> w_centre;
+    int rc;
+    if (L.is_1x1) {   // [cout][cin][1][1] -> [cout][cin][3][3] with the centre tap set
+        if ((rc = get_weight(h, conv + ".weight", (size_t)L.cout * cin, &w))) return rc;
+        w_centre.assign((size_t)L.cout * cin * 9, 0.f);
+        for (size_t i = 0; i < (size_t)L.cout * cin; ++i) w_centre[i * 9 + 4] = (*w)[i];
+        w = &w_centre;
+    } else {
+        rc = get_weight(h, conv + ".weight", (size_t)L.cout * cin * 9, &w);
+    }
     if (rc) return rc;
     rc = get_weight(h, conv + ".bias", (size_t)L.cout, &b);
     if (rc) return rc;
@@ -609,6 +646,7 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     a.n_images = n_images;
     a.Cmask = L.cout; a.Csplit = L.csplit; a.Cmask2 = L.cout;
     a.relu = L.relu;
+    a.accumulate = L.accumulate;
     a.tiles_y = (gh + ci.TH - 1) / ci.TH;
     a.tiles_x = (gw + ci.TW - 1) / ci.TW;
     a.slice_groups = (n + ci.TS - 1) / ci.TS;
@@ -900,7 +938,7 @@ extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info*
     out->height = L.H; out->width = L.W;
     out->upsample = L.upsample; out->pooled = L.t_pool >= 0; out->dual_source = L.t_src2 >= 0;
     // an up-convolution works on the up-sampled grid, which a centre pad leaves smaller than the skip tensor it is padded to
-    out->flops_per_slice = 2.0 * out->cin * out->cout * 9.0 * (L.upsample ? 4.0 * (L.H / 2) * (L.W / 2) : (double)L.H * L.W);
+    out->flops_per_slice = 2.0 * out->cin * out->cout * (L.is_1x1 ? 1.0 : 9.0) * (L.upsample ? 4.0 * (L.H / 2) * (L.W / 2) : (double)L.H * L.W);
     {
         // executed on the matrix pipe: padded K and N, full tiles, 4 taps per output pixel for the sub-pixel form
         const ConvConfigInfo ci = conv_config_info(L.cfg);

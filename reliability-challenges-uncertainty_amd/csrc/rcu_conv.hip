@@ -149,13 +149,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&
                 mk = a.mask2[(size_t)n * a.Cmask2 + (co - a.Csplit)];
             const float scale = al * mk, shift = bb * mk + be;
             const int yb = y0 + 4 * by, xb = x0 + 8 * bx + 4 * half;
+            float* const obase = a.out + ((size_t)(n * OH + oy0 + yb * OS + pa) * OW + ox0 + xb * OS + pb) * a.CoutP + co;
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float t = acc[mi][ni][i] * scale + shift;
+                if (a.accumulate && yb + (i >> 2) < a.H && xb + (i & 3) < a.W) t += obase[(i >> 2) * row_stride + (i & 3) * col_stride];
                 v[i] = a.relu ? fmaxf(t, 0.f) : t;
             }
-            float* const obase = a.out + ((size_t)(n * OH + oy0 + yb * OS + pa) * OW + ox0 + xb * OS + pb) * a.CoutP + co;
             if (full_tile) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) obase[(i >> 2) * row_stride + (i & 3) * col_stride] = v[i];

@@ -33,6 +33,8 @@ struct ConvArgs {
     int Cmask;           // real channel count of the dropout site (mask row length)
     int Csplit, Cmask2;  // mask2 row = [N][Cmask2], applies to channel co - Csplit
     int relu;            // 1: max(0, .) epilogue
+    int accumulate;      // direct kernels: 1 = the unit's result is ADDED to what `out` holds (ConvResidualBlock: the 1x1 residual
+                         // conv has been written there), before the 2x2 max-pool
     int tiles_y, tiles_x, slice_groups;
     int NT;              // output-channel tiles
     uint32_t magic_ntw, magic_tx, magic_ty;   // ceil(2^32 / d) for d = NTW_total, tiles_x, tiles_y (0: divide): the Winograd kernels

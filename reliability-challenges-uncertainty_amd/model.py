@@ -63,11 +63,9 @@ class UNet(nn.Module):
                  dropout=DEFAULT_DROPOUT, dropout_center: int = None, residual=False, sigma_out=False,
                  provide_features=False, bn=True):
         super().__init__()
-        if residual:
-            raise NotImplementedError('residual blocks are outside the MI355X hot path (no shipped config uses them)')
         self.nb_classes, self.in_channels, self.depth = nb_classes, in_channels, depth
         self.start_filters, self.dropout, self.dropout_center = start_filters, dropout, dropout_center
-        self.sigma_out, self.bn = sigma_out, bn
+        self.sigma_out, self.bn, self.residual = sigma_out, bn, bool(residual)
         # unet.py:135-136, 178-179: when set, ``features`` is the input of conv_cls after every forward --
         # here a [N, C, H, W] VIEW of the handle's channels-last workspace tensor (no copy), valid until the
         # next forward (``.clone()`` it to keep it; it is reset to None when the plan it points into is rebuilt or
@@ -90,6 +88,8 @@ class UNet(nn.Module):
         def block(prefix, cin, cout, rule):
             for i in range(2):
                 unit('{}.{}'.format(prefix, i), cin if i == 0 else cout, cout, _has_dropout(dropout, rule, i))
+            if residual:   # ConvResidualBlock (unet.py:42-60): "<block>.residual", a 1x1 conv of the block input
+                _add(self, prefix[:-len('.block')] + '.residual', nn.Conv2d(cin, cout, 1))
 
         cin, cout = in_channels, start_filters
         for lvl in range(depth):
@@ -150,7 +150,8 @@ class UNet(nn.Module):
         desc = _lib.UnetDesc(nb_classes=self.nb_classes, in_channels=self.in_channels, depth=self.depth,
                              start_filters=self.start_filters, has_dropout=int(self.dropout is not None),
                              dropout_center=-1 if self.dropout_center is None else int(self.dropout_center),
-                             sigma_out=int(self.sigma_out), bn=int(self.bn), height=h, width=w, max_batch=max_batch)
+                             sigma_out=int(self.sigma_out), bn=int(self.bn), height=h, width=w, max_batch=max_batch,
+                             residual=int(self.residual))
         handle = ctypes.c_void_p()
         _lib.check(lib.rcu_unet_create(ctypes.byref(desc), ctypes.byref(handle)))
         try:

@@ -590,12 +590,97 @@ def g13_postnet():
     save('g13_postnet', **arrays)
 
 
+def g14_unet_residual():
+    """ConvResidualBlock (unet.py:42-60, ``residual=True``): eval pass and one MC pass with the masks the reference drew; a second
+    model with dropout_center and a size that 2^depth does not divide (residual blocks + centre pad together)."""
+    import common.utils.torchhelper as ref_th
+    params = dict(nb_classes=2, in_channels=4, depth=3, start_filters=4, dropout=0.3, residual=True)
+    model = make_unet(14, **params)
+    gen = torch.Generator().manual_seed(141)
+    x = torch.randn(2, 4, 32, 24, generator=gen)
+    site_names = [n for n, _ in dropout_modules(model)]
+    arrays = {}
+    with torch.no_grad():
+        arrays['logits_eval'] = model(x).numpy()
+        torch.manual_seed(22)
+        ref_th.set_dropout_mode(model, True)
+        y, recs = capture_masks(model, lambda: model(x))
+        ref_th.set_dropout_mode(model, False)
+    arrays['logits_mc'] = y.numpy()
+    for s_, (_, mask) in enumerate(recs):
+        arrays['mask_{}'.format(s_)] = mask
+    save('g14_unet_residual', params=np.array(repr(params)), x=x.numpy(), sites=np.array(site_names), **arrays,
+         **state_to_npz(model))
+    params2 = dict(nb_classes=3, in_channels=3, depth=2, start_filters=8, dropout=0.2, dropout_center=2, residual=True, sigma_out=True)
+    model2 = make_unet(15, **params2)
+    x2 = torch.rand(1, 3, 22, 30, generator=gen)
+    with torch.no_grad():
+        logits2, sigma2 = model2(x2)
+    save('g14_unet_residual_b', params=np.array(repr(params2)), x=x2.numpy(), logits=logits2.numpy(), sigma=sigma2.numpy(),
+         **state_to_npz(model2))
+
+
+def g15_unet_centre_pad():
+    """Sizes 2^depth does not divide: the up-convolution is zero-padded around its centre to the skip tensor's size
+    (unet.py:110-116; the max-pool floors, unet.py:89)."""
+    out = {}
+    for tag, (cin, shape) in {'a': (4, (2, 40, 36)), 'b': (3, (1, 50, 30)), 'c': (4, (1, 37, 19))}.items():
+        params = dict(nb_classes=2, in_channels=cin, depth=4, start_filters=4, dropout=0.05)
+        model = make_unet(16 + ord(tag), **params)
+        gen = torch.Generator().manual_seed(150 + ord(tag))
+        x = torch.randn(shape[0], cin, shape[1], shape[2], generator=gen)
+        with torch.no_grad():
+            y = model(x)
+        assert y.shape[-2:] == x.shape[-2:]
+        out.update({'params_' + tag: np.array(repr(params)), 'x_' + tag: x.numpy(), 'logits_' + tag: y.numpy()})
+        out.update(state_to_npz(model, 'sd_{}::'.format(tag)))
+    save('g15_unet_centre_pad', **out)
+
+
+def g16_postnet_wide():
+    """PostNet (postnet.py:6-18) on more than 32 feature channels (a U-Net with start_filters 48 / 64) and with MC-dropout inside
+    (Conv2dBnRelu with a dropout rate, masks captured)."""
+    import common.model.postnet as ref_postnet
+    import common.utils.torchhelper as ref_th
+    gen = torch.Generator().manual_seed(161)
+    arrays = {}
+    for tag, (c, classes, convs) in {'a': (64, 2, 3), 'b': (48, 3, 2), 'c': (40, 2, 4)}.items():
+        torch.manual_seed(30 + ord(tag))
+        post = ref_postnet.PostNet(c, classes, nb_convs=convs)
+        randomise_bn(post, gen)
+        post.eval()
+        f = torch.randn(2, c, 12, 20, generator=gen)
+        with torch.no_grad():
+            arrays['features_' + tag] = f.numpy()
+            arrays['logits_' + tag] = post(f).numpy()
+        arrays['shape_' + tag] = np.array([c, classes, convs])
+        arrays.update(state_to_npz(post, 'post_{}::'.format(tag)))
+    torch.manual_seed(40)
+    post = ref_postnet.PostNet(32, 2, nb_convs=3, dropout=0.3)
+    randomise_bn(post, gen)
+    post.eval()
+    f = torch.randn(3, 32, 8, 16, generator=gen)
+    with torch.no_grad():
+        arrays['features_d'] = f.numpy()
+        arrays['logits_d_eval'] = post(f).numpy()
+        torch.manual_seed(41)
+        ref_th.set_dropout_mode(post, True)
+        y, recs = capture_masks(post, lambda: post(f))
+        ref_th.set_dropout_mode(post, False)
+    arrays['logits_d_mc'] = y.numpy()
+    for s_, (_, mask) in enumerate(recs):
+        arrays['mask_d_{}'.format(s_)] = mask
+    arrays.update(state_to_npz(post, 'post_d::'))
+    save('g16_postnet_wide', **arrays)
+
+
 def main():
     install_reference()
     torch.set_num_threads(4)
     torch.set_grad_enabled(False)
     for fn in (g1_unet_eval, g2_unet_mc, g3_unet_center, g4_unet_sigma, g5_unet_isic, g6_mc_summary,
-               g7_mc_step_end2end, g8_ece, g9_uncertainty, g10_prep, g11_fullsize_digest, g12_eval_csv, g13_postnet):
+               g7_mc_step_end2end, g8_ece, g9_uncertainty, g10_prep, g11_fullsize_digest, g12_eval_csv, g13_postnet, g14_unet_residual, g15_unet_centre_pad,
+               g16_postnet_wide):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

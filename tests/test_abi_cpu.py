@@ -69,8 +69,11 @@ def test_model_mirror_keeps_reference_surface():
     m.load_state_dict({'module.' + k: v for k, v in m.state_dict().items()})       # DataParallel prefix
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 32, 32))                                                # CPU tensor: no fallback
-    with pytest.raises(NotImplementedError):
-        UNet(2, 4, residual=True)
+    res = UNet(2, 4, depth=2, start_filters=8, residual=True)                       # ConvResidualBlock: "<block>.residual" 1x1 convs
+    assert {k for k in res.state_dict() if 'residual' in k} == {
+        p + s for p in ('down_convs.0.block.residual', 'down_convs.1.block.residual', 'bottom_convs.residual',
+                        'up_convs.0.block.residual', 'up_convs.1.block.residual') for s in ('.weight', '.bias')}
+    assert tuple(res.state_dict()['up_convs.0.block.residual.weight'].shape) == (16, 32, 1, 1)
     center = UNet(2, 4, depth=4, start_filters=32, dropout=0.5, dropout_center=4)
     assert len(center.dropout_sites()) == 9
     nodrop = UNet(2, 4, dropout=None)

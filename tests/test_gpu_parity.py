@@ -923,3 +923,64 @@ def test_pass_groups_bit_identical_to_single_passes(dev):
     assert float((bc.output['probabilities'] - bc2.output['probabilities']).abs().mean()) < 0.02
     with pytest.raises(Exception):
         model.forward_accumulate(x, steps.McStatistics(n, 2, h, w, dev), passes=0)
+
+
+def test_unet_residual_blocks_golden(golden, dev):
+    """ConvResidualBlock (common/model/unet.py:42-60, ``residual=True``): reference golden G14 -- eval pass, an MC pass under the
+    reference's masks, and the combination with dropout_center, a sigma head, three classes and a centre-padded size."""
+    g = golden('g14_unet_residual')
+    m = _model(golden_params(g), golden_state(g), dev)
+    assert [s[0] for s in m.dropout_sites()] == list(g['sites'])
+    assert sum(k.endswith('.residual.weight') for k in m.state_dict()) == 7      # 3 down + bottom + 3 up blocks
+    x = torch.from_numpy(g['x']).to(dev)
+    assert _maxdiff(m(x).cpu().numpy(), g['logits_eval']) < LOGIT_TOL
+    masks = [g['mask_{}'.format(s)] for s in range(len(g['sites']))]
+    assert _maxdiff(m(x, masks).cpu().numpy(), g['logits_mc']) < LOGIT_TOL
+    gb = golden('g14_unet_residual_b')
+    mb = _model(golden_params(gb), golden_state(gb), dev)
+    logits, sigma = mb(torch.from_numpy(gb['x']).to(dev))
+    assert _maxdiff(logits.cpu().numpy(), gb['logits']) < LOGIT_TOL
+    assert _maxdiff(sigma.cpu().numpy(), gb['sigma']) < LOGIT_TOL
+
+
+def test_unet_residual_full_width_vs_oracle(dev):
+    """Residual blocks at the shipped width on the BraTS slice size: the residual 1x1 convs take the Winograd kernels (a 3x3 unit
+    with only its centre tap set), the adding second units the direct ones; with masks, and through the fused statistics path."""
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05, residual=True)
+    st = uo.synthetic_state(41, **params)
+    g = torch.Generator().manual_seed(15)
+    n, h, w = 2, 192, 128
+    x = torch.randn(n, 4, h, w, generator=g)
+    _, sites = uo.unet_plan(**params)
+    mask_sets = [uo.sample_masks(sites, n, 0.3, g) for _ in range(2)]
+    m = _model(params, st, dev)
+    rows = m.layer_table(h, w, n)
+    assert len(rows) == 23 + 9                                         # nine residual convs
+    assert any(r['name'].endswith('.residual') and 'winograd' in r['kernel'] for r in rows)
+    for mk in (None, mask_sets[0]):
+        ref = uo.unet_forward(st, x, mk, **params).numpy()
+        scale = max(1.0, float(np.abs(ref).max()))                     # un-normalised sums: the logits can be of O(10)
+        assert _maxdiff(m(x.to(dev), mk).cpu().numpy(), ref) < LOGIT_TOL * scale
+    bc = steps.BatchContext({'images': x}, 0)
+    ctx = steps.TorchTestContext('cuda', m)
+    steps.McPredictStep(2, masks=mask_sets)(bc, None, ctx)
+    steps.MultiPredictionSummary()(bc, None, ctx)
+    ws, multi = so.mc_probabilities(lambda xx, mk: uo.unet_forward(st, xx, mk, **params), x, mask_sets)
+    ref = so.multi_prediction_summary(multi)
+    assert _maxdiff(bc.output['probabilities'].cpu().numpy(), ref['probabilities'].numpy()) < PROB_TOL
+    assert _maxdiff(bc.output['ws_probabilities'].cpu().numpy(), ws.numpy()) < PROB_TOL
+
+
+def test_unet_centre_pad_golden(golden, dev):
+    """Reference golden G15: sizes 2^depth does not divide (unet.py:89, 110-116)."""
+    g = golden('g15_unet_centre_pad')
+    for tag in ('a', 'b', 'c'):
+        params = eval(str(g['params_' + tag]), {'__builtins__': {}}, {'dict': dict})
+        st = {k[len('sd_{}::'.format(tag)):]: v for k, v in g.items() if k.startswith('sd_{}::'.format(tag))}
+        m = _model(params, st, dev)
+        y = m(torch.from_numpy(g['x_' + tag]).to(dev)).cpu().numpy()
+        assert y.shape == g['logits_' + tag].shape
+        assert _maxdiff(y, g['logits_' + tag]) < LOGIT_TOL, tag

@@ -245,3 +245,42 @@ def test_g13_postnet_and_features(golden):
         state = {k[len(tag) + 2:]: g[k] for k in g if k.startswith(tag + '::')}
         out = uo.postnet_forward(state, g['features'], nb_convs)
         assert np.max(np.abs(out.numpy() - g['logits' if tag == 'post' else 'logits5'])) < 1e-5
+
+
+def test_g14_residual_blocks(golden):
+    """ConvResidualBlock (unet.py:42-60): second unit without ReLU, 1x1 conv of the block input added, nothing behind the sum."""
+    g = golden('g14_unet_residual')
+    p, st = golden_params(g), golden_state(g)
+    _, sites = uo.unet_plan(**p)
+    assert [s[0] for s in sites] == list(g['sites'])
+    assert any(k.endswith('.residual.weight') for k in st)
+    masks = [g['mask_{}'.format(s)] for s in range(len(sites))]
+    assert any((m == 0).any() for m in masks)
+    _close(uo.unet_forward(st, g['x'], None, **p).numpy(), g['logits_eval'], 5e-6)
+    _close(uo.unet_forward(st, g['x'], masks, **p).numpy(), g['logits_mc'], 5e-6)
+    gb = golden('g14_unet_residual_b')      # + dropout_center, sigma head, 3 classes, a size 2^depth does not divide
+    logits, sigma = uo.unet_forward(golden_state(gb), gb['x'], None, **golden_params(gb))
+    _close(logits.numpy(), gb['logits'], 5e-6)
+    _close(sigma.numpy(), gb['sigma'], 5e-6)
+
+
+def test_g15_centre_pad(golden):
+    """Sizes that 2^depth does not divide (unet.py:89, 110-116)."""
+    g = golden('g15_unet_centre_pad')
+    for tag in ('a', 'b', 'c'):
+        p = eval(str(g['params_' + tag]), {'__builtins__': {}}, {'dict': dict})
+        st = {k[len('sd_{}::'.format(tag)):]: v for k, v in g.items() if k.startswith('sd_{}::'.format(tag))}
+        _close(uo.unet_forward(st, g['x_' + tag], None, **p).numpy(), g['logits_' + tag], 5e-6)
+
+
+def test_g16_postnet_wide_and_mc(golden):
+    g = golden('g16_postnet_wide')
+    for tag in ('a', 'b', 'c'):
+        c, classes, convs = (int(v) for v in g['shape_' + tag])
+        st = {k[len('post_{}::'.format(tag)):]: v for k, v in g.items() if k.startswith('post_{}::'.format(tag))}
+        _close(uo.postnet_forward(st, g['features_' + tag], nb_convs=convs).numpy(), g['logits_' + tag], 5e-6)
+    st = {k[len('post_d::'):]: v for k, v in g.items() if k.startswith('post_d::')}
+    _close(uo.postnet_forward(st, g['features_d'], nb_convs=3).numpy(), g['logits_d_eval'], 5e-6)
+    masks = [g['mask_d_{}'.format(s)] for s in range(3)]
+    assert any((m == 0).any() for m in masks)
+    _close(uo.postnet_forward(st, g['features_d'], nb_convs=3, masks=masks).numpy(), g['logits_d_mc'], 5e-6)
