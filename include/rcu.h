@@ -162,10 +162,12 @@ int rcu_postnet_create(int in_channels, int nb_classes, int nb_convs, int bn, rc
 void rcu_postnet_destroy(rcu_postnet* h);
 int rcu_postnet_load_weight(rcu_postnet* h, const char* name, const float* host_data, size_t count);
 int rcu_postnet_finalize_weights(rcu_postnet* h);
-/* features: NHWC float32 [n*hw][channel_pitch] (channel_pitch >= 32, multiple of 4; channels beyond in_channels are
- * ignored); logits_dev: float32 [n][nb_classes][hw]. */
-int rcu_postnet_forward(rcu_postnet* h, const float* features_dev, int channel_pitch, int n, int hw, float* logits_dev,
-                        void* stream);
+/* in_channels <= 96.  features: NHWC float32 [n*hw][channel_pitch] (channel_pitch >= in_channels rounded up to 32, a multiple of 4;
+ * the padding channels up to the next multiple of 32 must hold zeros or finite values -- their weights are zero);
+ * masks_dev: NULL (eval / no Dropout2d) or the factors {0, 1/(1-p)} of one MC pass, float32 [nb_convs][n][in_channels]
+ * (Dropout2d sits between conv and BatchNorm in every hidden unit, common/model/unet.py:14-15); logits_dev: float32 [n][nb_classes][hw]. */
+int rcu_postnet_forward(rcu_postnet* h, const float* features_dev, int channel_pitch, int n, int hw, const float* masks_dev,
+                        float* logits_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Step seam: per-voxel sufficient statistics over T passes / K members

@@ -64,7 +64,7 @@ SIGNATURES = {
     'rcu_postnet_destroy': (None, [c_void_p]),
     'rcu_postnet_load_weight': (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
     'rcu_postnet_finalize_weights': (c_int, [c_void_p]),
-    'rcu_postnet_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'rcu_postnet_forward': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'rcu_unet_num_layers': (c_int, [c_void_p]),
     'rcu_unet_layer_info': (c_int, [c_void_p, c_int, POINTER(LayerInfo)]),
     'rcu_unet_run_layer': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

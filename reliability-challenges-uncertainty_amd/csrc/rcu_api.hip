@@ -807,18 +807,23 @@ extern "C" int rcu_unet_features(const rcu_unet* h, const float** features_dev, 
 struct rcu_postnet {
     int in_channels = 0, nb_classes = 0, nb_convs = 0, bn = 1;
     std::map<std::string, std::vector<float>> host_weights;
-    float* packed = nullptr;
+    float* packed = nullptr;      // eval image of the layers
+    float* packed_mc = nullptr;   // MC-dropout image (see rcu_postnet_finalize_weights)
     bool finalized = false;
 };
 
 extern "C" int rcu_postnet_create(int in_channels, int nb_classes, int nb_convs, int bn, rcu_postnet** out)
 {
     if (!out) return fail(RCU_ERR_INVALID, "rcu_postnet_create: null argument");
-    if (in_channels < 1 || in_channels > 32)
-        return fail(RCU_ERR_INVALID, "PostNet kernel handles 1..32 feature channels (U-Net start_filters <= 32)");
+    if (in_channels < 1 || in_channels > 32 * PN_MAX_BLOCKS)
+        return fail(RCU_ERR_INVALID, "PostNet kernel handles 1.." + std::to_string(32 * PN_MAX_BLOCKS) + " feature channels");
     if (nb_classes < 1 || nb_classes > 32) return fail(RCU_ERR_INVALID, "PostNet kernel handles 1..32 classes");
     if (nb_convs < 0 || nb_convs + 1 > PN_MAX_LAYERS)
         return fail(RCU_ERR_INVALID, "PostNet kernel handles at most " + std::to_string(PN_MAX_LAYERS - 1) + " hidden convs");
+    const int cb = (in_channels + 31) / 32;
+    if ((size_t)(nb_convs + 1) * pn_layer_floats(cb) * sizeof(float) > 160 * 1024)
+        return fail(RCU_ERR_INVALID, "PostNet: the packed layers of " + std::to_string(nb_convs) + " hidden convs over " +
+                                         std::to_string(in_channels) + " channels do not fit the 160 KB of LDS");
     rcu_postnet* h = new rcu_postnet;
     h->in_channels = in_channels; h->nb_classes = nb_classes; h->nb_convs = nb_convs; h->bn = bn ? 1 : 0;
     *out = h;
@@ -829,6 +834,7 @@ extern "C" void rcu_postnet_destroy(rcu_postnet* h)
 {
     if (!h) return;
     if (h->packed) (void)hipFree(h->packed);
+    if (h->packed_mc) (void)hipFree(h->packed_mc);
     delete h;
 }
 
@@ -853,23 +859,36 @@ static int postnet_weight(rcu_postnet* h, const std::string& key, size_t count, 
     return RCU_OK;
 }
 
-// folded 32x32 (zero padded) layer -> the LDS image of rcu_postnet.hip: weights [j][lane][4], bias [j][h][4]
-static void postnet_pack_layer(const float (*w)[32], const float* b, float* dst)
+// folded [32 cb][32 cb] (zero padded) layer -> the LDS image of rcu_postnet.hip: weight tiles [cob][cib][j][lane][4], accumulator
+// start values [cob][j][h][4], constants behind the dropout factor [cob][j][h][4]
+static void postnet_pack_layer(int cb, const std::vector<float>& w, const std::vector<float>& start, const std::vector<float>& after,
+                               float* dst)
 {
-    for (int j = 0; j < 4; ++j)
-        for (int lane = 0; lane < 64; ++lane)
-            for (int e = 0; e < 4; ++e) dst[(j * 64 + lane) * 4 + e] = w[lane & 31][8 * j + 4 * (lane >> 5) + e];
-    float* bd = dst + 4 * 64 * 4;
-    for (int j = 0; j < 4; ++j)
-        for (int hf = 0; hf < 2; ++hf)
-            for (int e = 0; e < 4; ++e) bd[(j * 2 + hf) * 4 + e] = b[8 * j + 4 * hf + e];
+    const int cp = 32 * cb;
+    for (int cob = 0; cob < cb; ++cob)
+        for (int cib = 0; cib < cb; ++cib)
+            for (int j = 0; j < 4; ++j)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e)
+                        dst[((((cob * cb + cib) * 4 + j) * 64) + lane) * 4 + e] =
+                            w[(size_t)(32 * cob + (lane & 31)) * cp + 32 * cib + 8 * j + 4 * (lane >> 5) + e];
+    float* bd = dst + cb * cb * 1024;
+    for (int which = 0; which < 2; ++which)
+        for (int cob = 0; cob < cb; ++cob)
+            for (int j = 0; j < 4; ++j)
+                for (int hf = 0; hf < 2; ++hf)
+                    for (int e = 0; e < 4; ++e)
+                        bd[which * cb * 32 + ((cob * 4 + j) * 2 + hf) * 4 + e] = (which ? after : start)[32 * cob + 8 * j + 4 * hf + e];
 }
 
 extern "C" int rcu_postnet_finalize_weights(rcu_postnet* h)
 {
     if (!h) return fail(RCU_ERR_INVALID, "rcu_postnet_finalize_weights: null handle");
-    const int C = h->in_channels, L = h->nb_convs + 1;
-    std::vector<float> packed((size_t)L * PN_LAYER_FLOATS, 0.f);
+    const int C = h->in_channels, L = h->nb_convs + 1, cb = (C + 31) / 32, cp = 32 * cb;
+    const size_t layer = pn_layer_floats(cb);
+    // two images: eval (accumulators start from the whole folded bias) and MC (they start from alpha * conv bias; the dropout factor
+    // and BatchNorm's shift follow the MFMAs)
+    std::vector<float> packed((size_t)L * layer, 0.f), packed_mc((size_t)L * layer, 0.f);
     for (int l = 0; l < L; ++l) {
         const bool last = (l == h->nb_convs);
         const std::string pre = last ? "conv_logits" : "convs." + std::to_string(l) + ".conv2d_batch_relu.conv";
@@ -878,10 +897,10 @@ extern "C" int rcu_postnet_finalize_weights(rcu_postnet* h)
         int rc = postnet_weight(h, pre + ".weight", (size_t)cout * C, &w);
         if (rc) return rc;
         if ((rc = postnet_weight(h, pre + ".bias", cout, &b))) return rc;
-        float wf[32][32] = {}, bf[32] = {};
+        std::vector<float> wf((size_t)cp * cp, 0.f), b_conv(cp, 0.f), b_shift(cp, 0.f), b_all(cp, 0.f);
         for (int o = 0; o < cout; ++o) {
             float alpha = 1.f, beta = 0.f, mean = 0.f;
-            if (!last && h->bn) {   // Conv -> BatchNorm(eval): y = gamma (conv - mean) / sqrt(var + eps) + beta
+            if (!last && h->bn) {   // Conv -> [Dropout2d] -> BatchNorm(eval): y = gamma (m conv - mean) / sqrt(var + eps) + beta
                 const std::string bp = "convs." + std::to_string(l) + ".conv2d_batch_relu.bn";
                 const std::vector<float>*g, *be, *rm, *rv;
                 if ((rc = postnet_weight(h, bp + ".weight", C, &g))) return rc;
@@ -892,27 +911,33 @@ extern "C" int rcu_postnet_finalize_weights(rcu_postnet* h)
                 beta = (*be)[o];
                 mean = (*rm)[o];
             }
-            for (int i = 0; i < C; ++i) wf[o][i] = alpha * (*w)[(size_t)o * C + i];
-            bf[o] = alpha * ((*b)[o] - mean) + beta;
+            for (int i = 0; i < C; ++i) wf[(size_t)o * cp + i] = alpha * (*w)[(size_t)o * C + i];
+            b_all[o] = alpha * ((*b)[o] - mean) + beta;
+            b_conv[o] = alpha * (*b)[o];
+            b_shift[o] = beta - alpha * mean;
         }
-        postnet_pack_layer(wf, bf, packed.data() + (size_t)l * PN_LAYER_FLOATS);
+        postnet_pack_layer(cb, wf, b_all, std::vector<float>(cp, 0.f), packed.data() + (size_t)l * layer);
+        postnet_pack_layer(cb, wf, last ? b_all : b_conv, b_shift, packed_mc.data() + (size_t)l * layer);
     }
     if (!h->packed) RCU_HIP(hipMalloc(reinterpret_cast<void**>(&h->packed), packed.size() * sizeof(float)));
+    if (!h->packed_mc) RCU_HIP(hipMalloc(reinterpret_cast<void**>(&h->packed_mc), packed_mc.size() * sizeof(float)));
     RCU_HIP(hipMemcpy(h->packed, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    RCU_HIP(hipMemcpy(h->packed_mc, packed_mc.data(), packed_mc.size() * sizeof(float), hipMemcpyHostToDevice));
     h->finalized = true;
     return RCU_OK;
 }
 
 extern "C" int rcu_postnet_forward(rcu_postnet* h, const float* features_dev, int channel_pitch, int n, int hw,
-                                   float* logits_dev, void* stream)
+                                   const float* masks_dev, float* logits_dev, void* stream)
 {
     if (!h || !features_dev || !logits_dev) return fail(RCU_ERR_INVALID, "rcu_postnet_forward: null argument");
     if (!h->finalized) return fail(RCU_ERR_STATE, "rcu_postnet_forward before rcu_postnet_finalize_weights");
     if (n < 0 || hw < 1) return fail(RCU_ERR_INVALID, "rcu_postnet_forward: bad shape");
-    if (channel_pitch < 32 || channel_pitch % 4)
-        return fail(RCU_ERR_INVALID, "rcu_postnet_forward: channel pitch must be >= 32 floats and a multiple of 4");
-    RCU_HIP(launch_postnet(features_dev, channel_pitch, (size_t)n * hw, hw, h->packed, h->nb_convs + 1, h->nb_classes,
-                           logits_dev, static_cast<hipStream_t>(stream)));
+    const int cb = (h->in_channels + 31) / 32;
+    if (channel_pitch < 32 * cb || channel_pitch % 4)
+        return fail(RCU_ERR_INVALID, "rcu_postnet_forward: channel pitch must be >= in_channels rounded up to 32 and a multiple of 4");
+    RCU_HIP(launch_postnet(features_dev, channel_pitch, (size_t)n * hw, hw, masks_dev ? h->packed_mc : h->packed, h->nb_convs + 1,
+                           h->nb_classes, h->in_channels, masks_dev, logits_dev, static_cast<hipStream_t>(stream)));
     return RCU_OK;
 }
 

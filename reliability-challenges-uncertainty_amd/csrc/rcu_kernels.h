@@ -175,9 +175,12 @@ hipError_t launch_norm_entropy(const float* p_fg, size_t n, double* out_f64, flo
 // ---------------------------------------------------------------------------------------------
 // PostNet: fused 1x1-conv stack on the U-Net feature map (rcu_postnet.hip)
 // ---------------------------------------------------------------------------------------------
-constexpr int PN_LAYER_FLOATS = 4 * 64 * 4 + 4 * 2 * 4;   // packed weights + bias of one 32x32 layer
+// packed layer of CB x CB blocks of 32 channels: weight tiles + accumulator start values + constants behind the dropout factor
+constexpr int pn_layer_floats(int cb) { return cb * cb * 1024 + 2 * cb * 32; }
 constexpr int PN_MAX_LAYERS = 12;
+constexpr int PN_MAX_BLOCKS = 3;   // up to 96 feature channels (the packed layers live in LDS: n_layers * pn_layer_floats <= 160 KB)
+// masks: null, or Dropout2d factors [n_layers - 1][images][channels] of an MC pass
 hipError_t launch_postnet(const float* x_nhwc, int channel_pitch, size_t nvox, int hw, const float* packed, int n_layers,
-                          int nb_classes, float* logits_nchw, hipStream_t stream);
+                          int nb_classes, int channels, const float* masks, float* logits_nchw, hipStream_t stream);
 
 }  // namespace rcu

@@ -422,26 +422,53 @@ class PostNet(nn.Module):
         self._handle_entry = (handle, self._weights_version)
         return handle
 
-    def forward(self, x):
+    def sample_masks(self, n, device, generator=None):
+        """Dropout2d factors {0, 1/(1-p)} of one pass, ``[nb_convs][n][C]`` (ones where a module is in eval mode); None when the
+        network has no dropout modules or none of them is in train mode."""
+        if not self._dropouts or not any(m.training for m in self._dropouts):
+            return None
+        rows = []
+        for m in self._dropouts:
+            if m.training and 0 < m.p < 1:
+                keep = 1.0 - float(m.p)
+                rows.append(torch.empty(n * self.in_channels, device=device).bernoulli_(keep, generator=generator).div_(keep))
+            elif m.training and m.p >= 1:
+                rows.append(torch.zeros(n * self.in_channels, device=device))
+            else:
+                rows.append(torch.ones(n * self.in_channels, device=device))
+        return torch.cat(rows)
+
+    def forward(self, x, masks=None):
+        """``masks``: None -> eval mode, or sampled if any Dropout2d is in train mode (set_dropout_mode); a list of per-conv
+        ``[N, C]`` arrays / a concatenated device tensor to inject."""
         if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != self.in_channels:
             raise ValueError('expected a [N, {}, H, W] tensor'.format(self.in_channels))
         if not x.is_cuda:
             raise RuntimeError('rcu_amd.model.PostNet only runs on the GPU (librcu_hip); got a {} tensor'.format(x.device))
-        if any(m.training for m in self._dropouts):
-            raise NotImplementedError('MC-dropout inside PostNet is not part of the reference test scripts; call .eval()')
         n, c, h, w = x.shape
+        if masks is None:
+            masks = self.sample_masks(n, x.device)
+        elif isinstance(masks, (list, tuple)):
+            if len(masks) != self.nb_convs:
+                raise ValueError('expected {} dropout masks, got {}'.format(self.nb_convs, len(masks)))
+            masks = torch.cat([torch.as_tensor(m, dtype=torch.float32).reshape(n * c) for m in masks]).to(x.device)
+        if masks is not None:
+            masks = masks.to(torch.float32).contiguous()
+            if masks.numel() != self.nb_convs * n * c:
+                raise ValueError('dropout masks must hold nb_convs x N x C factors')
+        cp = (c + 31) // 32 * 32
         nhwc = x.permute(0, 2, 3, 1)
         pitch = nhwc.stride(2)
-        in_place = (x.dtype == torch.float32 and nhwc.stride(3) == 1 and pitch >= 32 and pitch % 4 == 0 and
+        in_place = (x.dtype == torch.float32 and nhwc.stride(3) == 1 and pitch >= cp and pitch % 4 == 0 and
                     nhwc.stride(1) == w * pitch and nhwc.stride(0) == h * w * pitch and x.data_ptr() % 16 == 0)
-        if not in_place:      # generic input: channels-last copy padded to the 32-float voxel pitch of the kernel
-            pitch = 32
+        if not in_place:      # generic input: channels-last copy, zero padded to the kernel's voxel pitch (a multiple of 32 floats)
+            pitch = cp
             buf = torch.zeros((n, h, w, pitch), device=x.device, dtype=torch.float32)
             buf[..., :c] = nhwc
             nhwc = buf
         logits = torch.empty((n, self.nb_classes, h, w), device=x.device, dtype=torch.float32)
         _lib.check(_lib.load().rcu_postnet_forward(self._handle(), ctypes.c_void_p(nhwc.data_ptr()), pitch, n, h * w,
-                                                   _lib.ptr(logits), _lib.current_stream()))
+                                                   _lib.ptr(masks), _lib.ptr(logits), _lib.current_stream()))
         return logits
 
 

@@ -581,7 +581,32 @@ def test_postnet_full_width_vs_oracle(dev):
         ref = uo.postnet_forward(state, x, nb_convs)
         assert _maxdiff(post(x.to(dev)).cpu(), ref) < 2e-5
     with pytest.raises(Exception):
-        PostNet(64, 2).to(dev)(torch.zeros(1, 64, 8, 8, device=dev))      # wider than the kernel handles: loud
+        PostNet(128, 2).to(dev)(torch.zeros(1, 128, 8, 8, device=dev))    # wider than the kernel handles (96 channels): loud
+
+
+def test_postnet_wide_and_mc_dropout_golden(golden, dev):
+    """Reference golden G16: PostNet over 64 / 48 / 40 feature channels (U-Nets with start_filters > 32) and MC-dropout inside
+    PostNet (a Dropout2d between conv and BatchNorm of every hidden unit) under the reference's masks; sampled masks too."""
+    from rcu_amd import steps
+    from rcu_amd.model import PostNet
+    g = golden('g16_postnet_wide')
+    for tag in ('a', 'b', 'c'):
+        c, classes, convs = (int(v) for v in g['shape_' + tag])
+        post = PostNet(c, classes, nb_convs=convs).to(dev)
+        post.load_state_dict({k[len('post_{}::'.format(tag)):]: torch.as_tensor(v) for k, v in g.items() if k.startswith('post_{}::'.format(tag))})
+        assert _maxdiff(post(torch.as_tensor(g['features_' + tag]).to(dev)).cpu(), g['logits_' + tag]) < 2e-5, tag
+    post = PostNet(32, 2, nb_convs=3, dropout=0.3).to(dev)
+    post.load_state_dict({k[len('post_d::'):]: torch.as_tensor(v) for k, v in g.items() if k.startswith('post_d::')})
+    f = torch.as_tensor(g['features_d']).to(dev)
+    assert _maxdiff(post(f).cpu(), g['logits_d_eval']) < 2e-5
+    masks = [g['mask_d_{}'.format(s)] for s in range(3)]
+    assert _maxdiff(post(f, masks).cpu(), g['logits_d_mc']) < 2e-5
+    steps.set_dropout_mode(post, True)
+    torch.manual_seed(3)
+    a, b = post(f), post(f)
+    steps.set_dropout_mode(post, False)
+    assert float((a - b).abs().max()) > 1e-3                      # two stochastic passes differ ...
+    assert _maxdiff(post(f).cpu(), g['logits_d_eval']) < 2e-5     # ... and eval mode is back afterwards
 
 
 # ---------------------------------------------------------------------------------- calibration
