@@ -445,7 +445,19 @@ def main():
         pg = out['probabilities'][idx][:, 1].cpu().numpy()
         pc = ref['probabilities'][:, 1].numpy()
         tg, mk = target_cpu[sel].numpy(), mask_cpu[sel].numpy()
-        parity['ece_delta_vs_cpu'] = abs(ev.ece_binary(pg, tg, mask=mk) - co.ece_binary(np.stack([1 - pc, pc], -1), tg, mask=mk))
+        # the metric seam on the CPU: ECE + normalised entropy + the uncertainty-error counts of the bnf_ue action's 11
+        # thresholds on the oracle's maps of the sample slices, timed, next to the forward passes
+        t_c = time.perf_counter()
+        pair = np.stack([1 - pc, pc], -1)
+        ece_cpu = co.ece_binary(pair, tg, mask=mk)
+        unc = co.normalised_entropy(pair)
+        pred_c = (pc > 0.5).astype(np.uint8)
+        for thr in [0.05] + [0.1 * k for k in range(1, 10)] + [0.95]:
+            co.uncertainty_counts(pred_c, tg, unc > thr, mask=mk)
+        cpu['metric_seam_s'] = time.perf_counter() - t_c
+        cpu['metric_seam'] = 'ECE + normalised entropy + 11 uncertainty-error count passes (numpy, one thread) on {} of {} slices'.format(
+            len(sel), n_slices)
+        parity['ece_delta_vs_cpu'] = abs(ev.ece_binary(pg, tg, mask=mk) - ece_cpu)
 
     units = T * (n_slices if isic else 1)
     shape = '{}x{}x{}'.format(ISIC_CHANNELS, height, width) if isic else '4x160x192x128'
