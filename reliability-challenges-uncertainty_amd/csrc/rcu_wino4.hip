@@ -117,6 +117,9 @@ __device__ __forceinline__ WinoEpiRaw wino4_epilogue_load(const ConvArgs& a, int
 // allocate it).  The compiler never holds a value there; the build is audited for that (tests/test_abi_cpu.py: no scratch, no
 // v_accvgpr_* outside the asm statements).  The accumulators of cout block 1 at positions 18..25 are ordinary VGPR variables
 // multiplied by the VGPR form of the instruction.
+//   s_nop 11 (closing the VGPR-form MFMAs): to hipcc an asm output is ready when the statement ends; should it ever copy or spill one of
+//   these accumulator tuples right behind the statement it must not read the MFMA's destination early (8 passes: 12 wait states).
+//   The wave would wait for the matrix pipe in that time anyway: no measurable cost.
 //   s_nop 1 (opening every MFMA; it costs no matrix time, tools/microbench/gen_mfma_valu_1wave.py): the wait states between a VALU
 //   write of an operand and the MFMA reading it, which hipcc does not add inside asm -- and hipcc is free to sink a transform
 //   operation down to the MFMA that consumes it (a build with the nop on the first MFMA of a group only gave wrong results).
@@ -147,9 +150,9 @@ __device__ __forceinline__ void wino4_mfma(f32x4 (&accv)[8], float av, float wv)
     if constexpr (PROBE) asm volatile("s_nop 7\n\ts_nop 7");
     if constexpr (wino4_in_vgpr(B, P)) {
         if constexpr (ZERO)
-            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(accv[P - 18]) : "v"(av), "v"(wv));
+            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0\n\ts_nop 11" : "=v"(accv[P - 18]) : "v"(av), "v"(wv));
         else
-            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[P - 18]) : "v"(av), "v"(wv));
+            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\ts_nop 11" : "+v"(accv[P - 18]) : "v"(av), "v"(wv));
     } else {
         constexpr int R = wino4_areg(B, P);
         if constexpr (ZERO && NOP)
