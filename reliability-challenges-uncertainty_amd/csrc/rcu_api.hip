@@ -157,6 +157,9 @@ static int pick_config(const ConvLayer& L, int n_slices)
             if (L.H % 32 == 0) return CONV_CFG_WINO4_T32x32_N32;
             if (L.H % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_WINO4_S2T16x32_N32;
         }
+        if (w4_mode != 0 && (L.coutp >= 64 || w4_mode == 2) && L.name2.empty() && !is_head_unit(L) && L.W == 16 && L.H % 8 == 0 &&
+            n_slices % 8 == 0)
+            return CONV_CFG_WINO4_S8T8x16_N32;
         if (L.coutp == 32 && L.H % 16 == 0 && L.W % 32 == 0) return CONV_CFG_WINO_T16x32_N32;
         if (L.coutp > 32 && L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T16x16_N64;
         if (L.coutp > 32 && L.H % 8 == 0 && L.W % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_WINO_S2T8x16_N64;

@@ -79,6 +79,7 @@ enum ConvConfig {
     // Winograd F(4x4,3x3) kernels (rcu_wino4.hip): 36 positions, one wave per SIMD (288 accumulator registers), 32 couts
     CONV_CFG_WINO4_T32x32_N32,                   // 32x32-pixel tile (64 Winograd tiles of 4x4)
     CONV_CFG_WINO4_S2T16x32_N32,                 // 16x32 pixels of two consecutive slices
+    CONV_CFG_WINO4_S8T8x16_N32,                  // 8x16 pixels of eight consecutive slices, images 16 pixels wide
     CONV_CFG_END
 };
 

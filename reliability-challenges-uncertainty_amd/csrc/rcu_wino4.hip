@@ -39,12 +39,17 @@ namespace rcu {
 
 // Workgroup tile: WS slice groups x WR block rows of MFMA row blocks; a block = SB slices x BR tile rows x BC tile columns = 16
 // tiles of 4x4 pixels spanning the tile's full width.
-template <int SB_, int BR_, int BC_, int WS_, int WR_>
+// FULLW: the tile spans the image's width (checked by the launcher), so the halo columns are zero padding and are not staged at all:
+// the LDS image holds TW positions per row and the lanes of the first / last tile column zero their outer patch column themselves.
+// What it buys is LDS: eight slices of 8x16 pixels (the 24x16 level) fit the 160 KB only without the two halo columns.
+template <int SB_, int BR_, int BC_, int WS_, int WR_, bool FULLW_ = false>
 struct Wino4Tile {
     static constexpr int SB = SB_, BR = BR_, BC = BC_, WS = WS_, WR = WR_;
+    static constexpr bool FULLW = FULLW_;
     static constexpr int TS = SB * WS, TH = 4 * BR * WR, TW = 4 * BC;
     static constexpr int BN = 32, KC = 8, THREADS = 256, WAVES = 4, NPOS = 36;
-    static constexpr int PITCH = (TW + 2 + 3) / 4 * 4;                       // positions per halo row, a multiple of 4
+    static constexpr int XCOLS = FULLW ? TW : TW + 2;                        // staged pixel columns per row: x = -1 .. TW, or 0 .. TW - 1
+    static constexpr int PITCH = (XCOLS + 3) / 4 * 4;                        // positions per halo row, a multiple of 4
     static constexpr int SLICE_POS = ((TH + 2) * PITCH + 15) / 16 * 16;      // positions per slice image, a multiple of 16
     static constexpr int A_POS = 2 * TS * SLICE_POS;                         // 16-byte units: [slice][halo row][position][channel half]
     static constexpr int A_PIECES = (A_POS + 63) / 64;
@@ -81,8 +86,9 @@ __device__ __forceinline__ uint32_t wino4_slot_geometry(int j, int wave, int lan
     const int s = rem / T::SLICE_POS, r2 = rem % T::SLICE_POS;
     const int yy = r2 / T::PITCH, pos = r2 % T::PITCH;
     const int x = pos ^ T::swizzle(pos, s, yy);             // the swizzle only moves a position inside its aligned group of four
-    const bool real = f < T::A_POS && yy < T::TH + 2 && x < T::TW + 2;
-    return real ? (uint32_t)(x | (yy << 8) | (s << 16) | (hh << 24)) : 0xFFFFFFFFu;
+    const bool real = f < T::A_POS && yy < T::TH + 2 && x < T::XCOLS;
+    // the x field is the column in halo coordinates (image column + 1), whichever layout the image has
+    return real ? (uint32_t)((x + (T::FULLW ? 1 : 0)) | (yy << 8) | (s << 16) | (hh << 24)) : 0xFFFFFFFFu;
 }
 
 template <class T>
@@ -307,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
     // fragment addresses (dword offsets inside a buffer) of the lane's patch columns j = 0..5, for patch rows 0..3 ([0]) and 4..5
     // ([1]: the swizzle's row bit flips); the row itself is an immediate offset
     int aCol[2][6];
+    bool zero_left = false, zero_right = false;   // FULLW: this lane's patch column 0 / 5 lies outside the image
     {
         int bs, by, sb, tr, tc;
         T::block_origin(wave, bs, by);
@@ -317,9 +324,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                const int x = 4 * tc + j;
+                int x = 4 * tc + j - (T::FULLW ? 1 : 0);   // staged column of patch column j
+                if (T::FULLW) x = min(max(x, 0), T::TW - 1);   // the two columns outside read a neighbour and are zeroed below
                 aCol[ip][j] = base + 8 * (x ^ T::swizzle(x, s, R0 + 4 * ip));
             }
+        if (T::FULLW) {
+            zero_left = tc == 0;
+            zero_right = tc == T::BC - 1;
+        }
     }
     const int b_addr = T::A_DW + (kq * T::BN + 2 * m16) * 2;
     const uint32_t w_voff = (uint32_t)(lane * 16);
@@ -393,6 +405,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         for (int j = 0; j < 6; ++j)
             // volatile: keeps hipcc from fusing pairs of these reads into ds_read2_b64
             d[6 * i + j] = *(const volatile __attribute__((address_space(3))) f32x2*)(Ab + aCol[i >> 2][j] + i * (T::PITCH * 8));
+        if constexpr (T::FULLW) {   // zero padding left and right of the image
+            const f32x2 z = {0.f, 0.f};
+            d[6 * i] = zero_left ? z : d[6 * i];
+            d[6 * i + 5] = zero_right ? z : d[6 * i + 5];
+        }
     };
     auto load_weights = [&](f32x4 (&bv)[36], const float* Ab, int p) { bv[p] = *reinterpret_cast<const f32x4*>(Ab + b_addr + p * (8 * T::BN)); };
     // B^T d B in place on channel pairs (packed operations).  One-dimensional transform of (x0..x5):
@@ -579,10 +596,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
 
 using W4Cfg0 = Wino4Tile<1, 2, 8, 1, 4>;   // 32x32 pixels of one slice
 using W4Cfg1 = Wino4Tile<1, 2, 8, 2, 2>;   // 16x32 pixels of two consecutive slices (heights not divisible by 32)
+using W4Cfg2 = Wino4Tile<2, 2, 4, 4, 1, true>;   // 8x16 pixels of eight consecutive slices, full image width (the 24x16 level)
 
-static const ConvConfigInfo kWino4Info[2] = {
+static const ConvConfigInfo kWino4Info[3] = {
     {W4Cfg0::TS, W4Cfg0::TH, W4Cfg0::TW, W4Cfg0::BN, 8, 36, "conv3x3_winograd4<T32x32,N32,K8>", 8, 0, 3},
     {W4Cfg1::TS, W4Cfg1::TH, W4Cfg1::TW, W4Cfg1::BN, 8, 36, "conv3x3_winograd4<S2T16x32,N32,K8>", 8, 0, 3},
+    {W4Cfg2::TS, W4Cfg2::TH, W4Cfg2::TW, W4Cfg2::BN, 8, 36, "conv3x3_winograd4<S8T8x16,N32,K8>", 8, 0, 3},
 };
 
 const ConvConfigInfo& wino4_config_info(int cfg) { return kWino4Info[cfg - CONV_CFG_WINO4_T32x32_N32]; }
@@ -603,7 +622,7 @@ static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
 {
     const int nchunks = (a.C1 + a.C2) / T::KC;
     if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
-        (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 || a.mask2 != nullptr ||
+        (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 || (T::FULLW && a.W != T::TW) || a.mask2 != nullptr ||
         (size_t)a.N * a.H * a.W * a.CoutP * 4 >= ((size_t)1 << 31))
         return hipErrorInvalidValue;
 #ifdef RCU_WINO4_ABLATIONS   // timing experiments of tools/wino4_check.py (make EXTRA=-DRCU_WINO4_ABLATIONS); results are wrong
@@ -628,6 +647,7 @@ hipError_t launch_conv_wino4(int cfg, const ConvArgs& a, hipStream_t stream)
     switch (cfg) {
         case CONV_CFG_WINO4_T32x32_N32: return launch_wino4_cfg<W4Cfg0>(a, stream);
         case CONV_CFG_WINO4_S2T16x32_N32: return launch_wino4_cfg<W4Cfg1>(a, stream);
+        case CONV_CFG_WINO4_S8T8x16_N32: return launch_wino4_cfg<W4Cfg2>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }
