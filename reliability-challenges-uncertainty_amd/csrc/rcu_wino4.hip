@@ -291,6 +291,19 @@ __host__ __device__ constexpr int wino4_pos_of(int q) { return 6 * wino4_row_of(
 
 // VAR: timing ablations for tools/wino4_check.py (wrong results): bit 0 no LDS-DMA inside the chunks, bit 1 no epilogue, bit 2 no
 // input transform, bit 3 no chunk barrier
+#ifdef RCU_WINO4_ABLATIONS
+// VAR bit 7: s_memtime per tile and wave (tile start, chunks done, epilogue done, vmcnt(0), barrier, first fragments read)
+__device__ uint64_t g_w4_trace[256 * 4 * 4 * 8];
+extern "C" __attribute__((visibility("default"))) int rcu_debug_w4_trace(uint64_t* dst)   // copies the trace out and clears it
+{
+    void* p = nullptr;
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_w4_trace), sizeof(g_w4_trace));
+    if (e == hipSuccess) e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_w4_trace));
+    if (e == hipSuccess) e = hipMemset(p, 0, sizeof(g_w4_trace));
+    return (int)e;
+}
+#endif
+
 template <class T, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, const int total_items)
 {
@@ -573,6 +586,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         wino_static_for<0, AHEAD>([&](auto q_c) { load_weights(bvA, smem, wino4_pos_of(decltype(q_c)::value)); });
     };
     load_first();
+#ifdef RCU_WINO4_ABLATIONS
+    uint64_t tr0 = (VAR & 128) != 0 ? __builtin_amdgcn_s_memtime() : 0;
+#endif
 
     for (;;) {
         chunk(std::integral_constant<int, 0>{}, std::true_type{}, 0, dA, dB, bvA, bvB);
@@ -581,12 +597,36 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
             chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc, dA, dB, bvA, bvB);
             chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1, dB, dA, bvB, bvA);
         }
+#ifdef RCU_WINO4_ABLATIONS
+        uint64_t tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
+        if constexpr ((VAR & 128) != 0) tr1 = __builtin_amdgcn_s_memtime();
+#endif
         if constexpr ((VAR & 2) == 0)
             wino4_epilogue<T>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wave, lane);
+#ifdef RCU_WINO4_ABLATIONS
+        if constexpr ((VAR & 128) != 0) tr2 = __builtin_amdgcn_s_memtime();
+#endif
         if (!has_next) break;
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's first chunk has landed (and this tile's stores have left)
+#ifdef RCU_WINO4_ABLATIONS
+        if constexpr ((VAR & 128) != 0) tr3 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+#ifdef RCU_WINO4_ABLATIONS
+        if constexpr ((VAR & 128) != 0) tr4 = __builtin_amdgcn_s_memtime();
+#endif
         load_first();
+#ifdef RCU_WINO4_ABLATIONS
+        if constexpr ((VAR & 128) != 0) {
+            const uint64_t tr5 = __builtin_amdgcn_s_memtime();
+            const int k = (item - (int)blockIdx.x) / (int)gridDim.x;   // the workgroup's k-th tile
+            if (lane == 0 && k < 4) {
+                uint64_t* t = g_w4_trace + (((size_t)blockIdx.x * 4 + wave) * 4 + k) * 8;
+                t[0] = tr0, t[1] = tr1, t[2] = tr2, t[3] = tr3, t[4] = tr4, t[5] = tr5;
+            }
+            tr0 = tr5;
+        }
+#endif
         item += (int)gridDim.x;
         tile = ntile;
         has_next = item + (int)gridDim.x < total_items;
@@ -636,6 +676,7 @@ static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
         case 15: return launch_wino4_var<T, 15>(a, stream);
         case 16: return launch_wino4_var<T, 16>(a, stream);
         case 64: return launch_wino4_var<T, 64>(a, stream);
+        case 128: return launch_wino4_var<T, 128>(a, stream);
         default: break;
     }
 #endif

@@ -47,7 +47,7 @@ def main():
     del m4, m2
     xb = bench.make_volume(20)[0][:n_big].to(dev)
     stb = {k: v.detach().cpu() for k, v in bench.make_model(20, 'cpu').state_dict().items()}
-    variants = [(True, v) for v in ((0, 1, 2, 3, 7) if os.environ.get('RCU_W4_ABLATE') else (0,))] + [(False, 0)]
+    variants = [(True, v) for v in ([int(t) for t in os.environ['RCU_W4_ABLATE'].split(',')] if os.environ.get('RCU_W4_ABLATE') else (0,))] + [(False, 0)]
     for wino4, var in variants:
         os.environ['RCU_W4_VARIANT'] = str(var)
         m = build(stb, dev, wino4, (h, w, n_big))
