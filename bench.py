@@ -202,8 +202,8 @@ def split_masks(model, flat, n, rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mc', type=int, default=20, help='T: stochastic passes per volume')
     ap.add_argument('--workload', choices=('brats', 'isic'), default='brats',
                     help='brats: 160 slices of 4x192x128 (the headline, BASELINE configs[2]); isic: 32 images of 3x256x256 (configs[1])')

@@ -187,10 +187,16 @@ __device__ __forceinline__ float wino4_acc(const f32x4 (&accv)[8])
 
 // Output transform + conv-unit epilogue of one finished tile.  acc[b][p][r]: MFMA block b (cout 2n+b), position p = 6 i + j,
 // tile r of the lane's four.
-template <class T>
+template <class T, int EV = 0>   // EV (ablation build): 1 stores out of range, 2 no store instructions, 4 no output transform
 __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&accv)[8], const WinoEpi& ep, int ntile, int n0, int y0, int x0,
                                                int wave, int lane)
 {
+    auto store16 = [&](const f32x4& o, const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, uint32_t soff) {
+        if constexpr ((EV & 2) != 0)
+            asm volatile("" ::"v"(o));
+        else
+            wino_store16(o, rs, (EV & 1) != 0 ? WINO_OOB : voff, soff);
+    };
     // every MFMA has long retired: the last chunk's barrier lies between them and this point; the nops cover the asm-to-asm case
     // (an MFMA's D read by v_accvgpr_read) the compiler cannot see
     asm volatile("s_nop 15\n\ts_nop 7");
@@ -223,6 +229,12 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
         {
             const f32x2 scale = {ep.scale[0], ep.scale[1]}, shift = {ep.shift[0], ep.shift[1]}, floor2 = {relu_floor, relu_floor};
             f32x2 nn[6][4];   // N[i][q] = sum_j M[i][j] A[j][q]
+            if constexpr ((EV & 4) != 0) {
+                wino_static_for<0, 16>([&](auto k_c) {
+                    constexpr int k = decltype(k_c)::value;
+                    y[k >> 2][k & 3] = f32x2{wino4_acc<0, k, r>(accv), wino4_acc<1, k, r>(accv)};
+                });
+            } else {
             wino_static_for<0, 6>([&](auto i_c) {
                 constexpr int i = decltype(i_c)::value;
                 auto m = [&](auto j_c) {
@@ -249,6 +261,7 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
                 y[2][q] = __builtin_elementwise_max(v2 * scale + shift, floor2);
                 y[3][q] = __builtin_elementwise_max(v3 * scale + shift, floor2);
             }
+            }
         }
         // Neighbouring lanes (couts 2n, 2n+1 | 2n+2, 2n+3 of the same pixels) trade pixel columns: the even lane ends up with four
         // couts of columns 0 and 2 of the tile, the odd lane with four couts of columns 1 and 3 -> 16-byte stores.
@@ -262,7 +275,7 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
                 recv.x = wino_swap_adjacent(send.x);
                 recv.y = wino_swap_adjacent(send.y);
                 const f32x4 o = odd ? f32x4{recv.x, recv.y, keep.x, keep.y} : f32x4{keep.x, keep.y, recv.x, recv.y};
-                wino_store16(o, ro, vo, (uint32_t)(4 * r + 2 * h2) * px_bytes + (uint32_t)aa * row_bytes);
+                store16(o, ro, vo, (uint32_t)(4 * r + 2 * h2) * px_bytes + (uint32_t)aa * row_bytes);
             }
         }
         if (pool) {   // wave-uniform; 2x2 pooled pixels per tile: the even lane stores four couts of pooled column 0, the odd lane of column 1
@@ -279,7 +292,7 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
                 recv.x = wino_swap_adjacent(send.x);
                 recv.y = wino_swap_adjacent(send.y);
                 const f32x4 o = odd ? f32x4{recv.x, recv.y, keep.x, keep.y} : f32x4{keep.x, keep.y, recv.x, recv.y};
-                wino_store16(o, rp, vp, (uint32_t)(2 * r) * px_bytes + (uint32_t)a2 * prow_bytes);
+                store16(o, rp, vp, (uint32_t)(2 * r) * px_bytes + (uint32_t)a2 * prow_bytes);
             }
         }
     });
@@ -292,7 +305,9 @@ __host__ __device__ constexpr int wino4_pos_of(int q) { return 6 * wino4_row_of(
 // VAR: timing ablations for tools/wino4_check.py (wrong results): bit 0 no LDS-DMA inside the chunks, bit 1 no epilogue, bit 2 no
 // input transform, bit 3 no chunk barrier
 #ifdef RCU_WINO4_ABLATIONS
-// VAR bit 7: s_memtime per tile and wave (tile start, chunks done, epilogue done, vmcnt(0), barrier, first fragments read)
+// VAR bits 8..10: epilogue ablations (EV of wino4_epilogue); bit 7: s_memtime per tile and wave (tile start, chunks done, epilogue
+// done, vmcnt(0), barrier, first fragments read) -- kept in a type that is empty for the other variants, so that they compile to what
+// they would be without it (the kernel sits at 500 of 512 registers: a dead variable is enough to make hipcc spill)
 __device__ uint64_t g_w4_trace[256 * 4 * 4 * 8];
 extern "C" __attribute__((visibility("default"))) int rcu_debug_w4_trace(uint64_t* dst)   // copies the trace out and clears it
 {
@@ -302,6 +317,33 @@ extern "C" __attribute__((visibility("default"))) int rcu_debug_w4_trace(uint64_
     if (e == hipSuccess) e = hipMemset(p, 0, sizeof(g_w4_trace));
     return (int)e;
 }
+template <bool ON>
+struct Wino4Trace {
+    uint32_t t[6];
+    __device__ __forceinline__ void mark(int i) { t[i] = (uint32_t)__builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void flush(int item, int wave, int lane)
+    {
+        const int k = (item - (int)blockIdx.x) / (int)gridDim.x;   // the workgroup's k-th tile
+        if (lane == 0 && k < 4) {
+            uint64_t* o = g_w4_trace + (((size_t)blockIdx.x * 4 + wave) * 4 + k) * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o[i] = (1u << 30) + (t[i] - t[0]);
+        }
+        t[0] = t[5];
+    }
+};
+template <>
+struct Wino4Trace<false> {
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(int, int, int) {}
+};
+#define WINO4_TRACE_DECL Wino4Trace<(VAR & 128) != 0> w4trace
+#define WINO4_TRACE_MARK(i) w4trace.mark(i)
+#define WINO4_TRACE_FLUSH() w4trace.flush(item, wave, lane)
+#else
+#define WINO4_TRACE_DECL
+#define WINO4_TRACE_MARK(i)
+#define WINO4_TRACE_FLUSH()
 #endif
 
 template <class T, int VAR = 0>
@@ -586,9 +628,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         wino_static_for<0, AHEAD>([&](auto q_c) { load_weights(bvA, smem, wino4_pos_of(decltype(q_c)::value)); });
     };
     load_first();
-#ifdef RCU_WINO4_ABLATIONS
-    uint64_t tr0 = (VAR & 128) != 0 ? __builtin_amdgcn_s_memtime() : 0;
-#endif
+    WINO4_TRACE_DECL;
+    WINO4_TRACE_MARK(0);
 
     for (;;) {
         chunk(std::integral_constant<int, 0>{}, std::true_type{}, 0, dA, dB, bvA, bvB);
@@ -597,36 +638,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
             chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc, dA, dB, bvA, bvB);
             chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1, dB, dA, bvB, bvA);
         }
-#ifdef RCU_WINO4_ABLATIONS
-        uint64_t tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
-        if constexpr ((VAR & 128) != 0) tr1 = __builtin_amdgcn_s_memtime();
-#endif
+        WINO4_TRACE_MARK(1);
         if constexpr ((VAR & 2) == 0)
-            wino4_epilogue<T>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wave, lane);
-#ifdef RCU_WINO4_ABLATIONS
-        if constexpr ((VAR & 128) != 0) tr2 = __builtin_amdgcn_s_memtime();
-#endif
+            wino4_epilogue<T, (VAR >> 8)>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wave, lane);
+        WINO4_TRACE_MARK(2);
         if (!has_next) break;
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's first chunk has landed (and this tile's stores have left)
-#ifdef RCU_WINO4_ABLATIONS
-        if constexpr ((VAR & 128) != 0) tr3 = __builtin_amdgcn_s_memtime();
-#endif
+        WINO4_TRACE_MARK(3);
         __syncthreads();
-#ifdef RCU_WINO4_ABLATIONS
-        if constexpr ((VAR & 128) != 0) tr4 = __builtin_amdgcn_s_memtime();
-#endif
+        WINO4_TRACE_MARK(4);
         load_first();
-#ifdef RCU_WINO4_ABLATIONS
-        if constexpr ((VAR & 128) != 0) {
-            const uint64_t tr5 = __builtin_amdgcn_s_memtime();
-            const int k = (item - (int)blockIdx.x) / (int)gridDim.x;   // the workgroup's k-th tile
-            if (lane == 0 && k < 4) {
-                uint64_t* t = g_w4_trace + (((size_t)blockIdx.x * 4 + wave) * 4 + k) * 8;
-                t[0] = tr0, t[1] = tr1, t[2] = tr2, t[3] = tr3, t[4] = tr4, t[5] = tr5;
-            }
-            tr0 = tr5;
-        }
-#endif
+        WINO4_TRACE_MARK(5);
+        WINO4_TRACE_FLUSH();
         item += (int)gridDim.x;
         tile = ntile;
         has_next = item + (int)gridDim.x < total_items;
@@ -677,6 +700,13 @@ static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
         case 16: return launch_wino4_var<T, 16>(a, stream);
         case 64: return launch_wino4_var<T, 64>(a, stream);
         case 128: return launch_wino4_var<T, 128>(a, stream);
+        case 256: return launch_wino4_var<T, 256>(a, stream);
+        case 512: return launch_wino4_var<T, 512>(a, stream);
+        case 1024: return launch_wino4_var<T, 1024>(a, stream);
+        case 128 + 256: return launch_wino4_var<T, 128 + 256>(a, stream);
+        case 128 + 512: return launch_wino4_var<T, 128 + 512>(a, stream);
+        case 128 + 1024: return launch_wino4_var<T, 128 + 1024>(a, stream);
+        case 128 + 1024 + 512: return launch_wino4_var<T, 128 + 1024 + 512>(a, stream);
         default: break;
     }
 #endif

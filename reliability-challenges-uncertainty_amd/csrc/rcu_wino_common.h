@@ -35,7 +35,10 @@ __device__ __forceinline__ const ConvArgs& wino_cold_args()
 // pixels, different ones per run).  Two wait states, pinned right behind the store.
 __device__ __forceinline__ void wino_store16(const f32x4& v, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff)
 {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff, soff, 0);
+#ifndef RCU_STORE_AUX
+#define RCU_STORE_AUX 0
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff, soff, RCU_STORE_AUX);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 1");
     __builtin_amdgcn_sched_barrier(0);

@@ -8,10 +8,11 @@ OUT=$R/gpurun_out/$TAG
 P=/tmp/prof_$TAG
 mkdir -p $OUT $P
 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $OUT/pytest_gpu.txt
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cut -c1-300 $OUT/bench_default.json
-python bench.py --workload isic --steps 5 > $OUT/bench_isic.json 2> $OUT/bench_isic.err; cut -c1-200 $OUT/bench_isic.json
-python bench.py --ensemble 10 --steps 2 > $OUT/bench_ensemble10.json 2> $OUT/bench_ensemble10.err; cut -c1-200 $OUT/bench_ensemble10.json
-python bench.py --aleatoric --mc 50 --steps 2 --no-cpu-baseline > $OUT/bench_aleatoric_mc50.json 2> $OUT/bench_aleatoric_mc50.err; cut -c1-200 $OUT/bench_aleatoric_mc50.json
+python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; cut -c1-300 $OUT/bench_default.json   # the driver's flags
+python bench.py --no-ws --no-cpu-baseline > $OUT/bench_no_ws.json 2> $OUT/bench_no_ws.err; cut -c1-200 $OUT/bench_no_ws.json
+python bench.py --workload isic > $OUT/bench_isic.json 2> $OUT/bench_isic.err; cut -c1-200 $OUT/bench_isic.json
+python bench.py --ensemble 10 > $OUT/bench_ensemble10.json 2> $OUT/bench_ensemble10.err; cut -c1-200 $OUT/bench_ensemble10.json
+python bench.py --aleatoric --mc 50 --steps 4 --no-cpu-baseline > $OUT/bench_aleatoric_mc50.json 2> $OUT/bench_aleatoric_mc50.err; cut -c1-200 $OUT/bench_aleatoric_mc50.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $P/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $P/pmc_fetch.log 2>&1

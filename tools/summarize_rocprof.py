@@ -32,7 +32,7 @@ def short(name):
         tile = ('S{}'.format(ts) if ts != '1' else '') + 'T{}x{}'.format(th, tw)
         return '{}<{},N{},K8>{}'.format('conv3x3_winograd' if kind == 'conv' else 'upconv_winograd', tile, bn,
                                         '+head' if ', true>' in name else '')
-    m = re.search(r'conv_wino4_stream<rcu::Wino4Tile<(\d+), (\d+), (\d+), (\d+), (\d+)>', name)
+    m = re.search(r'conv_wino4_stream<rcu::Wino4Tile<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, \w+)?>', name)
     if m:   # block = SB slices x BR x BC tiles of 4x4 pixels, workgroup = WS x WR blocks
         sb, br, bc, ws, wr = (int(v) for v in m.groups())
         ts, th, tw = sb * ws, 4 * br * wr, 4 * bc
