@@ -623,6 +623,7 @@ struct FusedHead {
     float* logits;
     void* stats;
     int flags;
+    int passes;   // pass group: the batch holds `passes` x (n / passes) samples, all adding into the statistics of n / passes images
 };
 
 static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks, hipStream_t stream, const FusedHead* head = nullptr,
@@ -670,7 +671,9 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
         cfg = CONV_CFG_WINO_T16x32_N32_HEAD;
         a.head_w = h->w_cls; a.head_b = h->b_cls;
         a.head_logits = head->logits; a.head_stats = head->stats; a.head_flags = head->flags;
-        a.head_V = (size_t)n * L.H * L.W;
+        a.head_passes = head->passes;
+        a.head_images = n / head->passes;
+        a.head_V = (size_t)a.head_images * L.H * L.W;
     }
     RCU_HIP(launch_conv3x3(cfg, a, stream));
     return RCU_OK;
@@ -700,14 +703,15 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
                                   passes, stream));
     if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
     // conv_cls.0 and the classifier as one kernel where the shapes allow (the shipped configurations; RCU_FUSE_HEAD=0
-    // keeps them apart): two classes, no sigma twin, one pass per sample, 32-cout Winograd tile
+    // keeps them apart): two classes, no sigma twin, 32-cout Winograd tile; the passes of a pass group run back to back on the
+    // workgroup that owns the tile, so their read-modify-writes of the statistics are ordered (pass 0 first, as head_kernel adds them)
     const ConvLayer& last = h->layers.back();
     const char* const fuse_env = getenv("RCU_FUSE_HEAD");
-    const bool fuse = last.cfg == CONV_CFG_WINO_T16x32_N32 && h->d.nb_classes == 2 && last.name2.empty() && passes == 1 &&
+    const bool fuse = last.cfg == CONV_CFG_WINO_T16x32_N32 && h->d.nb_classes == 2 && last.name2.empty() &&
                       sigma == nullptr && (logits != nullptr || stats != nullptr) && h->head_cph == 32 &&
                       !(fuse_env && atoi(fuse_env) == 0);
     for (const ConvLayer& L : h->layers) {
-        const FusedHead fh{logits, stats, flags};
+        const FusedHead fh{logits, stats, flags, passes};
         int rc = run_layer(h, L, n, masks, stream, (fuse && &L == &last) ? &fh : nullptr, direct_input ? x : nullptr, n_one);
         if (rc) return rc;
         if (ev) RCU_HIP(hipEventRecord(*ev++, stream));

@@ -47,7 +47,9 @@ struct ConvArgs {
     float* head_logits;    // NCHW [N][2][H*W] or null
     void* head_stats;      // MC statistics blob or null
     int head_flags;        // MC_MI | MC_VAR
-    size_t head_V;         // voxels of the pass = N * H * W
+    size_t head_V;         // voxels of one pass = images * H * W
+    int head_passes;       // MC passes in this launch: sample t * head_images + i is image i (pass groups); its statistics entry is i's
+    int head_images;
 };
 
 enum ConvConfig {

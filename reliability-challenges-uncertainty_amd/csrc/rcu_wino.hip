@@ -134,7 +134,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
 // through this epilogue and a pass through head_kernel (pass groups) give the same bits.
 constexpr int WINO_HEAD_PITCH = 34;
 template <class T>
-__device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x4 (&acc)[2][16], const WinoEpi& ep, int n0, int y0,
+__device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x4 (&acc)[2][16], const WinoEpi& ep, int n0, int nstat, int y0,
                                                    int x0, int wm, int wn, int lane, int tid, float* hl)
 {
     static_assert(T::TS == 1 && T::TH * T::TW == T::THREADS && T::BN == 32 && T::SW == 1, "one pixel per thread");
@@ -199,7 +199,7 @@ __device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x
         }
         if (a.head_stats != nullptr) {
             softmax_inplace<2>(l);
-            accumulate_voxel<2>(a.head_stats, (size_t)n0 * HW + hw, a.head_V, a.head_flags, l);
+            accumulate_voxel<2>(a.head_stats, (size_t)nstat * HW + hw, a.head_V, a.head_flags, l);   // nstat: the image the sample is a pass of
         }
     }
 }
@@ -246,8 +246,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
 
     // dp*: the plan the LDS-DMA works from -- the current tile's until its last chunk is being multiplied, then the
     // next tile's; tile / ntile: coordinates of the tile being multiplied and of the workgroup's next one
+    // HEAD: total_items counts the tiles of ONE pass; the workgroup that owns a tile runs the tile of every pass of the group back to
+    // back (sample n0 + pass * head_images), so the passes' read-modify-writes of a voxel's statistics are ordered
     int item = wino_xcd_virtual_block(a.NT < 4 ? 4 : a.NT);
-    bool has_next = item + (int)gridDim.x < total_items;
+    [[maybe_unused]] int pass = 0;
+    auto more_passes = [&]() {
+        if constexpr (HEAD) return pass + 1 < wino_cold_args().head_passes;
+        return false;
+    };
+    bool has_next = more_passes() || item + (int)gridDim.x < total_items;
     WinoTileId tile = wino_tile_id<T>(a, item), ntile = tile;
     uint32_t dp[T::NA], geo[T::NA];
     int dp_wtile = tile.wtile;
@@ -315,7 +322,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
         const bool more = kc + 1 < nchunks;
         if (!more && has_next) {   // last chunk of the tile: from here on the DMA works on the workgroup's next tile
             const ConvArgs& ca = wino_cold_args();   // tile counts and image extents are not kept in SGPRs either
-            ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
+            if (more_passes()) {
+                ntile = tile;
+                ntile.n0 = tile.n0 + ca.head_images;
+            } else {
+                ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
+            }
             dp_wtile = ntile.wtile;
 #pragma unroll
             for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(ca, ntile, geo[j]);
@@ -399,13 +411,19 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
             chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1);
         }
         if constexpr (HEAD)
-            wino_epilogue_head<T>(wino_cold_args(), acc, wino_epilogue_fold(epr), tile.n0, tile.y0, tile.x0, wm, wn, lane, tid, smem + 2 * T::BUF_DW);
+            wino_epilogue_head<T>(wino_cold_args(), acc, wino_epilogue_fold(epr), tile.n0, tile.n0 - pass * wino_cold_args().head_images, tile.y0, tile.x0, wm,
+                                  wn, lane, tid, smem + 2 * T::BUF_DW);
         else
             wino_epilogue<T>(wino_cold_args(), acc, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wm, wn, lane);
         if (!has_next) break;
-        item += (int)gridDim.x;
+        if (more_passes()) {
+            ++pass;
+        } else {
+            pass = 0;
+            item += (int)gridDim.x;
+        }
         tile = ntile;
-        has_next = item + (int)gridDim.x < total_items;
+        has_next = more_passes() || item + (int)gridDim.x < total_items;
     }
 #endif
 }
@@ -430,7 +448,9 @@ static hipError_t launch_wino_cfg(const ConvArgs& a, hipStream_t stream)
 {
     constexpr int lds_bytes = T::LDS_BYTES + (HEAD ? T::TH * T::TW * WINO_HEAD_PITCH * 4 : 0);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
-    if (HEAD && (a.head_w == nullptr || a.NT != 1 || a.pooled != nullptr || a.mask2 != nullptr)) return hipErrorInvalidValue;
+    if (HEAD && (a.head_w == nullptr || a.NT != 1 || a.pooled != nullptr || a.mask2 != nullptr || a.head_passes < 1 ||
+                 a.head_images * a.head_passes != a.N || (a.head_passes > 1 && a.head_logits != nullptr)))
+        return hipErrorInvalidValue;
     const int nchunks = (a.C1 + a.C2) / T::KC;
     if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
         (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 ||
@@ -438,7 +458,8 @@ static hipError_t launch_wino_cfg(const ConvArgs& a, hipStream_t stream)
         return hipErrorInvalidValue;
     hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_stream<T, HEAD>), lds_bytes);
     if (e != hipSuccess) return e;
-    const unsigned items = (unsigned)a.NT * a.tiles_x * a.tiles_y * a.slice_groups;
+    // HEAD: the work items of one pass (TS == 1: a slice group is a sample); the kernel runs every pass of the group on each
+    const unsigned items = (unsigned)a.NT * a.tiles_x * a.tiles_y * (HEAD ? a.head_images : a.slice_groups);
     const unsigned grid = items < 256u ? items : 256u;
     hipLaunchKernelGGL((conv_wino_stream<T, HEAD>), dim3(grid), dim3(T::THREADS), lds_bytes, stream, a, (int)items);
     return hipGetLastError();

@@ -316,7 +316,8 @@ def test_winograd_sigma_head_and_eval_mode(dev):
 def test_fused_head_matches_head_kernel_bitwise(dev, monkeypatch):
     """conv_cls.0 with the 1x1 classifier + softmax + statistics in its epilogue (csrc/rcu_wino.hip, wino_epilogue_head)
     against the separate head kernel (RCU_FUSE_HEAD=0): logits, MC statistics (incl. variance / mutual information) and
-    a pass group (always the head kernel) must carry the same bits."""
+    pass groups (the fused epilogue runs the passes of a tile back to back on the workgroup that owns it, in pass order -- the
+    order in which head_kernel adds them) must carry the same bits."""
     from oracle import unet_oracle as uo
     from rcu_amd import steps
     params = dict(nb_classes=2, in_channels=4, depth=3, start_filters=32, dropout=0.05)
@@ -342,18 +343,31 @@ def test_fused_head_matches_head_kernel_bitwise(dev, monkeypatch):
             m.forward_accumulate(x.to(dev), stats, ms, passes=1)
         return stats.blob.cpu().numpy()
 
+    def run_groups(do_mi, do_var, passes):   # `passes` passes per launch: sample t * 3 + i is image i under mask rows [t * 3 + i]
+        stats = steps.McStatistics(3, 2, 64, 64, dev, do_mi=do_mi, do_var=do_var)
+        for t in range(0, T, passes):
+            group = mask_sets[t:t + passes]
+            m.forward_accumulate(x.to(dev), stats, group if len(group) > 1 else group[0], passes=len(group))
+        return stats.blob.cpu().numpy()
+
+    flag_sets = ((False, False), (True, False), (True, True))
     monkeypatch.setenv('RCU_FUSE_HEAD', '1')
     lf, of = run()
-    bf = [run_single_passes(*f) for f in ((False, False), (True, False), (True, True))]
+    bf = [run_single_passes(*f) for f in flag_sets]
+    gf = [run_groups(*f, passes) for f in flag_sets for passes in (2, 3, 4)]
     monkeypatch.setenv('RCU_FUSE_HEAD', '0')
     lu, ou = run()
-    bu = [run_single_passes(*f) for f in ((False, False), (True, False), (True, True))]
+    bu = [run_single_passes(*f) for f in flag_sets]
+    gu = [run_groups(*f, passes) for f in flag_sets for passes in (2, 3, 4)]
     assert np.array_equal(lf, lu)
     assert set(of) == set(ou)
     for k in of:
         assert np.array_equal(of[k], ou[k]), k
     for a_, b_ in zip(bf, bu):
         assert np.array_equal(a_, b_)
+    for i, (a_, b_) in enumerate(zip(gf, gu)):
+        assert np.array_equal(a_, b_), i
+        assert np.array_equal(a_, bf[i // 3]), i      # and a group adds up to what its passes add one by one
     ref = uo.unet_forward(st, x, mask_sets[0], **params).numpy()
     assert _maxdiff(lf, ref) < LOGIT_TOL
 
