@@ -213,6 +213,8 @@ def main():
     ap.add_argument('--pass-group', type=int, default=0,
                     help='MC passes of a rank per launch (N * g samples per batch); 0 = McPredictStep\'s rule, GROUP_PIXELS // (N*H*W): 2 for the '
                          '160-slice volume, 3 for the ISIC batch')
+    ap.add_argument('--lanes', type=int, default=2,
+                    help='HIP streams a rank spreads the launches of a volume over (one workspace + statistics blob each; rcu_amd.distributed)')
     ap.add_argument('--ensemble', type=int, default=0, metavar='K',
                     help='K ensemble members (seeds 20..20+K-1) instead of T MC passes (BASELINE config "BraTS ensemble")')
     ap.add_argument('--aleatoric', action='store_true',
@@ -263,14 +265,14 @@ def main():
     if args.ensemble:
         T = args.ensemble
         members = [model] + [make_model(seed + k, device, params=params) for k in range(1, T)]
-        runner = rdist.ShardedEnsembleRunner(members, rank=rank, world=world)
+        runner = rdist.ShardedEnsembleRunner(members, rank=rank, world=world, lanes=args.lanes)
     elif args.aleatoric:
         members = [model]
-        runner = rdist.ShardedAleatoricMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed)
+        runner = rdist.ShardedAleatoricMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed, lanes=args.lanes)
     else:
         members = [model]
         runner = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed,
-                                       pass_group=args.pass_group)
+                                       pass_group=args.pass_group, lanes=args.lanes)
     # dropout masks: drawn per (seed, volume, pass) by the runner -- the same T samples whatever the world size
 
     def one_step(k, xin=x):
@@ -340,8 +342,48 @@ def main():
         with_h2d = dict(value=T * (n_slices if isic else 1) / dt, ms_per_step=dt * 1e3, h2d_bytes=x_cpu.numel() * 4,
                         note='pinned host volume copied on the launch stream inside every step; not the headline value')
 
-    # ---- roofline of the dominant kernel (this rank's launches in the timed region).  A launch covers one pass of the volume, or
-    # pass_group passes (n_slices * g samples) where the runner grouped them: FLOPs count the passes, launches the kernel launches.
+    # ---- stream lanes: in the timed region the kernels of different lanes overlap (that is their point: a lane fills the gaps between
+    # the dependent layers of the other), so a kernel's start-to-end time there includes the other lane's work and says nothing about
+    # the kernel.  The roofline record below is therefore taken from a SERIAL leg -- the same steps on one lane, HIP events between the
+    # kernels -- right behind the timed region; the timed region's own (overlapped) event times are kept under `timed_region`.
+    timed_region = None
+    if args.lanes > 1:
+        dom_ms = {}
+        for L, ms in zip(model.layer_table(height, width, n_slices * args.pass_group), slot_ms[1:]):
+            dom_ms[L['kernel']] = dom_ms.get(L['kernel'], 0.0) + ms
+        timed_region = dict(lanes=args.lanes, wall_ms_per_forward=elapsed * 1e3 / passes_run, profiled_launches_lane0=launches,
+                            kernel_ms_per_launch_lane0={k_: v / max(launches, 1) for k_, v in dom_ms.items()},
+                            note='start-to-end times of lane 0\'s kernels while the other lane(s) run: overlapped, not exclusive')
+        if args.ensemble:
+            serial = rdist.ShardedEnsembleRunner(members, lanes=1)        # rank 0 alone: no collective in this leg
+        elif args.aleatoric:
+            serial = rdist.ShardedAleatoricMcRunner(model, T, ws_pass=not args.no_ws, seed=seed, lanes=1)
+        else:
+            serial = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, seed=seed, pass_group=args.pass_group, lanes=1)
+        serial_steps = max(1, min(args.steps, 2))
+        first = last_step + 8
+        serial.step(x, first - 1)                     # warm (the lane-0 workspace is the one the timed region used)
+        serial_jobs = [j for k in range(first, first + serial_steps) for j in serial.jobs_of(k, 0)]
+        for i, m in enumerate(members):
+            count = sum(1 for j in serial_jobs if j - 1 == i) if args.ensemble else len(serial_jobs)
+            m.profile_begin(height, width, n_slices * args.pass_group, max(count, 1))
+        serial.forwards_run = 0
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for k in range(first, first + serial_steps):
+            serial.step(x, k)
+        torch.cuda.synchronize()
+        timed_region['serial_leg'] = dict(steps=serial_steps, ms_per_step=(time.perf_counter() - ts) * 1e3 / serial_steps)
+        passes_run = max(serial.forwards_run, 1)
+        launches, slot_ms = 0, None
+        for m in members:
+            cnt, ms = m.profile_collect(height, width, n_slices * args.pass_group)
+            launches += cnt
+            slot_ms = ms if slot_ms is None else [a + b for a, b in zip(slot_ms, ms)]
+
+    # ---- roofline of the dominant kernel (this rank's launches in the timed region; with stream lanes: in the serial leg above).  A launch
+    # covers one pass of the volume, or pass_group passes (n_slices * g samples) where the runner grouped them: FLOPs count the passes,
+    # launches the kernel launches.
     g = args.pass_group
     layers = model.layer_table(height, width, n_slices * g)
     per_kernel = {}
@@ -376,6 +418,9 @@ def main():
                     per_kernel={k_: dict(ms_per_forward=e['ms'] / passes_run, tflops_executed=tf(e['issued'], e['ms']),
                                          frac=tf(e['issued'], e['ms']) / PEAK_FP32_MFMA_TFLOPS,
                                          tflops_canonical=tf(e['flops'], e['ms'])) for k_, e in per_kernel.items()})
+    roofline['measured_in'] = 'the timed region' if timed_region is None else 'a serial leg behind the timed region (one lane; see timed_region)'
+    if timed_region is not None:
+        roofline['timed_region'] = timed_region
     # the fused head (1x1 classifier conv + softmax + entropy + accumulate into the statistics): an HBM scan.
     # It reads the 32-channel feature map instead of logits (the logits never exist in HBM) and
     # read-modify-writes the S=2 float32 statistics planes (94.4 MB per sample-volume if
@@ -485,7 +530,7 @@ def main():
                                 .format('aleatoric + MC' if args.aleatoric else 'baseline_mc', ', sigma_out' if args.aleatoric else '',
                                         T, '' if args.no_ws else ' + weight-scaling pass')),
                    'T': T, 'ws_pass': not (args.no_ws or args.ensemble), 'slices': n_slices, 'height': height, 'width': width,
-                   'pass_group': g,
+                   'pass_group': g, 'lanes': args.lanes,
                    'sharding': 'passes over ranks, one RCCL sum-reduce of the statistics per step' if world > 1 else 'none',
                    'gflop_per_sample_{}'.format(unit_name): conv_flops / passes_run / 1e9 / (n_slices if isic else 1)},
         'n_ranks_seen': n_ranks_seen,

@@ -57,7 +57,7 @@ class UNet(nn.Module):
     DEFAULT_DEPTH = 4
     DEFAULT_START_FILTERS = 16
     DEFAULT_DROPOUT = 0.2
-    MAX_HANDLES = 4          # cached (height, width) plans incl. their workspaces
+    MAX_HANDLES = 6          # cached (height, width[, lane]) plans incl. their workspaces
 
     def __init__(self, nb_classes, in_channels, depth=DEFAULT_DEPTH, start_filters=DEFAULT_START_FILTERS,
                  dropout=DEFAULT_DROPOUT, dropout_center: int = None, residual=False, sigma_out=False,
@@ -136,16 +136,20 @@ class UNet(nn.Module):
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
 
-    def _handle(self, h, w, n):
+    def _handle(self, h, w, n, lane=0):
+        """The library handle (plan + packed weights + activation workspace) for images of h x w, batches up to n.  ``lane``: launches
+        that run concurrently on different HIP streams (rcu_amd.distributed: stream lanes) need a workspace each; a lane is a
+        second, third ... handle of the same shape."""
         lib = _lib.load()
-        entry = self._handles.get((h, w))
+        slot = (h, w) if lane == 0 else (h, w, lane)
+        entry = self._handles.get(slot)
         if entry is not None and entry[1] >= n and entry[2] == self._weights_version:
-            self._handles[(h, w)] = self._handles.pop((h, w))     # most recently used last
+            self._handles[slot] = self._handles.pop(slot)     # most recently used last
             return entry[0]
         max_batch = n if entry is None else max(n, entry[1])
         if entry is not None:
             lib.rcu_unet_destroy(entry[0])
-            del self._handles[(h, w)]
+            del self._handles[slot]
             self.features = None     # ``features`` may be a view into that handle's workspace: valid until the next forward only
         desc = _lib.UnetDesc(nb_classes=self.nb_classes, in_channels=self.in_channels, depth=self.depth,
                              start_filters=self.start_filters, has_dropout=int(self.dropout is not None),
@@ -165,7 +169,7 @@ class UNet(nn.Module):
         except Exception:
             lib.rcu_unet_destroy(handle)
             raise
-        self._handles[(h, w)] = (handle, max_batch, self._weights_version)
+        self._handles[slot] = (handle, max_batch, self._weights_version)
         while len(self._handles) > self.MAX_HANDLES:    # images of many different sizes: drop the least recently used plan
             old = next(iter(self._handles))
             lib.rcu_unet_destroy(self._handles.pop(old)[0])
@@ -257,7 +261,7 @@ class UNet(nn.Module):
         nhwc = _lib.device_view(ptr.value, (n, h, w, pitch.value), device, owner=self)
         return nhwc[..., :ch.value].permute(0, 3, 1, 2)
 
-    def forward_accumulate(self, x, stats, masks=None, passes=1):
+    def forward_accumulate(self, x, stats, masks=None, passes=1, lane=0):
         """One pass -- or ``passes`` stochastic passes as ONE batch of N * passes samples -- fused with softmax +
         accumulation into ``stats`` (rcu_amd.steps.McStatistics): neither logits nor probabilities reach HBM.
         ``masks`` for a pass group: a concatenated device tensor with N * passes rows per site, or a list of
@@ -268,7 +272,7 @@ class UNet(nn.Module):
             raise ValueError('statistics blob shape does not match the batch')
         if passes < 1:
             raise ValueError('passes must be >= 1')
-        handle = self._handle(h, w, n * passes)
+        handle = self._handle(h, w, n * passes, lane)
         if passes == 1:
             if masks is None and self.mc_active():
                 masks = self.sample_masks(n, x.device)
@@ -288,7 +292,7 @@ class UNet(nn.Module):
                                                                       _lib.current_stream()))
         stats.count += passes
 
-    def forward_accumulate_sigma(self, x, stats, sigma_sum, masks=None, is_log_sigma=False):
+    def forward_accumulate_sigma(self, x, stats, sigma_sum, masks=None, is_log_sigma=False, lane=0):
         """EXTENSION (BASELINE config "aleatoric + MC", not in the reference): one stochastic pass of a ``sigma_out`` model --
         softmax(logits) into ``stats`` as in ``forward_accumulate`` and this pass's sigma (|raw|, or exp(raw)) added to the
         float32 ``[N, C, H, W]`` tensor ``sigma_sum``; neither logits nor sigma reach HBM as volumes of their own."""
@@ -301,7 +305,7 @@ class UNet(nn.Module):
         if (tuple(sigma_sum.shape) != (n, self.nb_classes, h, w) or sigma_sum.dtype != torch.float32 or
                 not sigma_sum.is_contiguous() or sigma_sum.device != x.device):
             raise ValueError('sigma_sum must be a contiguous float32 [N, C, H, W] tensor on the input device')
-        handle = self._handle(h, w, n)
+        handle = self._handle(h, w, n, lane)
         if masks is None and self.mc_active():
             masks = self.sample_masks(n, x.device)
         elif isinstance(masks, (list, tuple)):

@@ -372,6 +372,63 @@ def test_fused_head_matches_head_kernel_bitwise(dev, monkeypatch):
     assert _maxdiff(lf, ref) < LOGIT_TOL
 
 
+def test_stream_lanes_match_one_lane_and_the_oracle(dev):
+    """rcu_amd.distributed: the launches of a volume spread over 2 or 3 HIP streams (a workspace and a statistics blob per lane,
+    merged by addition) -- MC passes in pairs with all statistics, the sigma-head extension, ensemble members.  The summary must
+    agree with the one-lane run to float32 summation order, be the same bits run after run (the assignment launch -> lane is
+    fixed), and the MC case must agree with the oracle under the same masks."""
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import distributed as rdist
+    params = dict(nb_classes=2, in_channels=4, depth=3, start_filters=32, dropout=0.1)
+    st = uo.synthetic_state(29, **params)
+    g = torch.Generator().manual_seed(12)
+    n, h, w, T = 4, 64, 64, 7
+    x = torch.randn(n, 4, h, w, generator=g)
+    _, sites = uo.unet_plan(**params)
+    mask_sets = [uo.sample_masks(sites, n, 0.1, g) for _ in range(T)]
+    m = _model(params, st, dev)
+    xd = x.to(dev)
+
+    def run(lanes, **kw):
+        r = rdist.ShardedMcRunner(m, T, ws_pass=True, do_mi=True, do_var=True, pass_group=2, lanes=lanes, **kw)
+        return {k: v.cpu().numpy() for k, v in r.step(xd, 3, mask_sets).items()}
+
+    one = run(1)
+    ws, multi = so.mc_probabilities(lambda xx, mk: uo.unet_forward(st, xx, mk, **params), x, mask_sets)
+    ref = so.multi_prediction_summary(multi, do_mi=True, do_var=True)
+    ref['ws_probabilities'] = ws
+    for lanes in (2, 3):
+        a, b = run(lanes), run(lanes)
+        assert set(a) == set(one) == set(ref)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (lanes, k)
+            assert _maxdiff(a[k], one[k]) < 1e-6, (lanes, k)
+            assert _maxdiff(a[k], np.asarray(ref[k])) < PROB_TOL, (lanes, k)
+    # masks drawn by the runner (seed, volume, pass): the same samples on every lane count
+    drawn = [{k: v.cpu().numpy() for k, v in rdist.ShardedMcRunner(m, T, seed=5, pass_group=2, lanes=lanes).step(xd, 1).items()}
+             for lanes in (1, 2)]
+    for k in drawn[0]:
+        assert _maxdiff(drawn[0][k], drawn[1][k]) < 1e-6, k
+
+    # sigma-head extension: the per-pass sigma sums ride with the statistics, lane by lane
+    sp = dict(params, sigma_out=True)
+    sts = uo.synthetic_state(31, **sp)
+    ms = _model(sp, sts, dev)
+    _, sigma_sites = uo.unet_plan(**sp)
+    sigma_masks = [uo.sample_masks(sigma_sites, n, 0.1, g) for _ in range(T)]
+    outs = [{k: v.cpu().numpy() for k, v in rdist.ShardedAleatoricMcRunner(ms, T, lanes=lanes).step(xd, 2, sigma_masks).items()} for lanes in (1, 2)]
+    assert 'sigma' in outs[0] and 'ws_sigma' in outs[0]
+    for k in outs[0]:
+        assert _maxdiff(outs[0][k], outs[1][k]) < 1e-6, k
+
+    # ensemble members on two lanes
+    members = [_model(params, uo.synthetic_state(40 + i, **params), dev) for i in range(3)]
+    outs = [{k: v.cpu().numpy() for k, v in rdist.ShardedEnsembleRunner(members, do_mi=True, lanes=lanes).step(xd).items()} for lanes in (1, 2)]
+    for k in outs[0]:
+        assert _maxdiff(outs[0][k], outs[1][k]) < 1e-6, k
+
+
 def test_unet_g11_reference_digest(golden, dev):
     """Full-width weights rebuilt by replaying the reference constructor's draws; the committed strided
     logits came from the reference itself."""

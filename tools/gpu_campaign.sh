@@ -14,12 +14,16 @@ python bench.py --workload isic > $OUT/bench_isic.json 2> $OUT/bench_isic.err; c
 python bench.py --ensemble 10 > $OUT/bench_ensemble10.json 2> $OUT/bench_ensemble10.err; cut -c1-200 $OUT/bench_ensemble10.json
 python bench.py --aleatoric --mc 50 --steps 4 --no-cpu-baseline > $OUT/bench_aleatoric_mc50.json 2> $OUT/bench_aleatoric_mc50.err; cut -c1-200 $OUT/bench_aleatoric_mc50.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $P/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $P/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $P/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/pmc_sq -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $P/pmc_sq.log 2>&1
+# kernel times: one lane (exclusive durations, what bench.py's roofline record is taken from); then the default two lanes, whose kernels overlap
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --lanes 1 > $P/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats2 -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $P/stats2.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --lanes 1 > $P/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --lanes 1 > $P/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/pmc_sq -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --lanes 1 > $P/pmc_sq.log 2>&1
 cd $R
 python tools/summarize_rocprof.py stats $(find $P/stats -name "*kernel_stats.csv" | head -1) $OUT/bench_steps2_kernel_stats.csv
+python tools/summarize_rocprof.py stats $(find $P/stats2 -name "*kernel_stats.csv" | head -1) $OUT/bench_steps2_lanes2_kernel_stats.csv
+python bench.py --lanes 1 --no-cpu-baseline --steps 20 --warmup 5 > $OUT/bench_lanes1.json 2> $OUT/bench_lanes1.err; cut -c1-200 $OUT/bench_lanes1.json
 python tools/summarize_rocprof.py pmc $P/pmc_fetch $P/pmc_write $P/pmc_sq $OUT/bench_pmc.json
 head -12 $OUT/bench_steps2_kernel_stats.csv
 ls -la $OUT

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Do MC passes on S HIP streams (one model replica + statistics blob each) overlap their kernel tails?"""
+"""Do MC passes on S HIP streams (one model replica + statistics blob each) overlap their kernel tails?
+    python tools/stream_overlap_probe.py [passes per launch: 1 (default) or 2]"""
 import os
 import sys
 import time
@@ -16,6 +17,7 @@ def main():
     dev = torch.device('cuda')
     x = bench.make_volume(20)[0].to(dev)
     T = 20
+    group = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     for S in (1, 2, 3):
         models = [bench.make_model(20, dev) for _ in range(S)]
         streams = [torch.cuda.Stream() for _ in range(S)]
@@ -26,13 +28,13 @@ def main():
         for rep in range(2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for t in range(T):
+            for t in range(T // group):
                 s = t % S
                 with torch.cuda.stream(streams[s]):
-                    models[s].forward_accumulate(x, stats[s])
+                    models[s].forward_accumulate(x, stats[s], passes=group)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        print('streams {}: {:.1f} ms for {} passes = {:.2f} ms/pass'.format(S, dt * 1e3, T, dt * 1e3 / T))
+        print('streams {}, {} pass(es) per launch: {:.1f} ms for {} passes = {:.2f} ms/pass'.format(S, group, dt * 1e3, T, dt * 1e3 / T))
         del models, stats
 
 
