@@ -172,7 +172,6 @@ class ShardedMcRunner:
         self.seed = seed
         self.pass_group = max(1, int(pass_group))
         self.lanes = max(1, int(lanes))
-        self._side_streams = None
         self._generator = None
         self.forwards_run = 0          # launches of this rank (a pass group counts its passes)
 
@@ -213,29 +212,10 @@ class ShardedMcRunner:
     def _run_jobs(self, x, step_index, mask_sets):
         flat, stats, ws = self.engine.buffers(x, self.ws_pass)
         jobs = self.jobs_of(step_index, self.rank)
-        # stream lanes: lane 0 = the caller's stream and the volume's statistics, lanes 1.. = side streams with statistics of their own
-        n_lanes = self.lanes if (x.is_cuda and hasattr(self.engine, 'side_statistics')) else 1
-        lane_stats, current = [stats], None
-        if n_lanes > 1:
-            if self._side_streams is None:
-                self._side_streams = [torch.cuda.Stream(device=x.device) for _ in range(n_lanes - 1)]
-            current = torch.cuda.current_stream(x.device)
-            for side in self._side_streams:
-                side.wait_stream(current)                  # the input (and everything else the caller prepared) is ready
-                x.record_stream(side)
-                with torch.cuda.stream(side):
-                    lane_stats.append(self.engine.side_statistics(x))
-        launch = 0
-
-        def on_lane(run):
-            nonlocal launch
-            lane = launch % n_lanes
-            launch += 1
-            if lane == 0:
-                run(stats, 0)
-            else:
-                with torch.cuda.stream(self._side_streams[lane - 1]):
-                    run(lane_stats[lane], lane)
+        # stream lanes (rcu_amd.steps.StreamLanes): lane 0 = the caller's stream and the volume's statistics
+        lanes = steps_mod.StreamLanes(x.device, self.lanes if (x.is_cuda and hasattr(self.engine, 'side_statistics')) else 1)
+        lanes.begin(stats, lambda: self.engine.side_statistics(x), inputs=(x,))
+        on_lane = lanes.run
 
         i = 0
         while i < len(jobs):
@@ -260,12 +240,8 @@ class ShardedMcRunner:
             else:
                 on_lane(lambda st, lane, job=jobs[i]: self._run_job(job, x, st, ws, mask_sets, step_index, lane))
                 i += 1
-        for side, st in zip(self._side_streams or [], lane_stats[1:]):
-            current.wait_stream(side)
-            self.engine.merge(stats, st)                   # on the caller's stream, after the lane's last launch
-            st.blob.record_stream(current)
-            if getattr(st, 'sigma_sum', None) is not None:
-                st.sigma_sum.record_stream(current)
+        if lanes.count > 1:
+            lanes.end(self.engine.merge)
         return flat, stats, ws
 
     def step(self, x, step_index=0, mask_sets=None):

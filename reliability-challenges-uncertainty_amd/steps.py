@@ -160,6 +160,75 @@ class McStatistics:
         return out
 
 
+class StreamLanes:
+    """The launches of one batch spread over ``count`` HIP streams in turn (lane 0 = the caller's stream).  Consecutive layers of a
+    forward pass depend on each other, so a stream idles while a layer's last workgroups finish and the next layer's first ones
+    start; MC passes / ensemble members are independent, and a second lane fills those gaps (tools/stream_overlap_probe.py: 6.63 ->
+    6.27 ms per pass on the 160-slice volume).  Every lane needs an activation workspace (``lane=`` of UNet.forward_accumulate) and a
+    statistics blob of its own; blobs are plain sums, so the side lanes' are added into lane 0's at the end.  The assignment launch ->
+    lane is fixed (round robin), so the result does not depend on timing.
+
+        lanes = StreamLanes(device, 2)
+        lane_stats = lanes.begin(stats, make_side_stats, inputs=(images,))
+        for each launch: lanes.run(lambda st, lane: model.forward_accumulate(images, st, masks, lane=lane))
+        lanes.end(merge)            # merge(stats, side_stats) on the caller's stream
+    """
+
+    _side = {}       # (device index, lane) -> stream: side streams are shared by all steps of the process
+
+    def __init__(self, device, count):
+        device = torch.device(device)
+        self.count = max(1, int(count)) if device.type == 'cuda' else 1
+        self.device = device
+        self.streams = []
+        for lane in range(1, self.count):
+            key = (device.index if device.index is not None else torch.cuda.current_device(), lane)
+            if key not in StreamLanes._side:
+                StreamLanes._side[key] = torch.cuda.Stream(device=device)
+            self.streams.append(StreamLanes._side[key])
+        self._stats, self._launch, self._current = [], 0, None
+
+    def begin(self, stats, make_side_stats, inputs=()):
+        self._stats, self._launch = [stats], 0
+        if self.count > 1:
+            self._current = torch.cuda.current_stream(self.device)
+            for side in self.streams:
+                side.wait_stream(self._current)          # the inputs (and whatever else the caller prepared) are ready
+                for t in inputs:
+                    t.record_stream(side)
+                with torch.cuda.stream(side):
+                    self._stats.append(make_side_stats())     # zeroed on its own stream
+        return self._stats
+
+    def run(self, launch, lane=None):
+        """launch(statistics of the lane, lane index) on the next lane (or on ``lane``)."""
+        if lane is None:
+            lane = self._launch % self.count
+            self._launch += 1
+        if lane == 0:
+            launch(self._stats[0], 0)
+        else:
+            with torch.cuda.stream(self.streams[lane - 1]):
+                launch(self._stats[lane], lane)
+
+    def end(self, merge):
+        for side, st in zip(self.streams, self._stats[1:]):
+            self._current.wait_stream(side)
+            merge(self._stats[0], st)                    # on the caller's stream, behind the lane's last launch
+            for t in vars(st).values():
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self._current)
+        self._stats = self._stats[:1]
+
+
+def merge_statistics(stats, side):
+    """Add the statistics of a side lane into ``stats`` (plain sums, include/rcu.h rcu_mc_*)."""
+    stats.blob.add_(side.blob)
+    stats.count += side.count
+    if getattr(side, 'sigma_sum', None) is not None:
+        stats.sigma_sum.add_(side.sigma_sum)
+
+
 def softmax(logits):
     """F.softmax(logits, 1) on the HIP path."""
     logits = logits.to(torch.float32).contiguous()
@@ -210,9 +279,10 @@ class McPredictStep(BatchStep):
     # -- same statistics bit for bit; the workspace grows to that of a 320-slice batch (12 GB of the 288), not beyond, and
     # every tensor stays below the 2 GB the kernels' 32-bit buffer offsets reach.
     GROUP_PIXELS = 2 * 160 * 192 * 128
+    LANES = 2                # HIP streams the pass groups of a batch alternate over (StreamLanes)
 
     def __init__(self, mc_steps, do_mi=False, do_var=False, materialize=False, masks=None, ws_pass=True,
-                 group_pixels=None) -> None:
+                 group_pixels=None, lanes=None) -> None:
         super().__init__()
         self.mc_steps = mc_steps
         self.do_mi, self.do_var = do_mi, do_var
@@ -220,6 +290,7 @@ class McPredictStep(BatchStep):
         self.masks = masks          # optional: list (one per pass) of mask sets to inject instead of sampling
         self.ws_pass = ws_pass
         self.group_pixels = self.GROUP_PIXELS if group_pixels is None else group_pixels
+        self.lanes = self.LANES if lanes is None else lanes
 
     def __call__(self, batch_context, task_context, context) -> None:
         _check_context(context)
@@ -251,14 +322,18 @@ class McPredictStep(BatchStep):
         rng_state = torch.cuda.get_rng_state(dev) if (self.masks is None and dev.type == 'cuda') else None
         stats = McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var)
         group = max(1, self.group_pixels // (n * h * w))
+        lanes = StreamLanes(dev, min(self.lanes, -(-self.mc_steps // group)))
+        lanes.begin(stats, lambda: McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var), inputs=(images,))
         i = 0
-        while i < self.mc_steps:
+        while i < self.mc_steps:       # masks are drawn (host side: in launch order, whatever the lane) inside forward_accumulate
             g = min(group, self.mc_steps - i)
             if g == 1:
-                model.forward_accumulate(images, stats, None if self.masks is None else self.masks[i])
+                lanes.run(lambda st, lane, i=i: model.forward_accumulate(images, st, None if self.masks is None else self.masks[i], lane=lane))
             else:
-                model.forward_accumulate(images, stats, None if self.masks is None else self.masks[i:i + g], passes=g)
+                lanes.run(lambda st, lane, i=i, g=g: model.forward_accumulate(images, st, None if self.masks is None else self.masks[i:i + g],
+                                                                           passes=g, lane=lane))
             i += g
+        lanes.end(merge_statistics)
 
         def recipe(mi, var, materialize=False):
             now = torch.cuda.get_rng_state(dev) if rng_state is not None else None
@@ -313,8 +388,11 @@ class EnsemblePredictionStep(BatchStep):
                 if materialize:
                     return torch.stack([softmax(m(images)) for m in members])
                 st = McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var)
-                for m in members:
-                    m.forward_accumulate(images, st)
+                lanes = StreamLanes(images.device, min(McPredictStep.LANES, len(members)))
+                lanes.begin(st, lambda: McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var), inputs=(images,))
+                for m in members:      # every member is a model object of its own: its workspace is its own whatever the lane
+                    lanes.run(lambda s_, lane, m=m: m.forward_accumulate(images, s_))
+                lanes.end(merge_statistics)
                 st.recipe = run
                 return st
             batch_context.output['multi_probabilities'] = run(self.do_mi, self.do_var)

@@ -118,7 +118,8 @@ def test_real_data_shapes_full_width_vs_oracle(dev, cin, n, h, w):
 def test_pass_pair_of_the_full_volume_is_bit_identical_to_single_passes(dev):
     """The headline path runs the MC passes of a 160-slice volume two per launch (320 samples: the 48x32 / 24x16 / 12x8 levels
     then fill their last round of workgroups): rcu_unet_forward_accumulate_passes at N = 160 must give exactly the statistics of
-    two single-pass launches under the same masks, through McPredictStep too (its default GROUP_PIXELS pairs the passes)."""
+    two single-pass launches under the same masks, through McPredictStep too (its default GROUP_PIXELS pairs the passes; its default two
+    stream lanes change the summation order only)."""
     from oracle import unet_oracle as uo
     from rcu_amd import steps
     st = uo.synthetic_state(35, **PARAMS)
@@ -138,13 +139,17 @@ def test_pass_pair_of_the_full_volume_is_bit_identical_to_single_passes(dev):
     assert steps.McPredictStep.GROUP_PIXELS // (n * h * w) == 2
     ctx = steps.TorchTestContext('cuda', model)
     outs = []
-    for group_pixels in (0, None):
+    for group_pixels, lanes in ((0, 1), (None, 1), (None, 2), (None, 2)):
         bc = steps.BatchContext({'images': x}, 0)
-        steps.McPredictStep(4, do_mi=True, masks=mask_sets, group_pixels=group_pixels)(bc, None, ctx)
+        steps.McPredictStep(4, do_mi=True, masks=mask_sets, group_pixels=group_pixels, lanes=lanes)(bc, None, ctx)
         steps.MultiPredictionSummary(do_mi=True)(bc, None, ctx)
         outs.append(bc.output)
     for key in ('probabilities', 'entropy', 'mutual_info', 'ws_probabilities'):
-        assert torch.equal(outs[0][key], outs[1][key]), key
+        assert torch.equal(outs[0][key], outs[1][key]), key          # one stream: pairs == single passes, bit for bit
+        # two stream lanes (the default): each lane sums its own passes and the sums are added -- float32 summation order -- and the
+        # assignment of launches to lanes is fixed, so a second run gives the same bits
+        assert float((outs[2][key] - outs[1][key]).abs().max()) < 1e-6, key
+        assert torch.equal(outs[2][key], outs[3][key]), key
 
 
 @pytest.mark.timeout(900)
