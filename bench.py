@@ -348,11 +348,12 @@ def main():
     # kernels -- right behind the timed region; the timed region's own (overlapped) event times are kept under `timed_region`.
     timed_region = None
     if args.lanes > 1:
-        dom_ms = {}
+        dom_ms, dom_layers = {}, {}
         for L, ms in zip(model.layer_table(height, width, n_slices * args.pass_group), slot_ms[1:]):
             dom_ms[L['kernel']] = dom_ms.get(L['kernel'], 0.0) + ms
-        timed_region = dict(lanes=args.lanes, wall_ms_per_forward=elapsed * 1e3 / passes_run, profiled_launches_lane0=launches,
-                            kernel_ms_per_launch_lane0={k_: v / max(launches, 1) for k_, v in dom_ms.items()},
+            dom_layers[L['kernel']] = dom_layers.get(L['kernel'], 0) + 1
+        timed_region = dict(lanes=args.lanes, wall_ms_per_forward=elapsed * 1e3 / passes_run, profiled_forward_launches_lane0=launches,
+                            kernel_ms_per_launch_lane0={k_: v / max(launches * dom_layers[k_], 1) for k_, v in dom_ms.items()},
                             note='start-to-end times of lane 0\'s kernels while the other lane(s) run: overlapped, not exclusive')
         if args.ensemble:
             serial = rdist.ShardedEnsembleRunner(members, lanes=1)        # rank 0 alone: no collective in this leg
