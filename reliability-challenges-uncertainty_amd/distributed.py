@@ -214,7 +214,7 @@ class ShardedMcRunner:
         jobs = self.jobs_of(step_index, self.rank)
         # stream lanes (rcu_amd.steps.StreamLanes): lane 0 = the caller's stream and the volume's statistics
         lanes = steps_mod.StreamLanes(x.device, self.lanes if (x.is_cuda and hasattr(self.engine, 'side_statistics')) else 1)
-        lanes.begin(stats, lambda: self.engine.side_statistics(x), inputs=(x,))
+        lanes.begin(stats, lambda: self.engine.side_statistics(x), inputs=(x,), first=step_index if self.world > 1 else 0)
         on_lane = lanes.run
 
         i = 0

@@ -188,8 +188,10 @@ class StreamLanes:
             self.streams.append(StreamLanes._side[key])
         self._stats, self._launch, self._current = [], 0, None
 
-    def begin(self, stats, make_side_stats, inputs=()):
-        self._stats, self._launch = [stats], 0
+    def begin(self, stats, make_side_stats, inputs=(), first=0):
+        """``first``: lane of the first launch (a runner that gives a rank only two or three launches per volume rotates it from
+        volume to volume, so that the lanes carry the same load over a stream of volumes)."""
+        self._stats, self._launch = [stats], int(first) % self.count
         if self.count > 1:
             self._current = torch.cuda.current_stream(self.device)
             for side in self.streams:
