@@ -255,8 +255,8 @@ def main():
     params = ISIC_PARAMS if isic else MODEL_PARAMS
     n_slices, height, width = (ISIC_IMAGES, ISIC_HEIGHT, ISIC_WIDTH) if isic else (SLICES, HEIGHT, WIDTH)
     unit_name = 'image' if isic else 'volume'
-    if args.ensemble or args.aleatoric:
-        args.pass_group = 1                     # members / sigma-head passes run one per launch
+    if args.ensemble:
+        args.pass_group = 1                     # members run one per launch (they differ in their weights)
     elif args.pass_group < 1:
         args.pass_group = max(1, steps.McPredictStep.GROUP_PIXELS // (n_slices * height * width))
     model = make_model(seed, device, sigma_out=args.aleatoric, params=params)
@@ -268,7 +268,8 @@ def main():
         runner = rdist.ShardedEnsembleRunner(members, rank=rank, world=world, lanes=args.lanes)
     elif args.aleatoric:
         members = [model]
-        runner = rdist.ShardedAleatoricMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed, lanes=args.lanes)
+        runner = rdist.ShardedAleatoricMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed, lanes=args.lanes,
+                                                pass_group=args.pass_group)
     else:
         members = [model]
         runner = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed,
@@ -358,7 +359,7 @@ def main():
         if args.ensemble:
             serial = rdist.ShardedEnsembleRunner(members, lanes=1)        # rank 0 alone: no collective in this leg
         elif args.aleatoric:
-            serial = rdist.ShardedAleatoricMcRunner(model, T, ws_pass=not args.no_ws, seed=seed, lanes=1)
+            serial = rdist.ShardedAleatoricMcRunner(model, T, ws_pass=not args.no_ws, seed=seed, lanes=1, pass_group=args.pass_group)
         else:
             serial = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, seed=seed, pass_group=args.pass_group, lanes=1)
         serial_steps = max(1, min(args.steps, 2))

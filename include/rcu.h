@@ -120,6 +120,12 @@ int rcu_unet_forward_accumulate_passes(rcu_unet* h, const float* x_dev, int n, i
 int rcu_unet_forward_accumulate_sigma(rcu_unet* h, const float* x_dev, int n, const float* masks_dev, void* stats_dev,
                                       int flags, float* sigma_sum_dev, int is_log_sigma, void* stream);
 
+/* The same for a pass group (see rcu_unet_forward_accumulate_passes): `passes` stochastic passes of the n images as one batch of
+ * n * passes samples; statistics and sigma sums are added to in pass order -- the bits of `passes` calls of
+ * rcu_unet_forward_accumulate_sigma. */
+int rcu_unet_forward_accumulate_sigma_passes(rcu_unet* h, const float* x_dev, int n, int passes, const float* masks_dev,
+                                             void* stats_dev, int flags, float* sigma_sum_dev, int is_log_sigma, void* stream);
+
 /* Per-layer introspection for benchmarks: canonical FLOPs (2*Cin*Cout*9*H*W per slice, real
  * channel counts) and the kernel configuration chosen. */
 typedef struct rcu_layer_info {

@@ -59,6 +59,7 @@ SIGNATURES = {
     'rcu_unet_forward_accumulate': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'rcu_unet_forward_accumulate_passes': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'rcu_unet_forward_accumulate_sigma': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    'rcu_unet_forward_accumulate_sigma_passes': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     'rcu_unet_features': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int), POINTER(c_int)]),
     'rcu_postnet_create': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     'rcu_postnet_destroy': (None, [c_void_p]),

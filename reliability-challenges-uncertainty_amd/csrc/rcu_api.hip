@@ -794,6 +794,14 @@ extern "C" int rcu_unet_forward_accumulate_sigma(rcu_unet* h, const float* x_dev
                         static_cast<hipStream_t>(stream), 1, sigma_sum_dev, is_log_sigma ? 1 : 0);
 }
 
+extern "C" int rcu_unet_forward_accumulate_sigma_passes(rcu_unet* h, const float* x_dev, int n, int passes, const float* masks_dev,
+                                                        void* stats_dev, int flags, float* sigma_sum_dev, int is_log_sigma, void* stream)
+{
+    if (!stats_dev || !sigma_sum_dev) return fail(RCU_ERR_INVALID, "rcu_unet_forward_accumulate_sigma_passes: null stats / sigma sum");
+    return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR),
+                        static_cast<hipStream_t>(stream), passes, sigma_sum_dev, is_log_sigma ? 1 : 0);
+}
+
 extern "C" int rcu_unet_features(const rcu_unet* h, const float** features_dev, int* channels, int* channel_pitch)
 {
     if (!h || !features_dev) return fail(RCU_ERR_INVALID, "rcu_unet_features: null argument");

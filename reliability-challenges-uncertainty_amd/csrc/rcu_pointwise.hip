@@ -171,15 +171,36 @@ __global__ __launch_bounds__(PW_THREADS) void head_kernel(const HeadArgs a)
     float l[C], s[C];
     if (a.passes > 1) {   // pass group: statistics only; one read-modify-write for all passes of the group
         VoxelStats<C> st;
-        if (v < a.V) st.load(a.stats, v, a.V, a.stats_flags);
+        const size_t n = v / a.HW, hw = v % a.HW;
+        float ssum[C];   // sigma-head extension: the voxel's running sigma sum, added to in pass order like the statistics
+        if (v < a.V) {
+            st.load(a.stats, v, a.V, a.stats_flags);
+            if (a.sigma_sum != nullptr) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) ssum[c] = a.sigma_sum[(n * C + c) * a.HW + hw];
+            }
+        }
         for (int t = 0; t < a.passes; ++t) {
             head_logits<C>(a, a.act + (size_t)t * a.V * a.CP, v0, lane, l, s);
 #pragma unroll
             for (int c = 0; c < C; ++c) l[c] += a.b_cls[c];
             softmax_inplace<C>(l);
             st.add(a.stats_flags, l);
+            if (a.sigma_sum != nullptr) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float raw = s[c] + a.b_sig[c];
+                    ssum[c] += a.sigma_log ? expf(raw) : fabsf(raw);
+                }
+            }
         }
-        if (v < a.V) st.store(a.stats, v, a.V, a.stats_flags);
+        if (v < a.V) {
+            st.store(a.stats, v, a.V, a.stats_flags);
+            if (a.sigma_sum != nullptr) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) a.sigma_sum[(n * C + c) * a.HW + hw] = ssum[c];
+            }
+        }
         return;
     }
     head_logits<C>(a, a.act, v0, lane, l, s);

@@ -118,11 +118,9 @@ class AleatoricHipEngine(HipEngine):
                                            lib.ptr(ws_out[0]), lib.ptr(ws_out[1]), None, None, lib.current_stream()))
 
     def mc_pass(self, x, stats, masks=None, passes=1, lane=0):
-        if passes != 1:
-            raise ValueError('the sigma-head passes run one per launch')
         steps_mod.set_dropout_mode(self.model, True)
         try:
-            self.model.forward_accumulate_sigma(x, stats, stats.sigma_sum, masks, self.is_log_sigma, lane=lane)
+            self.model.forward_accumulate_sigma(x, stats, stats.sigma_sum, masks, self.is_log_sigma, lane=lane, passes=passes)
         finally:
             steps_mod.set_dropout_mode(self.model, False)
 
@@ -303,9 +301,11 @@ class ShardedAleatoricMcRunner(ShardedMcRunner):
     """ShardedMcRunner over AleatoricHipEngine (BASELINE config "BraTS aleatoric + MC: sigma-head U-Net, T = 50, samples sharded
     over 8 MI355X"): the summary gains ``sigma`` (mean over the passes) and ``ws_sigma``."""
 
-    def __init__(self, model, mc_steps, is_log_sigma=False, ws_pass=True, rank=0, world=1, do_mi=False, root=0, seed=0, lanes=1):
+    def __init__(self, model, mc_steps, is_log_sigma=False, ws_pass=True, rank=0, world=1, do_mi=False, root=0, seed=0, lanes=1,
+                 pass_group=1):
         super().__init__(model, mc_steps, ws_pass=ws_pass, rank=rank, world=world,
-                         engine=AleatoricHipEngine(model, is_log_sigma, do_mi), do_mi=do_mi, root=root, seed=seed, lanes=lanes)
+                         engine=AleatoricHipEngine(model, is_log_sigma, do_mi), do_mi=do_mi, root=root, seed=seed, lanes=lanes,
+                         pass_group=pass_group)
 
 
 class ShardedEnsembleRunner(ShardedMcRunner):

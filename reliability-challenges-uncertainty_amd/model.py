@@ -292,7 +292,7 @@ class UNet(nn.Module):
                                                                       _lib.current_stream()))
         stats.count += passes
 
-    def forward_accumulate_sigma(self, x, stats, sigma_sum, masks=None, is_log_sigma=False, lane=0):
+    def forward_accumulate_sigma(self, x, stats, sigma_sum, masks=None, is_log_sigma=False, lane=0, passes=1):
         """EXTENSION (BASELINE config "aleatoric + MC", not in the reference): one stochastic pass of a ``sigma_out`` model --
         softmax(logits) into ``stats`` as in ``forward_accumulate`` and this pass's sigma (|raw|, or exp(raw)) added to the
         float32 ``[N, C, H, W]`` tensor ``sigma_sum``; neither logits nor sigma reach HBM as volumes of their own."""
@@ -305,7 +305,21 @@ class UNet(nn.Module):
         if (tuple(sigma_sum.shape) != (n, self.nb_classes, h, w) or sigma_sum.dtype != torch.float32 or
                 not sigma_sum.is_contiguous() or sigma_sum.device != x.device):
             raise ValueError('sigma_sum must be a contiguous float32 [N, C, H, W] tensor on the input device')
-        handle = self._handle(h, w, n, lane)
+        if passes < 1:
+            raise ValueError('passes must be >= 1')
+        handle = self._handle(h, w, n * passes, lane)
+        if passes > 1:      # pass group (see forward_accumulate): ``masks`` = a list of ``passes`` mask sets or a concatenated tensor
+            if masks is None:
+                if not self.mc_active():
+                    raise ValueError('a pass group needs stochastic passes: set_dropout_mode(model, True) or inject masks')
+                masks = self.sample_masks(n * passes, x.device)
+            elif isinstance(masks, (list, tuple)):
+                masks = self.group_masks(masks, n, x.device)
+            _lib.check(_lib.load().rcu_unet_forward_accumulate_sigma_passes(handle, _lib.ptr(x), n, passes, _lib.ptr(masks),
+                                                                            _lib.ptr(stats.blob), stats.flags, _lib.ptr(sigma_sum),
+                                                                            int(bool(is_log_sigma)), _lib.current_stream()))
+            stats.count += passes
+            return
         if masks is None and self.mc_active():
             masks = self.sample_masks(n, x.device)
         elif isinstance(masks, (list, tuple)):

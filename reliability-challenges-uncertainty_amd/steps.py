@@ -494,11 +494,27 @@ class AleatoricMcPredictStep(BatchStep):
             batch_context.output['ws_sigma'] = sigma
         set_dropout_mode(model, is_train=True)
         try:
-            stats = McStatistics(n, c, h, w, images.device, self.do_mi, self.do_var)
-            sigma_sum = torch.zeros((n, c, h, w), device=images.device, dtype=torch.float32)
-            for i in range(self.mc_steps):
-                model.forward_accumulate_sigma(images, stats, sigma_sum, None if self.masks is None else self.masks[i],
-                                               self.is_log_sigma)
+            dev = images.device
+
+            def fresh():
+                st = McStatistics(n, c, h, w, dev, self.do_mi, self.do_var)
+                st.sigma_sum = torch.zeros((n, c, h, w), device=dev, dtype=torch.float32)
+                return st
+
+            stats = fresh()
+            sigma_sum = stats.sigma_sum
+            # pass groups and stream lanes as in McPredictStep: g passes per launch, launches alternating over two HIP streams
+            group = max(1, McPredictStep.GROUP_PIXELS // (n * h * w))
+            lanes = StreamLanes(dev, min(McPredictStep.LANES, -(-self.mc_steps // group)))
+            lanes.begin(stats, fresh, inputs=(images,))
+            i = 0
+            while i < self.mc_steps:
+                g = min(group, self.mc_steps - i)
+                masks = None if self.masks is None else (self.masks[i] if g == 1 else self.masks[i:i + g])
+                lanes.run(lambda st, lane, masks=masks, g=g: model.forward_accumulate_sigma(images, st, st.sigma_sum, masks, self.is_log_sigma,
+                                                                                         lane=lane, passes=g))
+                i += g
+            lanes.end(merge_statistics)
             batch_context.output['multi_probabilities'] = stats
             batch_context.output['sigma'] = sigma_sum.div_(float(max(self.mc_steps, 1)))
         finally:
