@@ -429,9 +429,9 @@ def main():
     # logits were materialised; here 4*V*32 + 2*2*4*V bytes, V = voxels).
     vox = n_slices * height * width
     head_bytes = 4.0 * vox * 32 + 2 * 2 * 4.0 * vox
-    # In the timed region the classifier + softmax + statistics update run inside conv_cls.0's epilogue (one pass per
-    # sample, two classes: csrc/rcu_wino.hip, wino_epilogue_head) and have no launch of their own; the standalone head kernel
-    # -- the path of pass groups and of the sigma / feature outputs, same arithmetic, same bits -- is timed here, outside
+    # In the timed region the classifier + softmax + statistics update run inside conv_cls.0's epilogue (two classes:
+    # csrc/rcu_wino.hip, wino_epilogue_head; pass groups too) and have no launch of their own; the standalone head kernel
+    # -- the path of the sigma / feature outputs and of more than two classes, same arithmetic, same bits -- is timed here, outside
     # the timed region, on the same volume (RCU_FUSE_HEAD=0 is read per forward).
     fused_head_ms = slot_ms[-1] / passes_run
     os.environ['RCU_FUSE_HEAD'] = '0'
