@@ -322,7 +322,12 @@ class ShardedEnsembleRunner(ShardedMcRunner):
         self.members = members
 
     def _run_job(self, job, x, stats, ws, mask_sets, step_index=0, lane=0):
-        self.engine.member_pass(self.members[job - 1], x, stats)     # every member has its own model object = its own workspace
+        # A member is a model object of its own, but over a stream of volumes it can come up on either lane (the job rotation of a
+        # multi-rank run): the lane's workspace, so that launches of one member on two streams can never share activations
+        if lane:
+            self.engine.member_pass(self.members[job - 1], x, stats, lane=lane)
+        else:
+            self.engine.member_pass(self.members[job - 1], x, stats)
         self.forwards_run += 1
 
 

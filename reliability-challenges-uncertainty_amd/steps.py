@@ -392,8 +392,8 @@ class EnsemblePredictionStep(BatchStep):
                 st = McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var)
                 lanes = StreamLanes(images.device, min(McPredictStep.LANES, len(members)))
                 lanes.begin(st, lambda: McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var), inputs=(images,))
-                for m in members:      # every member is a model object of its own: its workspace is its own whatever the lane
-                    lanes.run(lambda s_, lane, m=m: m.forward_accumulate(images, s_))
+                for m in members:      # (a member keeps to its lane from batch to batch: one workspace per member)
+                    lanes.run(lambda s_, lane, m=m: m.forward_accumulate(images, s_, lane=lane))
                 lanes.end(merge_statistics)
                 st.recipe = run
                 return st
