@@ -20,6 +20,7 @@ sums, updated by the fused forward+softmax+accumulate kernel) under ``multi_prob
 (a real ``[T, N, C, H, W]`` tensor), and the summary accepts either form.
 """
 import abc
+import os
 
 import torch
 
@@ -281,7 +282,7 @@ class McPredictStep(BatchStep):
     # -- same statistics bit for bit; the workspace grows to that of a 320-slice batch (12 GB of the 288), not beyond, and
     # every tensor stays below the 2 GB the kernels' 32-bit buffer offsets reach.
     GROUP_PIXELS = 2 * 160 * 192 * 128
-    LANES = 2                # HIP streams the pass groups of a batch alternate over (StreamLanes)
+    LANES = max(1, int(os.environ.get('RCU_STREAM_LANES', '2')))   # HIP streams the pass groups of a batch alternate over (StreamLanes)
 
     def __init__(self, mc_steps, do_mi=False, do_var=False, materialize=False, masks=None, ws_pass=True,
                  group_pixels=None, lanes=None) -> None:
