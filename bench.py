@@ -14,7 +14,9 @@ volume inside is reported next to it (`with_h2d`).  N > 1 shards the T+1 forward
 JSON schema.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (HIP events recorded on the
-launch stream inside the timed region, see rcu_unet_profile_begin in include/rcu.h); `cpu_baseline`
+launch stream between the kernels, see rcu_unet_profile_begin in include/rcu.h -- inside the timed region with
+`--lanes 1`; with the default two stream lanes the kernels of the lanes overlap there, so the record comes from a serial
+leg right behind the timed region and the overlapped times are kept under `roofline.timed_region`); `cpu_baseline`
 is the oracle (a port of the reference's CPU path, pinned against golden vectors) timed on a bounded
 sample of the same workload on this box's host cores -- the SAME slices, weights and dropout masks as the
 last timed step, so the sample doubles as the parity check of the timed output (`parity`).
