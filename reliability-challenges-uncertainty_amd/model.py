@@ -176,6 +176,11 @@ class UNet(nn.Module):
             self.features = None
         return handle
 
+    def reserve(self, h, w, n, lane=0):
+        """Make the plan and the activation workspace for batches of up to ``n`` images of h x w now (a step that knows it will run pass
+        groups of n * g samples calls this before its first, smaller forward: one plan instead of a small one that is replaced)."""
+        self._handle(h, w, n, lane)
+
     # ------------------------------------------------------------------ dropout
     def dropout_sites(self):
         """[(state_dict-style name, channels)] in execution order."""

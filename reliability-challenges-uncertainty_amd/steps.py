@@ -300,6 +300,9 @@ class McPredictStep(BatchStep):
         images = _images_to_device(batch_context, context)
         model = context.model
 
+        if isinstance(model, model_mod.UNet) and not self.materialize:     # the plan for the pass groups, before the smaller first forward
+            n, _, h, w = images.shape
+            model.reserve(h, w, n * min(self.mc_steps, max(1, self.group_pixels // (n * h * w))))
         if self.ws_pass:
             batch_context.output['ws_probabilities'] = softmax(model(images))
 
