@@ -55,7 +55,9 @@ def main():
     dt = time.perf_counter() - t0
     print('{} subjects, T={}, batch_size {}: {:.2f} s total, {:.2f} s per subject ({:.1f} MC-sample-volumes/s end to end)'
           .format(n_subjects, mc, batch, dt, dt / n_subjects, mc * n_subjects / dt))
-    pstats.Stats(prof).sort_stats('cumulative').print_stats(22)
+    st = pstats.Stats(prof)
+    st.sort_stats('cumulative').print_stats(22)
+    st.sort_stats('tottime').print_stats(14)
 
 
 if __name__ == '__main__':
