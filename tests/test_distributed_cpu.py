@@ -171,6 +171,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def test_stream_lanes_are_one_lane_off_the_gpu():
+    """rcu_amd.steps.StreamLanes on a CPU device: one lane whatever was asked for -- every launch runs in place, in order, on the
+    statistics it was given, and there is nothing to merge (the gloo runs below rely on that)."""
+    from rcu_amd import steps
+    lanes = steps.StreamLanes('cpu', 3)
+    assert lanes.count == 1 and lanes.streams == []
+    stats = object()
+    got = lanes.begin(stats, lambda: pytest.fail('no side statistics on one lane'), inputs=(torch.zeros(2),), first=5)
+    assert got == [stats]
+    seen = []
+    for k in range(4):
+        lanes.run(lambda st, lane, k=k: seen.append((k, st is stats, lane)))
+    assert seen == [(k, True, 0) for k in range(4)]
+    lanes.end(lambda a, b: pytest.fail('nothing to merge on one lane'))
+
+
 def test_job_partition_properties():
     sys.path.insert(0, ROOT)
     from rcu_amd.distributed import ShardedMcRunner
