@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 P=/tmp/prof_$TAG
 mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVES --output-format csv -d $P/p1 -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $P/p1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVES --output-format csv -d $P/p1 -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --lanes 1 > $P/p1.log 2>&1
 cd $R
 python - <<PY
 import sys, os

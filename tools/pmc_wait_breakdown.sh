@@ -8,7 +8,7 @@ P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MI
 P3="SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_IFETCH SQ_INSTS_MFMA SQ_INSTS_VMEM"
 i=1
 for P in "$P1" "$P2" "$P3"; do
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/$TAG/p$i -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/$TAG/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/$TAG/p$i -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --lanes 1 > $R/gpurun_out/$TAG/p$i.log 2>&1
   i=$((i+1))
 done
 cd $R
