@@ -189,7 +189,13 @@ def self_launch(n_gpus):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    # the contract is ONE JSON line on stdout: relay rank 0's line and send whatever else the ranks' libraries print there to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        target = sys.stdout if line.lstrip().startswith('{"metric"') else sys.stderr
+        target.write(line)
+        target.flush()
+    return proc.wait()
 
 
 def split_masks(model, flat, n, rows):
