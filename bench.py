@@ -30,6 +30,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')   # as rcu_amd/__init__.py does (before torch touches the HIP runtime)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

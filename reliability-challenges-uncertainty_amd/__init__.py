@@ -6,4 +6,12 @@ Host-side mirror of the reference's three seams:
   metrics -> rcu_amd.evaluation (EceBinaryNumpy, UncertaintyAndCorrectionEvalNumpy, ...)
 Everything computes through librcu_hip.so (include/rcu.h); there is no CPU fallback.
 """
+import os as _os_env
+
+# Kernel arguments in device memory: the HIP runtime then does not pull them over PCIe at every launch.  A forward pass is 23 dependent
+# launches and the GPU idles between them for about the launch latency (measured on the headline bench: 149.5 -> 150.8
+# MC-sample-volumes/s).  Read by the runtime when it initialises, so it has to be in the environment before the first HIP call; a
+# value the user has set wins.
+_os_env.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+
 __version__ = '0.1.0'
