@@ -303,23 +303,30 @@ class McPredictStep(BatchStep):
         if isinstance(model, model_mod.UNet) and not self.materialize:     # the plan for the pass groups, before the smaller first forward
             n, _, h, w = images.shape
             model.reserve(h, w, n * min(self.mc_steps, max(1, self.group_pixels // (n * h * w))))
-        if self.ws_pass:
+        fused = not self.materialize and isinstance(model, model_mod.UNet)
+        if self.ws_pass and not fused:
             batch_context.output['ws_probabilities'] = softmax(model(images))
+
+        def ws_pass():      # fused path: issued on lane 0 once the lanes are set up, so that the side lane starts its first group beside it
+            set_dropout_mode(model, is_train=False)
+            batch_context.output['ws_probabilities'] = softmax(model(images))
+            set_dropout_mode(model, is_train=True)
 
         set_dropout_mode(model, is_train=True)
         try:
-            if self.materialize or not isinstance(model, model_mod.UNet):
+            if not fused:
                 probs = []
                 for i in range(self.mc_steps):
                     logits = model(images) if self.masks is None else model(images, self.masks[i])
                     probs.append(softmax(logits))
                 batch_context.output['multi_probabilities'] = torch.stack(probs)
             else:
-                batch_context.output['multi_probabilities'] = self._fused_passes(model, images, self.do_mi, self.do_var)
+                batch_context.output['multi_probabilities'] = self._fused_passes(model, images, self.do_mi, self.do_var,
+                                                                                 before=ws_pass if self.ws_pass else None)
         finally:
             set_dropout_mode(model, is_train=False)   # reset to eval for the next batch (customsteps.py:39)
 
-    def _fused_passes(self, model, images, do_mi, do_var):
+    def _fused_passes(self, model, images, do_mi, do_var, before=None):
         """The T passes into per-voxel statistics (dropout mode is on).  The statistics carry a recipe that replays the passes
         -- same images, same masks: the device generator is put back to where the sampling started -- so that
         ``MultiPredictionSummary(do_mi / do_var)`` decides alone which outputs exist, as in the reference (customsteps.py:44-48)."""
@@ -330,6 +337,8 @@ class McPredictStep(BatchStep):
         group = max(1, self.group_pixels // (n * h * w))
         lanes = StreamLanes(dev, min(self.lanes, -(-self.mc_steps // group)))
         lanes.begin(stats, lambda: McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var), inputs=(images,))
+        if before is not None:
+            before()                   # (the weight-scaling pass, on the caller's stream)
         i = 0
         while i < self.mc_steps:       # masks are drawn (host side: in launch order, whatever the lane) inside forward_accumulate
             g = min(group, self.mc_steps - i)
