@@ -17,6 +17,7 @@ issues the reduce on RCCL's own stream, finalises on a side stream of the root a
 volume (T+1 = 21 jobs on 8 GPUs: 21 forward passes per rank per 8 volumes instead of 3 per volume).
 """
 import collections
+import os
 
 import torch
 import torch.distributed as dist
@@ -161,8 +162,15 @@ class ShardedMcRunner:
     assignment launch -> lane is fixed, so the result does not depend on timing."""
 
     def __init__(self, model, mc_steps, ws_pass=True, rank=0, world=1, engine=None, do_mi=False, do_var=False,
-                 root=0, seed=0, pass_group=1, lanes=1):
+                 root=0, seed=0, pass_group=1, lanes=1, ws_transport=None):
         self.engine = engine if engine is not None else HipEngine(model, do_mi, do_var)
+        # How the weight-scaling probabilities reach the root: 'reduce' -- in the tail of the ONE reduce buffer (zeros on every rank
+        # but their owner; one collective per volume, twice the bytes on every link) -- or 'p2p': the reduce carries the statistics
+        # only and the owner of job 0 sends its tail to the root (nothing when the root owns it): half the bytes on the links the
+        # send does not use.  RCU_WS_TRANSPORT overrides the default.
+        self.ws_transport = ws_transport or os.environ.get('RCU_WS_TRANSPORT', 'reduce')
+        if self.ws_transport not in ('reduce', 'p2p'):
+            raise ValueError('ws_transport must be "reduce" or "p2p"')
         self.mc_steps = mc_steps
         self.ws_pass = ws_pass
         self.rank, self.world, self.root = rank, world, root
@@ -207,6 +215,10 @@ class ShardedMcRunner:
                 self.engine.mc_pass(x, stats, masks)
         self.forwards_run += 1
 
+    def _lane_of(self, job, count):
+        """Fixed lane of a job, or None: the launches of a volume take the lanes in turn."""
+        return None
+
     def _run_jobs(self, x, step_index, mask_sets):
         flat, stats, ws = self.engine.buffers(x, self.ws_pass)
         jobs = self.jobs_of(step_index, self.rank)
@@ -236,11 +248,34 @@ class ShardedMcRunner:
                 self._run_job(0, x, stats, ws, mask_sets, step_index)
                 i += 1
             else:
-                on_lane(lambda st, lane, job=jobs[i]: self._run_job(job, x, st, ws, mask_sets, step_index, lane))
+                on_lane(lambda st, lane, job=jobs[i]: self._run_job(job, x, st, ws, mask_sets, step_index, lane),
+                        self._lane_of(jobs[i], lanes.count))
                 i += 1
         if lanes.count > 1:
             lanes.end(self.engine.merge)
         return flat, stats, ws
+
+    def ws_owner(self, step_index):
+        """Rank that runs the weight-scaling pass (job 0) of volume ``step_index``."""
+        return (step_index * self.jobs_per_step) % self.world
+
+    def _exchange(self, flat, ws, step_index, async_op):
+        """The data exchange of one volume -> list of work handles (empty: everything completed).  'reduce': ONE sum-reduce of
+        [statistics | ws].  'p2p': the sum-reduce covers the statistics (everything in front of the ws tail) and the owner of the
+        weight-scaling pass sends the tail to the root."""
+        if ws is None or self.ws_transport == 'reduce':
+            w = dist.reduce(flat, dst=self.root, op=dist.ReduceOp.SUM, async_op=async_op)
+            return [w] if async_op else []
+        head = flat[:flat.numel() - ws.numel()]
+        tail = flat[flat.numel() - ws.numel():]
+        works = [dist.reduce(head, dst=self.root, op=dist.ReduceOp.SUM, async_op=async_op)]
+        owner = self.ws_owner(step_index)
+        if owner != self.root:
+            if self.rank == owner:
+                works.append(dist.isend(tail, dst=self.root) if async_op else dist.send(tail, dst=self.root))
+            elif self.rank == self.root:
+                works.append(dist.irecv(tail, src=owner) if async_op else dist.recv(tail, src=owner))
+        return [w for w in works if w is not None and not isinstance(w, int)] if async_op else []
 
     def step(self, x, step_index=0, mask_sets=None):
         """One volume.  Returns the summary dict on the root rank (probabilities, entropy, ... and
@@ -248,7 +283,8 @@ class ShardedMcRunner:
         mask sets, indexed by MC pass."""
         flat, stats, ws = self._run_jobs(x, step_index, mask_sets)
         if self.world > 1:
-            dist.reduce(flat, dst=self.root, op=dist.ReduceOp.SUM)          # statistics (+ ws): THE collective of the volume
+            for w in self._exchange(flat, ws, step_index, async_op=False):
+                w.wait()
         if self.rank != self.root:
             return None
         out = self.engine.finalize(stats, self.mc_steps)
@@ -268,7 +304,7 @@ class ShardedMcRunner:
         while len(self._inflight) >= depth:
             self._inflight.popleft().retire()
         flat, stats, ws = self._run_jobs(x, step_index, mask_sets)
-        works = [dist.reduce(flat, dst=self.root, op=dist.ReduceOp.SUM, async_op=True)]
+        works = self._exchange(flat, ws, step_index, async_op=True)
         pending = PendingSummary(None, works=works, keep=(flat, ws))
         if self.rank == self.root:
             if self._side is not None:
@@ -321,9 +357,12 @@ class ShardedEnsembleRunner(ShardedMcRunner):
                          engine=engine, do_mi=do_mi, do_var=do_var, root=root, lanes=lanes)
         self.members = members
 
+    def _lane_of(self, job, count):
+        # A member keeps to one lane whatever the job rotation of a multi-rank run does: it needs ONE activation workspace (a handle
+        # per (member, lane) would be two: 12 GB each at 160 slices, never evicted -- handles are per member)
+        return (job - 1) % count
+
     def _run_job(self, job, x, stats, ws, mask_sets, step_index=0, lane=0):
-        # A member is a model object of its own, but over a stream of volumes it can come up on either lane (the job rotation of a
-        # multi-rank run): the lane's workspace, so that launches of one member on two streams can never share activations
         if lane:
             self.engine.member_pass(self.members[job - 1], x, stats, lane=lane)
         else:

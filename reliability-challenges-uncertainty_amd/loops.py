@@ -238,14 +238,21 @@ class SubjectAssembler:
         self.subjects_ready = set()
 
     def add_batch(self, to_assemble: dict, batch: dict, last_batch=False):
-        for b, (si, k) in enumerate(zip(batch['subject_index'], batch['slice_index'])):
-            si, k = int(si), int(k)
+        subjects = [int(v) for v in batch['subject_index']]
+        slices = [int(v) for v in batch['slice_index']]
+        b, n = 0, len(subjects)
+        while b < n:                 # runs of consecutive slices of one subject are copied as blocks
+            e = b + 1
+            while e < n and subjects[e] == subjects[b] and slices[e] == slices[e - 1] + 1:
+                e += 1
+            si, k = subjects[b], slices[b]
             store = self.volumes.setdefault(si, {})
             for key, value in to_assemble.items():
                 if key not in store:
                     depth = int(batch['shape'][b][0])
                     store[key] = np.zeros((depth,) + value.shape[1:], dtype=value.dtype)
-                store[key][k] = value[b]
+                store[key][k:k + (e - b)] = value[b:e]
+            b = e
         current = int(batch['subject_index'][-1])
         for si in self.volumes:
             if last_batch or si != current:
@@ -293,48 +300,170 @@ def tensor_to_numpy(tensor):
     return tensor.cpu().numpy()
 
 
-def prefetch(iterable, depth=2, pin=False):
+def merge_batches(batches):
+    """Concatenate collated dict batches (rcu_amd.data.CollateDict: stacked tensors + per-sample lists) along the sample axis."""
+    if len(batches) == 1:
+        return batches[0]
+    out = {}
+    for key, first in batches[0].items():
+        if torch.is_tensor(first):
+            out[key] = torch.cat([b[key] for b in batches])
+        elif isinstance(first, (list, tuple)):
+            out[key] = [v for b in batches for v in b[key]]
+        else:
+            out[key] = first
+    return out
+
+
+def _batch_pixels(batch, entry='images'):
+    v = batch.get(entry) if isinstance(batch, dict) else None
+    if not torch.is_tensor(v) or v.dim() < 3:
+        return None
+    return int(v.shape[0]) * int(v.shape[-1]) * int(v.shape[-2])
+
+
+def coalesced(iterable, max_pixels, entry='images'):
+    """Merge consecutive loader batches while the merged batch stays within ``max_pixels`` (samples x height x width of ``entry``)
+    and the per-sample shapes agree.  The reference's ``batch_size`` is a loader setting: a forward pass is independent per sample
+    (tests: batch-split invariance, bit for bit), so the outputs do not depend on how the slices are batched -- but the GPU fills
+    only from about 160 BraTS slices on, and the shipped YAML files feed 32."""
+    pending, pixels = [], 0
+    for batch in iterable:
+        px = _batch_pixels(batch, entry)
+        if px is None:                              # not a dict batch with an image tensor: passed through
+            if pending:
+                yield merge_batches(pending)
+                pending, pixels = [], 0
+            yield batch
+            continue
+        if pending:
+            same = pending[0][entry].shape[1:] == batch[entry].shape[1:] and pending[0].keys() == batch.keys()
+            if not same or pixels + px > max_pixels:
+                yield merge_batches(pending)
+                pending, pixels = [], 0
+        pending.append(batch)
+        pixels += px
+        if pixels >= max_pixels:
+            yield merge_batches(pending)
+            pending, pixels = [], 0
+    if pending:
+        yield merge_batches(pending)
+
+
+class _Staged:
+    """One pinned host buffer of the loader's staging ring.  The worker fills it and hands it to the test loop inside a batch; the
+    loop gives it back (``release``) with a CUDA event recorded behind the step's host-to-device copy, and the worker waits for
+    that event before it writes the buffer again."""
+
+    def __init__(self, shape, dtype):
+        self.tensor = torch.empty(shape, dtype=dtype, pin_memory=True)
+        self.event = None
+        self.busy = False
+
+
+def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
     """Iterate ``iterable`` from a background thread, ``depth`` items ahead: the loader's work for the next batches (file reads,
     decompression -- zlib and numpy release the GIL -- transforms, collation) overlaps the GPU work of the current one.  ``pin``:
-    floating-point tensors of a dict batch are moved to pinned host memory there too, so that the step's host-to-device copy is
-    asynchronous and the test loop keeps the GPU's queue filled instead of waiting for each copy."""
+    the ``pin_entries`` of a dict batch (the tensors a step copies to the device) are staged in pinned host memory there too, so
+    that the step's host-to-device copy is asynchronous.  Yields ``(item, release)``: call ``release()`` once the copies of the
+    item's pinned entries have been ENQUEUED (it records a CUDA event; the buffer is not written again before that event has
+    completed).  Entries the steps keep on the host (labels) are never staged: they are the loader's own tensors.
+    Closing the generator (or an exception in the consumer) stops the worker."""
     import queue
     import threading
     q = queue.Queue(maxsize=depth)
     done = object()
-
-    # pinned staging buffers, allocated once per (entry, shape) and used in turn: depth queued + one with the consumer + one
-    # whose copy to the device may still be in flight (pinning per batch costs more than the copy it speeds up)
-    ring, turn = {}, [0]
+    stop = threading.Event()
+    cond = threading.Condition()
+    ring = {}          # (entry, shape, dtype) -> [_Staged]
 
     def staged(key, v):
         bufs = ring.setdefault((key, tuple(v.shape), v.dtype), [])
-        if len(bufs) < depth + 2:
-            bufs.append(torch.empty(v.shape, dtype=v.dtype, pin_memory=True))
-        buf = bufs[turn[0] % len(bufs)]
-        buf.copy_(v)
+        with cond:
+            while True:
+                free = [b for b in bufs if not b.busy]
+                if free or len(bufs) < depth + 3:      # depth queued + one being filled + one with the consumer + one in flight
+                    break
+                cond.wait(0.05)
+                if stop.is_set():
+                    return None
+            if free:
+                buf = free[0]
+            else:
+                buf = _Staged(v.shape, v.dtype)
+                bufs.append(buf)
+            buf.busy = True
+        if buf.event is not None:
+            buf.event.synchronize()                    # the copy that read this buffer last has finished
+            buf.event = None
+        buf.tensor.copy_(v)
         return buf
+
+    def put(entry):
+        while not stop.is_set():
+            try:
+                q.put(entry, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def worker():
         try:
             for item in iterable:
+                held = []
                 if pin and isinstance(item, dict):
-                    item = {k: (staged(k, v) if torch.is_tensor(v) and v.is_floating_point() and not v.is_cuda else v)
-                            for k, v in item.items()}
-                    turn[0] += 1
-                q.put((item, None))
-            q.put((done, None))
+                    item = dict(item)
+                    for k in pin_entries:
+                        v = item.get(k)
+                        if torch.is_tensor(v) and v.is_floating_point() and not v.is_cuda:
+                            buf = staged(k, v)
+                            if buf is None:
+                                return
+                            item[k] = buf.tensor
+                            held.append(buf)
+                if not put((item, held, None)):
+                    return
+            put((done, [], None))
         except BaseException as exc:  # noqa: BLE001 - re-raised in the consumer
-            q.put((done, exc))
+            put((done, [], exc))
 
-    threading.Thread(target=worker, daemon=True, name='rcu-loader').start()
-    while True:
-        item, exc = q.get()
-        if item is done:
-            if exc is not None:
-                raise exc
-            return
-        yield item
+    thread = threading.Thread(target=worker, daemon=True, name='rcu-loader')
+    thread.start()
+
+    def releaser(held):
+        def release():
+            if not held:
+                return
+            event = None
+            if torch.cuda.is_available():
+                event = torch.cuda.Event()
+                event.record()
+            with cond:
+                for buf in held:
+                    buf.event = event
+                    buf.busy = False
+                cond.notify_all()
+            held.clear()
+        return release
+
+    try:
+        while True:
+            item, held, exc = q.get()
+            if item is done:
+                if exc is not None:
+                    raise exc
+                return
+            yield item, releaser(held)
+    finally:
+        stop.set()
+        with cond:
+            cond.notify_all()
+        try:                       # unblock a worker waiting in q.put
+            while True:
+                q.get_nowait()
+        except queue.Empty:
+            pass
 
 
 class _Download:
@@ -370,16 +499,37 @@ class _Download:
         return {k: v.numpy() for k, v in self.arrays.items()}
 
 
+def _with_last_flag(iterable):
+    """(item, is_last) pairs: one item of lookahead."""
+    it = iter(iterable)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, False
+        cur = nxt
+    yield cur, True
+
+
 class Test:
+    """``pipelined`` (default: on for a CUDA device, ``RCU_PIPELINE=0`` switches it off): batch k + 1 is loaded and its GPU work
+    enqueued while the outputs of batch k come to the host, so "batch k + 1 start" fires before "subjects of batch k" / "batch k
+    end"; with ``pipelined=False`` every callback comes in the reference's order (loops.py:176-235).
+    ``coalesce`` (pipelined only; default ``RCU_COALESCE`` or one BraTS volume = 160 x 192 x 128 pixels; 0 = off): consecutive
+    loader batches are merged up to that many samples x height x width before the steps run -- the hooks then see the merged batch."""
     __test__ = False
+    COALESCE_PIXELS = 160 * 192 * 128
 
     def __init__(self, steps: list, subject_steps: list = None, subject_assembler=None, entries: tuple = None,
-                 convert_fn=tensor_to_numpy):
+                 convert_fn=tensor_to_numpy, pipelined=None, coalesce=None):
         self.steps = steps
         self.subject_steps = subject_steps or []
         self.subject_assembler = subject_assembler
         self.entries = entries
         self.convert_fn = convert_fn
+        self.pipelined = pipelined
+        self.coalesce = coalesce
 
     def __call__(self, context, build_test, hook: TestLoopHook = TestLoopHook()):
         hook.on_startup()
@@ -398,22 +548,36 @@ class Test:
         # batch k come to the host -- and its subjects are assembled, evaluated and written -- while batch k + 1 computes.  Per
         # batch the order of the callbacks is the reference's (batch start, steps, subject start / steps / end, batch end); only
         # "batch k + 1 start" now comes before "subjects of batch k".  A custom convert_fn or a CPU device keeps the plain order.
-        pipelined = (self.convert_fn is tensor_to_numpy and self.subject_assembler is not None and
-                     getattr(context.device, 'type', 'cpu') == 'cuda')
+        pipelined = self.pipelined
+        if pipelined is None:
+            pipelined = os.environ.get('RCU_PIPELINE', '1') != '0'
+        pipelined = bool(pipelined) and (self.convert_fn is tensor_to_numpy and self.subject_assembler is not None and
+                                         getattr(context.device, 'type', 'cpu') == 'cuda')
         side = torch.cuda.Stream(device=context.device) if pipelined else None
+        loader = task_context.data.loader
+        if pipelined:
+            coalesce = self.coalesce if self.coalesce is not None else int(os.environ.get('RCU_COALESCE', self.COALESCE_PIXELS))
+            if coalesce > 0:
+                loader = coalesced(loader, coalesce)
         waiting = None
-        for i, batch in enumerate(prefetch(task_context.data.loader, pin=pipelined)):
-            batch_context = BatchContext(batch, i)
-            hook.on_test_batch_start(batch_context, task_context, context)
-            download = self._run_steps(batch_context, task_context, context, side, i & 1)
+        batches = prefetch(loader, pin=pipelined)
+        try:
+            for i, ((batch, release), last) in enumerate(_with_last_flag(batches)):
+                batch_context = BatchContext(batch, i)
+                batch_context.more['last_batch'] = last
+                hook.on_test_batch_start(batch_context, task_context, context)
+                download = self._run_steps(batch_context, task_context, context, side, i & 1)
+                release()                     # the step's host-to-device copies are enqueued: the staging buffers may go back
+                if waiting is not None:
+                    self._finish_batch(*waiting, task_context, context, hook)
+                waiting = (batch_context, download)
+                if not pipelined:
+                    self._finish_batch(*waiting, task_context, context, hook)
+                    waiting = None
             if waiting is not None:
                 self._finish_batch(*waiting, task_context, context, hook)
-            waiting = (batch_context, download)
-            if not pipelined:
-                self._finish_batch(*waiting, task_context, context, hook)
-                waiting = None
-        if waiting is not None:
-            self._finish_batch(*waiting, task_context, context, hook)
+        finally:
+            batches.close()                   # stops the loader thread, also when a step or a hook raised
         hook.on_test_end(task_context, context)
         hook.on_termination(context)
 
@@ -439,7 +603,9 @@ class Test:
                 for key, value in self._kept(batch_context).items():
                     value = steps_mod.channel_to_end(value)
                     to_assemble[key] = self.convert_fn(value) if self.convert_fn else value
-            last = batch_context.batch_index == task_context.data.nb_batches - 1
+            last = batch_context.more.get('last_batch')
+            if last is None:
+                last = batch_context.batch_index == task_context.data.nb_batches - 1
             self.subject_assembler.add_batch(to_assemble, batch_context.input, last_batch=last)
 
             for subject_index in sorted(self.subject_assembler.subjects_ready, key=str):

@@ -252,15 +252,28 @@ def join_all():
         fut.result()
 
 
-def write_subject(test_dir, subject, probabilities, properties=None, sigma=None, in_background=True):
+def argmax_last(probabilities):
+    """``np.argmax(probabilities, axis=-1)`` (int64, first maximum wins, a NaN counts as the maximum): for two classes one compare
+    instead of numpy's generic reduction over a two-element axis."""
+    probabilities = np.asarray(probabilities)
+    if probabilities.shape[-1] != 2 or probabilities.dtype.kind != 'f':
+        return np.argmax(probabilities, axis=-1)
+    p0, p1 = probabilities[..., 0], probabilities[..., 1]
+    return ((p1 > p0) | ((p1 != p1) & (p0 == p0))).astype(np.int64)
+
+
+def write_subject(test_dir, subject, probabilities, properties=None, sigma=None, in_background=True, prediction=None):
     """What the reference's ``WriteHook._on_test_subject_end`` does for one assembled subject:
     ``probabilities`` is channel-last ``[..., C]`` float32; writes ``{subject}_probabilities.nii.gz``
     (foreground class), ``{subject}_prediction.nii.gz`` (argmax, uint8) and, for aleatoric runs,
-    ``{subject}_sigma.nii.gz`` (sigma of the predicted class; bin-dl/brats_test_aleatoric.py:95-110)."""
+    ``{subject}_sigma.nii.gz`` (sigma of the predicted class; bin-dl/brats_test_aleatoric.py:95-110).
+    ``prediction``: the arg-max of ``probabilities`` where the caller has it already."""
 
     # one job per file: the files of a subject compress side by side, and the argmax stays off the test loop's thread
     def predict():
-        return np.argmax(probabilities, axis=-1).astype(np.uint8)
+        if prediction is not None:
+            return np.asarray(prediction).astype(np.uint8)
+        return argmax_last(probabilities).astype(np.uint8)
 
     def write_probabilities():
         write(os.path.join(test_dir, '{}_probabilities.nii.gz'.format(subject)),

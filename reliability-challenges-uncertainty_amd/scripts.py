@@ -45,9 +45,10 @@ class EvalSubjectStep(loops.SubjectStep):
 
     def __call__(self, subject_context, task_context, context) -> None:
         probabilities = subject_context.subject_data['probabilities']
-        prediction = np.argmax(probabilities, axis=-1)
+        prediction = nifti.argmax_last(probabilities)
         if self.keep_prediction:
             subject_context.subject_data['prediction'] = prediction
+        subject_context.more['prediction'] = prediction      # the writer hook takes it from here instead of a second arg-max
         target = subject_context.subject_data['labels']
         if self.squeeze_labels:
             target = target.squeeze(-1)
@@ -69,7 +70,8 @@ class WriteHook(loops.TestLoopHook):
         data = subject_context.subject_data
         subject = data.get('subject', subject_context.subject_index)
         nifti.write_subject(context.test_dir, subject, data['probabilities'], data.get('properties'),
-                            data['sigma'] if self.with_sigma else None, in_background=self.in_background)
+                            data['sigma'] if self.with_sigma else None, in_background=self.in_background,
+                            prediction=subject_context.more.get('prediction'))
         if self.link_inputs:   # ISIC: symlink image and label next to the outputs
             files = context.test_data.dataset.get_files_by_id(subject_context.subject_index)
             for key in ('label_paths', 'image_paths'):

@@ -20,6 +20,7 @@ sums, updated by the fused forward+softmax+accumulate kernel) under ``multi_prob
 (a real ``[T, N, C, H, W]`` tensor), and the summary accepts either form.
 """
 import abc
+import logging
 import os
 
 import torch
@@ -416,6 +417,7 @@ class EnsemblePredictionStep(BatchStep):
 
 
 class MultiPredictionSummary(BatchStep):
+    _replay_warned = False
 
     def __init__(self, do_mi=False, do_var=False, remove_multi_probs=True) -> None:
         super().__init__()
@@ -436,6 +438,12 @@ class MultiPredictionSummary(BatchStep):
                 if stats.recipe is None:
                     raise ValueError('the statistics lack {} and cannot be replayed'.format(
                         'the entropy sum (do_mi)' if self.do_mi and not stats.do_mi else 'the squared sums (do_var)'))
+                if not MultiPredictionSummary._replay_warned:
+                    MultiPredictionSummary._replay_warned = True
+                    logging.getLogger(__name__).warning(
+                        'MultiPredictionSummary(do_mi=%s, do_var=%s) asks for more than the predict step tracked: the passes run a '
+                        'second time under the same masks (construct the predict step with the same flags to avoid it)',
+                        self.do_mi, self.do_var)
                 stats = stats.recipe(self.do_mi or stats.do_mi, self.do_var or stats.do_var)
         else:
             t, n, c, h, w = multi.shape

@@ -133,6 +133,17 @@ def _worker(rank, world, port, out_dir):
         else:
             assert out is None
     runner.drain()
+    # the weight-scaling probabilities by send / recv from their owner instead of in the tail of the reduce buffer
+    # (root 1: with T + 1 = 6 jobs on 2 ranks job 0 always runs on rank 0, so the tail really travels)
+    p2p = ShardedMcRunner(None, T, ws_pass=True, rank=rank, world=world, engine=OracleEngine(state), ws_transport='p2p', root=1)
+    pend = [p2p.step_async(x, step, mask_sets) for step in range(3)] + [PendingNow(p2p.step(x, 3, mask_sets))]
+    for step, p in enumerate(pend):
+        out = p.result()
+        if rank == 1:
+            np.savez(os.path.join(out_dir, 'p2p{}.npz'.format(step)), **{k: v.numpy() for k, v in out.items()})
+        else:
+            assert out is None
+    p2p.drain()
     # masks drawn per (seed, volume, pass): the result must not depend on the world size, with and without pass groups
     for name, group in (('seeded', 1), ('seeded_grouped', 2)):
         rs = ShardedMcRunner(None, T, ws_pass=True, rank=rank, world=world, engine=OracleEngine(state), seed=5, pass_group=group)
@@ -163,6 +174,14 @@ def _worker(rank, world, port, out_dir):
             np.savez(os.path.join(out_dir, 'sigma{}.npz'.format(step)), **{k: v.numpy() for k, v in out.items()})
     sig.drain()
     dist.destroy_process_group()
+
+
+class PendingNow:
+    def __init__(self, value):
+        self.value = value
+
+    def result(self):
+        return self.value
 
 
 def _free_port():
@@ -212,7 +231,8 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     state, x, mask_sets = _inputs()
     ws, multi = so.mc_probabilities(lambda xx, m: uo.unet_forward(state, xx, m, **PARAMS), x, mask_sets)
     ref = so.multi_prediction_summary(multi)
-    for name in ['step{}.npz'.format(k) for k in range(3)] + ['async{}.npz'.format(k) for k in range(3)]:
+    for name in (['step{}.npz'.format(k) for k in range(3)] + ['async{}.npz'.format(k) for k in range(3)] +
+                 ['p2p{}.npz'.format(k) for k in range(4)]):
         got = np.load(os.path.join(str(tmp_path), name))
         assert np.max(np.abs(got['ws_probabilities'] - ws.numpy())) < 1e-6
         assert np.max(np.abs(got['probabilities'] - ref['probabilities'].numpy())) < 1e-6
@@ -246,3 +266,98 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         assert np.max(np.abs(got['sigma'] - s_ref.numpy())) < 1e-5 * max(1.0, float(s_ref.max()))
         assert np.max(np.abs(got['ws_probabilities'] - torch.softmax(lg0, 1).numpy())) < 1e-6
         assert np.max(np.abs(got['ws_sigma'] - raw0.abs().numpy())) < 1e-6 * max(1.0, float(raw0.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------ world 8
+# The shapes of the 8-GPU runs (BASELINE configs[2..4]: T = 20 MC passes, K = 10 members, T = 50 sigma-head passes) on 8 gloo
+# ranks: job partition, pass groups, the lane rotation argument (lanes collapse to one on a CPU device, the rotation code still
+# runs), one collective per volume, both ws transports -- against the single-process result, and the forward counts per rank.
+W8_PARAMS = dict(nb_classes=2, in_channels=4, depth=2, start_filters=4, dropout=0.3)
+W8_VOLUMES = 8
+
+
+class TinyEngine(OracleEngine):
+    """OracleEngine over a depth-2 U-Net on 8x8 images: a forward pass takes a millisecond."""
+
+    def _fwd(self, state, x, masks):
+        return torch.softmax(self.uo.unet_forward(state, x, masks, **W8_PARAMS), 1)
+
+    def ws_pass(self, x, ws_out):
+        ws_out.copy_(self._fwd(self.state, x, None))
+
+    def sample_masks(self, x, generator, passes=1):
+        _, sites = self.uo.unet_plan(**W8_PARAMS)
+        return self.uo.sample_masks(sites, x.shape[0], W8_PARAMS['dropout'], generator)
+
+    def mc_pass(self, x, stats, masks=None, passes=1, lane=0):
+        for ms in ([masks] if passes == 1 else masks):
+            stats += self._fwd(self.state, x, ms)
+
+    def member_pass(self, member_state, x, stats, lane=0):
+        stats += self._fwd(member_state, x, None)
+
+
+def _w8_cases(rank, world):
+    from oracle import unet_oracle as uo
+    from rcu_amd.distributed import ShardedEnsembleRunner, ShardedMcRunner
+    state = uo.synthetic_state(11, **W8_PARAMS)
+    members = [uo.synthetic_state(200 + k, **W8_PARAMS) for k in range(10)]
+    x = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(8))
+    mk = lambda **kw: ShardedMcRunner(None, rank=rank, world=world, engine=TinyEngine(state), seed=3, lanes=2, **kw)  # noqa: E731
+    return x, {
+        'mc20': mk(mc_steps=20, ws_pass=True, pass_group=2),
+        'mc20_p2p': mk(mc_steps=20, ws_pass=True, pass_group=2, ws_transport='p2p'),
+        'mc50': mk(mc_steps=50, ws_pass=True, pass_group=2),
+        'ens10': ShardedEnsembleRunner(members, rank=rank, world=world, engine=TinyEngine(state), lanes=2),
+    }
+
+
+def _w8_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    x, cases = _w8_cases(rank, world)
+    counts = {}
+    for name, runner in cases.items():
+        pend = [runner.step_async(x, k) for k in range(W8_VOLUMES)]
+        outs = [p.result() for p in pend]
+        runner.drain()
+        counts[name] = runner.forwards_run
+        if rank == 0:
+            np.savez(os.path.join(out_dir, name + '.npz'),
+                     **{'{}_{}'.format(key, k): v.numpy() for k, out in enumerate(outs) for key, v in out.items()})
+        else:
+            assert all(o is None for o in outs)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, counts)
+    if rank == 0:
+        import json
+        with open(os.path.join(out_dir, 'counts.json'), 'w') as f:
+            json.dump(gathered, f)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_eight_rank_gloo_matches_single_process_and_balances(tmp_path):
+    import json
+    world = 8
+    mp.spawn(_w8_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    x, cases = _w8_cases(0, 1)
+    with open(os.path.join(str(tmp_path), 'counts.json')) as f:
+        counts = json.load(f)
+    for name, runner in cases.items():
+        got = np.load(os.path.join(str(tmp_path), name + '.npz'))
+        for k in range(W8_VOLUMES):
+            ref = runner.step(x, k)
+            assert set(ref) == {key[:-len('_{}'.format(k))] for key in got.files if key.endswith('_{}'.format(k))}
+            for key, v in ref.items():
+                assert np.max(np.abs(got['{}_{}'.format(key, k)] - v.numpy())) < 2e-6, (name, k, key)
+        per_rank = [c[name] for c in counts]
+        jobs = runner.jobs_per_step * W8_VOLUMES
+        assert sum(per_rank) == jobs and runner.forwards_run == jobs
+        # the rotation of the job list over the volumes: 8 volumes hand every rank the same number of forward passes
+        assert max(per_rank) - min(per_rank) <= (0 if jobs % world == 0 else 1), (name, per_rank)
+    # the three shapes: 21, 51 and 10 jobs per volume over 8 ranks
+    assert [c['mc20'] for c in counts] == [21] * 8 and [c['mc50'] for c in counts] == [51] * 8 and [c['ens10'] for c in counts] == [10] * 8
