@@ -5,8 +5,9 @@ i.e. 160 slices of 4 x 192 x 128), T = 20 MC-dropout passes, on N GPUs of one no
 One step = the reference's hot path for one volume (rechun/dl/customsteps.py:16-71):
     weight-scaling pass + T stochastic U-Net passes (softmax + running statistics fused in) ->
     [N > 1: one RCCL sum-reduce of the per-voxel statistics] -> mean probability + predictive entropy.
-Inputs are resident in HBM when the timed region starts (`value`); the same step with the host-to-device copy of the
-volume inside is reported next to it (`with_h2d`).  N > 1 shards the T+1 forward passes of every step over the ranks
+The host-to-device copy of every volume is INSIDE the timed region (SURVEY.md 8d's definition of the metric), prefetched from
+pinned memory on a copy stream while the previous volume computes (`value`); the same steps with the volume resident in HBM are
+reported next to it (`resident`).  N > 1 shards the T+1 forward passes of every step over the ranks
 (strong scaling).  Launch forms:
     python bench.py --gpus N ...                  (starts its N ranks itself, as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -31,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')   # as rcu_amd/__init__.py does (before torch touches the HIP runtime)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')        # likewise: a hardware queue per stream (lanes, input prefetch, finalize side stream)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -84,52 +86,111 @@ def make_isic_batch(seed, n=ISIC_IMAGES):
     return x, torch.ones_like(target, dtype=torch.bool), target
 
 
-def cpu_leg(members, params, x_cpu, sel, mask_sets_sel, with_ws, ensemble, budget_s):
+def _host_threads():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_leg(members, params, x_cpu, sel, mask_sets_sel, with_ws, ensemble, budget_s, thread_counts):
     """The oracle's CPU path (torch-CPU conv stack + torch aggregation, oracle/) on the slices `sel` of the volume with the
-    weights and the dropout masks of the last timed step.  -> (cpu_baseline dict, reference summary on those slices)."""
+    weights and the dropout masks of the last timed step.  BASELINE.md section 4's protocol on a bounded sample: per thread count
+    (all host threads, and 32 next to it when the box has more) one warm-up forward, then the MEDIAN of three timed runs of the
+    whole sample (weight-scaling pass + T passes + aggregation); `value` is the faster of the two settings.
+    -> (cpu_baseline dict, reference summary on those slices)."""
     from oracle import summary_oracle as so
     from oracle import unet_oracle as uo
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    threads = min(avail, 32)
-    torch.set_num_threads(threads)
     states = [{k: v.detach().cpu() for k, v in m.state_dict().items()} for m in members]
     xs = x_cpu[sel].contiguous()
     fwd = [lambda xx, m, st=st: uo.unet_forward(st, xx, m, **params) for st in states]
-    fwd[0](xs[:2], None)                        # warm-up (thread pool, primitive caches)
-    t0 = time.perf_counter()
-    if ensemble:
-        multi = so.ensemble_probabilities(fwd, xs)
-        ws = None
-    else:
-        ws, multi = so.mc_probabilities(fwd[0], xs, mask_sets_sel)
-    ref = so.multi_prediction_summary(multi)
-    dt = time.perf_counter() - t0
+    n_total = x_cpu.shape[0]
+    ref, runs, t_all = None, {}, time.perf_counter()
+    for threads in thread_counts:
+        torch.set_num_threads(threads)
+        fwd[0](xs[:2], None)                        # warm-up (thread pool, primitive caches)
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            if ensemble:
+                multi = so.ensemble_probabilities(fwd, xs)
+                ws = None
+            else:
+                ws, multi = so.mc_probabilities(fwd[0], xs, mask_sets_sel)
+            ref = so.multi_prediction_summary(multi)
+            times.append(time.perf_counter() - t0)
+        runs[threads] = sorted(times)[1]
     if ws is not None and with_ws:
         ref['ws_probabilities'] = ws
     passes = multi.shape[0]
-    n_total = x_cpu.shape[0]
     units = passes * len(sel) / n_total            # sample-volume equivalents (the ws pass is timed, not counted)
-    return dict(value=units / dt, cores=threads, kind='port',
-                sample='{} of {} slices x ({} {}{}) through oracle/ (torch-CPU, {} of {} host threads) in {:.1f} s (budget {:.0f} s)'
-                       .format(len(sel), n_total, passes, 'members' if ensemble else 'MC passes', '' if ensemble else ' + ws pass',
-                               threads, avail, dt, budget_s)), ref
+    best = min(runs, key=runs.get)
+    return dict(value=units / runs[best], cores=best, kind='port',
+                by_threads={str(t): units / dt for t, dt in runs.items()}, host_threads=_host_threads(),
+                protocol='1 warm-up + median of 3 timed runs per thread count (BASELINE.md 4), on a bounded sample',
+                sample='{} of {} slices x ({} {}{}) through oracle/ (torch-CPU); median run {:.2f} s at {} threads; the whole leg took {:.1f} s '
+                       '(budget {:.0f} s)'.format(len(sel), n_total, passes, 'members' if ensemble else 'MC passes',
+                                                  '' if ensemble else ' + ws pass', runs[best], best, time.perf_counter() - t_all,
+                                                  budget_s)), ref
 
 
-def cpu_probe_slices(member, params, x_cpu, passes_total, budget_s, n_max=32):
-    """How many slices the CPU leg can take within budget_s: one timed 4-slice forward of the oracle."""
+def cpu_thread_probe(threads, params, height, width, timeout_s=40.0):
+    """Seconds per slice of the oracle's forward at ``threads`` intra-op threads, measured in a child process that is killed after
+    ``timeout_s`` (-> None): on a box whose visible host threads are not all ours to use (a 256-thread host shared between pods)
+    torch-CPU at the full thread count can take minutes for a forward that 32 threads finish in a second, and a thread pool that has
+    gone down that road cannot be stopped from inside the process."""
+    import subprocess
+    code = ('import sys, time, torch\n'
+            'sys.path.insert(0, {root!r})\n'
+            'from oracle import unet_oracle as uo\n'
+            'torch.set_num_threads({threads})\n'
+            'params = {params!r}\n'
+            'st = uo.synthetic_state(1, **params)\n'
+            'x = torch.randn(4, params["in_channels"], {h}, {w})\n'
+            'uo.unet_forward(st, x[:2], None, **params)\n'
+            't0 = time.perf_counter()\n'
+            'uo.unet_forward(st, x, None, **params)\n'
+            'print("PER_SLICE", (time.perf_counter() - t0) / 4)\n').format(root=ROOT, threads=int(threads), params=dict(params),
+                                                                           h=height, w=width)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    try:
+        r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return None
+    for line in r.stdout.splitlines():
+        if line.startswith('PER_SLICE'):
+            return float(line.split()[1])
+    return None
+
+
+def cpu_thread_counts(params, height, width):
+    """Thread counts of the CPU leg: every host thread and 32 next to it on a bigger box -- each only if its probe
+    (a child process under a timeout) shows it usable: a count whose 4-slice forward does not finish, or runs more than 4x slower
+    per slice than the best count, is reported as skipped instead of timed.  -> ([usable counts], {count: probe result})."""
+    host = _host_threads()
+    counts = [host] + ([32] if host > 32 else [])
+    probes = {c: cpu_thread_probe(c, params, height, width) for c in counts}
+    finished = {c: v for c, v in probes.items() if v is not None}
+    if not finished:
+        return [min(host, 32)], probes
+    best = min(finished.values())
+    return [c for c in counts if c in finished and finished[c] <= 4.0 * best], probes
+
+
+def cpu_probe_slices(member, params, x_cpu, passes_total, budget_s, thread_counts, n_max=32):
+    """How many slices the CPU leg can take within budget_s (three timed runs + a warm-up per thread count): one timed 4-slice forward
+    of the oracle at the first thread count -- the sample is about that size, so the probe is representative."""
     from oracle import unet_oracle as uo
-    torch.set_num_threads(min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 32))
+    torch.set_num_threads(thread_counts[0])
     state = {k: v.detach().cpu() for k, v in member.state_dict().items()}
     xs = x_cpu[:4].contiguous()
-    uo.unet_forward(state, xs[:1], None, **params)
+    uo.unet_forward(state, xs[:2], None, **params)
     t0 = time.perf_counter()
     uo.unet_forward(state, xs, None, **params)
     per_slice = (time.perf_counter() - t0) / 4
-    n = int(0.5 * budget_s / max(per_slice * passes_total, 1e-6))   # 0.5: a 32-slice forward takes about twice as long per slice as this probe
-    return max(4, min(n_max, x_cpu.shape[0], n // 4 * 4))
+    runs = 3.2 * len(thread_counts)                 # three timed runs + warm-up and set-up per thread count
+    n = int(budget_s / max(per_slice * passes_total * runs, 1e-6))
+    return max(2, min(n_max, x_cpu.shape[0], n // 2 * 2))
 
 
 def calibration_kernels(device, volumes=160, reps=5):
@@ -179,6 +240,70 @@ def calibration_kernels(device, volumes=160, reps=5):
     return out
 
 
+class VolumePrefetcher:
+    """The host-to-device copy of the volume inside the timed region (SURVEY.md 8d: the metric counts "H2D of x";
+    rechun/dl/customsteps.py:20 is where the reference moves the batch to the device): volume k + 1 goes from pinned host memory into
+    one of two device buffers on a copy stream while volume k computes; the compute stream waits for ONE event per volume, and the
+    copy stream does not overwrite a buffer before the step that read it has been issued completely (event behind the step)."""
+
+    def __init__(self, x_cpu, device, depth=2):
+        self.x_pin = x_cpu.pin_memory()
+        self.bufs = [torch.empty(x_cpu.shape, device=device, dtype=x_cpu.dtype) for _ in range(depth)]
+        self.stream = torch.cuda.Stream(device=device)
+        self.ready = [None] * depth
+        self.free = [None] * depth
+        self.bytes = x_cpu.numel() * x_cpu.element_size()
+
+    def issue(self, k):
+        slot = k % len(self.bufs)
+        with torch.cuda.stream(self.stream):
+            if self.free[slot] is not None:
+                self.stream.wait_event(self.free[slot])
+            self.bufs[slot].copy_(self.x_pin, non_blocking=True)
+            self.ready[slot] = torch.cuda.Event()
+            self.ready[slot].record(self.stream)
+
+    def get(self, k):
+        slot = k % len(self.bufs)
+        torch.cuda.current_stream().wait_event(self.ready[slot])
+        return self.bufs[slot]
+
+    def done(self, k):
+        slot = k % len(self.bufs)
+        self.free[slot] = torch.cuda.Event()
+        self.free[slot].record()
+
+
+def aggregation_kernels(device, n_slices, height, width, reps=5):
+    """The standalone aggregation kernels of the step seam (rcu_mc_accumulate: softmax of a logits volume into the statistics;
+    rcu_mc_finalize: mean + entropy out of them; rechun/dl/customsteps.py:57-61), timed with events on the launch stream.
+    ALGORITHMIC bytes: accumulate V*C*4 logits + 2*S*4*V statistics read-modify-write (S = 2); finalize S*4*V read +
+    (C+1)*4*V written."""
+    from rcu_amd import steps
+    vox = n_slices * height * width
+    logits = torch.randn((n_slices, 2, height, width), device=device)
+    stats = steps.McStatistics(n_slices, 2, height, width, device)
+    out = {}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    for name, fn, nbytes in (('mc_accumulate_kernel', lambda: stats.accumulate(logits), vox * (2 * 4 + 2 * 2 * 4)),
+                             ('mc_finalize_kernel', lambda: stats.finalize(), vox * (2 * 4 + 3 * 4))):
+        ms = timed(fn)
+        out[name] = dict(bound='hbm', avg_launch_ms=ms, bytes_per_launch=nbytes, achieved=nbytes / ms / 1e6, peak=PEAK_HBM_GBS,
+                         unit='GB/s', frac=nbytes / ms / 1e6 / PEAK_HBM_GBS)
+    return out
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
     as a child process on a free rendezvous port of 127.0.0.1.  Never an exec, and only from a process that has made no GPU call."""
@@ -217,7 +342,10 @@ def main():
     ap.add_argument('--workload', choices=('brats', 'isic'), default='brats',
                     help='brats: 160 slices of 4x192x128 (the headline, BASELINE configs[2]); isic: 32 images of 3x256x256 (configs[1])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-budget', type=float, default=12.0, help='seconds of CPU work the oracle leg may take (bounded sample)')
+    ap.add_argument('--cpu-budget', type=float, default=24.0, help='seconds of CPU work the oracle leg may take (bounded sample)')
+    ap.add_argument('--ws-transport', choices=('reduce', 'p2p'), default=None,
+                    help='N > 1: the weight-scaling probabilities in the tail of the one reduce buffer (default) or by send / recv from '
+                         'their owner (rcu_amd.distributed.ShardedMcRunner)')
     ap.add_argument('--no-ws', action='store_true', help='skip the deterministic weight-scaling pass')
     ap.add_argument('--pass-group', type=int, default=0,
                     help='MC passes of a rank per launch (N * g samples per batch); 0 = McPredictStep\'s rule, GROUP_PIXELS // (N*H*W): 2 for the '
@@ -228,7 +356,12 @@ def main():
                     help='K ensemble members (seeds 20..20+K-1) instead of T MC passes (BASELINE config "BraTS ensemble")')
     ap.add_argument('--aleatoric', action='store_true',
                     help='sigma-head U-Net, per-pass sigma averaged next to the MC statistics (BASELINE config "BraTS aleatoric + MC", use --mc 50)')
+    ap.add_argument('--watchdog', type=float, default=1500.0,
+                    help='seconds after which a run that has not finished dumps the stacks of all threads to stderr and exits (0 = off)')
     args = ap.parse_args()
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
     if args.aleatoric and args.ensemble:
         raise SystemExit('--aleatoric and --ensemble exclude each other')
 
@@ -279,10 +412,11 @@ def main():
         members = [model]
         runner = rdist.ShardedAleatoricMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed, lanes=args.lanes,
                                                 pass_group=args.pass_group)
+        runner.ws_transport = args.ws_transport or runner.ws_transport
     else:
         members = [model]
         runner = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed,
-                                       pass_group=args.pass_group, lanes=args.lanes)
+                                       pass_group=args.pass_group, lanes=args.lanes, ws_transport=args.ws_transport)
     # dropout masks: drawn per (seed, volume, pass) by the runner -- the same T samples whatever the world size
 
     def one_step(k, xin=x):
@@ -299,12 +433,23 @@ def main():
         m.profile_begin(height, width, n_slices * args.pass_group, max(count, 1))
     runner.forwards_run = 0
 
+    feeder = VolumePrefetcher(x_cpu, device)
+    first_step, end_step = args.warmup, args.warmup + args.steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pending = [one_step(k) for k in range(args.warmup, args.warmup + args.steps)]
+    # THE timed region: per volume the host-to-device copy (prefetched: volume k + 1 travels while volume k computes), the
+    # weight-scaling pass, the T stochastic passes, [N > 1: the reduce] and the finalize
+    feeder.issue(first_step)
+    pending = []
+    for k in range(first_step, end_step):
+        xin = feeder.get(k)
+        if k + 1 < end_step:
+            feeder.issue(k + 1)
+        pending.append(one_step(k, xin))
+        feeder.done(k)
     out = [p.result() for p in pending][-1]
     runner.drain()
     torch.cuda.synchronize()
@@ -329,28 +474,32 @@ def main():
         cnt, ms = m.profile_collect(height, width, n_slices * args.pass_group)
         launches += cnt
         slot_ms = ms if slot_ms is None else [a + b for a, b in zip(slot_ms, ms)]
+    # ---- the same steps with the volume already resident in HBM (the secondary figure; all ranks take part)
+    forwards_timed = runner.forwards_run
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    pend_r = [one_step(k) for k in range(end_step, end_step + args.steps)]
+    for p_ in pend_r:
+        p_.result()
+    runner.drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed_resident = time.perf_counter() - t1
+    if world > 1:
+        tmax = torch.tensor([elapsed_resident], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed_resident = float(tmax.item())
+    del pend_r
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    last_step = args.warmup + args.steps - 1
-
-    # ---- the same step with the host-to-device copy of the volume inside (SURVEY.md 8d counts it; `value` does not:
-    # inputs are resident when its timed region starts).  Pinned host buffer, copy on the launch stream.  N = 1 only.
-    with_h2d = None
-    if world == 1:
-        x_pin = x_cpu.pin_memory()
-        x_dev = torch.empty_like(x)
-        reps = max(1, min(args.steps, 2))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for k in range(reps):
-            x_dev.copy_(x_pin, non_blocking=True)
-            one_step(last_step + 1 + k, x_dev).result()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / reps
-        with_h2d = dict(value=T * (n_slices if isic else 1) / dt, ms_per_step=dt * 1e3, h2d_bytes=x_cpu.numel() * 4,
-                        note='pinned host volume copied on the launch stream inside every step; not the headline value')
+    last_step = end_step - 1
 
     # ---- stream lanes: in the timed region the kernels of different lanes overlap (that is their point: a lane fills the gaps between
     # the dependent layers of the other), so a kernel's start-to-end time there includes the other lane's work and says nothing about
@@ -372,7 +521,7 @@ def main():
         else:
             serial = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, seed=seed, pass_group=args.pass_group, lanes=1)
         serial_steps = max(1, min(args.steps, 2))
-        first = last_step + 8
+        first = end_step + args.steps + 8
         serial.step(x, first - 1)                     # warm (the lane-0 workspace is the one the timed region used)
         serial_jobs = [j for k in range(first, first + serial_steps) for j in serial.jobs_of(k, 0)]
         for i, m in enumerate(members):
@@ -462,12 +611,15 @@ def main():
     roofline['aggregation'] = dict(bound='hbm', kernel='head_kernel', achieved=head_bytes / head_ms / 1e6, peak=PEAK_HBM_GBS,
                                    unit='GB/s', frac=head_bytes / head_ms / 1e6 / PEAK_HBM_GBS, bytes_per_launch=head_bytes,
                                    avg_launch_ms=head_ms, measured='standalone launches outside the timed region')
+    roofline['aggregation'].update(aggregation_kernels(device, n_slices, height, width))
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(pmc_path) and not isic:
         with open(pmc_path) as f:
             pmc = json.load(f)
         if dominant in pmc:
             roofline['traffic'] = pmc[dominant]
+            roofline['traffic_source'] = ('profiles/pmc_traffic.json: HBM bytes per launch from a builder-run rocprofv3 --pmc pass '
+                                          '(separate run; not measured in this process)')
 
     # ---- parity, outside the timed region, of the TIMED output (last step): ECE on the GPU maps vs the oracle on the same maps,
     # and -- the CPU leg -- the oracle's own forward passes on a slice sample of the same volume under the same dropout masks
@@ -481,16 +633,42 @@ def main():
         ece_oracle = co.ece_binary(np.stack([1 - p_np, p_np], -1), target_cpu.numpy(), mask=mask_cpu.numpy())
         parity['ece_delta_same_maps'] = abs(ece_gpu - ece_oracle)
         parity['bin_ids_equal'] = bool(np.array_equal(ev.bin_ids(p_np), co.bin_ids(p_np.reshape(-1))))
+    if not args.no_cpu_baseline:
+        # the uncertainty-error counts (bnf_ue action: 11 thresholds, numpyfunctions.py:86-107) of the TIMED output: (i) on the same
+        # device-computed normalised entropy map the GPU counts must equal the C oracle's, integer for integer; (ii) against the
+        # oracle's own numpy entropy (ToEntropy, analysis.py:189-203: numpy's log differs from the device's in the last ulp) the counts
+        # may differ by at most the voxels whose two entropies fall on different sides of a threshold -- the tie census
+        from oracle import c_oracle
+        thr_ue = list(ev.UE_THRESHOLDS)
+        u_dev = ev.normalised_entropy(p_fg, as_float64=True)
+        got = ev.uncertainty_counts(pred, target_cpu, u_dev, thresholds=thr_ue, mask=mask_cpu)[0].astype(np.int64)
+        pred_np, tg_np, mk_np = pred.cpu().numpy(), target_cpu.numpy(), mask_cpu.numpy().astype(np.uint8)
+        u_dev_np = u_dev.cpu().numpy()
+        same = c_oracle.unc_counts(u_dev_np, pred_np, tg_np, mk_np, thr_ue).astype(np.int64)
+        u_np = co.normalised_entropy(np.stack([1 - p_np, p_np], -1))
+        ref_counts = c_oracle.unc_counts(u_np, pred_np, tg_np, mk_np, thr_ue).astype(np.int64)
+        inside = mk_np.reshape(-1) != 0
+        ties = [int(np.count_nonzero(((u_dev_np.reshape(-1) > t) != (u_np.reshape(-1) > t)) & inside)) for t in thr_ue]
+        delta = np.abs(got - ref_counts)
+        parity['ue_counts_equal'] = bool(np.array_equal(got, same))
+        parity['ue_tie_voxels'] = ties
+        parity['ue_max_count_delta_vs_numpy_entropy'] = [int(v) for v in delta.max(axis=1)]
+        parity['ue_counts_within_ties'] = bool(all(int(delta[i].max()) <= ties[i] for i in range(len(thr_ue))))
+        parity['ue_max_abs_dentropy'] = float(np.max(np.abs(u_dev_np - u_np)))
+        parity['ue_voxels'] = int(np.count_nonzero(inside))
     if not args.no_cpu_baseline and world == 1 and not args.aleatoric:     # the CPU leg: rank 0 at N=1 only
         passes_total = T + (0 if (args.ensemble or args.no_ws) else 1)
-        n_sel = cpu_probe_slices(model, params, x_cpu, passes_total, args.cpu_budget)
+        thread_counts, thread_probes = cpu_thread_counts(params, height, width)
+        n_sel = cpu_probe_slices(model, params, x_cpu, passes_total, args.cpu_budget, thread_counts)
         sel = np.unique(np.linspace(0, n_slices - 1, n_sel).round().astype(np.int64))     # first, last and evenly between
         mask_sets_sel = None
         if not args.ensemble:
             mask_sets_sel = [split_masks(model, runner.masks_of(x, last_step, j), n_slices, torch.as_tensor(sel))
                              for j in range(1, T + 1)]
-        cpu, ref = cpu_leg(members, params, x_cpu, sel, mask_sets_sel, not args.no_ws, bool(args.ensemble), args.cpu_budget)
+        cpu, ref = cpu_leg(members, params, x_cpu, sel, mask_sets_sel, not args.no_ws, bool(args.ensemble), args.cpu_budget, thread_counts)
         cpu['unit'] = 'member-{}s/s'.format(unit_name) if args.ensemble else 'MC-sample-{}s/s'.format(unit_name)
+        cpu['thread_probes_s_per_slice'] = {str(c): ('did not finish a 4-slice forward in 40 s: skipped' if v is None else v)
+                                            for c, v in thread_probes.items()}
         if isic:
             cpu['value'] *= n_slices                      # images, not batches
         idx = torch.as_tensor(sel, device=device)
@@ -542,11 +720,16 @@ def main():
                                         T, '' if args.no_ws else ' + weight-scaling pass')),
                    'T': T, 'ws_pass': not (args.no_ws or args.ensemble), 'slices': n_slices, 'height': height, 'width': width,
                    'pass_group': g, 'lanes': args.lanes,
+                   'h2d': 'prefetched, inside timed region ({} MB per {} from pinned host memory on a copy stream, one event wait per '
+                          '{}; rechun/dl/customsteps.py:20)'.format(feeder.bytes // 1000000, unit_name if not isic else 'batch',
+                                                                    unit_name if not isic else 'batch'),
                    'sharding': 'passes over ranks, one RCCL sum-reduce of the statistics per step' if world > 1 else 'none',
                    'gflop_per_sample_{}'.format(unit_name): conv_flops / passes_run / 1e9 / (n_slices if isic else 1)},
         'n_ranks_seen': n_ranks_seen,
         'forwards_per_rank': forwards_per_rank,
-        'with_h2d': with_h2d,
+        'resident': dict(value=units * args.steps / elapsed_resident, ms_per_step=elapsed_resident / args.steps * 1e3, steps=args.steps,
+                         note='the same steps with the volume already in HBM when the clock starts (no host-to-device copy): the '
+                              'secondary figure; `value` has the prefetched copy inside'),
         'roofline': roofline,
         'calibration_kernels': calibration_kernels(device) if (world == 1 and not isic) else None,
         'cpu_baseline': cpu,

@@ -27,6 +27,9 @@ from . import nifti
 
 
 # ------------------------------------------------------------------------------------ transforms
+# Every transform also has a ``batched`` form that takes a dict of BLOCKS (``[n, ...]`` arrays: n consecutive samples) and gives, per
+# sample, exactly what ``__call__`` gives for that sample alone: VolumeDataset builds a loader batch from a few blocks of a volume
+# instead of from 32 per-slice dicts (160 Python-level samples per BraTS subject cost more than the GPU work of the subject).
 class Permute:
     def __init__(self, permutation, entries=('images', 'labels')):
         self.permutation, self.entries = tuple(permutation), tuple(entries)
@@ -36,6 +39,12 @@ class Permute:
             if e in sample:
                 sample[e] = np.transpose(sample[e], self.permutation)
         return sample
+
+    def batched(self, block):
+        for e in self.entries:
+            if e in block:
+                block[e] = np.transpose(block[e], (0,) + tuple(p % (block[e].ndim - 1) + 1 for p in self.permutation))
+        return block
 
 
 class Squeeze:
@@ -48,6 +57,17 @@ class Squeeze:
                 sample[e] = np.squeeze(sample[e], self.axis)
         return sample
 
+    def batched(self, block):
+        for e in self.entries:
+            if e in block:
+                a = block[e]
+                if self.axis is None:      # every axis of length one, but never the block axis
+                    block[e] = a.reshape((a.shape[0],) + tuple(d for d in a.shape[1:] if d != 1))
+                else:
+                    axes = self.axis if isinstance(self.axis, (tuple, list)) else (self.axis,)
+                    block[e] = np.squeeze(a, tuple(ax % (a.ndim - 1) + 1 for ax in axes))
+        return block
+
 
 class UnSqueeze:
     def __init__(self, axis=-1, entries=('images', 'labels')):
@@ -58,6 +78,13 @@ class UnSqueeze:
             if e in sample:
                 sample[e] = np.expand_dims(sample[e], self.axis)
         return sample
+
+    def batched(self, block):
+        for e in self.entries:
+            if e in block:
+                a = block[e]
+                block[e] = np.expand_dims(a, self.axis % a.ndim + 1)      # position among the sample's ndim + 1 output axes, shifted by the block axis
+        return block
 
 
 class IntensityRescale:
@@ -75,6 +102,18 @@ class IntensityRescale:
                 sample[e] = a * (self.upper - self.lower) + self.lower
         return sample
 
+    def batched(self, block):
+        for e in self.entries:
+            if e in block:
+                a = block[e].astype(np.float32)
+                flat = a.reshape(a.shape[0], -1)
+                shape = (a.shape[0],) + (1,) * (a.ndim - 1)
+                lo, hi = flat.min(axis=1).reshape(shape), flat.max(axis=1).reshape(shape)
+                span = np.where(hi > lo, hi - lo, np.float32(1))
+                a = np.where(hi > lo, (a - lo) / span, np.float32(0)).astype(np.float32)
+                block[e] = a * (self.upper - self.lower) + self.lower
+        return block
+
 
 class Compose:
     def __init__(self, transforms):
@@ -84,6 +123,15 @@ class Compose:
         for t in self.transforms:
             sample = t(sample)
         return sample
+
+    @property
+    def batchable(self):
+        return all(hasattr(t, 'batched') and (not isinstance(t, Compose) or t.batchable) for t in self.transforms)
+
+    def batched(self, block):
+        for t in self.transforms:
+            block = t.batched(block)
+        return block
 
 
 transform_registry = {'permute': Permute, 'squeeze': Squeeze, 'unsqueeze': UnSqueeze, 'rescale': IntensityRescale}
@@ -122,6 +170,36 @@ def _npz_member_shape(path, name):
         return tuple(reader(f)[0])
 
 
+def _npz_member_mmap(path, name):
+    """Array ``name`` of an UNCOMPRESSED .npz file (np.savez: ZIP_STORED members) as a read-only memory map of the file, or None
+    when the member is deflated / not a plain array: no read, no CRC pass, no copy -- a slice of the volume is a view of the page
+    cache (np.load reads and checksums the whole 63 MB volume for the first slice of a BraTS subject)."""
+    import struct
+    import zipfile
+    try:
+        with zipfile.ZipFile(path) as z:
+            info = z.getinfo(name + '.npy')
+            if info.compress_type != zipfile.ZIP_STORED:
+                return None
+            header_offset = info.header_offset
+        with open(path, 'rb') as f:
+            f.seek(header_offset)
+            local = f.read(30)
+            if local[:4] != b'PK\x03\x04':
+                return None
+            n_name, n_extra = struct.unpack('<HH', local[26:30])
+            f.seek(header_offset + 30 + n_name + n_extra)
+            version = np.lib.format.read_magic(f)
+            reader = np.lib.format.read_array_header_1_0 if version == (1, 0) else np.lib.format.read_array_header_2_0
+            shape, fortran, dtype = reader(f)
+            if dtype.hasobject:
+                return None
+            offset = f.tell()
+        return np.memmap(path, dtype=dtype, mode='r', shape=tuple(shape), offset=offset, order='F' if fortran else 'C')
+    except (KeyError, OSError, ValueError, struct.error):
+        return None
+
+
 class VolumeDataset(torch_data.Dataset):
     """One sample = one slice (axis 0) of one subject; subjects in sorted order, optionally a subset."""
 
@@ -149,6 +227,7 @@ class VolumeDataset(torch_data.Dataset):
             self.index.extend((si, k) for k in range(shape[0]))
         # the last few subjects read: the loader thread is on subject i + 1 when the test loop asks for the labels of subject i
         self._cache = collections.OrderedDict()
+        self._small = collections.OrderedDict()
         self._cache_lock = threading.Lock()
 
     def _volume(self, si):
@@ -157,12 +236,26 @@ class VolumeDataset(torch_data.Dataset):
             if vol is not None:
                 return vol
         with np.load(self.files[si]) as z:
-            vol = {k: z[k] for k in z.files}
+            vol = {}
+            for k in z.files:
+                big = k == 'images'          # the image volume: mapped, not read (labels and geometry are small: read)
+                arr = _npz_member_mmap(self.files[si], k) if big else None
+                vol[k] = arr if arr is not None else z[k]
         with self._cache_lock:
             self._cache[si] = vol
             while len(self._cache) > 3:
                 self._cache.popitem(last=False)
+            # labels and geometry of the last subjects, kept apart from the image volumes: the test loop asks for them (direct_extract)
+            # several subjects behind the loader thread
+            self._small[si] = {k: v for k, v in vol.items() if k != 'images'}
+            while len(self._small) > 32:
+                self._small.popitem(last=False)
         return vol
+
+    def _subject_entries(self, si):
+        with self._cache_lock:
+            small = self._small.get(si)
+        return small if small is not None else self._volume(si)
 
     def __len__(self):
         return len(self.index)
@@ -170,15 +263,55 @@ class VolumeDataset(torch_data.Dataset):
     def __getitem__(self, i):
         si, k = self.index[i]
         vol = self._volume(si)
-        sample = {'images': vol['images'][k], 'subject_index': si, 'slice_index': k,
+        images = vol['images'][k]
+        if isinstance(images, np.memmap):
+            images = np.array(images)        # out of the read-only file mapping: a slice the transforms and the collate may own
+        sample = {'images': images, 'subject_index': si, 'slice_index': k,
                   'shape': tuple(self.shapes[si][:3]), 'sample_index': i}
         if 'labels' in self.slice_categories:     # extractor `data: {categories: [images, labels]}` (auxiliary_segm)
             sample['labels'] = vol['labels'][k]
         return self.transform(sample)
 
+    def __getitems__(self, indices):
+        """A loader batch at once (torch's DataLoader calls this with the batch's indices when it exists): runs of consecutive
+        slices of one subject are taken from the volume as blocks and go through the batched forms of the transforms -> a
+        ``PreCollated`` batch, equal entry for entry to what CollateDict makes of the per-slice samples."""
+        if not getattr(self.transform, 'batchable', False) or os.environ.get('RCU_BLOCK_LOADER', '1') == '0':
+            return [self[i] for i in indices]
+        keys = ('images', 'labels') if 'labels' in self.slice_categories else ('images',)
+        blocks = {k: [] for k in keys}
+        meta = {'subject_index': [], 'slice_index': [], 'shape': [], 'sample_index': []}
+        b, n = 0, len(indices)
+        while b < n:
+            si, k0 = self.index[indices[b]]
+            e = b + 1
+            while e < n and indices[e] == indices[e - 1] + 1 and self.index[indices[e]][0] == si:
+                e += 1
+            vol = self._volume(si)
+            block = self.transform.batched({k: np.asarray(vol[k][k0:k0 + (e - b)]) for k in keys})
+            for k in keys:
+                blocks[k].append(block[k])
+            for i in indices[b:e]:
+                meta['subject_index'].append(si)
+                meta['slice_index'].append(self.index[i][1])
+                meta['shape'].append(tuple(self.shapes[si][:3]))
+                meta['sample_index'].append(i)
+            b = e
+        out = PreCollated()
+        for k in keys:
+            shape = (n,) + tuple(blocks[k][0].shape[1:])
+            dst = np.empty(shape, dtype=blocks[k][0].dtype)          # one (transposing) copy per block, straight out of the file mapping
+            at = 0
+            for blk in blocks[k]:
+                dst[at:at + blk.shape[0]] = blk
+                at += blk.shape[0]
+            out[k] = torch.from_numpy(dst)
+        out.update(meta)
+        return out
+
     def direct_extract(self, subject_index, entries=('labels', 'properties', 'subject')):
         """Per-subject entries of the ``direct_extractor`` list (names, data(labels), files, properties, subject)."""
-        vol = self._volume(subject_index)
+        vol = self._subject_entries(subject_index)
         out = {}
         if 'labels' in entries and 'labels' in vol:
             out['labels'] = vol['labels']
@@ -247,6 +380,10 @@ class IsicDataset(torch_data.Dataset):
 
 
 # ---------------------------------------------------------------------------- collate and loading
+class PreCollated(dict):
+    """A batch a dataset has collated itself (VolumeDataset.__getitems__)."""
+
+
 class CollateDict:
     """Stack the tensor entries, keep everything else as per-sample lists (common/data/collate.py:4-16)."""
 
@@ -254,6 +391,8 @@ class CollateDict:
         self.entries = entries
 
     def __call__(self, batch):
+        if isinstance(batch, PreCollated):
+            return dict(batch)
         out = {}
         for key in batch[0]:
             if key in self.entries:

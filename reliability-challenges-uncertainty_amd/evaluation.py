@@ -32,7 +32,10 @@ def _device():
 def _to_dev(a, dtype):
     if isinstance(a, torch.Tensor):
         return a.to(device=_device(), dtype=dtype).contiguous()
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device=_device(), dtype=dtype)
+    a = np.ascontiguousarray(a)
+    if dtype == torch.uint8 and a.dtype.kind in 'iub' and a.dtype.itemsize > 1:
+        a = a.astype(np.uint8)       # the cast torch would make on the device (wraps alike), made before the copy: an eighth of the bytes for int64 label maps
+    return torch.from_numpy(a).to(device=_device(), dtype=dtype)
 
 
 # ------------------------------------------------------------------------------------------- ECE

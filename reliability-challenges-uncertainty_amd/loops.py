@@ -10,6 +10,7 @@ Mirrors
 The loop hands every kept output entry to the assembler channel-last as numpy (loops.py:214-220), exactly
 like the reference, so writer hooks and subject steps see the same arrays.
 """
+import contextlib
 import csv
 import logging
 import os
@@ -315,6 +316,10 @@ def merge_batches(batches):
     return out
 
 
+class BatchGroup(list):
+    """Consecutive loader batches to be merged into one (see ``coalesced``)."""
+
+
 def _batch_pixels(batch, entry='images'):
     v = batch.get(entry) if isinstance(batch, dict) else None
     if not torch.is_tensor(v) or v.dim() < 3:
@@ -322,11 +327,14 @@ def _batch_pixels(batch, entry='images'):
     return int(v.shape[0]) * int(v.shape[-1]) * int(v.shape[-2])
 
 
-def coalesced(iterable, max_pixels, entry='images'):
+def coalesced(iterable, max_pixels, entry='images', lazy=False):
     """Merge consecutive loader batches while the merged batch stays within ``max_pixels`` (samples x height x width of ``entry``)
     and the per-sample shapes agree.  The reference's ``batch_size`` is a loader setting: a forward pass is independent per sample
     (tests: batch-split invariance, bit for bit), so the outputs do not depend on how the slices are batched -- but the GPU fills
-    only from about 160 BraTS slices on, and the shipped YAML files feed 32."""
+    only from about 160 BraTS slices on, and the shipped YAML files feed 32.
+    ``lazy``: groups of two or more batches are handed on as a ``BatchGroup`` (a list) for the consumer to merge -- ``prefetch`` copies
+    the pieces of a pinned entry straight into its staging buffer instead of concatenating first."""
+    merge_batches = BatchGroup if lazy else globals()['merge_batches']
     pending, pixels = [], 0
     for batch in iterable:
         px = _batch_pixels(batch, entry)
@@ -378,7 +386,9 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
     ring = {}          # (entry, shape, dtype) -> [_Staged]
 
     def staged(key, v):
-        bufs = ring.setdefault((key, tuple(v.shape), v.dtype), [])
+        pieces = v if isinstance(v, list) else [v]          # a list: the pieces of a batch group, merged by the copy itself
+        shape = (sum(int(t.shape[0]) for t in pieces),) + tuple(pieces[0].shape[1:])
+        bufs = ring.setdefault((key, shape, pieces[0].dtype), [])
         with cond:
             while True:
                 free = [b for b in bufs if not b.busy]
@@ -390,13 +400,16 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
             if free:
                 buf = free[0]
             else:
-                buf = _Staged(v.shape, v.dtype)
+                buf = _Staged(shape, pieces[0].dtype)
                 bufs.append(buf)
             buf.busy = True
         if buf.event is not None:
             buf.event.synchronize()                    # the copy that read this buffer last has finished
             buf.event = None
-        buf.tensor.copy_(v)
+        at = 0
+        for t in pieces:
+            buf.tensor[at:at + t.shape[0]].copy_(t)
+            at += t.shape[0]
         return buf
 
     def put(entry):
@@ -408,22 +421,57 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
                 continue
         return False
 
+    timing = os.environ.get('RCU_LOOP_TIMING') == '1'
+    spent = {'load': 0.0, 'stage': 0.0, 'items': 0}
+
+    def timed_iter():
+        it = iter(iterable)
+        while True:
+            t0 = time.perf_counter()
+            try:
+                item = next(it)
+            except StopIteration:
+                return
+            spent['load'] += time.perf_counter() - t0
+            spent['items'] += 1
+            yield item
+
     def worker():
         try:
-            for item in iterable:
+            for item in (timed_iter() if timing else iterable):
+                t_stage = time.perf_counter()
                 held = []
+                group = item if isinstance(item, BatchGroup) else None
+                if group is not None:
+                    keys = list(group[0].keys())
+                    direct = [k for k in pin_entries if torch.is_tensor(group[0].get(k)) and group[0][k].is_floating_point()
+                              and not group[0][k].is_cuda] if (pin and len(group) > 1) else []
+                    rest = merge_batches([{k: v for k, v in b.items() if k not in direct} for b in group])
+                    item = {}
+                    for k in keys:
+                        if k in direct:                   # merged by the copy into the staging buffer
+                            buf = staged(k, [b[k] for b in group])
+                            if buf is None:
+                                return
+                            item[k] = buf.tensor
+                            held.append(buf)
+                        else:
+                            item[k] = rest[k]
                 if pin and isinstance(item, dict):
                     item = dict(item)
                     for k in pin_entries:
                         v = item.get(k)
-                        if torch.is_tensor(v) and v.is_floating_point() and not v.is_cuda:
+                        if torch.is_tensor(v) and v.is_floating_point() and not v.is_cuda and not v.is_pinned():
                             buf = staged(k, v)
                             if buf is None:
                                 return
                             item[k] = buf.tensor
                             held.append(buf)
+                spent['stage'] += time.perf_counter() - t_stage
                 if not put((item, held, None)):
                     return
+            if timing:
+                logging.info('loader thread: {items} items, {load:.3f} s loading + collating, {stage:.3f} s merging + staging'.format(**spent))
             put((done, [], None))
         except BaseException as exc:  # noqa: BLE001 - re-raised in the consumer
             put((done, [], exc))
@@ -554,11 +602,12 @@ class Test:
         pipelined = bool(pipelined) and (self.convert_fn is tensor_to_numpy and self.subject_assembler is not None and
                                          getattr(context.device, 'type', 'cpu') == 'cuda')
         side = torch.cuda.Stream(device=context.device) if pipelined else None
+        self._subject_stream = torch.cuda.Stream(device=context.device) if pipelined else None
         loader = task_context.data.loader
         if pipelined:
             coalesce = self.coalesce if self.coalesce is not None else int(os.environ.get('RCU_COALESCE', self.COALESCE_PIXELS))
             if coalesce > 0:
-                loader = coalesced(loader, coalesce)
+                loader = coalesced(loader, coalesce, lazy=True)
         waiting = None
         batches = prefetch(loader, pin=pipelined)
         try:
@@ -608,15 +657,19 @@ class Test:
                 last = batch_context.batch_index == task_context.data.nb_batches - 1
             self.subject_assembler.add_batch(to_assemble, batch_context.input, last_batch=last)
 
-            for subject_index in sorted(self.subject_assembler.subjects_ready, key=str):
-                subject_data = self.subject_assembler.get_assembled_subject(subject_index)
-                subject_context = SubjectContext(subject_index, subject_data)
-                hook.on_test_subject_start(subject_context, task_context, context)
-                for subject_step in self.subject_steps:
-                    subject_step(subject_context, task_context, context)
-                if subject_context.metrics:
-                    task_context.history.add(subject_context.metrics, 'subject_metrics')
-                hook.on_test_subject_end(subject_context, task_context, context)
+            # Pipelined: the subject steps and hooks run with a stream of their own as the current one.  Their GPU work (the metric
+            # seam: Dice counts of the assembled subject) is independent of the batch steps', but on the compute stream every small
+            # host-to-device copy of theirs would queue behind the NEXT batch's forward passes, which are already enqueued there.
+            with (torch.cuda.stream(self._subject_stream) if download is not None else contextlib.nullcontext()):
+                for subject_index in sorted(self.subject_assembler.subjects_ready, key=str):
+                    subject_data = self.subject_assembler.get_assembled_subject(subject_index)
+                    subject_context = SubjectContext(subject_index, subject_data)
+                    hook.on_test_subject_start(subject_context, task_context, context)
+                    for subject_step in self.subject_steps:
+                        subject_step(subject_context, task_context, context)
+                    if subject_context.metrics:
+                        task_context.history.add(subject_context.metrics, 'subject_metrics')
+                    hook.on_test_subject_end(subject_context, task_context, context)
         hook.on_test_batch_end(batch_context, task_context, context)
 
     def _test_batch(self, batch_context, task_context, context, hook):

@@ -144,7 +144,9 @@ def write(path, array, properties=None, compresslevel=None):
     payload = bytes(hdr) + b'\x00\x00\x00\x00' + array.tobytes()
     if str(path).endswith('.gz'):
         level = compresslevel if compresslevel is not None else (1 if array.dtype.kind == 'f' else 3)
-        with gzip.open(path, 'wb', compresslevel=level) as f:
+        # mtime 0: the file is a function of the voxels and the geometry alone (a run writes the same bytes whenever, and in
+        # whatever order, its writer threads get to it)
+        with gzip.GzipFile(path, 'wb', compresslevel=level, mtime=0) as f:
             f.write(payload)
     else:
         with open(path, 'wb') as f:
@@ -252,14 +254,14 @@ def join_all():
         fut.result()
 
 
-def argmax_last(probabilities):
-    """``np.argmax(probabilities, axis=-1)`` (int64, first maximum wins, a NaN counts as the maximum): for two classes one compare
-    instead of numpy's generic reduction over a two-element axis."""
+def argmax_last(probabilities, dtype=np.int64):
+    """``np.argmax(probabilities, axis=-1)`` (first maximum wins, a NaN counts as the maximum) as ``dtype``: for two classes one
+    compare instead of numpy's generic reduction over a two-element axis."""
     probabilities = np.asarray(probabilities)
     if probabilities.shape[-1] != 2 or probabilities.dtype.kind != 'f':
-        return np.argmax(probabilities, axis=-1)
+        return np.argmax(probabilities, axis=-1).astype(dtype, copy=False)
     p0, p1 = probabilities[..., 0], probabilities[..., 1]
-    return ((p1 > p0) | ((p1 != p1) & (p0 == p0))).astype(np.int64)
+    return ((p1 > p0) | ((p1 != p1) & (p0 == p0))).view(np.uint8).astype(dtype, copy=False)
 
 
 def write_subject(test_dir, subject, probabilities, properties=None, sigma=None, in_background=True, prediction=None):
@@ -273,7 +275,7 @@ def write_subject(test_dir, subject, probabilities, properties=None, sigma=None,
     def predict():
         if prediction is not None:
             return np.asarray(prediction).astype(np.uint8)
-        return argmax_last(probabilities).astype(np.uint8)
+        return argmax_last(probabilities, np.uint8)
 
     def write_probabilities():
         write(os.path.join(test_dir, '{}_probabilities.nii.gz'.format(subject)),

@@ -45,9 +45,9 @@ class EvalSubjectStep(loops.SubjectStep):
 
     def __call__(self, subject_context, task_context, context) -> None:
         probabilities = subject_context.subject_data['probabilities']
-        prediction = nifti.argmax_last(probabilities)
+        prediction = nifti.argmax_last(probabilities, np.uint8)      # (class indices: uint8 holds them; np.argmax's int64 where it is kept)
         if self.keep_prediction:
-            subject_context.subject_data['prediction'] = prediction
+            subject_context.subject_data['prediction'] = prediction.astype(np.int64)
         subject_context.more['prediction'] = prediction      # the writer hook takes it from here instead of a second arg-max
         target = subject_context.subject_data['labels']
         if self.squeeze_labels:

@@ -674,13 +674,54 @@ def g16_postnet_wide():
     save('g16_postnet_wide', **arrays)
 
 
+def g17_unet_no_bn():
+    """The model-seam switches no shipped config uses: ``bn=False`` (Conv2dBnRelu skips the BatchNorm, unet.py:16-17; UNet passes
+    the flag to every block and to both heads, unet.py:128-164) and ``dropout=None`` (no Dropout2d modules at all, unet.py:14-15,
+    63-72).  a: bn=False with dropout (eval pass + one MC pass under the masks the reference drew); b: bn=False, dropout=None,
+    sigma head; c: bn=True, dropout=None."""
+    import common.utils.torchhelper as ref_th
+    gen = torch.Generator().manual_seed(171)
+    arrays = {}
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=4, dropout=0.3, bn=False)
+    model = make_unet(17, **params)
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in model.modules())
+    x = torch.randn(2, 4, 32, 32, generator=gen)
+    site_names = [n for n, _ in dropout_modules(model)]
+    with torch.no_grad():
+        arrays['logits_a_eval'] = model(x).numpy()
+        torch.manual_seed(23)
+        ref_th.set_dropout_mode(model, True)
+        y, recs = capture_masks(model, lambda: model(x))
+        ref_th.set_dropout_mode(model, False)
+    arrays['logits_a_mc'] = y.numpy()
+    for s_, (_, mask) in enumerate(recs):
+        arrays['mask_a_{}'.format(s_)] = mask
+    arrays.update(params_a=np.array(repr(params)), x_a=x.numpy(), sites_a=np.array(site_names))
+    arrays.update(state_to_npz(model, 'sd_a::'))
+    params_b = dict(nb_classes=2, in_channels=3, depth=3, start_filters=8, dropout=None, bn=False, sigma_out=True)
+    model_b = make_unet(18, **params_b)
+    assert not dropout_modules(model_b)
+    xb = torch.rand(1, 3, 24, 40, generator=gen)
+    with torch.no_grad():
+        lb, sb = model_b(xb)
+    arrays.update(params_b=np.array(repr(params_b)), x_b=xb.numpy(), logits_b=lb.numpy(), sigma_b=sb.numpy())
+    arrays.update(state_to_npz(model_b, 'sd_b::'))
+    params_c = dict(nb_classes=2, in_channels=4, depth=4, start_filters=4, dropout=None)
+    model_c = make_unet(19, **params_c)
+    xc = torch.randn(2, 4, 32, 48, generator=gen)
+    with torch.no_grad():
+        arrays.update(params_c=np.array(repr(params_c)), x_c=xc.numpy(), logits_c=model_c(xc).numpy())
+    arrays.update(state_to_npz(model_c, 'sd_c::'))
+    save('g17_unet_no_bn', **arrays)
+
+
 def main():
     install_reference()
     torch.set_num_threads(4)
     torch.set_grad_enabled(False)
     for fn in (g1_unet_eval, g2_unet_mc, g3_unet_center, g4_unet_sigma, g5_unet_isic, g6_mc_summary,
                g7_mc_step_end2end, g8_ece, g9_uncertainty, g10_prep, g11_fullsize_digest, g12_eval_csv, g13_postnet, g14_unet_residual, g15_unet_centre_pad,
-               g16_postnet_wide):
+               g16_postnet_wide, g17_unet_no_bn):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

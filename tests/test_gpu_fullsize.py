@@ -175,3 +175,109 @@ def test_centre_pad_shapes_full_width_vs_oracle(dev, cin, n, h, w):
         assert _maxdiff(out, ref) < LOGIT_TOL
     if n > 1:
         assert np.array_equal(m(x[:1].to(dev), [mk[:1] for mk in masks]).cpu().numpy(), out[:1])
+
+
+def _split_masks(model, flat, n, rows):
+    """Concatenated device mask tensor [site][n][C_site] -> per-site [len(rows), C_site] CPU tensors."""
+    out, off = [], 0
+    for _, c in model.dropout_sites():
+        out.append(flat[off:off + n * c].view(n, c)[rows].cpu())
+        off += n * c
+    return out
+
+
+@pytest.mark.timeout(1200)
+def test_ensemble_of_ten_members_on_the_full_volume(dev):
+    """BASELINE configs[3] at full size on one GPU: K = 10 members over the 160-slice volume through the runner the bench uses
+    (ShardedEnsembleRunner, two stream lanes, one launch per member).  Eight slices against the oracle's ten forwards; the 160-slice
+    launches bit-identical to 8-slice launches of the same slices (one lane); lanes and member order change the float32 summation
+    order only; same bits run after run; the step seam (EnsemblePredictionStep) gives the runner's result."""
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import distributed as rdist
+    from rcu_amd import steps
+    K = 10
+    n, h, w = 160, 192, 128
+    states = [uo.synthetic_state(50 + k, **PARAMS) for k in range(K)]
+    members = [_model(PARAMS, st, dev) for st in states]
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, 4, h, w, generator=g)
+    xd = x.to(dev)
+    sel = np.r_[0:3, 78:81, 158:160]
+    two = rdist.ShardedEnsembleRunner(members, lanes=2)
+    out = two.step(xd, 0)
+    assert two.forwards_run == K and set(out) == {'probabilities', 'entropy'}
+    again = two.step(xd, 1)
+    for key in out:
+        assert torch.equal(out[key], again[key]), key                       # fixed launch -> lane assignment: same bits
+    one = rdist.ShardedEnsembleRunner(members, lanes=1).step(xd, 0)
+    rev = rdist.ShardedEnsembleRunner(members[::-1], lanes=1).step(xd, 0)
+    for key in out:
+        assert float((out[key] - one[key]).abs().max()) < 1e-6, key
+        assert float((rev[key] - one[key]).abs().max()) < 1e-6, key
+    small = rdist.ShardedEnsembleRunner([_model(PARAMS, st, dev) for st in states], lanes=1).step(xd[sel], 0)
+    for key in out:
+        assert torch.equal(one[key][sel], small[key]), key                  # a slice does not depend on the batch it runs in
+    multi = so.ensemble_probabilities([lambda xx, m, st=st: uo.unet_forward(st, xx, m, **PARAMS) for st in states], x[sel])
+    ref = so.multi_prediction_summary(multi)
+    for key in ('probabilities', 'entropy'):
+        assert _maxdiff(out[key][sel].cpu().numpy(), ref[key].numpy()) < PROB_TOL, key
+    bc = steps.BatchContext({'images': x}, 0)
+    ctx = steps.TorchTestContext('cuda', members[0])
+    steps.EnsemblePredictionStep(members[1:])(bc, None, ctx)
+    steps.MultiPredictionSummary()(bc, None, ctx)
+    for key in ('probabilities', 'entropy'):
+        assert torch.equal(bc.output[key], out[key]), key
+    p = out['probabilities']
+    assert float((p.sum(1) - 1).abs().max()) < 1e-6 and float(out['entropy'].min()) >= 0 and float(out['entropy'].max()) <= np.log(2) + 1e-6
+
+
+@pytest.mark.timeout(1200)
+def test_sigma_head_mc50_on_the_full_volume(dev):
+    """BASELINE configs[4] at full size on one GPU: sigma-head U-Net, T = 50 stochastic passes + the weight-scaling pass over the
+    160-slice volume through ShardedAleatoricMcRunner (pass pairs, two stream lanes, masks drawn per (seed, volume, pass)).  Four
+    slices against the composed oracle (the reference's pieces: customsteps.py:16-39, brats_test_aleatoric.py:57-73) under the very
+    masks the runner drew; pass pairs == single passes bit for bit (one lane); lanes within float32 summation order; same seed, same
+    bits."""
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import distributed as rdist
+    params = dict(PARAMS, sigma_out=True)
+    st = uo.synthetic_state(61, **params)
+    T = 50
+    n, h, w = 160, 192, 128
+    model = _model(params, st, dev)
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(n, 4, h, w, generator=g)
+    xd = x.to(dev)
+    sel = np.array([0, 79, 80, 159])
+    runner = rdist.ShardedAleatoricMcRunner(model, T, seed=7, lanes=2, pass_group=2)
+    out = runner.step(xd, 3)
+    assert runner.forwards_run == T + 1
+    assert set(out) == {'probabilities', 'entropy', 'sigma', 'ws_probabilities', 'ws_sigma'}
+    again = rdist.ShardedAleatoricMcRunner(model, T, seed=7, lanes=2, pass_group=2).step(xd, 3)
+    pairs = rdist.ShardedAleatoricMcRunner(model, T, seed=7, lanes=1, pass_group=2).step(xd, 3)
+    singles = rdist.ShardedAleatoricMcRunner(model, T, seed=7, lanes=1, pass_group=1).step(xd, 3)
+    other = rdist.ShardedAleatoricMcRunner(model, T, seed=8, lanes=2, pass_group=2).step(xd, 3)
+    for key in out:
+        assert torch.equal(out[key], again[key]), key
+        assert torch.equal(pairs[key], singles[key]), key
+        assert float((out[key] - pairs[key]).abs().max()) < 1e-5 * max(1.0, float(pairs[key].abs().max())), key
+    assert float((out['probabilities'] - other['probabilities']).abs().max()) > 1e-5          # the seed matters
+    assert torch.equal(out['ws_probabilities'], other['ws_probabilities'])                     # ... but not for the deterministic pass
+    # the composed oracle on four slices under the runner's masks
+    rows = torch.as_tensor(sel)
+    mask_sets = [_split_masks(model, runner.masks_of(xd, 3, j), n, rows) for j in range(1, T + 1)]
+    xs = x[sel]
+    lg0, raw0 = uo.unet_forward(st, xs, None, **params)
+    passes = [uo.unet_forward(st, xs, mk, **params) for mk in mask_sets]
+    multi = torch.stack([torch.softmax(lg, 1) for lg, _ in passes])
+    ref = so.multi_prediction_summary(multi)
+    sigma_ref = torch.stack([raw.abs() for _, raw in passes]).mean(0)
+    assert _maxdiff(out['probabilities'][sel].cpu().numpy(), ref['probabilities'].numpy()) < PROB_TOL
+    assert _maxdiff(out['entropy'][sel].cpu().numpy(), ref['entropy'].numpy()) < PROB_TOL
+    assert _maxdiff(out['ws_probabilities'][sel].cpu().numpy(), torch.softmax(lg0, 1).numpy()) < PROB_TOL
+    scale = max(1.0, float(sigma_ref.max()))
+    assert _maxdiff(out['sigma'][sel].cpu().numpy(), sigma_ref.numpy()) < PROB_TOL * scale
+    assert _maxdiff(out['ws_sigma'][sel].cpu().numpy(), raw0.abs().numpy()) < PROB_TOL * scale
+    assert float(out['sigma'].min()) >= 0

@@ -11,6 +11,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_two_ranks_one_gpu_pipelined_matches_single_rank():
@@ -30,15 +37,16 @@ def test_two_ranks_one_gpu_pipelined_matches_single_rank():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('port,extra', [(29541, ['--mc', '4']), (29542, ['--mc', '4', '--aleatoric']), (29543, ['--ensemble', '3'])])
-def test_bench_two_ranks_through_torch_distributed_run(port, extra):
+@pytest.mark.parametrize('extra', [['--mc', '4'], ['--mc', '4', '--aleatoric'], ['--ensemble', '3'], ['--mc', '4', '--ws-transport', 'p2p']],
+                         ids=['mc', 'aleatoric', 'ensemble', 'mc-ws-p2p'])
+def test_bench_two_ranks_through_torch_distributed_run(extra):
     """The driver's N>1 launch line (python -m torch.distributed.run ... bench.py --gpus N) with both ranks on the one
     GPU of the test box over gloo (test-only switches of bench.py): rank 0 prints the one JSON line -- for the MC-dropout
     workload, its sigma-head extension and the ensemble workload."""
     import json
     env = dict(os.environ, RCU_BENCH_SINGLE_DEVICE='1', RCU_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
+           '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
            '--warmup', '1'] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

@@ -1099,3 +1099,63 @@ def test_unet_centre_pad_golden(golden, dev):
         y = m(torch.from_numpy(g['x_' + tag]).to(dev)).cpu().numpy()
         assert y.shape == g['logits_' + tag].shape
         assert _maxdiff(y, g['logits_' + tag]) < LOGIT_TOL, tag
+
+
+def test_unet_no_batchnorm_no_dropout_golden(golden, dev):
+    """Reference golden G17: ``bn=False`` (Conv2dBnRelu without BatchNorm, unet.py:16-17; every block and both heads,
+    unet.py:128-164) with dropout -- eval pass and an MC pass under the reference's masks --, ``bn=False, dropout=None`` with a
+    sigma head, and ``dropout=None`` with BatchNorm: the model-seam switches no shipped config uses."""
+    from rcu_amd import steps
+    g = golden('g17_unet_no_bn')
+
+    def tagged(tag):
+        params = eval(str(g['params_' + tag]), {'__builtins__': {}}, {'dict': dict})
+        st = {k[len('sd_{}::'.format(tag)):]: v for k, v in g.items() if k.startswith('sd_{}::'.format(tag))}
+        return params, st
+
+    params, st = tagged('a')
+    m = _model(params, st, dev)
+    assert not any('.bn.' in k for k in m.state_dict()) and [s[0] for s in m.dropout_sites()] == list(g['sites_a'])
+    x = torch.from_numpy(g['x_a']).to(dev)
+    assert _maxdiff(m(x).cpu().numpy(), g['logits_a_eval']) < LOGIT_TOL
+    masks = [g['mask_a_{}'.format(s)] for s in range(len(g['sites_a']))]
+    assert _maxdiff(m(x, masks).cpu().numpy(), g['logits_a_mc']) < LOGIT_TOL
+    params, st = tagged('b')
+    mb = _model(params, st, dev)
+    assert mb.dropout_sites() == [] and not mb.mc_active()
+    steps.set_dropout_mode(mb, True)                 # nothing to switch on: still deterministic
+    logits, sigma = mb(torch.from_numpy(g['x_b']).to(dev))
+    assert _maxdiff(logits.cpu().numpy(), g['logits_b']) < LOGIT_TOL
+    assert _maxdiff(sigma.cpu().numpy(), g['sigma_b']) < LOGIT_TOL
+    params, st = tagged('c')
+    mc = _model(params, st, dev)
+    assert _maxdiff(mc(torch.from_numpy(g['x_c']).to(dev)).cpu().numpy(), g['logits_c']) < LOGIT_TOL
+
+
+def test_unet_no_batchnorm_full_width_vs_oracle(dev):
+    """bn=False at the shipped width on the BraTS slice size (the Winograd kernels, the fused classifier head): eval pass, an MC pass
+    under injected masks, and the fused statistics path against the oracle."""
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05, bn=False)
+    st = uo.synthetic_state(43, **params)
+    assert not any('.bn.' in k for k in st)
+    g = torch.Generator().manual_seed(16)
+    n, h, w = 2, 192, 128
+    x = torch.randn(n, 4, h, w, generator=g)
+    _, sites = uo.unet_plan(**params)
+    mask_sets = [uo.sample_masks(sites, n, 0.3, g) for _ in range(2)]
+    m = _model(params, st, dev)
+    for mk in (None, mask_sets[0]):
+        ref = uo.unet_forward(st, x, mk, **params).numpy()
+        scale = max(1.0, float(np.abs(ref).max()))       # no normalisation anywhere: the logits can be of O(10)
+        assert _maxdiff(m(x.to(dev), mk).cpu().numpy(), ref) < LOGIT_TOL * scale
+    bc = steps.BatchContext({'images': x}, 0)
+    ctx = steps.TorchTestContext('cuda', m)
+    steps.McPredictStep(2, masks=mask_sets)(bc, None, ctx)
+    steps.MultiPredictionSummary()(bc, None, ctx)
+    ws, multi = so.mc_probabilities(lambda xx, mk: uo.unet_forward(st, xx, mk, **params), x, mask_sets)
+    ref = so.multi_prediction_summary(multi)
+    assert _maxdiff(bc.output['probabilities'].cpu().numpy(), ref['probabilities'].numpy()) < PROB_TOL
+    assert _maxdiff(bc.output['ws_probabilities'].cpu().numpy(), ws.numpy()) < PROB_TOL

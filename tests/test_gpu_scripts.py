@@ -133,6 +133,35 @@ def test_brats_ensemble_and_aleatoric_then_eval(tmp_path):
     assert [r['subject_name'] for r in rows] == sorted(vols) and all(0 <= float(r['ece']) <= 1 for r in rows)
 
 
+def _files(ctx):
+    return {os.path.basename(f): open(f, 'rb').read() for f in sorted(glob.glob(os.path.join(ctx.test_dir, '*.nii.gz')))}
+
+
+def test_pipelined_coalesced_loop_writes_the_files_of_the_serial_loop(tmp_path, monkeypatch):
+    """The test loop's pipeline (loader thread, batches coalesced up to a volume, outputs downloaded on a side stream, NIfTI files
+    written by a pool of threads) must not change a byte of what the reference-ordered serial loop writes: deterministic config --
+    default loop against RCU_PIPELINE=0 (which also means no coalescing), whole .nii.gz files compared; MC-dropout config -- masks are
+    drawn per batch, so the batches are kept as the loader makes them (RCU_COALESCE=0) and the pipelined loop is compared with the
+    serial one under the same seed."""
+    from rcu_amd import scripts
+    cfg_det, vols, _, _ = _setup(tmp_path / 'det')
+    fast = _files(scripts.test_default('brats', cfg_det, None))
+    monkeypatch.setenv('RCU_PIPELINE', '0')
+    slow = _files(scripts.test_default('brats', cfg_det, None))
+    monkeypatch.delenv('RCU_PIPELINE')
+    assert sorted(fast) == sorted(slow) and len(fast) == 2 * len(vols)
+    for name in fast:
+        assert fast[name] == slow[name], name
+    cfg_mc, vols_mc, _, _ = _setup(tmp_path / 'mc', mc=4)
+    monkeypatch.setenv('RCU_COALESCE', '0')
+    fast = _files(scripts.test_default('brats', cfg_mc, None))
+    monkeypatch.setenv('RCU_PIPELINE', '0')
+    slow = _files(scripts.test_default('brats', cfg_mc, None))
+    assert len(fast) == 2 * len(vols_mc)
+    for name in fast:
+        assert fast[name] == slow[name], name
+
+
 ISIC_MC_YAML = """
 config:
   test_name: isic_test_baseline_mc
@@ -202,6 +231,52 @@ def test_isic_default_script_mc2(tmp_path):
         assert np.array_equal(pred, (p > 0.5).astype(np.uint8)) or np.mean(pred == (p > 0.5)) > 0.9999
         assert os.path.islink(os.path.join(ctx.test_dir, id_ + '.jpg'))
         assert os.path.islink(os.path.join(ctx.test_dir, id_ + '_segmentation.png'))
+
+
+@pytest.mark.parametrize('coalesce', ['0', None], ids=['batch-per-image', 'coalesced'])
+def test_isic_many_batches_keep_their_own_labels(tmp_path, monkeypatch, coalesce):
+    """Ten ISIC subjects, batch_size 1, float labels (the shipped configs rescale ``labels``): with RCU_COALESCE=0 the pipelined loop
+    runs ten batches -- more than the loader's staging ring holds -- and every subject's Dice must be the Dice of ITS prediction
+    against ITS label image (labels are kept on the host by PrepareSubjectStep until the batch is finished: a staging buffer reused
+    too early would hand a later batch's labels to an earlier subject).  Coalesced (the default) the ten images run as one batch and
+    give the same files."""
+    from PIL import Image
+    from oracle import calib_oracle as co
+    from oracle import unet_oracle as uo
+    from rcu_amd import management as mgt
+    from rcu_amd import nifti, scripts
+    if coalesce is not None:
+        monkeypatch.setenv('RCU_COALESCE', coalesce)
+    params = dict(nb_classes=2, in_channels=3, depth=4, start_filters=8, dropout=0.05)
+    prefix = tmp_path / 'isic_many' / 'ISIC-2017_Test_v2'
+    img_dir, lab_dir = str(prefix) + '_Data', str(prefix) + '_Part1_GroundTruth'
+    os.makedirs(img_dir)
+    os.makedirs(lab_dir)
+    rng = np.random.RandomState(6)
+    ids = ['ISIC_00001{:02d}'.format(i) for i in range(10)]
+    labels = {}
+    for i, id_ in enumerate(ids):
+        Image.fromarray(rng.randint(0, 255, (64, 64, 3)).astype(np.uint8)).save(os.path.join(img_dir, id_ + '.jpg'))
+        lab = np.zeros((64, 64), np.uint8)
+        lab[2 * i:2 * i + 8 + 5 * i, 3 * i:3 * i + 30] = 255               # a different rectangle (and area) per subject
+        labels[id_] = lab
+        Image.fromarray(lab).save(os.path.join(lab_dir, id_ + '_segmentation.png'))
+    st = uo.synthetic_state(23, **params)
+    mf = mgt.ModelFiles(str(tmp_path / 'train'), 'isic')
+    mgt.save_model(mf, 'unet', params, st)
+    cfg_path = str(tmp_path / 'test_isic_baseline_mc.yaml')
+    with open(cfg_path, 'w') as f:
+        f.write(ISIC_MC_YAML.format(test_dir=str(tmp_path / 'out'), model_dir=mf.model_dir, dataset=str(prefix)))
+    ctx = scripts.test_default('isic', cfg_path, None)
+    rows = {r['subject']: r for r in csv.DictReader(open(os.path.join(ctx.test_dir, 'metrics.csv')))}
+    assert sorted(rows) == ids
+    dices = []
+    for id_ in ids:
+        pred = nifti.read(os.path.join(ctx.test_dir, id_ + '_prediction.nii.gz'))[0]
+        tp, tn, fp, fn, n = co.confusion_counts(pred, (labels[id_] > 127).astype(np.uint8))
+        dices.append(co.dice_from_counts(tp, fp, fn))
+        assert abs(float(rows[id_]['dice']) - dices[-1]) < 1e-12, id_
+    assert len(set(round(d, 9) for d in dices)) > 5          # the subjects are told apart by their labels
 
 
 def _confidence(ctx, name):

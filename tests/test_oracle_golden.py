@@ -284,3 +284,30 @@ def test_g16_postnet_wide_and_mc(golden):
     masks = [g['mask_d_{}'.format(s)] for s in range(3)]
     assert any((m == 0).any() for m in masks)
     _close(uo.postnet_forward(st, g['features_d'], nb_convs=3, masks=masks).numpy(), g['logits_d_mc'], 5e-6)
+
+
+def _tagged(g, tag):
+    params = eval(str(g['params_' + tag]), {'__builtins__': {}}, {'dict': dict})
+    st = {k[len('sd_{}::'.format(tag)):]: v for k, v in g.items() if k.startswith('sd_{}::'.format(tag))}
+    return params, st
+
+
+def test_g17_no_batchnorm_and_no_dropout(golden):
+    """bn=False (unet.py:16-17, 128-164) and dropout=None (unet.py:14-15): the switches no shipped config uses."""
+    g = golden('g17_unet_no_bn')
+    p, st = _tagged(g, 'a')
+    assert p['bn'] is False and not any('.bn.' in k for k in st)
+    _, sites = uo.unet_plan(**p)
+    assert [s[0] for s in sites] == list(g['sites_a'])
+    masks = [g['mask_a_{}'.format(s)] for s in range(len(sites))]
+    assert any((m == 0).any() for m in masks)
+    _close(uo.unet_forward(st, g['x_a'], None, **p).numpy(), g['logits_a_eval'], 5e-6)
+    _close(uo.unet_forward(st, g['x_a'], masks, **p).numpy(), g['logits_a_mc'], 5e-6)
+    p, st = _tagged(g, 'b')
+    assert p['dropout'] is None and uo.unet_plan(**p)[1] == []
+    logits, sigma = uo.unet_forward(st, g['x_b'], None, **p)
+    _close(logits.numpy(), g['logits_b'], 5e-6)
+    _close(sigma.numpy(), g['sigma_b'], 5e-6)
+    p, st = _tagged(g, 'c')
+    assert uo.unet_plan(**p)[1] == [] and any('.bn.' in k for k in st)
+    _close(uo.unet_forward(st, g['x_c'], None, **p).numpy(), g['logits_c'], 5e-6)

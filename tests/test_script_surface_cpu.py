@@ -311,3 +311,65 @@ def test_directories_mirror_and_eval_command_line(tmp_path, monkeypatch):
                         '--act', 'minmax'], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and 'RCU_BRATS_ORIG_DATA_DIR' in r.stderr
     assert "to_evaluate: ['baseline_mc']" in r.stdout and "eval_actions: ['minmax']" in r.stdout
+
+
+def test_coalesced_batches_and_prefetch_protocol():
+    """rcu_amd.loops.coalesced merges collated loader batches up to a pixel budget (tensors concatenated, per-sample lists joined) and
+    never across a change of the image shape; prefetch hands every item out with a release callback, stages only the entries it is
+    told to, and its loader thread stops when the consumer stops early."""
+    import threading
+    import torch
+    from rcu_amd import loops
+
+    def batch(i, n, h=4, w=4):
+        return {'images': torch.full((n, 2, h, w), float(i)), 'labels': torch.full((n, h, w), float(i)),
+                'subject_index': [i] * n, 'slice_index': list(range(n))}
+
+    src = [batch(0, 2), batch(1, 2), batch(2, 2), batch(3, 2, 8, 8), batch(4, 3), 'not a dict', batch(5, 1)]
+    out = list(loops.coalesced(src, max_pixels=4 * 16))
+    assert [b['images'].shape[0] if isinstance(b, dict) else b for b in out] == [4, 2, 2, 3, 'not a dict', 1]
+    assert out[0]['subject_index'] == [0, 0, 1, 1] and out[0]['slice_index'] == [0, 1, 0, 1]
+    assert torch.equal(out[0]['labels'][:, 0, 0], torch.tensor([0., 0., 1., 1.]))
+    assert out[2]['images'].shape[-1] == 8
+    assert [b['images'].shape[0] for b in loops.coalesced(src[:3], max_pixels=1)] == [2, 2, 2]      # a budget below one batch: as loaded
+    got = []
+    for item, release in loops.prefetch(iter(src[:3]), depth=1):
+        got.append(int(item['images'][0, 0, 0, 0]))
+        release()
+    assert got == [0, 1, 2]
+    before = threading.active_count()
+    gen = loops.prefetch(iter([batch(i, 1) for i in range(50)]), depth=1)
+    next(gen)
+    gen.close()                      # the consumer stops early: the loader thread must not stay blocked on its queue
+    for _ in range(100):
+        if threading.active_count() <= before:
+            break
+        threading.Event().wait(0.02)
+    assert threading.active_count() <= before
+
+    def boom():
+        yield batch(0, 1)
+        raise RuntimeError('loader failed')
+
+    with pytest.raises(RuntimeError, match='loader failed'):
+        for _item, release in loops.prefetch(boom()):
+            release()
+
+
+def test_check_min_max_raises_or_warns_like_the_reference():
+    """rechun/eval/helper.py:31-47: the maximum is checked first, then the minimum; ValueError unless only_warn (ToEntropy passes
+    only_warn=True, rechun/eval/analysis.py:202)."""
+    import warnings
+    from rcu_amd import evaluation as ev
+    ok = np.array([0.0, 0.5, 1.0], dtype=np.float32)
+    ev.check_min_max(ok)
+    with pytest.raises(ValueError, match='Found value larger than 1: "1.5"'):
+        ev.check_min_max(np.array([-1.0, 1.5]))
+    with pytest.raises(ValueError, match='Found value smaller than 0: "-0.25"'):
+        ev.check_min_max(np.array([-0.25, 1.0]))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ev.check_min_max(np.array([-1.0, 1.5]), only_warn=True)
+    assert [str(x.message) for x in w] == ['Found value larger than 1: "1.5"', 'Found value smaller than 0: "-1.0"']
+    with pytest.raises(ValueError, match='larger than 2'):
+        ev.check_min_max(np.array([3.0]), min_=1, max_=2)

@@ -11,6 +11,8 @@ for path in sys.argv[1:]:
         continue
     r = d['roofline']
     par = d.get('parity') or {}
-    print('{}: {:.2f} {} | {:.2f} ms/step | lanes {} group {} | dominant {} frac {:.3f} avg launch {:.4f} ms | conv {:.3f} ms/forward frac {:.3f} | dp {} bins {}'.format(
-        path, d['value'], d['unit'], d['ms_per_step'], d['config'].get('lanes'), d['config'].get('pass_group'), r['kernel'], r['frac'], r['avg_launch_ms'],
-        r['all_conv_kernels']['ms_per_forward'], r['all_conv_kernels']['frac'], par.get('max_abs_dprobabilities_vs_cpu'), par.get('bin_ids_equal')))
+    res = (d.get('resident') or {}).get('value')
+    print('{}: {:.2f} {} (resident {}) | {:.2f} ms/step | lanes {} group {} | dominant {} frac {:.3f} avg launch {:.4f} ms | conv {:.3f} ms/forward frac {:.3f} | dp {} bins {}'.format(
+        path, d['value'], d['unit'], None if res is None else round(res, 2), d['ms_per_step'], d['config'].get('lanes'), d['config'].get('pass_group'), r['kernel'], r['frac'], r['avg_launch_ms'],
+        r['all_conv_kernels']['ms_per_forward'], r['all_conv_kernels']['frac'], par.get('max_abs_dprobabilities_vs_cpu'), par.get('bin_ids_equal')) +
+          ' | ue equal {} within ties {}'.format(par.get('ue_counts_equal'), par.get('ue_counts_within_ties')))

@@ -47,16 +47,34 @@ def main():
     cfg = os.path.join(tmp, 'test_brats_baseline_mc.yaml')
     with open(cfg, 'w') as f:
         f.write(text)
+    stamps = []
+    inner = scripts.WriteHook.on_test_subject_end
+
+    def stamped(self, subject_context, task_context, context):
+        inner(self, subject_context, task_context, context)
+        stamps.append(time.perf_counter())
+
+    scripts.WriteHook.on_test_subject_end = stamped
+    profile = os.environ.get('RCU_SCRIPT_PROFILE', '1') != '0'
     prof = cProfile.Profile()
     t0 = time.perf_counter()
-    prof.enable()
+    if profile:
+        prof.enable()
     scripts.test_default('brats', cfg, None)
-    prof.disable()
+    if profile:
+        prof.disable()
     dt = time.perf_counter() - t0
-    print('{} subjects, T={}, batch_size {}: {:.2f} s total, {:.2f} s per subject ({:.1f} MC-sample-volumes/s end to end)'
-          .format(n_subjects, mc, batch, dt, dt / n_subjects, mc * n_subjects / dt))
+    print('{} subjects, T={}, batch_size {}: {:.2f} s total, {:.2f} s per subject ({:.1f} MC-sample-volumes/s end to end, start-up and '
+          'the final join of the writers included)'.format(n_subjects, mc, batch, dt, dt / n_subjects, mc * n_subjects / dt))
+    if len(stamps) > 2:
+        # steady state: from the hand-over of the first subject to the writers to the end of the run (the last subject's files joined)
+        steady = (t0 + dt - stamps[0]) / (len(stamps) - 1)
+        print('steady state (subjects 2..{}, incl. the final join): {:.3f} s per subject = {:.1f} MC-sample-volumes/s; start-up + first '
+              'subject {:.2f} s'.format(len(stamps), steady, mc / steady, stamps[0] - t0))
+    if not profile:
+        return
     st = pstats.Stats(prof)
-    st.sort_stats('cumulative').print_stats(22)
+    st.sort_stats("cumulative").print_stats(45)
     st.sort_stats('tottime').print_stats(14)
 
 
