@@ -178,19 +178,33 @@ def cpu_thread_counts(params, height, width):
 
 
 def cpu_probe_slices(member, params, x_cpu, passes_total, budget_s, thread_counts, n_max=32):
-    """How many slices the CPU leg can take within budget_s (three timed runs + a warm-up per thread count): one timed 4-slice forward
-    of the oracle at the first thread count -- the sample is about that size, so the probe is representative."""
+    """How many slices the CPU leg can take within budget_s (three timed runs + a warm-up per thread count).  The time per slice
+    depends on the batch (a 32-slice forward takes several times as long per slice as a 4-slice one: the activations fall out
+    of the caches), so the estimate is checked on a forward of the chosen size and the size shrunk until the prediction fits."""
     from oracle import unet_oracle as uo
     torch.set_num_threads(thread_counts[0])
     state = {k: v.detach().cpu() for k, v in member.state_dict().items()}
-    xs = x_cpu[:4].contiguous()
-    uo.unet_forward(state, xs[:2], None, **params)
-    t0 = time.perf_counter()
-    uo.unet_forward(state, xs, None, **params)
-    per_slice = (time.perf_counter() - t0) / 4
     runs = 3.2 * len(thread_counts)                 # three timed runs + warm-up and set-up per thread count
-    n = int(budget_s / max(per_slice * passes_total * runs, 1e-6))
-    return max(2, min(n_max, x_cpu.shape[0], n // 2 * 2))
+    uo.unet_forward(state, x_cpu[:2].contiguous(), None, **params)
+
+    def forward_s(n):
+        xs = x_cpu[:n].contiguous()
+        t0 = time.perf_counter()
+        uo.unet_forward(state, xs, None, **params)
+        return time.perf_counter() - t0
+
+    n = 4
+    per_slice = forward_s(n) / n
+    for _ in range(4):
+        fit = int(budget_s / max(per_slice * passes_total * runs, 1e-6))
+        fit = max(2, min(n_max, x_cpu.shape[0], fit // 2 * 2))
+        if fit == n:
+            break
+        n = fit
+        per_slice = forward_s(n) / n                # measured at the size the leg would run
+        if per_slice * n * passes_total * runs <= 1.15 * budget_s:
+            break
+    return n
 
 
 def calibration_kernels(device, volumes=160, reps=5):

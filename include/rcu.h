@@ -64,6 +64,8 @@ typedef struct rcu_unet_desc {
     int32_t max_batch;       /* largest N a forward call may pass; sizes the workspace */
     int32_t residual;        /* 1: ConvResidualBlock (common/model/unet.py:42-60) instead of ConvBlock: a block's second unit has no
                                 ReLU and a 1x1 conv of the block input ("<block>.residual") is added to its output */
+    int32_t provide_features; /* 1: rcu_unet_features will be called (unet.py:135-136, 178-179): the input of conv_cls.0 is kept
+                                channels-last; otherwise the library is free to hold it in its channel-blocked layout */
 } rcu_unet_desc;
 
 int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out);

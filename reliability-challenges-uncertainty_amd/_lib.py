@@ -28,7 +28,8 @@ class RcuError(RuntimeError):
 
 class UnetDesc(Structure):
     _fields_ = [(n, c_int32) for n in ('nb_classes', 'in_channels', 'depth', 'start_filters', 'has_dropout',
-                                       'dropout_center', 'sigma_out', 'bn', 'height', 'width', 'max_batch', 'residual')]
+                                       'dropout_center', 'sigma_out', 'bn', 'height', 'width', 'max_batch', 'residual',
+                                       'provide_features')]
 
 
 class LayerInfo(Structure):

@@ -60,6 +60,8 @@ struct Tensor {
     size_t floats_per_slice = 0;
     float* dev = nullptr;
     bool zero_fill = false;   // centre-padded up-conv output: the border is never written and must read as zero
+    int H = 0, W = 0, cp = 0;
+    bool blocked = false;     // [N][C/8][H][W][8] instead of NHWC (rcu_kernels.h, ConvArgs): decided per tensor by assign_layouts
 };
 
 struct rcu_unet {
@@ -86,6 +88,7 @@ static int prof_slots(const rcu_unet* h) { return (int)h->layers.size() + 3; }
 static int new_tensor(rcu_unet* h, int H, int W, int cp)
 {
     Tensor t;
+    t.H = H; t.W = W; t.cp = cp;
     t.floats_per_slice = (size_t)H * W * cp;
     h->tensors.push_back(t);
     return (int)h->tensors.size() - 1;
@@ -216,6 +219,8 @@ static void add_residual_conv(rcu_unet* h, const std::string& prefix, int cin1, 
     h->layers.push_back(L);
 }
 
+static void assign_layouts(rcu_unet* h);
+
 static int build_plan(rcu_unet* h)
 {
     const rcu_unet_desc& d = h->d;
@@ -306,7 +311,51 @@ static int build_plan(rcu_unet* h)
             return fail(RCU_ERR_INVALID, "internal: channel chunking does not divide for layer " + L.name);
         L.NT = (L.coutp + ci.BN - 1) / ci.BN;
     }
+    assign_layouts(h);
     return RCU_OK;
+}
+
+// Which activation tensors take the channel-blocked layout [N][C/8][H][W][8] (rcu_kernels.h, ConvArgs): every tensor all of whose
+// producers and consumers are Winograd kernels (rcu_first.hip as a producer), except the network input, the head unit's output
+// (head_kernel reads channels-last) and -- when the caller wants rcu_unet_features -- the feature tensor.  The two sources of a
+// cat-free decoder unit share one layout.  RCU_ACT_LAYOUT=nhwc keeps everything channels-last (A/B tests).
+static bool cfg_reads_blocked(int cfg)
+{
+    return (cfg >= CONV_CFG_WINO_T16x16_N64 && cfg <= CONV_CFG_UPW_S8T4x8_N64) || (cfg >= CONV_CFG_WINO4_T32x32_N32 && cfg < CONV_CFG_END);
+}
+static bool cfg_writes_blocked(int cfg) { return cfg_reads_blocked(cfg) || cfg == CONV_CFG_FIRST_T8x32; }
+
+static void assign_layouts(rcu_unet* h)
+{
+    const char* const env = getenv("RCU_ACT_LAYOUT");
+    const bool on = !(env && (strcmp(env, "nhwc") == 0 || strcmp(env, "0") == 0));
+    for (Tensor& t : h->tensors) t.blocked = on && t.cp % 8 == 0 && !t.zero_fill;
+    h->tensors[h->t_input].blocked = false;
+    h->tensors[h->t_head].blocked = false;
+    if (h->d.provide_features) h->tensors[h->layers.back().t_src1].blocked = false;
+    for (bool changed = true; changed;) {
+        changed = false;
+        auto clear = [&](int t) {
+            if (t >= 0 && h->tensors[t].blocked) {
+                h->tensors[t].blocked = false;
+                changed = true;
+            }
+        };
+        for (const ConvLayer& L : h->layers) {
+            if (!cfg_reads_blocked(L.cfg)) {
+                clear(L.t_src1);
+                clear(L.t_src2);
+            }
+            if (!cfg_writes_blocked(L.cfg)) {
+                clear(L.t_out);
+                clear(L.t_pool);
+            }
+            if (L.t_src2 >= 0 && h->tensors[L.t_src1].blocked != h->tensors[L.t_src2].blocked) {
+                clear(L.t_src1);
+                clear(L.t_src2);
+            }
+        }
+    }
 }
 
 extern "C" const char* rcu_last_error(void) { return g_last_error.c_str(); }
@@ -663,6 +712,15 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
         };
         a.magic_ntw = magic(a.NTW_total); a.magic_tx = magic(a.tiles_x); a.magic_ty = magic(a.tiles_y);
     }
+    {
+        auto strides = [](const Tensor& t, uint32_t& pix_bytes, uint32_t& chunk_bytes) {
+            pix_bytes = t.blocked ? 32u : (uint32_t)t.cp * 4u;
+            chunk_bytes = t.blocked ? (uint32_t)(t.H * t.W) * 32u : 32u;
+        };
+        strides(h->tensors[L.t_src1], a.in_pix_bytes, a.in_chunk_bytes);
+        strides(h->tensors[L.t_out], a.out_pix_bytes, a.out_chunk_bytes);
+        if (L.t_pool >= 0) strides(h->tensors[L.t_pool], a.pool_pix_bytes, a.pool_chunk_bytes);
+    }
     a.src1_bytes = (uint32_t)std::min<size_t>(h->tensors[L.t_src1].floats_per_slice * (size_t)n * 4, 0xFFFFFFFFu);
     a.src2_bytes = L.t_src2 >= 0 ? (uint32_t)std::min<size_t>(h->tensors[L.t_src2].floats_per_slice * (size_t)n * 4, 0xFFFFFFFFu) : 0u;
     a.wpack_bytes = (uint32_t)std::min<size_t>(L.wpack_floats * 4, 0xFFFFFFFFu);
@@ -808,6 +866,9 @@ extern "C" int rcu_unet_features(const rcu_unet* h, const float** features_dev, 
     if (!h->finalized) return fail(RCU_ERR_STATE, "rcu_unet_features before rcu_unet_finalize_weights");
     for (const ConvLayer& L : h->layers)
         if (L.name == "conv_cls.0.conv2d_batch_relu.conv") {
+            if (h->tensors[L.t_src1].blocked)
+                return fail(RCU_ERR_STATE, "rcu_unet_features: the handle was created without rcu_unet_desc.provide_features (the feature "
+                                           "tensor is held channel-blocked)");
             *features_dev = h->tensors[L.t_src1].dev;
             if (channels) *channels = L.cin1;
             if (channel_pitch) *channel_pitch = L.c1p;

@@ -108,13 +108,15 @@ __global__ __launch_bounds__(FIRST_THREADS) void conv3x3_first_kernel(const Conv
 #pragma unroll
                     for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[tap][ks][b], xv, acc[b], 0, 0, 0);
                 }
-            float* const op = a.out + ((size_t)(n * a.H + y0 + r) * a.W + x0 + c0 + n16) * a.CoutP + 4 * g;
+            // (sample, pixel, channel b * 16 + 4 g): NHWC or blocked [C/8][H][W][8], see ConvArgs
+            char* const op = reinterpret_cast<char*>(a.out) + (size_t)n * a.H * a.W * a.CoutP * 4 +
+                             (size_t)((y0 + r) * a.W + x0 + c0 + n16) * a.out_pix_bytes + (size_t)(g >> 1) * a.out_chunk_bytes + (g & 1) * 16;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 f32x4 v = acc[b] * scale[b] + shift[b];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], floor_v);
-                *reinterpret_cast<f32x4*>(op + b * 16) = v;
+                *reinterpret_cast<f32x4*>(op + (size_t)(2 * b) * a.out_chunk_bytes) = v;
             }
         }
     }

@@ -9,8 +9,14 @@ namespace rcu {
 // ---------------------------------------------------------------------------------------------
 // conv3x3 implicit GEMM (rcu_conv.hip)
 // ---------------------------------------------------------------------------------------------
-// Activations are NHWC fp32 with the channel count padded to a multiple of 32 (the network input to
-// a multiple of 8); padded channels hold zeros.  One launch covers every slice of the batch.
+// Activations are fp32 with the channel count padded to a multiple of 32 (the network input to a multiple of 8); padded
+// channels hold zeros.  One launch covers every slice of the batch.  Two layouts of a [N][H][W][C] tensor:
+//   NHWC     a pixel's C channels are contiguous                                   (every kernel)
+//   blocked  [N][C/8][H][W][8]: a pixel's 8-channel group (the Cin chunk of the Winograd kernels) is 32 contiguous bytes and
+//            the groups of neighbouring pixels follow each other, so an LDS-DMA instruction that stages 8 channels of 32..64
+//            pixels touches 8..16 whole 128-byte lines instead of 32..64 quarter lines (Winograd kernels + rcu_first.hip only)
+// Both are addressed as  sample * (H W C 4) + chunk * chunk_bytes + (y W + x) * pix_bytes + (c mod 8) * 4  with
+//   NHWC: pix_bytes = 4 C, chunk_bytes = 32;   blocked: pix_bytes = 32, chunk_bytes = 32 H W.
 struct ConvArgs {
     const float* src1;   // [N][H][W][C1]   first  K-range (channels [0, C1))
     const float* src2;   // [N][H][W][C2]   second K-range (cat-free decoder), may be null (C2 = 0)
@@ -41,6 +47,10 @@ struct ConvArgs {
                                               // split a work item into tile coordinates with s_mul_hi instead of three divisions
     int NTW_total;       // weight tiles per Cin chunk = NT (3x3) or 4 * NT (sub-pixel: one set per parity class)
     uint32_t src1_bytes, src2_bytes, wpack_bytes;   // buffer-resource ranges (Winograd kernels)
+    // layout of the sources (both alike), of `out` and of `pooled` (see above); 0 / 0 = NHWC for the kernels that know nothing else
+    uint32_t in_pix_bytes, in_chunk_bytes;
+    uint32_t out_pix_bytes, out_chunk_bytes;
+    uint32_t pool_pix_bytes, pool_chunk_bytes;
     // fused 1x1 head of conv_cls.0 (rcu_wino.hip, two classes): when head_w is set the conv unit's output stays on chip
     const float* head_w;   // [2][32] 1x1 weights, head_b[2] bias
     const float* head_b;

@@ -63,10 +63,10 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
     const int odd = n16 & 1;
     // Whole tiles only (checked by the launcher) and tensors below 2 GB: stores through a buffer resource, one per-lane byte offset
     // per tile, the steps between a lane's pixels in SGPRs -- no 64-bit address arithmetic, no per-store predicates.
-    const uint32_t row_bytes = (uint32_t)(a.W * a.CoutP) * 4u;
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (uint32_t)(a.N * a.H) * row_bytes, 0x00020000);
-    const uint32_t vo = ((uint32_t)((n * a.H + yb) * a.W + xb + odd) * (uint32_t)a.CoutP + (uint32_t)(co - 2 * odd)) * 4u;
-    const uint32_t px_step = (uint32_t)a.CoutP * 8u;   // two pixels to the right
+    const uint32_t row_bytes = (uint32_t)a.W * a.out_pix_bytes;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (uint32_t)(a.N * a.H * a.W) * (uint32_t)a.CoutP * 4u, 0x00020000);
+    const uint32_t vo = wino_out_offset(n, a.H * a.W, a.CoutP, (uint32_t)(yb * a.W + xb + odd), co - 2 * odd, a.out_pix_bytes, a.out_chunk_bytes);
+    const uint32_t px_step = 2u * a.out_pix_bytes;   // two pixels to the right
     f32x2 mx[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -114,7 +114,9 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
         const int Hp = a.H >> 1, Wp = a.W >> 1;
         const __amdgpu_buffer_rsrc_t rp =
             __builtin_amdgcn_make_buffer_rsrc(a.pooled, 0, (uint32_t)(a.N * Hp * Wp * a.CoutP) * 4u, 0x00020000);
-        const uint32_t vp = ((uint32_t)((n * Hp + (yb >> 1)) * Wp + (xb >> 1) + odd) * (uint32_t)a.CoutP + (uint32_t)(co - 2 * odd)) * 4u;
+        const uint32_t vp = wino_out_offset(n, Hp * Wp, a.CoutP, (uint32_t)((yb >> 1) * Wp + (xb >> 1) + odd), co - 2 * odd, a.pool_pix_bytes,
+                                            a.pool_chunk_bytes);
+        const uint32_t pp_step = 2u * a.pool_pix_bytes;
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
             const f32x2 send = odd ? mx[r] : mx[r + 1];
@@ -122,7 +124,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
             recv.x = wino_swap_adjacent(send.x);
             recv.y = wino_swap_adjacent(send.y);
             const f32x4 o = odd ? f32x4{recv.x, recv.y, mx[r + 1].x, mx[r + 1].y} : f32x4{mx[r].x, mx[r].y, recv.x, recv.y};
-            wino_store16(o, rp, vp, (r >> 1) * px_step);
+            wino_store16(o, rp, vp, (r >> 1) * pp_step);
         }
     }
 }
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
     const int m16 = lane & 15, kq = lane >> 4;
     const int nchunks = (a.C1 + a.C2) / KC;   // even, >= 4 (checked by the launcher)
     const uint32_t wchunk_bytes = (uint32_t)a.NT * T::W_DW * 4u;
+    const uint32_t in_chunk_bytes = a.in_chunk_bytes;
 
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1), 0, a.src1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 =
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
         const int c0 = kc * KC;
         j.active = active;
         j.first = c0 < a.C1;
-        j.cb = (uint32_t)((j.first ? c0 : c0 - a.C1) * 4);
+        j.cb = wino_chunk_offset(in_chunk_bytes, j.first ? c0 : c0 - a.C1);
         j.wso = (uint32_t)kc * wchunk_bytes + (uint32_t)wtile * (T::W_DW * 4u);
         j.lb = (uint32_t)buf * (T::BUF_DW * 4u);
         return j;

@@ -211,17 +211,20 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
     const int xb = x0 + 4 * tc;           // left pixel column of the lane's first tile
     const float relu_floor = a.relu ? 0.f : -__builtin_inff();
     const int odd = n16 & 1;
-    const uint32_t row_bytes = (uint32_t)(a.W * a.CoutP) * 4u;
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (uint32_t)(a.N * a.H) * row_bytes, 0x00020000);
+    const uint32_t row_bytes = (uint32_t)a.W * a.out_pix_bytes;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (uint32_t)(a.N * a.H * a.W) * (uint32_t)a.CoutP * 4u, 0x00020000);
     // lanes without an output (slices beyond the batch) store out of range: the buffer resource drops the write
-    const uint32_t vo = live ? ((uint32_t)((n * a.H + yb) * a.W + xb + odd) * (uint32_t)a.CoutP + (uint32_t)(co - 2 * odd)) * 4u : WINO_OOB;
-    const uint32_t px_bytes = (uint32_t)a.CoutP * 4u;
+    const uint32_t vo = live ? wino_out_offset(n, a.H * a.W, a.CoutP, (uint32_t)(yb * a.W + xb + odd), co - 2 * odd, a.out_pix_bytes, a.out_chunk_bytes)
+                             : WINO_OOB;
+    const uint32_t px_bytes = a.out_pix_bytes;
     const bool pool = a.pooled != nullptr;
     const int Hp = a.H >> 1, Wp = a.W >> 1;
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(pool ? a.pooled : a.out, 0,
                                                                        pool ? (uint32_t)(a.N * Hp * Wp * a.CoutP) * 4u : 0u, 0x00020000);
-    const uint32_t vp = live ? ((uint32_t)((n * Hp + (yb >> 1)) * Wp + (xb >> 1) + odd) * (uint32_t)a.CoutP + (uint32_t)(co - 2 * odd)) * 4u : WINO_OOB;
-    const uint32_t prow_bytes = (uint32_t)(Wp * a.CoutP) * 4u;
+    const uint32_t vp = live ? wino_out_offset(n, Hp * Wp, a.CoutP, (uint32_t)((yb >> 1) * Wp + (xb >> 1) + odd), co - 2 * odd, a.pool_pix_bytes,
+                                               a.pool_chunk_bytes)
+                             : WINO_OOB;
+    const uint32_t prow_bytes = (uint32_t)Wp * a.pool_pix_bytes, ppx_bytes = a.pool_pix_bytes;
     wino_static_for<0, 4>([&](auto r_c) {
         constexpr int r = decltype(r_c)::value;
         f32x2 y[4][4];   // [row][col], components = the two couts: packed operations throughout (one instruction costs the same
@@ -292,7 +295,7 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
                 recv.x = wino_swap_adjacent(send.x);
                 recv.y = wino_swap_adjacent(send.y);
                 const f32x4 o = odd ? f32x4{recv.x, recv.y, keep.x, keep.y} : f32x4{keep.x, keep.y, recv.x, recv.y};
-                store16(o, rp, vp, (uint32_t)(2 * r) * px_bytes + (uint32_t)a2 * prow_bytes);
+                store16(o, rp, vp, (uint32_t)(2 * r) * ppx_bytes + (uint32_t)a2 * prow_bytes);
             }
         }
     });
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
     const int m16 = lane & 15, kq = lane >> 4;
     const int nchunks = (a.C1 + a.C2) / KC;   // even, >= 4 (checked by the launcher)
     const uint32_t wchunk_bytes = (uint32_t)a.NT * T::W_DW * 4u;
+    const uint32_t in_chunk_bytes = a.in_chunk_bytes;
 
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1), 0, a.src1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 =
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         const int c0 = kc * KC;
         const bool first = c0 < a.C1;
         j.rs = first ? rs1 : rs2;
-        j.cb = active ? (uint32_t)((first ? c0 : c0 - a.C1) * 4) : WINO_OOB;
+        j.cb = active ? wino_chunk_offset(in_chunk_bytes, first ? c0 : c0 - a.C1) : WINO_OOB;
         j.wso = active ? (uint32_t)kc * wchunk_bytes + (uint32_t)wtile * (T::W_DW * 4u) : WINO_OOB;
         j.lb = (uint32_t)buf * (T::BUF_DW * 4u);
         return j;

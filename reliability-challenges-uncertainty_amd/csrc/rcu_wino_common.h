@@ -199,8 +199,18 @@ __device__ __forceinline__ uint32_t wino_slot_offset(const ConvArgs& a, const Wi
     const int x = geo & 0xFF, yy = (geo >> 8) & 0xFF, s = (geo >> 16) & 0xFF, hh = (geo >> 24) & 1;
     const int n = t.n0 + s, gy = t.y0 + yy - 1, gx = t.x0 + x - 1;
     const bool ok = geo != 0xFFFFFFFFu && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    const uint32_t pix = (uint32_t)((n * a.H + gy) * a.W + gx);
-    return ok ? (pix * (uint32_t)a.C1 + hh * 4) * 4u : WINO_OOB;   // C2 == C1 or 0 (checked by the launcher)
+    // sample * (H W C 4) + pixel * pix_bytes + half * 16 (ConvArgs: both layouts); the chunk's offset is added per chunk (wino_chunk_offset)
+    const uint32_t off = (uint32_t)n * ((uint32_t)(a.H * a.W) * (uint32_t)a.C1 * 4u) + (uint32_t)(gy * a.W + gx) * a.in_pix_bytes + (uint32_t)hh * 16u;
+    return ok ? off : WINO_OOB;   // C2 == C1 or 0 (checked by the launcher)
+}
+
+// byte offset of the 8-channel chunk that starts at channel c0 of a source tensor
+__device__ __forceinline__ uint32_t wino_chunk_offset(uint32_t in_chunk_bytes, int c0) { return (uint32_t)(c0 >> 3) * in_chunk_bytes; }
+
+// byte offset of (pixel index pix inside a sample of `hw` pixels, channel c -- a multiple of 4) of output sample n
+__device__ __forceinline__ uint32_t wino_out_offset(int n, int hw, int CoutP, uint32_t pix, int c, uint32_t pix_bytes, uint32_t chunk_bytes)
+{
+    return (uint32_t)n * ((uint32_t)hw * (uint32_t)CoutP * 4u) + (uint32_t)(c >> 3) * chunk_bytes + pix * pix_bytes + (uint32_t)(c & 7) * 4u;
 }
 
 }  // namespace rcu

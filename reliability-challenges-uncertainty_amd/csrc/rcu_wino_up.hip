@@ -41,9 +41,10 @@ __device__ __forceinline__ void wino_up_epilogue(const ConvArgs& a, const f32x4 
     const int odd = n16 & 1;
     const float relu_floor = a.relu ? 0.f : -__builtin_inff();
     // whole tiles only (checked by the launcher), output below 2 GB: buffer stores, one per-lane byte offset per tile, scalar steps
-    const uint32_t px_bytes = (uint32_t)a.CoutP * 4u, row_bytes = (uint32_t)OW * px_bytes;
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (uint32_t)(a.N * OH) * row_bytes, 0x00020000);
-    const uint32_t vo = ((uint32_t)((n * OH + 2 * lyb + pa) * OW + 2 * (lxb + odd)) * (uint32_t)a.CoutP + (uint32_t)(co - 2 * odd)) * 4u;
+    const uint32_t px_bytes = a.out_pix_bytes, row_bytes = (uint32_t)OW * px_bytes;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (uint32_t)(a.N * OH * OW) * (uint32_t)a.CoutP * 4u, 0x00020000);
+    const uint32_t vo = wino_out_offset(n, OH * OW, a.CoutP, (uint32_t)((2 * lyb + pa) * OW + 2 * (lxb + odd)), co - 2 * odd, a.out_pix_bytes,
+                                        a.out_chunk_bytes);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
     const int m16 = lane & 15, kq = lane >> 4;
     const int nchunks = a.C1 / KC;   // even, >= 4 (checked by the launcher); single source
     const uint32_t wchunk_bytes = (uint32_t)a.NTW_total * T::W_DW * 4u;
+    const uint32_t in_chunk_bytes = a.in_chunk_bytes;
 
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src1), 0, a.src1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpack), 0, a.wpack_bytes, 0x00020000);
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
     auto dma_job = [&](int wtile, int kc, int buf, bool active) {
         DmaJob j;
         j.active = active;
-        j.cb = (uint32_t)(kc * KC * 4);
+        j.cb = wino_chunk_offset(in_chunk_bytes, kc * KC);
         j.wso = (uint32_t)kc * wchunk_bytes + (uint32_t)wtile * (T::W_DW * 4u);
         j.lb = (uint32_t)buf * (T::BUF_DW * 4u);
         return j;

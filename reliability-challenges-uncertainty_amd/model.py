@@ -142,6 +142,8 @@ class UNet(nn.Module):
         second, third ... handle of the same shape."""
         lib = _lib.load()
         slot = (h, w) if lane == 0 else (h, w, lane)
+        if self.provide_features:      # a plan of its own: the feature tensor is kept channels-last (include/rcu.h, rcu_unet_desc)
+            slot = slot + ('features',)
         entry = self._handles.get(slot)
         if entry is not None and entry[1] >= n and entry[2] == self._weights_version:
             self._handles[slot] = self._handles.pop(slot)     # most recently used last
@@ -155,7 +157,7 @@ class UNet(nn.Module):
                              start_filters=self.start_filters, has_dropout=int(self.dropout is not None),
                              dropout_center=-1 if self.dropout_center is None else int(self.dropout_center),
                              sigma_out=int(self.sigma_out), bn=int(self.bn), height=h, width=w, max_batch=max_batch,
-                             residual=int(self.residual))
+                             residual=int(self.residual), provide_features=int(bool(self.provide_features)))
         handle = ctypes.c_void_p()
         _lib.check(lib.rcu_unet_create(ctypes.byref(desc), ctypes.byref(handle)))
         try:
