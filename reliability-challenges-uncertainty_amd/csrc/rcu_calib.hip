@@ -69,7 +69,7 @@ struct EcePartial {
 
 __device__ __forceinline__ unsigned long long ece_fixed_point(float q)
 {
-    q = fminf(fmaxf(q, 0.f), 1.99999988f);                 // NaN -> 0
+    q = __builtin_amdgcn_fmed3f(q, 0.f, 1.99999988f);       // one instruction; NaN -> 0 (v_med3_f32 returns the minimum of the others)
     // q + 2^10 in float64 has its unit in the last place at 2^-42: the fraction field IS q * 2^42, rounded to nearest
     // (float32 values >= 2^-18 exactly); three instructions instead of an exponent / mantissa / shift sequence
     const double d = (double)q + 1024.0;
@@ -111,17 +111,25 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned x)
     return x;
 }
 
-// Dynamic LDS of the histogram kernel: [wave][bin][lane] histogram words (see EcePartial), lookup table.
-static inline size_t ece_lds_bytes(int n_bins) { return (size_t)CB_WAVES * n_bins * 64 * 8 + (size_t)(n_bins + 1) * 4; }
+// Dynamic LDS of the histogram kernel: [wave][bin][lane] histogram words (see EcePartial).
+static inline size_t ece_lds_bytes(int n_bins) { return (size_t)CB_WAVES * n_bins * 64 * 8; }
 
 // bin = #{k : p >= t_k}, computed as a candidate floor(p * n_bins) plus one table lookup.  The edges are
 // k (1 + 1e-8) / n_bins, so p >= t_k implies p * n_bins > k and (k being representable, rounding monotonic)
 // the float product is >= k: the candidate is the bin or the bin + 1; lut[c] = t_{c-1} (lut[0] = -inf) decides.
 __device__ __forceinline__ int bin_lookup(float p, int n_bins, const float* lut)
 {
-    int c = (int)(p * (float)n_bins);          // NaN -> 0, +-inf saturate
-    c = max(0, min(c, n_bins - 1));
+    // clamped as a float (one v_med3_f32; NaN -> 0, +-inf saturate) and then truncated: the same integer as truncating first
+    const int c = (int)__builtin_amdgcn_fmed3f(p * (float)n_bins, 0.f, (float)(n_bins - 1));
     return c - ((p < lut[c]) ? 1 : 0);
+}
+
+// threads per bin of the histogram kernel's final reduction: the largest power of two with parts * n_bins <= CB_THREADS (>= 8)
+__device__ __forceinline__ int ece_parts(int nb)
+{
+    int parts = 64;
+    while (parts * nb > CB_THREADS) parts >>= 1;
+    return parts;
 }
 
 template <bool VEC>
@@ -130,13 +138,10 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
                                                                const BinThresholds th, EcePartial* __restrict__ partial)
 {
     extern __shared__ unsigned long long ece_smem[];
-    __shared__ unsigned s_cnt[CB_WAVES][MAX_BINS];
-    __shared__ unsigned s_pos[CB_WAVES][MAX_BINS];
-    __shared__ unsigned long long s_sum[CB_WAVES][MAX_BINS];
+    __shared__ float lut[MAX_BINS + 1];       // an object of its own: the compiler may then move the table reads across the histogram adds
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = th.n_bins;
     unsigned long long* const col = ece_smem + (size_t)wave * nb * 64 + lane;                // + bin * 64
-    float* const lut = reinterpret_cast<float*>(ece_smem + (size_t)CB_WAVES * nb * 64);
     for (int b = 0; b < nb; ++b) col[b * 64] = 0ull;
     if (tid <= nb) lut[tid] = (tid == 0) ? -INFINITY : th.t[min(tid, MAX_BINS - 1) - 1];
     __syncthreads();
@@ -145,10 +150,26 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
     const uint8_t* tv = target + vol * n;
     const uint8_t* mv = mask ? mask + vol * n : nullptr;
     const size_t base = (size_t)blockIdx.x * ELEMS_PER_BLOCK;
+    // branch-free: a voxel outside the mask adds a zero word to whatever bin its confidence names (an exec-mask round trip per voxel
+    // costs more than the LDS add it saves)
     auto add = [&](bool active, float q, bool pos) {
-        if (active) {
-            const int b = bin_lookup(q, nb, lut);
-            const unsigned long long word = ece_fixed_point(q) | (1ull << ECE_CNT_SHIFT) | ((unsigned long long)(pos ? 1u : 0u) << ECE_POS_SHIFT);
+        const int b = bin_lookup(q, nb, lut);
+        const unsigned hi = active ? ((1u << (ECE_CNT_SHIFT - 32)) | ((pos ? 1u : 0u) << (ECE_POS_SHIFT - 32))) : 0u;
+        const unsigned long long word = ece_fixed_point(active ? q : 0.f) | ((unsigned long long)hi << 32);
+        __hip_atomic_fetch_add(col + b * 64, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    };
+    // four voxels of a mask / target word pair: H holds per byte bit 0 = inside the mask, bit 7 = positive and inside, so a voxel's
+    // count / positive fields are ONE shift of its byte (count at bit 50, positive flag at bit 57: seven bits apart, like bits 0 and 7)
+    auto nonzero_bytes = [](unsigned w) { return ((w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u; };
+    auto add4 = [&](const float4& q, unsigned t4, unsigned m4) {
+        const unsigned A = nonzero_bytes(m4);
+        const unsigned H = A | ((A & nonzero_bytes(t4)) << 7);
+        const float qs[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned hb = (H >> (8 * k)) & 0xffu;
+            const int b = bin_lookup(qs[k], nb, lut);
+            const unsigned long long word = ece_fixed_point(hb != 0u ? qs[k] : 0.f) | ((unsigned long long)(hb << (ECE_CNT_SHIFT - 32)) << 32);
             __hip_atomic_fetch_add(col + b * 64, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     };
@@ -158,21 +179,16 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
         // (6 KiB per wave in flight; with a bounds check per round the compiler waits for every round)
         for (int r0 = 0; r0 < ROUNDS; r0 += BATCH) {
             float4 q[BATCH];
-            uchar4 t4[BATCH], m4[BATCH];
+            unsigned t4[BATCH], m4[BATCH];
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) {
                 const size_t e = base + ((size_t)(r0 + i) * CB_THREADS + tid) * 4;
                 q[i] = *reinterpret_cast<const float4*>(pv + e);
-                t4[i] = *reinterpret_cast<const uchar4*>(tv + e);
-                m4[i] = mv ? *reinterpret_cast<const uchar4*>(mv + e) : make_uchar4(1, 1, 1, 1);
+                t4[i] = *reinterpret_cast<const unsigned*>(tv + e);
+                m4[i] = mv ? *reinterpret_cast<const unsigned*>(mv + e) : 0x01010101u;
             }
 #pragma unroll
-            for (int i = 0; i < BATCH; ++i) {
-                add(m4[i].x != 0, q[i].x, t4[i].x != 0);
-                add(m4[i].y != 0, q[i].y, t4[i].y != 0);
-                add(m4[i].z != 0, q[i].z, t4[i].z != 0);
-                add(m4[i].w != 0, q[i].w, t4[i].w != 0);
-            }
+            for (int i = 0; i < BATCH; ++i) add4(q[i], t4[i], m4[i]);
         }
     } else if (VEC) {
         for (int r = 0; r < ROUNDS; ++r) {
@@ -194,29 +210,41 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
             if (e < n) add(mv ? mv[e] != 0 : true, pv[e], tv[e] != 0);
         }
     }
-    for (int b = 0; b < nb; ++b) {   // wavefront reduction of the 64 columns of this wave
-        const unsigned long long word = col[b * 64];
-        const unsigned c = wave_sum_u32((unsigned)(word >> ECE_CNT_SHIFT) & 127u), cpos = wave_sum_u32((unsigned)(word >> ECE_POS_SHIFT));
-        const unsigned long long sm = wave_sum_u64(word & ((1ull << ECE_CNT_SHIFT) - 1));
-        if (lane == 0) {
-            s_cnt[wave][b] = c;
-            s_pos[wave][b] = cpos;
-            s_sum[wave][b] = sm;
-        }
-    }
+    // Reduction of the workgroup's CB_WAVES x 64 columns straight out of LDS (integers: exact whatever the order): bin b belongs to
+    // `parts` consecutive threads (a power of two, 16 for ten bins), thread (b, k) adds the words j = k (mod parts) of the bin's 256
+    // -- 16 reads per thread where a butterfly over the wave's lanes took 24 cross-lane moves per bin and lane --, then the parts meet
+    // in a log2(parts)-step butterfly inside their wave.
     __syncthreads();
-    if (tid < MAX_BINS) {
-        EcePartial out;
-        out.count = 0;
-        out.sum_pos = 0;
-        out.sum_fix = 0;
-        if (tid < nb) {
-            for (int w = 0; w < CB_WAVES; ++w) {
-                out.count += s_cnt[w][tid];
-                out.sum_pos += s_pos[w][tid];
-                out.sum_fix += s_sum[w][tid];
+    {
+        const int parts = ece_parts(nb);
+        const int b = tid / parts, k = tid % parts;
+        unsigned c = 0, cpos = 0;
+        unsigned long long sm = 0;
+        if (b < nb) {
+            for (int i = 0; i < CB_WAVES * 64 / parts; ++i) {
+                const int j = (k + (i + b) * parts) & (CB_WAVES * 64 - 1);   // start rotated by the bin: the bins of a wave read different banks
+                const unsigned long long word = ece_smem[(size_t)(j >> 6) * nb * 64 + (size_t)b * 64 + (j & 63)];
+                c += (unsigned)(word >> ECE_CNT_SHIFT) & 127u;
+                cpos += (unsigned)(word >> ECE_POS_SHIFT);
+                sm += word & ((1ull << ECE_CNT_SHIFT) - 1);
             }
         }
+        for (int off = parts >> 1; off >= 1; off >>= 1) {
+            c += __shfl_xor(c, off, 64);
+            cpos += __shfl_xor(cpos, off, 64);
+            sm += __shfl_xor(sm, off, 64);
+        }
+        if (k == 0 && b < MAX_BINS) {
+            EcePartial out;
+            out.count = b < nb ? c : 0;
+            out.sum_pos = b < nb ? cpos : 0;
+            out.sum_fix = b < nb ? sm : 0;
+            partial[((size_t)vol * gridDim.x + blockIdx.x) * MAX_BINS + b] = out;
+        }
+    }
+    if (tid < MAX_BINS && tid >= CB_THREADS / ece_parts(nb)) {   // bins no thread group stands for: zero partials
+        EcePartial out;
+        out.count = out.sum_pos = out.sum_fix = 0;
         partial[((size_t)vol * gridDim.x + blockIdx.x) * MAX_BINS + tid] = out;
     }
 }
@@ -405,12 +433,8 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
 {
     extern __shared__ unsigned unc_smem[];           // [wave][(n_thr + 1) * 2][lane], two 16-bit cell counters per word
     __shared__ unsigned s_w[CB_WAVES][UNC_SLOTS];    // per wave: [m][cell] totals
-    __shared__ float s_cell_thr[UNC_CELLS];
-    __shared__ unsigned s_cell_base[UNC_CELLS];
-    if (threadIdx.x < UNC_CELLS) {
-        s_cell_thr[threadIdx.x] = th.cell_thr[threadIdx.x];
-        s_cell_base[threadIdx.x] = th.cell_base[threadIdx.x];
-    }
+    __shared__ float2 s_cell[UNC_CELLS];             // (threshold of the cell, thresholds below the cell as an integer in a float's bits): ONE read
+    if (threadIdx.x < UNC_CELLS) s_cell[threadIdx.x] = make_float2(th.cell_thr[threadIdx.x], __uint_as_float(th.cell_base[threadIdx.x]));
     __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ncol = (th.n_thr + 1) * 2;
@@ -422,23 +446,44 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
     const uint8_t* tv = target + vol * n;
     const uint8_t* mv = mask ? mask + vol * n : nullptr;
     const size_t base = (size_t)blockIdx.x * ELEMS_PER_BLOCK;
-    auto add = [&](bool active, double u, bool pr, bool tg) {
-        if (active) {
-            int m = 0;
-            if constexpr (std::is_same<U, float>::value) {   // full-rate float32 compares instead of float64 ones
-                const float uf = (float)u;                   // exact: u was converted from this float
-                if (th.n_cells > 0) {
-                    const int c = unc_cell_of(uf, th.cell_lo, th.cell_scale);
-                    m = (int)s_cell_base[c] + ((uf >= s_cell_thr[c]) ? 1 : 0);
-                } else {
-                    for (int t = 0; t < th.n_thr; ++t) m += (uf >= th.t32[t]) ? 1 : 0;
-                }
+    // m = number of thresholds u exceeds
+    auto exceeded = [&](U u) {
+        int m = 0;
+        if constexpr (std::is_same<U, float>::value) {   // full-rate float32 compares instead of float64 ones
+            if (th.n_cells > 0) {
+                // unc_cell_of with the clamp made on the float (one v_med3_f32; NaN -> 0): the same integer
+                const int c = (int)__builtin_amdgcn_fmed3f((u - th.cell_lo) * th.cell_scale, 0.f, (float)(UNC_CELLS - 1));
+                const float2 e = s_cell[c];
+                m = (int)__float_as_uint(e.y) + ((u >= e.x) ? 1 : 0);
             } else {
-                for (int t = 0; t < th.n_thr; ++t) m += (u > th.t[t]) ? 1 : 0;
+                for (int t = 0; t < th.n_thr; ++t) m += (u >= th.t32[t]) ? 1 : 0;
             }
-            const int cell = tg ? (pr ? 0 : 3) : (pr ? 2 : 1);
-            __hip_atomic_fetch_add(col + (m * 2 + (cell >> 1)) * 64, 1u << ((cell & 1) * 16), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
+            for (int t = 0; t < th.n_thr; ++t) m += ((double)u > th.t[t]) ? 1 : 0;
+        }
+        return m;
+    };
+    // cell = tp 0, tn 1, fp 2, fn 3 lives in column word (cell >> 1) = target XOR prediction, half (cell & 1) = NOT prediction
+    auto add = [&](bool active, U u, bool pr, bool tg) {
+        const int m = exceeded(u);
+        const int cell = tg ? (pr ? 0 : 3) : (pr ? 2 : 1);
+        // branch-free: a voxel outside the mask adds zero
+        __hip_atomic_fetch_add(col + (m * 2 + (cell >> 1)) * 64, active ? (1u << ((cell & 1) * 16)) : 0u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WAVEFRONT);
+    };
+    // four voxels of a (prediction, target, mask) word triple with the byte logic done once per word: X = target XOR prediction per
+    // byte (the column word), W = per byte 0x01 (inside the mask, predicted positive: low half) or 0x10 (inside, predicted negative:
+    // high half) or 0 -- (W_k * 0x1001) & 0x10001 is the voxel's increment
+    auto nonzero_bytes = [](unsigned w) { return ((w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u; };
+    auto add4 = [&](const U (&q)[4], unsigned p4, unsigned t4, unsigned m4) {
+        const unsigned A = nonzero_bytes(m4), P = nonzero_bytes(p4), T = nonzero_bytes(t4);
+        const unsigned X = T ^ P;
+        const unsigned W = (A & P) | ((A & ~P) << 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = exceeded(q[k]);
+            const unsigned x = (X >> (8 * k)) & 1u, wk = (W >> (8 * k)) & 0xffu;
+            __hip_atomic_fetch_add(col + (m * 2 + (int)x) * 64, (wk * 0x1001u) & 0x10001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     };
     const bool vec = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(uv) % (4 * sizeof(U)) == 0) &&
@@ -448,22 +493,17 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
     if (vec && base + ELEMS_PER_BLOCK <= n) {
         for (int r0 = 0; r0 < ROUNDS; r0 += BATCH) {   // loads of BATCH rounds in flight together
             U q[BATCH][4];
-            uchar4 p4[BATCH], t4[BATCH], m4[BATCH];
+            unsigned p4[BATCH], t4[BATCH], m4[BATCH];
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) {
                 const size_t e = base + ((size_t)(r0 + i) * CB_THREADS + tid) * 4;
                 load4(uv + e, q[i]);
-                p4[i] = *reinterpret_cast<const uchar4*>(pv + e);
-                t4[i] = *reinterpret_cast<const uchar4*>(tv + e);
-                m4[i] = mv ? *reinterpret_cast<const uchar4*>(mv + e) : make_uchar4(1, 1, 1, 1);
+                p4[i] = *reinterpret_cast<const unsigned*>(pv + e);
+                t4[i] = *reinterpret_cast<const unsigned*>(tv + e);
+                m4[i] = mv ? *reinterpret_cast<const unsigned*>(mv + e) : 0x01010101u;
             }
 #pragma unroll
-            for (int i = 0; i < BATCH; ++i) {
-                add(m4[i].x != 0, (double)q[i][0], p4[i].x != 0, t4[i].x != 0);
-                add(m4[i].y != 0, (double)q[i][1], p4[i].y != 0, t4[i].y != 0);
-                add(m4[i].z != 0, (double)q[i][2], p4[i].z != 0, t4[i].z != 0);
-                add(m4[i].w != 0, (double)q[i][3], p4[i].w != 0, t4[i].w != 0);
-            }
+            for (int i = 0; i < BATCH; ++i) add4(q[i], p4[i], t4[i], m4[i]);
         }
     } else if (vec) {
         for (int r = 0; r < ROUNDS; ++r) {
@@ -475,24 +515,40 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
                 const uchar4 t4 = *reinterpret_cast<const uchar4*>(tv + e);
                 uchar4 m4 = make_uchar4(1, 1, 1, 1);
                 if (mv) m4 = *reinterpret_cast<const uchar4*>(mv + e);
-                add(m4.x != 0, (double)q[0], p4.x != 0, t4.x != 0);
-                add(m4.y != 0, (double)q[1], p4.y != 0, t4.y != 0);
-                add(m4.z != 0, (double)q[2], p4.z != 0, t4.z != 0);
-                add(m4.w != 0, (double)q[3], p4.w != 0, t4.w != 0);
+                add(m4.x != 0, q[0], p4.x != 0, t4.x != 0);
+                add(m4.y != 0, q[1], p4.y != 0, t4.y != 0);
+                add(m4.z != 0, q[2], p4.z != 0, t4.z != 0);
+                add(m4.w != 0, q[3], p4.w != 0, t4.w != 0);
             }
         }
     } else {
         for (int r = 0; r < ELEMS_PER_BLOCK / CB_THREADS; ++r) {
             const size_t e = base + (size_t)r * CB_THREADS + tid;
-            if (e < n) add(mv ? mv[e] != 0 : true, (double)uv[e], pv[e] != 0, tv[e] != 0);
+            if (e < n) add(mv ? mv[e] != 0 : true, uv[e], pv[e] != 0, tv[e] != 0);
         }
     }
-    for (int k = 0; k < ncol; ++k) {   // wavefront reduction of this wave's 64 columns
-        const unsigned v = col[k * 64];
-        const unsigned lo = wave_sum_u32(v & 0xffffu), hi = wave_sum_u32(v >> 16);
-        if (lane == 0) {
-            s_w[wave][2 * k] = lo;
-            s_w[wave][2 * k + 1] = hi;
+    // Reduction of the wave's 64 columns straight out of LDS: lane (column k = lane >> 1, half h = lane & 1) adds the 32 words
+    // k * 64 + h, + 2, ... of column k (two 16-bit fields each, at most 64 per lane: no carry), then the two halves meet -- 32 reads
+    // per lane for 32 columns at a time where a butterfly per column took 12 cross-lane moves per column and lane.
+    __syncthreads();
+    {
+        const unsigned* const wcol = unc_smem + (size_t)wave * ncol * 64;
+        for (int k0 = 0; k0 < ncol; k0 += 32) {
+            const int k = k0 + (lane >> 1), h = lane & 1;
+            unsigned lo = 0, hi = 0;
+            if (k < ncol) {
+                for (int j = h; j < 64; j += 2) {
+                    const unsigned v = wcol[k * 64 + ((j + 2 * (lane >> 1)) & 63)];   // rotated start: the 64 lanes read 64 different banks
+                    lo += v & 0xffffu;
+                    hi += v >> 16;
+                }
+            }
+            lo += __shfl_xor(lo, 1, 64);
+            hi += __shfl_xor(hi, 1, 64);
+            if (k < ncol && h == 0) {
+                s_w[wave][2 * k] = lo;
+                s_w[wave][2 * k + 1] = hi;
+            }
         }
     }
     __syncthreads();

@@ -124,7 +124,10 @@ __device__ __forceinline__ void head_dot8(const float* __restrict__ row, const f
 }
 
 // logits (and raw sigma) of voxel v0 + lane out of the activations starting at `act` (bias not yet added)
-template <int C>
+// SIG: the sigma twin is wanted (raw sigma out, or the running sigma sum of the aleatoric + MC extension).  A template parameter: as
+// a run-time test inside the eight unrolled rounds it cost the plain path registers and a fifth of its speed (131 -> 162 us per launch
+// between rounds 1 and 2).
+template <int C, bool SIG>
 __device__ __forceinline__ void head_logits(const HeadArgs& a, const float* __restrict__ act, size_t v0, int lane,
                                             float (&l)[C], float (&s)[C])
 {
@@ -140,19 +143,19 @@ __device__ __forceinline__ void head_logits(const HeadArgs& a, const float* __re
         if (v < a.V) {
             const float* row = act + v * a.CP;
             head_dot8<C>(row, a.w_cls, a.CPh, sub, pl);
-            if ((a.sigma != nullptr || a.sigma_sum != nullptr)) head_dot8<C>(row + a.CPh, a.w_sig, a.CPh, sub, ps);
+            if constexpr (SIG) head_dot8<C>(row + a.CPh, a.w_sig, a.CPh, sub, ps);
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
 #pragma unroll
             for (int off = 1; off < 8; off <<= 1) {
                 pl[c] += __shfl_xor(pl[c], off, 64);
-                if ((a.sigma != nullptr || a.sigma_sum != nullptr)) ps[c] += __shfl_xor(ps[c], off, 64);
+                if constexpr (SIG) ps[c] += __shfl_xor(ps[c], off, 64);
             }
             // voxel (round*8 + j) lives in lanes 8j..8j+7; lane i wants voxel i = 8*(i>>3) + (i&7)
             const float tl = __shfl(pl[c], (lane & 7) * 8, 64);
             l[c] = (grp == round) ? tl : l[c];
-            if ((a.sigma != nullptr || a.sigma_sum != nullptr)) {
+            if constexpr (SIG) {
                 const float ts = __shfl(ps[c], (lane & 7) * 8, 64);
                 s[c] = (grp == round) ? ts : s[c];
             }
@@ -160,7 +163,7 @@ __device__ __forceinline__ void head_logits(const HeadArgs& a, const float* __re
     }
 }
 
-template <int C>
+template <int C, bool SIG>
 __global__ __launch_bounds__(PW_THREADS) void head_kernel(const HeadArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -175,18 +178,18 @@ __global__ __launch_bounds__(PW_THREADS) void head_kernel(const HeadArgs a)
         float ssum[C];   // sigma-head extension: the voxel's running sigma sum, added to in pass order like the statistics
         if (v < a.V) {
             st.load(a.stats, v, a.V, a.stats_flags);
-            if (a.sigma_sum != nullptr) {
+            if (SIG && a.sigma_sum != nullptr) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) ssum[c] = a.sigma_sum[(n * C + c) * a.HW + hw];
             }
         }
         for (int t = 0; t < a.passes; ++t) {
-            head_logits<C>(a, a.act + (size_t)t * a.V * a.CP, v0, lane, l, s);
+            head_logits<C, SIG>(a, a.act + (size_t)t * a.V * a.CP, v0, lane, l, s);
 #pragma unroll
             for (int c = 0; c < C; ++c) l[c] += a.b_cls[c];
             softmax_inplace<C>(l);
             st.add(a.stats_flags, l);
-            if (a.sigma_sum != nullptr) {
+            if (SIG && a.sigma_sum != nullptr) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const float raw = s[c] + a.b_sig[c];
@@ -196,14 +199,14 @@ __global__ __launch_bounds__(PW_THREADS) void head_kernel(const HeadArgs a)
         }
         if (v < a.V) {
             st.store(a.stats, v, a.V, a.stats_flags);
-            if (a.sigma_sum != nullptr) {
+            if (SIG && a.sigma_sum != nullptr) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) a.sigma_sum[(n * C + c) * a.HW + hw] = ssum[c];
             }
         }
         return;
     }
-    head_logits<C>(a, a.act, v0, lane, l, s);
+    head_logits<C, SIG>(a, a.act, v0, lane, l, s);
     if (v >= a.V) return;
     const size_t n = v / a.HW, hw = v % a.HW;
 #pragma unroll
@@ -212,11 +215,11 @@ __global__ __launch_bounds__(PW_THREADS) void head_kernel(const HeadArgs a)
 #pragma unroll
         for (int c = 0; c < C; ++c) a.logits[(n * C + c) * a.HW + hw] = l[c];
     }
-    if (a.sigma != nullptr) {
+    if (SIG && a.sigma != nullptr) {
 #pragma unroll
         for (int c = 0; c < C; ++c) a.sigma[(n * C + c) * a.HW + hw] = s[c] + a.b_sig[c];
     }
-    if (a.sigma_sum != nullptr) {
+    if (SIG && a.sigma_sum != nullptr) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float raw = s[c] + a.b_sig[c];
@@ -244,7 +247,11 @@ __global__ __launch_bounds__(PW_THREADS) void head_kernel(const HeadArgs a)
 
 hipError_t launch_head(const HeadArgs& a, hipStream_t stream)
 {
-    RCU_DISPATCH_C(a.C, hipLaunchKernelGGL(head_kernel<C_>, dim3(grid_for(a.V)), dim3(PW_THREADS), 0, stream, a));
+    if (a.sigma != nullptr || a.sigma_sum != nullptr) {
+        RCU_DISPATCH_C(a.C, hipLaunchKernelGGL((head_kernel<C_, true>), dim3(grid_for(a.V)), dim3(PW_THREADS), 0, stream, a));
+    } else {
+        RCU_DISPATCH_C(a.C, hipLaunchKernelGGL((head_kernel<C_, false>), dim3(grid_for(a.V)), dim3(PW_THREADS), 0, stream, a));
+    }
     return hipGetLastError();
 }
 
