@@ -449,6 +449,20 @@ def main():
 
     feeder = VolumePrefetcher(x_cpu, device)
     first_step, end_step = args.warmup, args.warmup + args.steps
+    resident_before = None
+    if os.environ.get('RCU_BENCH_RESIDENT_FIRST') == '1' and world == 1:      # diagnostic: drift between the legs
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for k in range(1000, 1000 + args.steps):
+            one_step(k).result()
+        torch.cuda.synchronize()
+        resident_before = (time.perf_counter() - tb) / args.steps * 1e3
+        for m in members:
+            m.profile_collect(height, width, n_slices * args.pass_group)
+        for i, m in enumerate(members):
+            count = sum(1 for j in my_jobs if j - 1 == i) if args.ensemble else len(my_jobs)
+            m.profile_begin(height, width, n_slices * args.pass_group, max(count, 1))
+        runner.forwards_run = 0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -742,6 +756,7 @@ def main():
         'n_ranks_seen': n_ranks_seen,
         'forwards_per_rank': forwards_per_rank,
         'resident': dict(value=units * args.steps / elapsed_resident, ms_per_step=elapsed_resident / args.steps * 1e3, steps=args.steps,
+                         ms_per_step_before_the_timed_region=resident_before,
                          note='the same steps with the volume already in HBM when the clock starts (no host-to-device copy): the '
                               'secondary figure; `value` has the prefetched copy inside'),
         'roofline': roofline,
