@@ -56,6 +56,11 @@ __global__ __launch_bounds__(FIRST_THREADS) void conv3x3_first_kernel(const Conv
     const int tiles_x = a.W / FIRST_TW, tiles_y = a.H / FIRST_TH;
     const float floor_v = a.relu ? 0.f : -__builtin_inff();
 
+    // Pass groups (x_nchw set, N = passes * n_images: sample p * n_images + i is image i under the masks of pass p): the convolution
+    // of an image tile is the same in every pass -- only the Dropout2d factors behind it differ --, so a tile is staged and multiplied
+    // ONCE and written once per pass (tiles_total then counts the tiles of the n_images images).
+    const int images = tiles_total / (tiles_x * tiles_y);     // (the launcher's rule: n_images for a pass group, N otherwise)
+    const int passes = a.N / images;
     for (int t = blockIdx.x; t < tiles_total; t += gridDim.x) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
         const int y0 = ty * FIRST_TH, x0 = tx * FIRST_TW;
@@ -78,45 +83,52 @@ __global__ __launch_bounds__(FIRST_THREADS) void conv3x3_first_kernel(const Conv
             }
             *reinterpret_cast<f32x4*>(&tile[ks][r][c][0]) = v;
         }
-        // Dropout2d factors of (sample n, the lane's channels); channels beyond the site's width are padding
-        f32x4 scale[NB], shift[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            f32x4 mk = {1.f, 1.f, 1.f, 1.f};
-            if (a.mask != nullptr) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = b * 16 + 4 * g + j;
-                    if (c < a.Cmask) mk[j] = a.mask[(size_t)n * a.Cmask + c];
-                }
-            }
-            scale[b] = al[b] * mk;
-            shift[b] = bb[b] * mk + be[b];
-        }
         __syncthreads();
+        f32x4 acc[4][NB];
 #pragma unroll
         for (int seg = 0; seg < 4; ++seg) {
             const int r = 2 * wave + (seg >> 1), c0 = 16 * (seg & 1);
-            f32x4 acc[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < NB; ++b) acc[seg][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const float xv = tile[ks][r + tap / 3][c0 + n16 + tap % 3][g];
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[tap][ks][b], xv, acc[b], 0, 0, 0);
+                    for (int b = 0; b < NB; ++b) acc[seg][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[tap][ks][b], xv, acc[seg][b], 0, 0, 0);
                 }
-            // (sample, pixel, channel b * 16 + 4 g): NHWC or blocked [C/8][H][W][8], see ConvArgs
-            char* const op = reinterpret_cast<char*>(a.out) + (size_t)n * a.H * a.W * a.CoutP * 4 +
-                             (size_t)((y0 + r) * a.W + x0 + c0 + n16) * a.out_pix_bytes + (size_t)(g >> 1) * a.out_chunk_bytes + (g & 1) * 16;
+        }
+        for (int pass = 0; pass < passes; ++pass) {
+            const int ns = pass * images + n;      // the sample this pass writes
+            // Dropout2d factors of (sample ns, the lane's channels); channels beyond the site's width are padding
+            f32x4 scale[NB], shift[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                f32x4 v = acc[b] * scale[b] + shift[b];
+                f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+                if (a.mask != nullptr) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], floor_v);
-                *reinterpret_cast<f32x4*>(op + (size_t)(2 * b) * a.out_chunk_bytes) = v;
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = b * 16 + 4 * g + j;
+                        if (c < a.Cmask) mk[j] = a.mask[(size_t)ns * a.Cmask + c];
+                    }
+                }
+                scale[b] = al[b] * mk;
+                shift[b] = bb[b] * mk + be[b];
+            }
+#pragma unroll
+            for (int seg = 0; seg < 4; ++seg) {
+                const int r = 2 * wave + (seg >> 1), c0 = 16 * (seg & 1);
+                // (sample, pixel, channel b * 16 + 4 g): NHWC or blocked [C/8][H][W][8], see ConvArgs
+                char* const op = reinterpret_cast<char*>(a.out) + (size_t)ns * a.H * a.W * a.CoutP * 4 +
+                                 (size_t)((y0 + r) * a.W + x0 + c0 + n16) * a.out_pix_bytes + (size_t)(g >> 1) * a.out_chunk_bytes + (g & 1) * 16;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    f32x4 v = acc[seg][b] * scale[b] + shift[b];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], floor_v);
+                    *reinterpret_cast<f32x4*>(op + (size_t)(2 * b) * a.out_chunk_bytes) = v;
+                }
             }
         }
     }
@@ -125,7 +137,9 @@ __global__ __launch_bounds__(FIRST_THREADS) void conv3x3_first_kernel(const Conv
 template <int KS, int NB>
 hipError_t launch_first(const ConvArgs& a, hipStream_t stream)
 {
-    const int tiles = (a.H / FIRST_TH) * (a.W / FIRST_TW) * a.N;
+    // pass groups of a forward call: one tile per IMAGE tile, written once per pass (see the kernel)
+    const int images = (a.x_nchw != nullptr && a.n_images > 0 && a.N % a.n_images == 0) ? a.n_images : a.N;
+    const int tiles = (a.H / FIRST_TH) * (a.W / FIRST_TW) * images;
     const int grid = tiles < 256 * 8 ? tiles : 256 * 8;
     hipLaunchKernelGGL((conv3x3_first_kernel<KS, NB>), dim3(grid), dim3(FIRST_THREADS), 0, stream, a, tiles);
     return hipGetLastError();
