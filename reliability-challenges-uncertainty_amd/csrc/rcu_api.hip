@@ -118,7 +118,9 @@ static int pick_config(const ConvLayer& L, int n_slices)
 {
     // Winograd kernels (rcu_wino.hip, rcu_wino_up.hip): 16/36 (conv units) and 9/36 (up-convolutions) of the
     // multiplications.  They address activations through 32-bit byte offsets of a buffer resource (tensors < 2 GB)
-    // and take whole tiles only.
+    // and take whole tiles only.  Tiles that span two or eight slices are taken whatever the batch the plan is sized for (a last
+    // group of slices that is not full reads zeros and stores nothing): the kernel of a layer -- and with it the bits of a slice's
+    // result -- does not depend on the batch size, as long as every tensor stays below 2 GB.
     // RCU_CONV_WINO=0 keeps every layer on the direct kernels of rcu_conv.hip (read at rcu_unet_create: A/B tests)
     const char* const wino_env = getenv("RCU_CONV_WINO");
     // a unit that adds to its output tensor (ConvResidualBlock's second unit) runs on the direct kernels, whose epilogue can
@@ -129,8 +131,8 @@ static int pick_config(const ConvLayer& L, int n_slices)
         const int lh = L.H / 2, lw = L.W / 2;
         if (L.coutp == 32 && lh % 16 == 0 && lw % 32 == 0) return CONV_CFG_UPW_T16x32_N32;
         if (L.coutp > 32 && lh % 16 == 0 && lw % 16 == 0) return CONV_CFG_UPW_T16x16_N64;
-        if (L.coutp > 32 && lh % 8 == 0 && lw % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_UPW_S2T8x16_N64;
-        if (L.coutp > 32 && lh % 4 == 0 && lw == 8 && n_slices % 8 == 0) return CONV_CFG_UPW_S8T4x8_N64;
+        if (L.coutp > 32 && lh % 8 == 0 && lw % 16 == 0) return CONV_CFG_UPW_S2T8x16_N64;
+        if (L.coutp > 32 && lh % 4 == 0 && lw == 8) return CONV_CFG_UPW_S8T4x8_N64;
     }
     if (L.upsample) {   // sub-pixel form; L.H x L.W is the OUTPUT grid, tiles run over the low-res input grid
         if (L.coutp <= 32) return ((L.H / 2) % 16 == 0 && (L.W / 2) % 16 == 0) ? CONV_CFG_UP_T16x16_N32 : CONV_CFG_UP_T8x16_N32;
@@ -148,25 +150,25 @@ static int pick_config(const ConvLayer& L, int n_slices)
         return CONV_CFG_T8x16_N32_FIRST;
     }
     if (wino_on && (L.c1p + L.c2p) % 32 == 0 && (L.c2p == 0 || L.c2p == L.c1p) && max_bytes < ((size_t)1 << 31)) {
-        // F(4x4,3x3) (rcu_wino4.hip) where its 32-pixel-wide tiles fit: 2.25 instead of 4 multiplications per output pixel.  Taken for
-        // layers with >= 64 output channels (measured per layer on the BraTS volume, tools/wino4_check.py: 1.1x at 32 -> 64 channels to
-        // 1.4x at 128 -> 128 and 256 -> 128 over F(2x2,3x3)); the 32-channel full-resolution layers are bound by their tile switches --
-        // four Cin chunks per tile, a cold fetch and an epilogue of a chunk's length each -- and stay on F(2x2,3x3), which runs two
-        // waves per SIMD there (0.36-0.64 ms against 0.39-0.69).  RCU_CONV_WINO4=0 keeps F(2x2,3x3) everywhere, =2 takes F(4x4,3x3)
-        // wherever it fits (A/B tests).
+        // F(4x4,3x3) (rcu_wino4.hip) where its 32-pixel-wide tiles fit: 2.25 instead of 4 multiplications per output pixel.  Measured
+        // per layer on the BraTS volume (tools/wino4_check.py, tools/layer_report.py): 1.1x at 32 -> 64 channels to 1.4x at 128 -> 128 and
+        // 256 -> 128 over F(2x2,3x3).  The 32-channel full-resolution layers -- four Cin chunks per tile, so a tile switch (cold fetch +
+        // epilogue) per four chunks -- lost to F(2x2,3x3) while the activations were channels-last (0.39-0.69 against 0.36-0.64 ms); with
+        // the channel-blocked layout, whose chunks are cold one at a time, they win too (round 3: 0.31 / 0.47 / 0.28 against
+        // 0.35 / 0.60 / 0.33 ms).  conv_cls.0 keeps its fused classifier head on F(2x2,3x3).  RCU_CONV_WINO4=0 keeps F(2x2,3x3)
+        // everywhere, =3 takes F(4x4,3x3) for the layers with >= 64 output channels only (the round-2 choice; A/B tests).
         const char* const w4_env = getenv("RCU_CONV_WINO4");
         const int w4_mode = w4_env ? atoi(w4_env) : 1;
-        if (w4_mode != 0 && (L.coutp >= 64 || w4_mode == 2) && L.name2.empty() && !is_head_unit(L) && L.W % 32 == 0) {
+        const bool w4_ok = w4_mode != 0 && (L.coutp >= 64 || w4_mode != 3) && L.name2.empty() && !is_head_unit(L);
+        if (w4_ok && L.W % 32 == 0) {
             if (L.H % 32 == 0) return CONV_CFG_WINO4_T32x32_N32;
-            if (L.H % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_WINO4_S2T16x32_N32;
+            if (L.H % 16 == 0) return CONV_CFG_WINO4_S2T16x32_N32;
         }
-        if (w4_mode != 0 && (L.coutp >= 64 || w4_mode == 2) && L.name2.empty() && !is_head_unit(L) && L.W == 16 && L.H % 8 == 0 &&
-            n_slices % 8 == 0)
-            return CONV_CFG_WINO4_S8T8x16_N32;
+        if (w4_ok && L.W == 16 && L.H % 8 == 0) return CONV_CFG_WINO4_S8T8x16_N32;
         if (L.coutp == 32 && L.H % 16 == 0 && L.W % 32 == 0) return CONV_CFG_WINO_T16x32_N32;
         if (L.coutp > 32 && L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T16x16_N64;
-        if (L.coutp > 32 && L.H % 8 == 0 && L.W % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_WINO_S2T8x16_N64;
-        if (L.coutp > 32 && L.H % 4 == 0 && L.W == 8 && n_slices % 8 == 0) return CONV_CFG_WINO_S8T4x8_N64;
+        if (L.coutp > 32 && L.H % 8 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_S2T8x16_N64;
+        if (L.coutp > 32 && L.H % 4 == 0 && L.W == 8) return CONV_CFG_WINO_S8T4x8_N64;
     }
     if (L.coutp > 32) {
         if (L.H == 12 && L.W == 8) return CONV_CFG_S2T12x8_N64;
