@@ -2,12 +2,12 @@
 # PMC passes (FETCH_SIZE / WRITE_SIZE / SQ counters, each in a run of its own with --kernel-trace only).  The raw CSVs
 # stay in /tmp on the box; only the condensed files land in gpurun_out/$TAG/ (merged back), to be copied into profiles/.
 #   gpurun --timeout 1500 -- 'bash tools/gpu_campaign.sh r01'
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 P=/tmp/prof_$TAG
 mkdir -p $OUT $P
-python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $OUT/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee $OUT/pytest_gpu.txt
 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; cut -c1-300 $OUT/bench_default.json   # the driver's flags
 python bench.py --no-ws --no-cpu-baseline > $OUT/bench_no_ws.json 2> $OUT/bench_no_ws.err; cut -c1-200 $OUT/bench_no_ws.json
 python bench.py --workload isic > $OUT/bench_isic.json 2> $OUT/bench_isic.err; cut -c1-200 $OUT/bench_isic.json
@@ -26,4 +26,8 @@ python tools/summarize_rocprof.py stats $(find $P/stats2 -name "*kernel_stats.cs
 python bench.py --lanes 1 --no-cpu-baseline --steps 20 --warmup 5 > $OUT/bench_lanes1.json 2> $OUT/bench_lanes1.err; cut -c1-200 $OUT/bench_lanes1.json
 python tools/summarize_rocprof.py pmc $P/pmc_fetch $P/pmc_write $P/pmc_sq $OUT/bench_pmc.json
 head -12 $OUT/bench_steps2_kernel_stats.csv
+timeout 600 bash tools/pmc_wait_breakdown.sh ${TAG}_waits > $OUT/wait_breakdown.txt 2>&1
+timeout 300 bash tools/pmc_inst_mix.sh ${TAG}_mix > $OUT/inst_mix.txt 2>&1
+timeout 200 python tools/calib_bench.py 160 > $OUT/calib_bench.json 2>/dev/null
+RCU_LOOP_TIMING=1 RCU_SCRIPT_PROFILE=0 timeout 200 python tools/script_throughput.py 16 20 32 2>&1 | grep -v "Holder\|conv2d_batch\|Conv2d\|Dropout2d\|BatchNorm2d\|^ *)\|^UNet\|^model" > $OUT/script_throughput.txt
 ls -la $OUT
