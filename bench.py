@@ -503,7 +503,6 @@ def main():
         launches += cnt
         slot_ms = ms if slot_ms is None else [a + b for a, b in zip(slot_ms, ms)]
     # ---- the same steps with the volume already resident in HBM (the secondary figure; all ranks take part)
-    forwards_timed = runner.forwards_run
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -275,7 +275,7 @@ class ShardedMcRunner:
                 works.append(dist.isend(tail, dst=self.root) if async_op else dist.send(tail, dst=self.root))
             elif self.rank == self.root:
                 works.append(dist.irecv(tail, src=owner) if async_op else dist.recv(tail, src=owner))
-        return [w for w in works if w is not None and not isinstance(w, int)] if async_op else []
+        return [w for w in works if w is not None] if async_op else []
 
     def step(self, x, step_index=0, mask_sets=None):
         """One volume.  Returns the summary dict on the root rank (probabilities, entropy, ... and

@@ -388,7 +388,10 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
     def staged(key, v):
         pieces = v if isinstance(v, list) else [v]          # a list: the pieces of a batch group, merged by the copy itself
         shape = (sum(int(t.shape[0]) for t in pieces),) + tuple(pieces[0].shape[1:])
-        bufs = ring.setdefault((key, shape, pieces[0].dtype), [])
+        ring_key = (key, shape, pieces[0].dtype)
+        if ring_key not in ring and len(ring) >= 4:        # batches of many shapes: drop the oldest shape's buffers (those still
+            ring.pop(next(iter(ring)))                     # in flight stay alive through the batches that hold them)
+        bufs = ring.setdefault(ring_key, [])
         with cond:
             while True:
                 free = [b for b in bufs if not b.busy]
@@ -533,10 +536,11 @@ class _Download:
                 if not value.is_cuda:                   # an entry a step left on the host (labels kept for the subject steps)
                     self.arrays[key] = value
                     continue
-                buf_key = (slot, key, tuple(value.shape), value.dtype)
-                host = self._buffers.get(buf_key)
-                if host is None:
-                    host = self._buffers[buf_key] = torch.empty(value.shape, dtype=value.dtype, pin_memory=True)
+                # one pinned buffer per (slot, entry): a batch of another shape replaces it (images of many sizes must not pile
+                # pinned memory up; the arrays of the previous batch of this slot have been consumed by then)
+                host = self._buffers.get((slot, key))
+                if host is None or host.shape != value.shape or host.dtype != value.dtype:
+                    host = self._buffers[(slot, key)] = torch.empty(value.shape, dtype=value.dtype, pin_memory=True)
                 host.copy_(value, non_blocking=True)
                 value.record_stream(stream)
                 self.arrays[key] = host
