@@ -298,15 +298,20 @@ class VolumeDataset(torch_data.Dataset):
                 meta['sample_index'].append(i)
             b = e
         out = PreCollated()
-        for k in keys:
+
+        def collated(k):
             shape = (n,) + tuple(blocks[k][0].shape[1:])
             dst = np.empty(shape, dtype=blocks[k][0].dtype)          # one (transposing) copy per block, straight out of the file mapping
             at = 0
             for blk in blocks[k]:
                 dst[at:at + blk.shape[0]] = blk
                 at += blk.shape[0]
-            out[k] = torch.from_numpy(dst)
+            return torch.from_numpy(dst)
+
+        out['images'] = collated('images')            # (the key order of the per-slice samples: images, the index entries, labels)
         out.update(meta)
+        if 'labels' in keys:
+            out['labels'] = collated('labels')
         return out
 
     def direct_extract(self, subject_index, entries=('labels', 'properties', 'subject')):

@@ -373,3 +373,58 @@ def test_check_min_max_raises_or_warns_like_the_reference():
     assert [str(x.message) for x in w] == ['Found value larger than 1: "1.5"', 'Found value smaller than 0: "-1.0"']
     with pytest.raises(ValueError, match='larger than 2'):
         ev.check_min_max(np.array([3.0]), min_=1, max_=2)
+
+
+def test_block_loader_equals_the_per_slice_loader(tmp_path, monkeypatch):
+    """VolumeDataset.__getitems__ (a loader batch cut out of the memory-mapped volume as blocks that go through the batched forms of
+    the transforms) gives, entry for entry and bit for bit, the batch CollateDict makes of the per-slice samples -- for every transform
+    the shipped YAML files use, batches that straddle subjects, and with the labels as a slice category; compressed .npz members fall
+    back to np.load."""
+    import torch
+    from rcu_amd import data as data_mod
+    rng = np.random.RandomState(0)
+    root = str(tmp_path / 'ds')
+    vols = {}
+    for i, depth in enumerate((7, 5, 3)):
+        x = rng.randn(depth, 12, 10, 4).astype(np.float32)
+        lab = (rng.rand(depth, 12, 10) < 0.3).astype(np.uint8)
+        vols['s{}'.format(i)] = (x, lab)
+        if i == 2:      # a deflated member cannot be mapped
+            os.makedirs(root, exist_ok=True)
+            np.savez_compressed(os.path.join(root, 's2.npz'), images=x, labels=lab)
+        else:
+            data_mod.write_volume(root, 's{}'.format(i), x, lab)
+    assert isinstance(data_mod._npz_member_mmap(os.path.join(root, 's0.npz'), 'images'), np.memmap)
+    assert data_mod._npz_member_mmap(os.path.join(root, 's2.npz'), 'images') is None
+    assert np.array_equal(data_mod._npz_member_mmap(os.path.join(root, 's1.npz'), 'images'), vols['s1'][0])
+
+    def transform():
+        return data_mod.Compose([data_mod.IntensityRescale(0, 1, entries=('images',)), data_mod.Permute((2, 0, 1), entries=('images',)),
+                                 data_mod.UnSqueeze(-1, entries=('labels',)), data_mod.Permute((2, 0, 1), entries=('labels',)),
+                                 data_mod.Squeeze(entries=('labels',))])
+
+    assert transform().batchable
+    for categories in (('images',), ('images', 'labels')):
+        ds = data_mod.VolumeDataset(root, transform(), slice_categories=categories)
+        fast = list(torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=data_mod.CollateDict()))
+        monkeypatch.setenv('RCU_BLOCK_LOADER', '0')
+        slow = list(torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=data_mod.CollateDict()))
+        monkeypatch.delenv('RCU_BLOCK_LOADER')
+        assert len(fast) == len(slow) == 4                       # 15 slices: batches straddle the subjects
+        for a, b in zip(fast, slow):
+            assert list(a.keys()) == list(b.keys())
+            for key in a:
+                if torch.is_tensor(a[key]):
+                    assert a[key].dtype == b[key].dtype and torch.equal(a[key], b[key]), key
+                else:
+                    assert list(a[key]) == list(b[key]), key
+    # a transform without a batched form keeps the per-slice path
+    class Odd:
+        def __call__(self, sample):
+            return sample
+    ds = data_mod.VolumeDataset(root, data_mod.Compose([Odd()]))
+    assert not ds.transform.batchable and isinstance(ds.__getitems__([0, 1]), list)
+    # direct_extract serves labels and geometry from the side cache after the image volumes have moved on
+    for si in range(3):
+        ds[ds.index.index((si, 0))]
+    assert np.array_equal(ds.direct_extract(0)['labels'], vols['s0'][1])
