@@ -472,11 +472,12 @@ def main():
     # weight-scaling pass, the T stochastic passes, [N > 1: the reduce] and the finalize
     feeder.issue(first_step)
     pending = []
+    diag = os.environ.get('RCU_BENCH_H2D_DIAG', '')      # diagnostics of the copy's cost: 'unused' = copies run, the steps read the resident volume
     for k in range(first_step, end_step):
-        xin = feeder.get(k)
+        xin = feeder.get(k) if diag != 'nowait' else feeder.bufs[k % len(feeder.bufs)]
         if k + 1 < end_step:
             feeder.issue(k + 1)
-        pending.append(one_step(k, xin))
+        pending.append(one_step(k, x if diag == 'unused' else xin))
         feeder.done(k)
     out = [p.result() for p in pending][-1]
     runner.drain()
