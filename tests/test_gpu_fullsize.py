@@ -281,3 +281,45 @@ def test_sigma_head_mc50_on_the_full_volume(dev):
     assert _maxdiff(out['sigma'][sel].cpu().numpy(), sigma_ref.numpy()) < PROB_TOL * scale
     assert _maxdiff(out['ws_sigma'][sel].cpu().numpy(), raw0.abs().numpy()) < PROB_TOL * scale
     assert float(out['sigma'].min()) >= 0
+
+
+@pytest.mark.timeout(1200)
+def test_isic_batch32_mc20_through_the_runner(dev):
+    """BASELINE configs[1] at full size: 32 images of 3 x 256 x 256, T = 20 MC-dropout passes + the weight-scaling pass through
+    ShardedMcRunner as `bench.py --workload isic` runs it (pass triples, two stream lanes, masks per (seed, volume, pass)).  Two images
+    against the oracle's 21 forwards under the runner's masks; pass groups == single passes bit for bit (one lane); lanes within
+    float32 summation order; same seed, same bits; all 32 images of the batch launch bit-identical to a 2-image launch."""
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import distributed as rdist
+    from rcu_amd import steps
+    params = dict(nb_classes=2, in_channels=3, depth=4, start_filters=32, dropout=0.05)
+    st = uo.synthetic_state(71, **params)
+    T, n, h, w = 20, 32, 256, 256
+    model = _model(params, st, dev)
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(n, 3, h, w, generator=g)
+    xd = x.to(dev)
+    group = steps.McPredictStep.GROUP_PIXELS // (n * h * w)
+    assert group == 3
+    sel = np.array([0, 31])
+    runner = rdist.ShardedMcRunner(model, T, seed=9, lanes=2, pass_group=group)
+    out = runner.step(xd, 2)
+    assert runner.forwards_run == T + 1 and set(out) == {'probabilities', 'entropy', 'ws_probabilities'}
+    again = rdist.ShardedMcRunner(model, T, seed=9, lanes=2, pass_group=group).step(xd, 2)
+    triples = rdist.ShardedMcRunner(model, T, seed=9, lanes=1, pass_group=group).step(xd, 2)
+    singles = rdist.ShardedMcRunner(model, T, seed=9, lanes=1, pass_group=1).step(xd, 2)
+    for key in out:
+        assert torch.equal(out[key], again[key]), key
+        assert torch.equal(triples[key], singles[key]), key
+        assert float((out[key] - triples[key]).abs().max()) < 1e-6, key
+    rows = torch.as_tensor(sel)
+    mask_sets = [_split_masks(model, runner.masks_of(xd, 2, j), n, rows) for j in range(1, T + 1)]
+    small = rdist.ShardedMcRunner(model, T, lanes=1, pass_group=1).step(xd[sel], 2, mask_sets=mask_sets)
+    for key in out:
+        assert torch.equal(singles[key][sel], small[key]), key          # an image does not depend on the batch it runs in
+    ws, multi = so.mc_probabilities(lambda xx, mk: uo.unet_forward(st, xx, mk, **params), x[sel], mask_sets)
+    ref = so.multi_prediction_summary(multi)
+    assert _maxdiff(out['probabilities'][sel].cpu().numpy(), ref['probabilities'].numpy()) < PROB_TOL
+    assert _maxdiff(out['entropy'][sel].cpu().numpy(), ref['entropy'].numpy()) < PROB_TOL
+    assert _maxdiff(out['ws_probabilities'][sel].cpu().numpy(), ws.numpy()) < PROB_TOL
