@@ -51,7 +51,10 @@ class HipEngine:
 
     def ws_pass(self, x, ws_out):
         steps_mod.set_dropout_mode(self.model, False)
-        ws_out.copy_(steps_mod.softmax(self.model(x)))
+        if ws_out.dtype == torch.float32 and ws_out.is_contiguous():
+            steps_mod.softmax(self.model(x), out=ws_out)          # straight into the reduce buffer's tail
+        else:                                                     # float64 statistics: the tail is float64 too
+            ws_out.copy_(steps_mod.softmax(self.model(x)))
 
     def sample_masks(self, x, generator, passes=1):
         """Dropout factors of ``passes`` stochastic passes over x (rows [site][passes * N][C_site]) from ``generator``."""

@@ -233,11 +233,14 @@ def merge_statistics(stats, side):
         stats.sigma_sum.add_(side.sigma_sum)
 
 
-def softmax(logits):
-    """F.softmax(logits, 1) on the HIP path."""
+def softmax(logits, out=None):
+    """F.softmax(logits, 1) on the HIP path (``out``: a contiguous float32 tensor of the same shape to write into)."""
     logits = logits.to(torch.float32).contiguous()
     n, c, h, w = logits.shape
-    out = torch.empty_like(logits)
+    if out is None:
+        out = torch.empty_like(logits)
+    elif out.shape != logits.shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != logits.device:
+        raise ValueError('out must be a contiguous float32 tensor of the shape and device of the logits')
     _lib.check(_lib.load().rcu_softmax(_lib.ptr(logits), _lib.ptr(out), n, h * w, c, _lib.current_stream()))
     return out
 
