@@ -1162,3 +1162,38 @@ def test_unet_no_batchnorm_full_width_vs_oracle(dev):
     ref = so.multi_prediction_summary(multi)
     assert _maxdiff(bc.output['probabilities'].cpu().numpy(), ref['probabilities'].numpy()) < PROB_TOL
     assert _maxdiff(bc.output['ws_probabilities'].cpu().numpy(), ws.numpy()) < PROB_TOL
+
+
+def test_channel_blocked_layout_gives_the_bits_of_channels_last(dev, monkeypatch):
+    """The activation layout between the Winograd kernels (channel-blocked [N][C/8][H][W][8]) is an addressing
+    choice: the same kernels on channels-last tensors (RCU_ACT_LAYOUT=nhwc) give the same bits -- logits with and without masks, the
+    fused statistics, the feature tap (which keeps its tensor channels-last in both), a sigma head, and a plan that mixes Winograd
+    and direct kernels (a size 2^depth does not divide)."""
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    g = torch.Generator().manual_seed(31)
+    for params, shape in ((dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05), (8, 4, 192, 128)),
+                          (dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05, sigma_out=True), (2, 4, 64, 64)),
+                          (dict(nb_classes=3, in_channels=3, depth=3, start_filters=16, dropout=0.2), (3, 3, 88, 72))):
+        st = uo.synthetic_state(45, **params)
+        x = torch.randn(*shape, generator=g)
+        _, sites = uo.unet_plan(**params)
+        masks = uo.sample_masks(sites, shape[0], 0.3, g)
+        outs = {}
+        for layout in ('blocked', 'nhwc'):
+            monkeypatch.setenv('RCU_ACT_LAYOUT', layout)
+            m = _model(params, st, dev)
+            m.provide_features = not params.get('sigma_out', False)
+            res = [m(x.to(dev)), m(x.to(dev), masks)]
+            res = [t for r in res for t in (r if isinstance(r, tuple) else (r,))]
+            if m.provide_features:
+                res.append(m.features.clone())
+            if params['nb_classes'] == 2 and not params.get('sigma_out', False):
+                stats = steps.McStatistics(shape[0], 2, shape[2], shape[3], dev, True, True)
+                m.forward_accumulate(x.to(dev), stats, masks)
+                res.append(stats.blob.clone())
+            outs[layout] = [t.cpu() for t in res]
+        monkeypatch.delenv('RCU_ACT_LAYOUT')
+        assert len(outs['blocked']) == len(outs['nhwc'])
+        for a, b in zip(outs['blocked'], outs['nhwc']):
+            assert torch.equal(a, b), (params, shape)
