@@ -159,7 +159,9 @@ static int pick_config(const ConvLayer& L, int n_slices)
         // everywhere, =3 takes F(4x4,3x3) for the layers with >= 64 output channels only (the round-2 choice; A/B tests).
         const char* const w4_env = getenv("RCU_CONV_WINO4");
         const int w4_mode = w4_env ? atoi(w4_env) : 1;
-        const bool w4_ok = w4_mode != 0 && (L.coutp >= 64 || w4_mode != 3) && L.name2.empty() && !is_head_unit(L);
+        // (the head unit stays on F(2x2,3x3) where its classifier can be fused into the epilogue -- one 32-cout tile, no sigma twin; the
+        // 64-cout cls + sigma twin unit has no fused form and takes F(4x4,3x3))
+        const bool w4_ok = w4_mode != 0 && (L.coutp >= 64 || w4_mode != 3) && !(is_head_unit(L) && L.name2.empty());
         if (w4_ok && L.W % 32 == 0) {
             if (L.H % 32 == 0) return CONV_CFG_WINO4_T32x32_N32;
             if (L.H % 16 == 0) return CONV_CFG_WINO4_S2T16x32_N32;

@@ -109,8 +109,12 @@ __device__ __forceinline__ WinoEpiRaw wino4_epilogue_load(const ConvArgs& a, int
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int c = co + b;
-            e.mk[b] = a.mask[(size_t)n * a.Cmask + min(c, a.Cmask - 1)];
-            e.site |= (c < a.Cmask ? 1 : 0) << b;
+            // the fused cls + sigma head unit: output channels >= Csplit belong to the twin's dropout site (as rcu_wino_common.h)
+            const bool second = a.mask2 != nullptr && c >= a.Csplit;
+            const int cm = second ? a.Cmask2 : a.Cmask, ci = second ? c - a.Csplit : c;
+            const float* const row = second ? a.mask2 + (size_t)n * a.Cmask2 : a.mask + (size_t)n * a.Cmask;
+            e.mk[b] = row[min(ci, cm - 1)];
+            e.site |= (ci < cm ? 1 : 0) << b;
         }
     }
     return e;
@@ -689,7 +693,7 @@ static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
 {
     const int nchunks = (a.C1 + a.C2) / T::KC;
     if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
-        (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 || (T::FULLW && a.W != T::TW) || a.mask2 != nullptr ||
+        (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 || (T::FULLW && a.W != T::TW) ||
         (size_t)a.N * a.H * a.W * a.CoutP * 4 >= ((size_t)1 << 31))
         return hipErrorInvalidValue;
 #ifdef RCU_WINO4_ABLATIONS   // timing experiments of tools/wino4_check.py (make EXTRA=-DRCU_WINO4_ABLATIONS); results are wrong
