@@ -10,9 +10,10 @@
 // Both histograms are HBM scans over 6-10 bytes per voxel and must not be instruction-bound (a wave64 VALU
 // instruction takes 4 cycles, so the budget at HBM speed is about 35 instructions per voxel).  Every lane owns a
 // private column [bin][lane] of a per-wave LDS histogram and adds to it with ds_add (no return value, no
-// conflicts, no cross-lane traffic in the streaming loop); once per workgroup the 64 columns of each wave are
-// folded by an xor-butterfly wavefront reduction, then the waves, then (second kernel) the workgroups, every
-// stage in a fixed order: counts are exact and the confidence sums are run-to-run deterministic.
+// conflicts, no cross-lane traffic in the streaming loop); once per workgroup the columns of its waves are added
+// straight out of LDS (a few lanes per bin, a short wavefront butterfly to join them), the workgroup's sums go into
+// per-volume accumulators with integer atomics, and a small second kernel writes the result.  Everything is integer
+// arithmetic (the confidences as 2^-42 fixed point): counts and confidence sums are exact, whatever the order.
 // Uncertainty thresholds that are not ascending take the general kernel (wavefront ballots per distinct key).
 // Bin indices are bit-exact with np.digitize: p is compared against the float32 thresholds
 // t_k = min{float32 t : t >= edge_k}.
@@ -62,11 +63,6 @@ struct UncThresholds {
 // Confidences are clamped to [0, 2): values a probability map cannot hold (the evaluation rejects them, rechun/eval/helper.py:8-12).
 static constexpr int ECE_FIX_BITS = 42, ECE_CNT_SHIFT = 50, ECE_POS_SHIFT = 57;
 
-struct EcePartial {
-    unsigned long long count, sum_pos;
-    unsigned long long sum_fix;   // sum of the fixed-point confidences of one workgroup (<= 16384 * 2^43)
-};
-
 __device__ __forceinline__ unsigned long long ece_fixed_point(float q)
 {
     q = __builtin_amdgcn_fmed3f(q, 0.f, 1.99999988f);       // one instruction; NaN -> 0 (v_med3_f32 returns the minimum of the others)
@@ -99,9 +95,16 @@ __device__ __forceinline__ double wave_sum(double x)
 
 static inline unsigned blocks_per_volume(size_t n) { return (unsigned)((n + ELEMS_PER_BLOCK - 1) / ELEMS_PER_BLOCK); }
 
+// Workspace of the histogram: one accumulator row per volume and bin (count, positives, the fixed-point confidence sum as two
+// 32-bit halves in 64-bit words: a volume's sum does not fit 64 bits, its halves do).  The workgroups add their sums with integer
+// atomics -- exact and order-free -- and a one-workgroup kernel turns the rows into the result; the launcher zeroes the rows.
+struct EceAccum {
+    unsigned long long count, sum_pos, sum_lo, sum_hi;
+};
 size_t ece_workspace_bytes(size_t n_per_volume, int n_volumes)
 {
-    return (size_t)blocks_per_volume(n_per_volume) * n_volumes * MAX_BINS * sizeof(EcePartial);
+    (void)n_per_volume;
+    return (size_t)n_volumes * MAX_BINS * sizeof(EceAccum);
 }
 
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned x)
@@ -111,7 +114,7 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned x)
     return x;
 }
 
-// Dynamic LDS of the histogram kernel: [wave][bin][lane] histogram words (see EcePartial).
+// Dynamic LDS of the histogram kernel: [wave][bin][lane] histogram words (fixed-point confidence | count | positives, see above).
 static inline size_t ece_lds_bytes(int n_bins) { return (size_t)CB_WAVES * n_bins * 64 * 8; }
 
 // bin = #{k : p >= t_k}, computed as a candidate floor(p * n_bins) plus one table lookup.  The edges are
@@ -135,7 +138,7 @@ __device__ __forceinline__ int ece_parts(int nb)
 template <bool VEC>
 __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __restrict__ p, const uint8_t* __restrict__ target,
                                                                const uint8_t* __restrict__ mask, size_t n,
-                                                               const BinThresholds th, EcePartial* __restrict__ partial)
+                                                               const BinThresholds th, EceAccum* __restrict__ accum)
 {
     extern __shared__ unsigned long long ece_smem[];
     __shared__ float lut[MAX_BINS + 1];       // an object of its own: the compiler may then move the table reads across the histogram adds
@@ -234,61 +237,30 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
             cpos += __shfl_xor(cpos, off, 64);
             sm += __shfl_xor(sm, off, 64);
         }
-        if (k == 0 && b < MAX_BINS) {
-            EcePartial out;
-            out.count = b < nb ? c : 0;
-            out.sum_pos = b < nb ? cpos : 0;
-            out.sum_fix = b < nb ? sm : 0;
-            partial[((size_t)vol * gridDim.x + blockIdx.x) * MAX_BINS + b] = out;
+        if (k == 0 && b < nb && c != 0) {      // (an empty bin adds nothing)
+            EceAccum* const row = accum + (size_t)vol * MAX_BINS + b;
+            atomicAdd(&row->count, (unsigned long long)c);
+            atomicAdd(&row->sum_pos, (unsigned long long)cpos);
+            atomicAdd(&row->sum_lo, sm & 0xFFFFFFFFull);
+            atomicAdd(&row->sum_hi, sm >> 32);
         }
-    }
-    if (tid < MAX_BINS && tid >= CB_THREADS / ece_parts(nb)) {   // bins no thread group stands for: zero partials
-        EcePartial out;
-        out.count = out.sum_pos = out.sum_fix = 0;
-        partial[((size_t)vol * gridDim.x + blockIdx.x) * MAX_BINS + tid] = out;
     }
 }
 
-// Second stage, one workgroup per volume: thread (row, bin) adds the partials of blocks row, row + ROWS, ... in
-// that order, then bin's thread adds the rows in order.
+// Second stage: accumulator rows -> result.  The two halves of the fixed-point sum are joined and rounded ONCE to float64: the
+// exact sum of the confidences to within 2^-43 per voxel, whatever order the workgroups added in.
 static constexpr int RED_THREADS = 256;
 
-__global__ __launch_bounds__(RED_THREADS) void ece_reduce_kernel(const EcePartial* __restrict__ partial, unsigned nblocks,
-                                                                  EceResult* __restrict__ result)
+__global__ __launch_bounds__(RED_THREADS) void ece_reduce_kernel(const EceAccum* __restrict__ accum, int n_volumes, EceResult* __restrict__ result)
 {
-    constexpr int ROWS = RED_THREADS / MAX_BINS;
-    // the fixed-point sums are added as two 32-bit halves in 64-bit integers (no overflow below 2^32 workgroups per volume) and
-    // turned into ONE double at the end: the exact sum of the confidences, rounded once
-    __shared__ unsigned long long s_c[ROWS][MAX_BINS], s_p[ROWS][MAX_BINS], s_lo[ROWS][MAX_BINS], s_hi[ROWS][MAX_BINS];
-    const int b = threadIdx.x % MAX_BINS, row = threadIdx.x / MAX_BINS;
-    const size_t vol = blockIdx.x;
-    unsigned long long c = 0, sp = 0, lo = 0, hi = 0;
-    for (unsigned k = row; k < nblocks; k += ROWS) {
-        const EcePartial q = partial[((size_t)vol * nblocks + k) * MAX_BINS + b];
-        c += q.count;
-        sp += q.sum_pos;
-        lo += q.sum_fix & 0xFFFFFFFFull;
-        hi += q.sum_fix >> 32;
-    }
-    s_c[row][b] = c;
-    s_p[row][b] = sp;
-    s_lo[row][b] = lo;
-    s_hi[row][b] = hi;
-    __syncthreads();
-    if (row == 0) {
-        c = 0, sp = 0, lo = 0, hi = 0;
-        for (int r = 0; r < ROWS; ++r) {
-            c += s_c[r][b];
-            sp += s_p[r][b];
-            lo += s_lo[r][b];
-            hi += s_hi[r][b];
-        }
-        hi += lo >> 32;
-        lo &= 0xFFFFFFFFull;
-        result[vol].count[b] = c;
-        result[vol].sum_pos[b] = sp;
-        result[vol].sum_conf[b] = ((double)hi * 4294967296.0 + (double)lo) * (1.0 / (double)(1ull << ECE_FIX_BITS));
-    }
+    const int i = blockIdx.x * RED_THREADS + threadIdx.x;
+    if (i >= n_volumes * MAX_BINS) return;
+    const int vol = i / MAX_BINS, b = i % MAX_BINS;
+    const EceAccum a = accum[i];
+    unsigned long long hi = a.sum_hi + (a.sum_lo >> 32), lo = a.sum_lo & 0xFFFFFFFFull;
+    result[vol].count[b] = a.count;
+    result[vol].sum_pos[b] = a.sum_pos;
+    result[vol].sum_conf[b] = ((double)hi * 4294967296.0 + (double)lo) * (1.0 / (double)(1ull << ECE_FIX_BITS));
 }
 
 hipError_t launch_ece_hist(const float* p, const uint8_t* target, const uint8_t* mask, size_t n, int n_volumes,
@@ -302,7 +274,11 @@ hipError_t launch_ece_hist(const float* p, const uint8_t* target, const uint8_t*
     if (nb == 0) {   // empty input: all-zero histogram
         return hipMemsetAsync(result_dev, 0, sizeof(EceResult) * n_volumes, stream);
     }
-    EcePartial* part = reinterpret_cast<EcePartial*>(workspace);
+    EceAccum* part = reinterpret_cast<EceAccum*>(workspace);
+    {
+        hipError_t e = hipMemsetAsync(part, 0, ece_workspace_bytes(n, n_volumes), stream);
+        if (e != hipSuccess) return e;
+    }
     const bool vec = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(p) % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(target) % 4 == 0) &&
                      (mask == nullptr || reinterpret_cast<uintptr_t>(mask) % 4 == 0);
@@ -318,7 +294,8 @@ hipError_t launch_ece_hist(const float* p, const uint8_t* target, const uint8_t*
     else
         hipLaunchKernelGGL(ece_hist_kernel<false>, dim3(nb, n_volumes), dim3(CB_THREADS), lds, stream, p, target, mask, n,
                            th, part);
-    hipLaunchKernelGGL(ece_reduce_kernel, dim3(n_volumes), dim3(RED_THREADS), 0, stream, part, nb, result_dev);
+    hipLaunchKernelGGL(ece_reduce_kernel, dim3((unsigned)((n_volumes * MAX_BINS + RED_THREADS - 1) / RED_THREADS)), dim3(RED_THREADS), 0, stream, part,
+                       n_volumes, result_dev);
     return hipGetLastError();
 }
 
@@ -345,9 +322,12 @@ hipError_t launch_bin_ids(const float* p, size_t n, const float* thr_host, int n
 // key = cell (tp=0, tn=1, fp=2, fn=3) | bitmask of exceeded thresholds << 2
 static constexpr int UNC_SLOTS = (MAX_THR + 1) * 4;   // [t][cell], t == n_thr row holds the base counts
 
+// Workspace of the counts: one row of UNC_SLOTS accumulators per volume, added to with integer atomics by the workgroups (exact,
+// order-free) and turned into the output layout by a small second kernel; the launcher zeroes it.
 size_t unc_workspace_bytes(size_t n_per_volume, int n_volumes)
 {
-    return (size_t)blocks_per_volume(n_per_volume) * n_volumes * UNC_SLOTS * sizeof(unsigned long long);
+    (void)n_per_volume;
+    return (size_t)n_volumes * UNC_SLOTS * sizeof(unsigned long long);
 }
 
 __device__ __forceinline__ void unc_wave_update(bool active, unsigned key, unsigned* w_slots, int n_thr, int lane)
@@ -406,7 +386,7 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_kernel(const U* __restr
     if (tid < UNC_SLOTS) {
         unsigned long long c = 0;
         for (int w = 0; w < CB_WAVES; ++w) c += s_slots[w][tid];
-        partial[((size_t)vol * gridDim.x + blockIdx.x) * UNC_SLOTS + tid] = c;
+        if (c != 0) atomicAdd(partial + (size_t)vol * UNC_SLOTS + tid, c);
     }
 }
 
@@ -560,35 +540,20 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
             for (int w = 0; w < CB_WAVES; ++w)
                 for (int m = m_lo; m <= th.n_thr; ++m) c += s_w[w][m * 4 + cell];
         }
-        partial[((size_t)vol * gridDim.x + blockIdx.x) * UNC_SLOTS + tid] = c;
+        if (c != 0) atomicAdd(partial + (size_t)vol * UNC_SLOTS + tid, c);
     }
 }
 
-__global__ __launch_bounds__(RED_THREADS) void unc_reduce_kernel(const unsigned long long* __restrict__ partial,
-                                                                  unsigned nblocks, int n_thr,
+__global__ __launch_bounds__(RED_THREADS) void unc_reduce_kernel(const unsigned long long* __restrict__ accum, int n_volumes, int n_thr,
                                                                   unsigned long long* __restrict__ out)
 {
-    constexpr int ROWS = RED_THREADS / UNC_SLOTS;    // threads beyond ROWS * UNC_SLOTS idle
-    __shared__ unsigned long long s[ROWS][UNC_SLOTS];
-    const int slot = threadIdx.x % UNC_SLOTS, row = threadIdx.x / UNC_SLOTS;
-    const size_t vol = blockIdx.x;
-    if (row < ROWS) {
-        unsigned long long c = 0;
-        for (unsigned k = row; k < nblocks; k += ROWS) c += partial[((size_t)vol * nblocks + k) * UNC_SLOTS + slot];
-        s[row][slot] = c;
-    }
-    __syncthreads();
-    const int t = slot / 4, cell = slot % 4;
-    if (row == 0 && t < n_thr) {
-        unsigned long long base = 0, cu = 0;
-        for (int r = 0; r < ROWS; ++r) {
-            base += s[r][n_thr * 4 + cell];
-            cu += s[r][slot];
-        }
-        unsigned long long* o = out + ((size_t)vol * n_thr + t) * 8;
-        o[cell] = base;      // tp, tn, fp, fn (same for every threshold)
-        o[4 + cell] = cu;    // tpu, tnu, fpu, fnu
-    }
+    const int i = blockIdx.x * RED_THREADS + threadIdx.x;      // (volume, threshold, cell)
+    if (i >= n_volumes * n_thr * 4) return;
+    const int cell = i % 4, t = (i / 4) % n_thr, vol = i / (4 * n_thr);
+    const unsigned long long* const row = accum + (size_t)vol * UNC_SLOTS;
+    unsigned long long* o = out + ((size_t)vol * n_thr + t) * 8;
+    o[cell] = row[n_thr * 4 + cell];      // tp, tn, fp, fn (same for every threshold)
+    o[4 + cell] = row[t * 4 + cell];      // tpu, tnu, fpu, fnu
 }
 
 hipError_t launch_unc_counts(const void* unc, int unc_is_f64, const uint8_t* prediction, const uint8_t* target,
@@ -643,6 +608,10 @@ hipError_t launch_unc_counts(const void* unc, int unc_is_f64, const uint8_t* pre
     const unsigned nb = blocks_per_volume(n);
     if (nb == 0) return hipMemsetAsync(out_dev, 0, sizeof(unsigned long long) * 8 * n_thr * n_volumes, stream);
     unsigned long long* part = reinterpret_cast<unsigned long long*>(workspace);
+    {
+        hipError_t e = hipMemsetAsync(part, 0, unc_workspace_bytes(n, n_volumes), stream);
+        if (e != hipSuccess) return e;
+    }
     bool ascending = true;
     for (int t = 1; t < n_thr; ++t) ascending = ascending && (thr_host[t - 1] <= thr_host[t]);
     if (ascending) {
@@ -659,7 +628,8 @@ hipError_t launch_unc_counts(const void* unc, int unc_is_f64, const uint8_t* pre
     else
         hipLaunchKernelGGL(unc_counts_kernel<float>, dim3(nb, n_volumes), dim3(CB_THREADS), 0, stream,
                            reinterpret_cast<const float*>(unc), prediction, target, mask, n, th, part);
-    hipLaunchKernelGGL(unc_reduce_kernel, dim3(n_volumes), dim3(RED_THREADS), 0, stream, part, nb, n_thr, out_dev);
+    hipLaunchKernelGGL(unc_reduce_kernel, dim3((unsigned)((n_volumes * n_thr * 4 + RED_THREADS - 1) / RED_THREADS)), dim3(RED_THREADS), 0, stream, part,
+                       n_volumes, n_thr, out_dev);
     return hipGetLastError();
 }
 
