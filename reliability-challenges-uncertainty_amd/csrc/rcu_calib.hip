@@ -13,13 +13,14 @@
 // conflicts, no cross-lane traffic in the streaming loop); once per workgroup the columns of its waves are added
 // straight out of LDS (a few lanes per bin, a short wavefront butterfly to join them), the workgroup's sums go into
 // per-volume accumulators with integer atomics, and a small second kernel writes the result.  Everything is integer
-// arithmetic (the confidences as 2^-42 fixed point): counts and confidence sums are exact, whatever the order.
+// arithmetic (the confidences as 2^-40 fixed point): counts and confidence sums are exact, whatever the order.
 // Uncertainty thresholds that are not ascending take the general kernel (wavefront ballots per distinct key).
 // Bin indices are bit-exact with np.digitize: p is compared against the float32 thresholds
 // t_k = min{float32 t : t >= edge_k}.
 #include "rcu_kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 namespace rcu {
@@ -55,21 +56,22 @@ struct UncThresholds {
     unsigned char cell_base[UNC_CELLS];
 };
 
-// One histogram word per voxel: the confidence as a 2^-42 fixed-point integer in bits 0..49, a count of one in bits 50..56 and the
-// positive flag in bits 57..63.  A lane sees at most ELEMS_PER_BLOCK / CB_THREADS = 64 voxels per workgroup, so neither count (<= 64) nor
-// the sum (<= 64 * 2 * 2^42 = 2^49) can carry into its neighbour, and ONE 64-bit LDS add records the voxel.  float32 confidences
-// >= 2^-18 convert exactly (24 mantissa bits above 2^-42), smaller ones are rounded to the nearest 2^-42, so a bin's confidence sum is
-// the exact real sum to within 2^-43 per voxel -- and integer adds commute: the histogram does not depend on the launch geometry.
+// One histogram word per voxel: the confidence as a 2^-40 fixed-point integer in bits 0..47, a count of one in bits 48..55 and the
+// positive flag in bits 56..63.  A lane sees at most ECE_MAX_BLOCKS * ELEMS_PER_BLOCK / CB_THREADS = 128 voxels per workgroup, so neither
+// count (<= 128) nor the sum (< 128 * 2 * 2^40 = 2^48) can carry into its neighbour, and ONE 64-bit LDS add records the voxel.  float32
+// confidences >= 2^-16 convert exactly (24 mantissa bits above 2^-40), smaller ones are rounded to the nearest 2^-40, so a bin's confidence
+// sum is the exact real sum to within 2^-41 per voxel -- and integer adds commute: the histogram does not depend on the launch geometry.
 // Confidences are clamped to [0, 2): values a probability map cannot hold (the evaluation rejects them, rechun/eval/helper.py:8-12).
-static constexpr int ECE_FIX_BITS = 42, ECE_CNT_SHIFT = 50, ECE_POS_SHIFT = 57;
+// (Round 3, later: 2^-40 and 8-bit fields instead of 2^-42 and 7-bit ones, so that a workgroup can take two blocks per prologue / reduction.)
+static constexpr int ECE_FIX_BITS = 40, ECE_CNT_SHIFT = 48, ECE_POS_SHIFT = 56, ECE_MAX_BLOCKS = 2;
 
 __device__ __forceinline__ unsigned long long ece_fixed_point(float q)
 {
     q = __builtin_amdgcn_fmed3f(q, 0.f, 1.99999988f);       // one instruction; NaN -> 0 (v_med3_f32 returns the minimum of the others)
-    // q + 2^10 in float64 has its unit in the last place at 2^-42: the fraction field IS q * 2^42, rounded to nearest
-    // (float32 values >= 2^-18 exactly); three instructions instead of an exponent / mantissa / shift sequence
-    const double d = (double)q + 1024.0;
-    return (unsigned long long)__double_as_longlong(d) - 0x4090000000000000ull;   // minus the bits of 1024.0
+    // q + 2^12 in float64 has its unit in the last place at 2^-40: the fraction field IS q * 2^40, rounded to nearest
+    // (float32 values >= 2^-16 exactly); three instructions instead of an exponent / mantissa / shift sequence
+    const double d = (double)q + 4096.0;
+    return (unsigned long long)__double_as_longlong(d) - 0x40B0000000000000ull;   // minus the bits of 4096.0
 }
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x)
@@ -94,6 +96,19 @@ __device__ __forceinline__ double wave_sum(double x)
 }
 
 static inline unsigned blocks_per_volume(size_t n) { return (unsigned)((n + ELEMS_PER_BLOCK - 1) / ELEMS_PER_BLOCK); }
+
+// Blocks a workgroup of a streaming histogram kernel takes: its prologue (zeroing the columns) and its reduction cost a few per cent of
+// a block's streaming time, so a large launch lets every workgroup take several consecutive blocks of its volume (measured, 160 BraTS
+// volumes: 2 blocks +4 %, 8 blocks +5 %, 16 blocks -- too few workgroups left for the tail -- +2 %) while a small one keeps one block
+// per workgroup and with it the chip full: at least four rounds of workgroups stay.  `env`: override for experiments.
+static inline unsigned blocks_per_workgroup(unsigned blocks, int n_volumes, unsigned cap, const char* env)
+{
+    const char* const v = getenv(env);
+    if (v != nullptr && atoi(v) >= 1) return (unsigned)atoi(v) < cap ? (unsigned)atoi(v) : cap;
+    const size_t resident = 256 * 6;   // workgroups the chip holds at a time (LDS-bound: 6-7 per CU)
+    const size_t k = (size_t)blocks * n_volumes / (4 * resident);
+    return (unsigned)(k < 1 ? 1 : k > cap ? cap : k);
+}
 
 // Workspace of the histogram: one accumulator row per volume and bin (count, positives, the fixed-point confidence sum as two
 // 32-bit halves in 64-bit words: a volume's sum does not fit 64 bits, its halves do).  The workgroups add their sums with integer
@@ -138,7 +153,7 @@ __device__ __forceinline__ int ece_parts(int nb)
 template <bool VEC>
 __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __restrict__ p, const uint8_t* __restrict__ target,
                                                                const uint8_t* __restrict__ mask, size_t n,
-                                                               const BinThresholds th, EceAccum* __restrict__ accum)
+                                                               const BinThresholds th, EceAccum* __restrict__ accum, unsigned blocks_per_wg, unsigned nblocks)
 {
     extern __shared__ unsigned long long ece_smem[];
     __shared__ float lut[MAX_BINS + 1];       // an object of its own: the compiler may then move the table reads across the histogram adds
@@ -152,7 +167,6 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
     const float* pv = p + vol * n;
     const uint8_t* tv = target + vol * n;
     const uint8_t* mv = mask ? mask + vol * n : nullptr;
-    const size_t base = (size_t)blockIdx.x * ELEMS_PER_BLOCK;
     // branch-free: a voxel outside the mask adds a zero word to whatever bin its confidence names (an exec-mask round trip per voxel
     // costs more than the LDS add it saves)
     auto add = [&](bool active, float q, bool pos) {
@@ -161,37 +175,47 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
         const unsigned long long word = ece_fixed_point(active ? q : 0.f) | ((unsigned long long)hi << 32);
         __hip_atomic_fetch_add(col + b * 64, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
-    // four voxels of a mask / target word pair: H holds per byte bit 0 = inside the mask, bit 7 = positive and inside, so a voxel's
-    // count / positive fields are ONE shift of its byte (count at bit 50, positive flag at bit 57: seven bits apart, like bits 0 and 7)
+    // four voxels of a mask / target word pair: A holds per byte 1 = inside the mask, P per byte 1 = positive and inside; a voxel's count /
+    // positive fields -- bytes 6 and 7 of its word -- are ONE byte permute of the two (v_perm_b32: bytes 3, 2 <- P.k, A.k; bytes 1, 0 <- 0)
     auto nonzero_bytes = [](unsigned w) { return ((w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u; };
     auto add4 = [&](const float4& q, unsigned t4, unsigned m4) {
         const unsigned A = nonzero_bytes(m4);
-        const unsigned H = A | ((A & nonzero_bytes(t4)) << 7);
+        const unsigned P = A & nonzero_bytes(t4);
         const float qs[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const unsigned hb = (H >> (8 * k)) & 0xffu;
+            const unsigned hi = __builtin_amdgcn_perm(P, A, 0x00000c0cu | ((4u + k) << 24) | ((unsigned)k << 16));
             const int b = bin_lookup(qs[k], nb, lut);
-            const unsigned long long word = ece_fixed_point(hb != 0u ? qs[k] : 0.f) | ((unsigned long long)(hb << (ECE_CNT_SHIFT - 32)) << 32);
+            const unsigned long long word = ece_fixed_point(hi != 0u ? qs[k] : 0.f) | ((unsigned long long)hi << 32);
             __hip_atomic_fetch_add(col + b * 64, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     };
     constexpr int ROUNDS = ELEMS_PER_BLOCK / (CB_THREADS * 4), BATCH = 4;
+    // the workgroup's blocks_per_wg (<= ECE_MAX_BLOCKS) consecutive blocks of the volume: one prologue and one reduction for all of them
+    const unsigned blk_end = min((blockIdx.x + 1) * blocks_per_wg, nblocks);
+    for (unsigned blk = blockIdx.x * blocks_per_wg; blk < blk_end; ++blk) {
+    const size_t base = (size_t)blk * ELEMS_PER_BLOCK;
     if (VEC && base + ELEMS_PER_BLOCK <= n) {
-        // whole block inside the volume: the loads of BATCH rounds are issued before the first is consumed
-        // (6 KiB per wave in flight; with a bounds check per round the compiler waits for every round)
-        for (int r0 = 0; r0 < ROUNDS; r0 += BATCH) {
-            float4 q[BATCH];
-            unsigned t4[BATCH], m4[BATCH];
+        // whole block inside the volume: the loads of BATCH rounds are issued before the first is consumed (with a bounds check per
+        // round the compiler waits for every round), and the loads of the next BATCH rounds before this batch is worked on: a wave
+        // keeps 6-12 KiB in flight through its arithmetic phases too
+        float4 q[2][BATCH];
+        unsigned t4[2][BATCH], m4[2][BATCH];
+        auto load = [&](int r0, int s) {
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) {
                 const size_t e = base + ((size_t)(r0 + i) * CB_THREADS + tid) * 4;
-                q[i] = *reinterpret_cast<const float4*>(pv + e);
-                t4[i] = *reinterpret_cast<const unsigned*>(tv + e);
-                m4[i] = mv ? *reinterpret_cast<const unsigned*>(mv + e) : 0x01010101u;
+                q[s][i] = *reinterpret_cast<const float4*>(pv + e);
+                t4[s][i] = *reinterpret_cast<const unsigned*>(tv + e);
+                m4[s][i] = mv ? *reinterpret_cast<const unsigned*>(mv + e) : 0x01010101u;
             }
+        };
+        load(0, 0);
 #pragma unroll
-            for (int i = 0; i < BATCH; ++i) add4(q[i], t4[i], m4[i]);
+        for (int g = 0; g < ROUNDS / BATCH; ++g) {
+            if (g + 1 < ROUNDS / BATCH) load((g + 1) * BATCH, (g + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) add4(q[g & 1][i], t4[g & 1][i], m4[g & 1][i]);
         }
     } else if (VEC) {
         for (int r = 0; r < ROUNDS; ++r) {
@@ -213,6 +237,7 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
             if (e < n) add(mv ? mv[e] != 0 : true, pv[e], tv[e] != 0);
         }
     }
+    }
     // Reduction of the workgroup's CB_WAVES x 64 columns straight out of LDS (integers: exact whatever the order): bin b belongs to
     // `parts` consecutive threads (a power of two, 16 for ten bins), thread (b, k) adds the words j = k (mod parts) of the bin's 256
     // -- 16 reads per thread where a butterfly over the wave's lanes took 24 cross-lane moves per bin and lane --, then the parts meet
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
             for (int i = 0; i < CB_WAVES * 64 / parts; ++i) {
                 const int j = (k + (i + b) * parts) & (CB_WAVES * 64 - 1);   // start rotated by the bin: the bins of a wave read different banks
                 const unsigned long long word = ece_smem[(size_t)(j >> 6) * nb * 64 + (size_t)b * 64 + (j & 63)];
-                c += (unsigned)(word >> ECE_CNT_SHIFT) & 127u;
+                c += (unsigned)(word >> ECE_CNT_SHIFT) & 255u;
                 cpos += (unsigned)(word >> ECE_POS_SHIFT);
                 sm += word & ((1ull << ECE_CNT_SHIFT) - 1);
             }
@@ -248,7 +273,7 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
 }
 
 // Second stage: accumulator rows -> result.  The two halves of the fixed-point sum are joined and rounded ONCE to float64: the
-// exact sum of the confidences to within 2^-43 per voxel, whatever order the workgroups added in.
+// exact sum of the confidences to within 2^-41 per voxel, whatever order the workgroups added in.
 static constexpr int RED_THREADS = 256;
 
 __global__ __launch_bounds__(RED_THREADS) void ece_reduce_kernel(const EceAccum* __restrict__ accum, int n_volumes, EceResult* __restrict__ result)
@@ -288,12 +313,14 @@ hipError_t launch_ece_hist(const float* p, const uint8_t* target, const uint8_t*
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    const unsigned bpw = blocks_per_workgroup(nb, n_volumes, ECE_MAX_BLOCKS, "RCU_ECE_BLOCKS_PER_WG");
+    const unsigned gx = (nb + bpw - 1) / bpw;
     if (vec)
-        hipLaunchKernelGGL(ece_hist_kernel<true>, dim3(nb, n_volumes), dim3(CB_THREADS), lds, stream, p, target, mask, n, th,
-                           part);
+        hipLaunchKernelGGL(ece_hist_kernel<true>, dim3(gx, n_volumes), dim3(CB_THREADS), lds, stream, p, target, mask, n, th,
+                           part, bpw, nb);
     else
-        hipLaunchKernelGGL(ece_hist_kernel<false>, dim3(nb, n_volumes), dim3(CB_THREADS), lds, stream, p, target, mask, n,
-                           th, part);
+        hipLaunchKernelGGL(ece_hist_kernel<false>, dim3(gx, n_volumes), dim3(CB_THREADS), lds, stream, p, target, mask, n,
+                           th, part, bpw, nb);
     hipLaunchKernelGGL(ece_reduce_kernel, dim3((unsigned)((n_volumes * MAX_BINS + RED_THREADS - 1) / RED_THREADS)), dim3(RED_THREADS), 0, stream, part,
                        n_volumes, result_dev);
     return hipGetLastError();
@@ -321,6 +348,7 @@ hipError_t launch_bin_ids(const float* p, size_t n, const float* thr_host, int n
 // ------------------------------------------------------------------------------- uncertainty-error counts
 // key = cell (tp=0, tn=1, fp=2, fn=3) | bitmask of exceeded thresholds << 2
 static constexpr int UNC_SLOTS = (MAX_THR + 1) * 4;   // [t][cell], t == n_thr row holds the base counts
+static constexpr int UNC_MAX_BLOCKS = 8;              // blocks per workgroup of the sorted kernel: 8 * 64 voxels per lane fit its 16-bit fields
 
 // Workspace of the counts: one row of UNC_SLOTS accumulators per volume, added to with integer atomics by the workgroups (exact,
 // order-free) and turned into the output layout by a small second kernel; the launcher zeroes it.
@@ -409,7 +437,7 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
                                                                         const uint8_t* __restrict__ target,
                                                                         const uint8_t* __restrict__ mask, size_t n,
                                                                         const UncThresholds th,
-                                                                        unsigned long long* __restrict__ partial)
+                                                                        unsigned long long* __restrict__ partial, unsigned blocks_per_wg, unsigned nblocks)
 {
     extern __shared__ unsigned unc_smem[];           // [wave][(n_thr + 1) * 2][lane], two 16-bit cell counters per word
     __shared__ unsigned s_w[CB_WAVES][UNC_SLOTS];    // per wave: [m][cell] totals
@@ -425,7 +453,6 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
     const uint8_t* pv = pred + vol * n;
     const uint8_t* tv = target + vol * n;
     const uint8_t* mv = mask ? mask + vol * n : nullptr;
-    const size_t base = (size_t)blockIdx.x * ELEMS_PER_BLOCK;
     // m = number of thresholds u exceeds
     auto exceeded = [&](U u) {
         int m = 0;
@@ -470,20 +497,31 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
                      (reinterpret_cast<uintptr_t>(pv) % 4 == 0) && (reinterpret_cast<uintptr_t>(tv) % 4 == 0) &&
                      (mv == nullptr || reinterpret_cast<uintptr_t>(mv) % 4 == 0);
     constexpr int ROUNDS = ELEMS_PER_BLOCK / (CB_THREADS * 4), BATCH = 4;
+    // the workgroup's blocks_per_wg (<= UNC_MAX_BLOCKS) consecutive blocks of the volume: one prologue and one reduction for all of them
+    // (a lane adds at most 64 voxels per block to a 16-bit field)
+    const unsigned blk_end = min((blockIdx.x + 1) * blocks_per_wg, nblocks);
+    for (unsigned blk = blockIdx.x * blocks_per_wg; blk < blk_end; ++blk) {
+    const size_t base = (size_t)blk * ELEMS_PER_BLOCK;
     if (vec && base + ELEMS_PER_BLOCK <= n) {
-        for (int r0 = 0; r0 < ROUNDS; r0 += BATCH) {   // loads of BATCH rounds in flight together
-            U q[BATCH][4];
-            unsigned p4[BATCH], t4[BATCH], m4[BATCH];
+        // loads of BATCH rounds in flight together, and those of the next BATCH rounds issued before this batch is worked on
+        U q[2][BATCH][4];
+        unsigned p4[2][BATCH], t4[2][BATCH], m4[2][BATCH];
+        auto load = [&](int r0, int s) {
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) {
                 const size_t e = base + ((size_t)(r0 + i) * CB_THREADS + tid) * 4;
-                load4(uv + e, q[i]);
-                p4[i] = *reinterpret_cast<const unsigned*>(pv + e);
-                t4[i] = *reinterpret_cast<const unsigned*>(tv + e);
-                m4[i] = mv ? *reinterpret_cast<const unsigned*>(mv + e) : 0x01010101u;
+                load4(uv + e, q[s][i]);
+                p4[s][i] = *reinterpret_cast<const unsigned*>(pv + e);
+                t4[s][i] = *reinterpret_cast<const unsigned*>(tv + e);
+                m4[s][i] = mv ? *reinterpret_cast<const unsigned*>(mv + e) : 0x01010101u;
             }
+        };
+        load(0, 0);
 #pragma unroll
-            for (int i = 0; i < BATCH; ++i) add4(q[i], p4[i], t4[i], m4[i]);
+        for (int g = 0; g < ROUNDS / BATCH; ++g) {
+            if (g + 1 < ROUNDS / BATCH) load((g + 1) * BATCH, (g + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) add4(q[g & 1][i], p4[g & 1][i], t4[g & 1][i], m4[g & 1][i]);
         }
     } else if (vec) {
         for (int r = 0; r < ROUNDS; ++r) {
@@ -507,8 +545,9 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
             if (e < n) add(mv ? mv[e] != 0 : true, uv[e], pv[e] != 0, tv[e] != 0);
         }
     }
+    }
     // Reduction of the wave's 64 columns straight out of LDS: lane (column k = lane >> 1, half h = lane & 1) adds the 32 words
-    // k * 64 + h, + 2, ... of column k (two 16-bit fields each, at most 64 per lane: no carry), then the two halves meet -- 32 reads
+    // k * 64 + h, + 2, ... of column k (two 16-bit fields each, at most 64 * UNC_MAX_BLOCKS per lane: no carry), then the two halves meet -- 32 reads
     // per lane for 32 columns at a time where a butterfly per column took 12 cross-lane moves per column and lane.
     __syncthreads();
     {
@@ -616,12 +655,14 @@ hipError_t launch_unc_counts(const void* unc, int unc_is_f64, const uint8_t* pre
     for (int t = 1; t < n_thr; ++t) ascending = ascending && (thr_host[t - 1] <= thr_host[t]);
     if (ascending) {
         const size_t lds = (size_t)CB_WAVES * (n_thr + 1) * 2 * 64 * sizeof(unsigned);
+        const unsigned bpw = blocks_per_workgroup(nb, n_volumes, UNC_MAX_BLOCKS, "RCU_UNC_BLOCKS_PER_WG");
+        const unsigned gx = (nb + bpw - 1) / bpw;
         if (unc_is_f64)
-            hipLaunchKernelGGL(unc_counts_sorted_kernel<double>, dim3(nb, n_volumes), dim3(CB_THREADS), lds, stream,
-                               reinterpret_cast<const double*>(unc), prediction, target, mask, n, th, part);
+            hipLaunchKernelGGL(unc_counts_sorted_kernel<double>, dim3(gx, n_volumes), dim3(CB_THREADS), lds, stream,
+                               reinterpret_cast<const double*>(unc), prediction, target, mask, n, th, part, bpw, nb);
         else
-            hipLaunchKernelGGL(unc_counts_sorted_kernel<float>, dim3(nb, n_volumes), dim3(CB_THREADS), lds, stream,
-                               reinterpret_cast<const float*>(unc), prediction, target, mask, n, th, part);
+            hipLaunchKernelGGL(unc_counts_sorted_kernel<float>, dim3(gx, n_volumes), dim3(CB_THREADS), lds, stream,
+                               reinterpret_cast<const float*>(unc), prediction, target, mask, n, th, part, bpw, nb);
     } else if (unc_is_f64)
         hipLaunchKernelGGL(unc_counts_kernel<double>, dim3(nb, n_volumes), dim3(CB_THREADS), 0, stream,
                            reinterpret_cast<const double*>(unc), prediction, target, mask, n, th, part);

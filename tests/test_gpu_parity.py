@@ -776,6 +776,41 @@ def test_ece_full_size_batched_properties(dev):
     assert np.array_equal(sc, sc2)    # run-to-run deterministic, float sums included
 
 
+def test_calibration_kernels_do_not_depend_on_blocks_per_workgroup(dev, monkeypatch):
+    """The workgroups of the histogram / count kernels take several consecutive blocks of a volume on large launches (the launcher decides;
+    RCU_ECE_BLOCKS_PER_WG / RCU_UNC_BLOCKS_PER_WG force it).  Integer sums: every choice gives the same numbers -- on sizes with a ragged last
+    block, a last workgroup with fewer blocks, sizes not divisible by four (scalar path), and with confidences below 2^-16 (rounded to 2^-40:
+    the sum stays within 2^-41 per voxel of the float64 sum)."""
+    from oracle import c_oracle
+    from oracle import calib_oracle as co
+    from rcu_amd import evaluation as ev
+    thr = co.float32_thresholds(10)
+    ue_thr = (0.05, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95)
+    g = torch.Generator(device='cuda').manual_seed(12)
+    for nv, n in ((3, 16384 * 5 + 4 * 77), (2, 16384 * 3), (1, 16384 * 2 + 3), (2, 999)):
+        p = torch.rand(nv, n, device=dev, generator=g)
+        p = torch.where(torch.rand(nv, n, device=dev, generator=g) < 0.5, p * 3e-6, p)        # half of them below 2^-16
+        t = (torch.rand(nv, n, device=dev, generator=g) < 0.3).to(torch.uint8)
+        m = (torch.rand(nv, n, device=dev, generator=g) < 0.6).to(torch.uint8)
+        pred = (p > 0.5).to(torch.uint8)
+        outs = []
+        for k_ece, k_unc in (('1', '1'), ('2', '3'), ('2', '8')):
+            monkeypatch.setenv('RCU_ECE_BLOCKS_PER_WG', k_ece)
+            monkeypatch.setenv('RCU_UNC_BLOCKS_PER_WG', k_unc)
+            cnt, sc, sp = ev.calibration_histogram(p, t, mask=m, n_volumes=nv)
+            c = ev.uncertainty_counts(pred, t, p, ue_thr, mask=m, n_volumes=nv)
+            outs.append((cnt, sc, sp, c))
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert np.array_equal(a, b), (nv, n)
+        cnt, sc, sp, c = outs[0]
+        for v in range(nv):
+            rc, rsc, rsp = c_oracle.ece_hist(p[v].cpu().numpy(), t[v].cpu().numpy(), m[v].cpu().numpy(), thr)
+            assert np.array_equal(cnt[v], rc.astype(np.int64)) and np.array_equal(sp[v], rsp.astype(np.int64))
+            assert np.all(np.abs(sc[v] - rsc) <= cnt[v] * 2.0 ** -41 + 1e-12 * np.abs(rsc)), (nv, n, v)
+        assert np.array_equal(c[..., :4].sum(-1)[:, 0], m.sum(1).cpu().numpy())
+
+
 def test_uncertainty_counts_golden(golden, dev):
     from rcu_amd import evaluation as ev
     g = golden('g9_uncertainty')
