@@ -65,13 +65,15 @@ struct UncThresholds {
 // (Round 3, later: 2^-40 and 8-bit fields instead of 2^-42 and 7-bit ones, so that a workgroup can take two blocks per prologue / reduction.)
 static constexpr int ECE_FIX_BITS = 40, ECE_CNT_SHIFT = 48, ECE_POS_SHIFT = 56, ECE_MAX_BLOCKS = 2;
 
-__device__ __forceinline__ unsigned long long ece_fixed_point(float q)
+// hi_flags: the count / positive bytes of the word (bytes 2 and 3 of its high half)
+__device__ __forceinline__ unsigned long long ece_word(float q, unsigned hi_flags)
 {
     q = __builtin_amdgcn_fmed3f(q, 0.f, 1.99999988f);       // one instruction; NaN -> 0 (v_med3_f32 returns the minimum of the others)
     // q + 2^12 in float64 has its unit in the last place at 2^-40: the fraction field IS q * 2^40, rounded to nearest
-    // (float32 values >= 2^-16 exactly); three instructions instead of an exponent / mantissa / shift sequence
-    const double d = (double)q + 4096.0;
-    return (unsigned long long)__double_as_longlong(d) - 0x40B0000000000000ull;   // minus the bits of 4096.0
+    // (float32 values >= 2^-16 exactly); the bits of 4096.0 leave and the flags enter the high half in ONE three-operand add
+    const unsigned long long d = (unsigned long long)__double_as_longlong((double)q + 4096.0);
+    const unsigned hi = (unsigned)(d >> 32) + hi_flags + (0u - 0x40B00000u);
+    return ((unsigned long long)hi << 32) | (unsigned)d;
 }
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long x)
@@ -172,8 +174,7 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
     auto add = [&](bool active, float q, bool pos) {
         const int b = bin_lookup(q, nb, lut);
         const unsigned hi = active ? ((1u << (ECE_CNT_SHIFT - 32)) | ((pos ? 1u : 0u) << (ECE_POS_SHIFT - 32))) : 0u;
-        const unsigned long long word = ece_fixed_point(active ? q : 0.f) | ((unsigned long long)hi << 32);
-        __hip_atomic_fetch_add(col + b * 64, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(col + b * 64, ece_word(active ? q : 0.f, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
     // four voxels of a mask / target word pair: A holds per byte 1 = inside the mask, P per byte 1 = positive and inside; a voxel's count /
     // positive fields -- bytes 6 and 7 of its word -- are ONE byte permute of the two (v_perm_b32: bytes 3, 2 <- P.k, A.k; bytes 1, 0 <- 0)
@@ -186,8 +187,7 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
         for (int k = 0; k < 4; ++k) {
             const unsigned hi = __builtin_amdgcn_perm(P, A, 0x00000c0cu | ((4u + k) << 24) | ((unsigned)k << 16));
             const int b = bin_lookup(qs[k], nb, lut);
-            const unsigned long long word = ece_fixed_point(hi != 0u ? qs[k] : 0.f) | ((unsigned long long)hi << 32);
-            __hip_atomic_fetch_add(col + b * 64, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(col + b * 64, ece_word(hi != 0u ? qs[k] : 0.f, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     };
     constexpr int ROUNDS = ELEMS_PER_BLOCK / (CB_THREADS * 4), BATCH = 4;
