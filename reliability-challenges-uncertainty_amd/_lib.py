@@ -9,7 +9,8 @@ from ctypes import (POINTER, Structure, c_char, c_char_p, c_double, c_float, c_i
                     c_uint64, c_void_p)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, 'librcu_hip.so')
+# RCU_HIP_LIBRARY: an experiment build of the same library (csrc/Makefile: BUILD= / OUT=) for the timing tools under tools/
+LIB_PATH = os.environ.get('RCU_HIP_LIBRARY') or os.path.join(PKG_DIR, 'librcu_hip.so')
 
 RCU_MC_MI = 1
 RCU_MC_VAR = 2

@@ -326,7 +326,7 @@ extern "C" __attribute__((visibility("default"))) int rcu_debug_w4_trace(uint64_
 }
 template <bool ON>
 struct Wino4Trace {
-    uint32_t t[6];
+    uint32_t t[8];   // 0 tile start, 1 chunks done, 2 epilogue done, 3 vmcnt(0), 4 barrier, 5 first fragments read, 6 / 7 end of the tile's chunk 0 / 1
     __device__ __forceinline__ void mark(int i) { t[i] = (uint32_t)__builtin_amdgcn_s_memtime(); }
     __device__ __forceinline__ void flush(int item, int wave, int lane)
     {
@@ -334,7 +334,7 @@ struct Wino4Trace {
         if (lane == 0 && k < 4) {
             uint64_t* o = g_w4_trace + (((size_t)blockIdx.x * 4 + wave) * 4 + k) * 8;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) o[i] = (1u << 30) + (t[i] - t[0]);
+            for (int i = 0; i < 8; ++i) o[i] = (1u << 30) + (t[i] - t[0]);
         }
         t[0] = t[5];
     }
@@ -641,7 +641,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
 
     for (;;) {
         chunk(std::integral_constant<int, 0>{}, std::true_type{}, 0, dA, dB, bvA, bvB);
+        WINO4_TRACE_MARK(6);
         chunk(std::integral_constant<int, 1>{}, std::false_type{}, 1, dB, dA, bvB, bvA);
+        WINO4_TRACE_MARK(7);
         for (int kc = 2; kc < nchunks; kc += 2) {
             chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc, dA, dB, bvA, bvB);
             chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1, dB, dA, bvB, bvA);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-tile s_memtime trace of the F(4x4,3x3) kernel (ablation build only: `make EXTRA=-DRCU_WINO4_ABLATIONS` in csrc/).
+"""Per-tile s_memtime trace of the F(4x4,3x3) kernel (ablation build only: `make BUILD=_build_ablate OUT=../librcu_hip_ablate.so EXTRA=-DRCU_WINO4_ABLATIONS` in csrc/, then
+RCU_HIP_LIBRARY=reliability-challenges-uncertainty_amd/librcu_hip_ablate.so).
 
     python tools/wino4_trace.py [layer name substring ...]
 
@@ -50,6 +51,13 @@ def main():
                                                                    L['cin'] // 8))
         for k, lab in enumerate(('chunk loop', 'epilogue', 'vmcnt(0)', 'barrier', 'first fragment reads')):
             print('    {:<22} median {:>8.0f}   p90 {:>8.0f} ticks'.format(lab, med[k], p90[k]))
+        # inside the chunk loop: the tile's chunk 0, chunk 1 and the rest (slots 6 / 7 = end of chunk 0 / 1, relative to the tile start)
+        t8 = buf[:, :, :3, :8].astype(np.int64).reshape(-1, 8)
+        t8 = t8[t8[:, 0] > 0]
+        c0, c1, rest = t8[:, 6] - t8[:, 0], t8[:, 7] - t8[:, 6], t8[:, 1] - t8[:, 7]
+        nch = L['cin'] // 8
+        print('    chunk 0 median {:>6.0f}  chunk 1 {:>6.0f}  chunks 2..{} {:>8.0f} = {:>6.0f} each'.format(
+            np.median(c0), np.median(c1), nch - 1, np.median(rest), np.median(rest) / max(nch - 2, 1)))
 
 
 if __name__ == '__main__':
