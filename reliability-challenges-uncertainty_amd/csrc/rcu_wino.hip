@@ -263,9 +263,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
     int dp_wtile = tile.wtile;
 #pragma unroll
     for (int j = 0; j < T::NA; ++j) {
-        geo[j] = wino_slot_geometry<T>(j, wave, lane);
+        geo[j] = wino_slot_plan<T>(a, wino_slot_geometry<T>(j, wave, lane));   // the slot's plan: tile-independent offset | border flags
         asm volatile("" : "+v"(geo[j]));   // one register per slot; keeps hipcc from carrying the unpacked fields instead
-        dp[j] = wino_slot_offset<T>(a, tile, geo[j]);
+        dp[j] = wino_slot_offset(geo[j], wino_tile_offset<T>(a, tile));
     }
 
     // LDS-DMA of Cin chunk kc of a tile into LDS buffer `buf`: the wave's NW weight pieces and NA input pieces of 1 KB.
@@ -332,8 +332,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
                 ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
             }
             dp_wtile = ntile.wtile;
+            const WinoTileOffset nto = wino_tile_offset<T>(ca, ntile);
 #pragma unroll
-            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(ca, ntile, geo[j]);
+            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset(geo[j], nto);
         }
         if (!more) epr = wino_epilogue_load<T>(wino_cold_args(), tile.wtile, tile.n0, wm, wn, lane);
         __builtin_amdgcn_sched_barrier(0);   // keep the address arithmetic above out of the register-heavy part below

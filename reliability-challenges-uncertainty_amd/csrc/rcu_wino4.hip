@@ -406,9 +406,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
     int dp_wtile = tile.wtile;
 #pragma unroll
     for (int j = 0; j < T::NA; ++j) {
-        geo[j] = wino4_slot_geometry<T>(j, wave, lane);
+        geo[j] = wino_slot_plan<T>(a, wino4_slot_geometry<T>(j, wave, lane));   // the slot's plan: tile-independent offset | border flags
         asm volatile("" : "+v"(geo[j]));
-        dp[j] = wino_slot_offset<T>(a, tile, geo[j]);
+        dp[j] = wino_slot_offset(geo[j], wino_tile_offset<T>(a, tile));
     }
 
     // LDS-DMA of Cin chunk kc of a tile into LDS buffer `buf`: the wave's NW weight pieces and NA input pieces of 1 KB.  No branch
@@ -544,8 +544,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
             const ConvArgs& ca = wino_cold_args();
             ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
             dp_wtile = ntile.wtile;
+            const WinoTileOffset nto = wino_tile_offset<T>(ca, ntile);
 #pragma unroll
-            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(ca, ntile, geo[j]);
+            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset(geo[j], nto);
         }
         // epilogue constants: loaded a chunk early, so that the barrier wait of the last-but-one chunk covers them and the epilogue
         // does not wait for memory (the LDS-DMA of the next tile is still in flight then)

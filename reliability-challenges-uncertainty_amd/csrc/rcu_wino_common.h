@@ -193,15 +193,40 @@ __device__ __forceinline__ uint32_t wino_slot_geometry(int j, int wave, int lane
     return real ? (uint32_t)(x | (yy << 8) | (s << 16) | (hh << 24)) : 0xFFFFFFFFu;
 }
 
+// The tile-independent part of a slot's byte offset -- slice, halo row and pixel column relative to the tile's origin -- with the slot's
+// border flags in its low four bits (offsets are multiples of 16): bit 0 the halo row above the tile, 1 the one below, 2 the halo column
+// left of it, 3 the one right of it.  Computed once per kernel from the packed geometry; a slot that holds nothing (pitch padding) gets
+// an offset beyond any tensor (tensors are < 2^31 bytes: checked by the launchers).
 template <class T>
-__device__ __forceinline__ uint32_t wino_slot_offset(const ConvArgs& a, const WinoTileId& t, uint32_t geo)
+__device__ __forceinline__ uint32_t wino_slot_plan(const ConvArgs& a, uint32_t geo)
 {
     const int x = geo & 0xFF, yy = (geo >> 8) & 0xFF, s = (geo >> 16) & 0xFF, hh = (geo >> 24) & 1;
-    const int n = t.n0 + s, gy = t.y0 + yy - 1, gx = t.x0 + x - 1;
-    const bool ok = geo != 0xFFFFFFFFu && n < a.N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     // sample * (H W C 4) + pixel * pix_bytes + half * 16 (ConvArgs: both layouts); the chunk's offset is added per chunk (wino_chunk_offset)
-    const uint32_t off = (uint32_t)n * ((uint32_t)(a.H * a.W) * (uint32_t)a.C1 * 4u) + (uint32_t)(gy * a.W + gx) * a.in_pix_bytes + (uint32_t)hh * 16u;
-    return ok ? off : WINO_OOB;   // C2 == C1 or 0 (checked by the launcher)
+    const uint32_t off = (uint32_t)s * ((uint32_t)(a.H * a.W) * (uint32_t)a.C1 * 4u) + (uint32_t)((yy - 1) * a.W + (x - 1)) * a.in_pix_bytes + (uint32_t)hh * 16u;
+    const uint32_t flags = (yy == 0 ? 1u : 0u) | (yy == T::TH + 1 ? 2u : 0u) | (x == 0 ? 4u : 0u) | (x == T::TW + 1 ? 8u : 0u);
+    return geo != 0xFFFFFFFFu ? (off | flags) : 0x80000000u;   // C2 == C1 or 0 (checked by the launcher): one plan for both sources
+}
+
+// What a tile adds to the plans of its slots (wave-uniform: scalar arithmetic): the byte offset of its origin, and which of the four
+// borders of the image it touches -- whole tiles only (launchers), so a halo row / column lies outside the image exactly when the tile
+// touches that border.  Slices beyond the batch need no flag: their offsets lie behind the tensor, where the buffer load returns zeros.
+struct WinoTileOffset {
+    uint32_t off, border;
+};
+template <class T>
+__device__ __forceinline__ WinoTileOffset wino_tile_offset(const ConvArgs& a, const WinoTileId& t)
+{
+    WinoTileOffset o;
+    o.off = (uint32_t)t.n0 * ((uint32_t)(a.H * a.W) * (uint32_t)a.C1 * 4u) + (uint32_t)(t.y0 * a.W + t.x0) * a.in_pix_bytes;
+    o.border = (t.y0 == 0 ? 1u : 0u) | (t.y0 + T::TH == a.H ? 2u : 0u) | (t.x0 == 0 ? 4u : 0u) | (t.x0 + T::TW == a.W ? 8u : 0u);
+    return o;
+}
+
+// Byte offset (into src1 and src2 alike) slot `plan` fetches for the tile: five fast instructions per slot and tile (the bounds checks and
+// multiplications of a from-scratch computation were ~20, two of them quarter-rate: 1.2k cycles per tile in the F(4x4,3x3) kernel).
+__device__ __forceinline__ uint32_t wino_slot_offset(uint32_t plan, const WinoTileOffset& t)
+{
+    return (plan & t.border) != 0u ? WINO_OOB : ((plan + t.off) & ~15u);
 }
 
 // byte offset of the 8-channel chunk that starts at channel c0 of a source tensor

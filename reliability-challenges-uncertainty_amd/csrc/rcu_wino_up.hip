@@ -129,9 +129,9 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
     int dp_wtile = tile.wtile;
 #pragma unroll
     for (int j = 0; j < T::NA; ++j) {
-        geo[j] = wino_slot_geometry<T>(j, wave, lane);
+        geo[j] = wino_slot_plan<T>(a, wino_slot_geometry<T>(j, wave, lane));   // the slot's plan: tile-independent offset | border flags
         asm volatile("" : "+v"(geo[j]));
-        dp[j] = wino_slot_offset<T>(a, tile, geo[j]);
+        dp[j] = wino_slot_offset(geo[j], wino_tile_offset<T>(a, tile));
     }
 
     struct DmaJob {
@@ -181,8 +181,9 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
             const ConvArgs& ca = wino_cold_args();   // tile counts and image extents are not kept in SGPRs either
             ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
             dp_wtile = ntile.wtile;
+            const WinoTileOffset nto = wino_tile_offset<T>(ca, ntile);
 #pragma unroll
-            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset<T>(ca, ntile, geo[j]);
+            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset(geo[j], nto);
         }
         __builtin_amdgcn_sched_barrier(0);
         const DmaJob job = dma_job(dp_wtile, more ? kc + 1 : 0, BUF ^ 1, more || has_next);
