@@ -464,7 +464,7 @@ static hipError_t launch_wino_cfg(const ConvArgs& a, hipStream_t stream)
     if (e != hipSuccess) return e;
     // HEAD: the work items of one pass (TS == 1: a slice group is a sample); the kernel runs every pass of the group on each
     const unsigned items = (unsigned)a.NT * a.tiles_x * a.tiles_y * (HEAD ? a.head_images : a.slice_groups);
-    const unsigned grid = items < 256u ? items : 256u;
+    const unsigned grid = wino_persistent_grid(items);
     hipLaunchKernelGGL((conv_wino_stream<T, HEAD>), dim3(grid), dim3(T::THREADS), lds_bytes, stream, a, (int)items);
     return hipGetLastError();
 }

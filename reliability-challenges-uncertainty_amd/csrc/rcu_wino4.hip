@@ -641,6 +641,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
     WINO4_TRACE_MARK(0);
 
     for (;;) {
+        if constexpr ((VAR & 32) != 0) {   // probe (wrong results): no zero-accumulator form of the tile's first chunk -- two copies of the chunk code instead of four
+            for (int kc = 0; kc < nchunks; kc += 2) {
+                chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc, dA, dB, bvA, bvB);
+                chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1, dB, dA, bvB, bvA);
+            }
+        } else {
         chunk(std::integral_constant<int, 0>{}, std::true_type{}, 0, dA, dB, bvA, bvB);
         WINO4_TRACE_MARK(6);
         chunk(std::integral_constant<int, 1>{}, std::false_type{}, 1, dB, dA, bvB, bvA);
@@ -648,6 +654,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         for (int kc = 2; kc < nchunks; kc += 2) {
             chunk(std::integral_constant<int, 0>{}, std::false_type{}, kc, dA, dB, bvA, bvB);
             chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1, dB, dA, bvB, bvA);
+        }
         }
         WINO4_TRACE_MARK(1);
         if constexpr ((VAR & 2) == 0)
@@ -686,7 +693,7 @@ static hipError_t launch_wino4_var(const ConvArgs& a, hipStream_t stream)
     hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino4_stream<T, VAR>), T::LDS_BYTES);
     if (e != hipSuccess) return e;
     const unsigned items = (unsigned)a.NT * a.tiles_x * a.tiles_y * a.slice_groups;
-    const unsigned grid = items < 256u ? items : 256u;
+    const unsigned grid = wino_persistent_grid(items);
     hipLaunchKernelGGL((conv_wino4_stream<T, VAR>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);
     return hipGetLastError();
 }
@@ -711,6 +718,7 @@ static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
         case 16: return launch_wino4_var<T, 16>(a, stream);
         case 64: return launch_wino4_var<T, 64>(a, stream);
         case 128: return launch_wino4_var<T, 128>(a, stream);
+        case 128 + 32: return launch_wino4_var<T, 128 + 32>(a, stream);
         case 256: return launch_wino4_var<T, 256>(a, stream);
         case 512: return launch_wino4_var<T, 512>(a, stream);
         case 1024: return launch_wino4_var<T, 1024>(a, stream);

@@ -1,6 +1,7 @@
 // Shared pieces of the Winograd kernels (rcu_wino.hip: F(2x2,3x3) conv unit; rcu_wino_up.hip: F(2x2,2x2) sub-pixel
 // up-convolution): tile geometry, LDS-DMA staging plan, epilogue constants.  gfx950 only.
 #pragma once
+#include <cstdlib>
 #include "rcu_kernels.h"
 
 #include <type_traits>
@@ -227,6 +228,17 @@ __device__ __forceinline__ WinoTileOffset wino_tile_offset(const ConvArgs& a, co
 __device__ __forceinline__ uint32_t wino_slot_offset(uint32_t plan, const WinoTileOffset& t)
 {
     return (plan & t.border) != 0u ? WINO_OOB : ((plan + t.off) & ~15u);
+}
+
+// workgroups of a persistent Winograd kernel: one per CU (RCU_PERSISTENT_GRID: experiments with kernels of two streams side by side)
+inline unsigned wino_persistent_grid(unsigned items)
+{
+    static const unsigned cap = [] {
+        const char* const v = getenv("RCU_PERSISTENT_GRID");
+        const int n = v ? atoi(v) : 0;
+        return n > 0 ? (unsigned)n : 256u;
+    }();
+    return items < cap ? items : cap;
 }
 
 // byte offset of the 8-channel chunk that starts at channel c0 of a source tensor

@@ -308,7 +308,7 @@ static hipError_t launch_wino_up_cfg(const ConvArgs& a, hipStream_t stream)
     hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&upconv_wino_stream<T>), T::LDS_BYTES);
     if (e != hipSuccess) return e;
     const unsigned items = (unsigned)a.NTW_total * a.tiles_x * a.tiles_y * a.slice_groups;
-    const unsigned grid = items < 256u ? items : 256u;
+    const unsigned grid = wino_persistent_grid(items);
     hipLaunchKernelGGL(upconv_wino_stream<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);
     return hipGetLastError();
 }
