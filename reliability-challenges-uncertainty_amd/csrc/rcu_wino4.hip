@@ -189,11 +189,30 @@ __device__ __forceinline__ float wino4_acc(const f32x4 (&accv)[8])
     }
 }
 
+// Per-lane parts of the epilogue's store offsets (output and pooled output): slice, pixel and cout pair of the lane's first tile relative to
+// the workgroup tile's origin and cout tile -- made once per kernel; a tile adds scalars (wino4_epilogue).
+struct Wino4StorePlan {
+    uint32_t out, pool;
+};
+template <class T>
+__device__ __forceinline__ Wino4StorePlan wino4_store_plan(const ConvArgs& a, int wave, int lane)
+{
+    int bs, by, sb, tr, tc;
+    T::block_origin(wave, bs, by);
+    T::tile_of(4 * (lane >> 4), sb, tr, tc);
+    const int n16 = lane & 15, odd = n16 & 1, c = 2 * n16 - 2 * odd;   // the even lane stores four couts of one pixel column, the odd lane of the next
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    Wino4StorePlan p;
+    p.out = wino_out_offset(bs + sb, a.H * a.W, a.CoutP, (uint32_t)((by + 4 * tr) * a.W + 4 * tc + odd), c, a.out_pix_bytes, a.out_chunk_bytes);
+    p.pool = wino_out_offset(bs + sb, Hp * Wp, a.CoutP, (uint32_t)(((by + 4 * tr) >> 1) * Wp + 2 * tc + odd), c, a.pool_pix_bytes, a.pool_chunk_bytes);
+    return p;
+}
+
 // Output transform + conv-unit epilogue of one finished tile.  acc[b][p][r]: MFMA block b (cout 2n+b), position p = 6 i + j,
 // tile r of the lane's four.
 template <class T, int EV = 0>   // EV (ablation build): 1 stores out of range, 2 no store instructions, 4 no output transform
 __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&accv)[8], const WinoEpi& ep, int ntile, int n0, int y0, int x0,
-                                               int wave, int lane)
+                                               int lane, const Wino4StorePlan& plan)
 {
     auto store16 = [&](const f32x4& o, const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, uint32_t soff) {
         if constexpr ((EV & 2) != 0)
@@ -204,31 +223,23 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
     // every MFMA has long retired: the last chunk's barrier lies between them and this point; the nops cover the asm-to-asm case
     // (an MFMA's D read by v_accvgpr_read) the compiler cannot see
     asm volatile("s_nop 15\n\ts_nop 7");
-    const int n16 = lane & 15, g = lane >> 4;
-    const int co = ntile * T::BN + 2 * n16;
-    int bs, by, sb, tr, tc;
-    T::block_origin(wave, bs, by);
-    T::tile_of(4 * g, sb, tr, tc);
-    const int n = n0 + bs + sb;
-    const bool live = co < a.CoutP && n < a.N;   // whole tiles only (launcher): false only for slices beyond the batch
-    const int yb = y0 + by + 4 * tr;      // top pixel row of the lane's tiles
-    const int xb = x0 + 4 * tc;           // left pixel column of the lane's first tile
+    const int odd = lane & 1;
+    // The kernel arguments the epilogue needs, read in ONE batch of scalar loads (a wave alone on its SIMD sits out every scalar-load round
+    // trip: the branches of the earlier form -- outputs alive? pooled? -- each fetched their own arguments behind the branch).
+    const int H = a.H, W = a.W, CoutP = a.CoutP, N = a.N;
+    const uint32_t px_bytes = a.out_pix_bytes, chunk_bytes = a.out_chunk_bytes, ppx_bytes = a.pool_pix_bytes, pchunk_bytes = a.pool_chunk_bytes;
+    float* const out = a.out;
+    float* const pooled = a.pooled;
     const float relu_floor = a.relu ? 0.f : -__builtin_inff();
-    const int odd = n16 & 1;
-    const uint32_t row_bytes = (uint32_t)a.W * a.out_pix_bytes;
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (uint32_t)(a.N * a.H * a.W) * (uint32_t)a.CoutP * 4u, 0x00020000);
-    // lanes without an output (slices beyond the batch) store out of range: the buffer resource drops the write
-    const uint32_t vo = live ? wino_out_offset(n, a.H * a.W, a.CoutP, (uint32_t)(yb * a.W + xb + odd), co - 2 * odd, a.out_pix_bytes, a.out_chunk_bytes)
-                             : WINO_OOB;
-    const uint32_t px_bytes = a.out_pix_bytes;
-    const bool pool = a.pooled != nullptr;
-    const int Hp = a.H >> 1, Wp = a.W >> 1;
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(pool ? a.pooled : a.out, 0,
-                                                                       pool ? (uint32_t)(a.N * Hp * Wp * a.CoutP) * 4u : 0u, 0x00020000);
-    const uint32_t vp = live ? wino_out_offset(n, Hp * Wp, a.CoutP, (uint32_t)((yb >> 1) * Wp + (xb >> 1) + odd), co - 2 * odd, a.pool_pix_bytes,
-                                               a.pool_chunk_bytes)
-                             : WINO_OOB;
-    const uint32_t prow_bytes = (uint32_t)Wp * a.pool_pix_bytes, ppx_bytes = a.pool_pix_bytes;
+    const bool pool = pooled != nullptr;
+    const int Hp = H >> 1, Wp = W >> 1;
+    const uint32_t row_bytes = (uint32_t)W * px_bytes, prow_bytes = (uint32_t)Wp * ppx_bytes;
+    // store offsets = the lane's plan (made once per kernel: everything but the tile's origin and cout tile) + the tile's scalars.  Lanes of
+    // slices beyond the batch need no flag: their offsets lie behind the tensor, where the buffer resource drops the write.
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, (uint32_t)(N * H * W) * (uint32_t)CoutP * 4u, 0x00020000);
+    const uint32_t vo = plan.out + wino_out_offset(n0, H * W, CoutP, (uint32_t)(y0 * W + x0), ntile * T::BN, px_bytes, chunk_bytes);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(pool ? pooled : out, 0, pool ? (uint32_t)(N * Hp * Wp * CoutP) * 4u : 0u, 0x00020000);
+    const uint32_t vp = plan.pool + wino_out_offset(n0, Hp * Wp, CoutP, (uint32_t)((y0 >> 1) * Wp + (x0 >> 1)), ntile * T::BN, ppx_bytes, pchunk_bytes);
     wino_static_for<0, 4>([&](auto r_c) {
         constexpr int r = decltype(r_c)::value;
         f32x2 y[4][4];   // [row][col], components = the two couts: packed operations throughout (one instruction costs the same
@@ -410,6 +421,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         asm volatile("" : "+v"(geo[j]));
         dp[j] = wino_slot_offset(geo[j], wino_tile_offset<T>(a, tile));
     }
+
+    Wino4StorePlan store_plan = wino4_store_plan<T>(a, wave, lane);
+    asm volatile("" : "+v"(store_plan.out), "+v"(store_plan.pool));   // two registers through the loop, not their ingredients
 
     // LDS-DMA of Cin chunk kc of a tile into LDS buffer `buf`: the wave's NW weight pieces and NA input pieces of 1 KB.  No branch
     // per piece: a job without work (behind the workgroup's last chunk) points out of range, where the buffer load writes zeros
@@ -658,7 +672,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         }
         WINO4_TRACE_MARK(1);
         if constexpr ((VAR & 2) == 0)
-            wino4_epilogue<T, (VAR >> 8)>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wave, lane);
+            wino4_epilogue<T, (VAR >> 8)>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, lane, store_plan);
         WINO4_TRACE_MARK(2);
         if (!has_next) break;
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's first chunk has landed (and this tile's stores have left)
