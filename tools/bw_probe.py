@@ -1,4 +1,6 @@
-import torch, time
+"""What torch's own streaming ops reach on this box (copy, sum, comparison + sum over 2.5 GB): the yardstick quoted in DESIGN.md 3.4.
+    python tools/bw_probe.py"""
+import torch
 dev=torch.device('cuda')
 n=160*160*192*128
 x=torch.rand(n,device=dev)
