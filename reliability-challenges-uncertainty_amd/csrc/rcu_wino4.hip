@@ -445,15 +445,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
     auto dma_piece = [&](const DmaJob& job, auto i_c) {
         constexpr int I = decltype(i_c)::value;
-        if constexpr (I < T::NW) {
-            if ((I + 1) * T::WAVES <= T::W_PIECES || I * T::WAVES + wave < T::W_PIECES)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + T::A_DW * 4 + (I * T::WAVES + wave) * 1024),
-                                                         16, w_voff, job.wso + (uint32_t)(I * T::WAVES + wave) * 1024u, 0, 0);
-        } else if constexpr (I < T::NW + T::NA) {
-            constexpr int j = I - T::NW;
+        // the input pieces first: they come from HBM (or another XCD's writes) and are waited for at the chunk's barrier, the weight pieces -- L2
+        // hits, shared by every workgroup of the cout tile -- can afford to be the late ones
+        if constexpr (I < T::NA) {
+            constexpr int j = I;
             if ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(job.rs, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16, dp[j],
                                                          job.cb, 0, 0);
+        } else if constexpr (I < T::NW + T::NA) {
+            constexpr int k = I - T::NA;
+            if ((k + 1) * T::WAVES <= T::W_PIECES || k * T::WAVES + wave < T::W_PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + T::A_DW * 4 + (k * T::WAVES + wave) * 1024),
+                                                         16, w_voff, job.wso + (uint32_t)(k * T::WAVES + wave) * 1024u, 0, 0);
         }
     };
 
