@@ -413,13 +413,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
     int item = wino_xcd_virtual_block(a.NT < 4 ? 4 : a.NT);
     bool has_next = item + (int)gridDim.x < total_items;
     WinoTileId tile = wino_tile_id<T>(a, item), ntile = tile;
-    uint32_t dp[T::NA], geo[T::NA];
-    int dp_wtile = tile.wtile;
+    // dp / dp_wtile: staging offsets and cout tile of the tile whose chunk the FRONT part of a chunk's LDS-DMA fetches (the chunk after the
+    // current one), dpn / dpn_wtile: of the tile the BACK part fetches (the chunk after that).  They differ in a tile's last-but-one chunk.
+    uint32_t dp[T::NA], dpn[T::NA], geo[T::NA];
+    int dp_wtile = tile.wtile, dpn_wtile = tile.wtile;
 #pragma unroll
     for (int j = 0; j < T::NA; ++j) {
         geo[j] = wino_slot_plan<T>(a, wino4_slot_geometry<T>(j, wave, lane));   // the slot's plan: tile-independent offset | border flags
         asm volatile("" : "+v"(geo[j]));
-        dp[j] = wino_slot_offset(geo[j], wino_tile_offset<T>(a, tile));
+        dp[j] = dpn[j] = wino_slot_offset(geo[j], wino_tile_offset<T>(a, tile));
     }
 
     Wino4StorePlan store_plan = wino4_store_plan<T>(a, wave, lane);
@@ -443,14 +445,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         return j;
     };
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
-    auto dma_piece = [&](const DmaJob& job, auto i_c) {
+    auto dma_piece = [&](const DmaJob& job, const uint32_t (&off)[T::NA], auto i_c) {
         constexpr int I = decltype(i_c)::value;
         // the input pieces first: they come from HBM (or another XCD's writes) and are waited for at the chunk's barrier, the weight pieces -- L2
         // hits, shared by every workgroup of the cout tile -- can afford to be the late ones
         if constexpr (I < T::NA) {
             constexpr int j = I;
             if ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(job.rs, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16, dp[j],
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(job.rs, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16, off[j],
                                                          job.cb, 0, 0);
         } else if constexpr (I < T::NW + T::NA) {
             constexpr int k = I - T::NA;
@@ -460,12 +462,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         }
     };
 
+    // The LDS-DMA runs TWO chunks ahead of the arithmetic: the first PB pieces of a chunk (input pieces: they come from HBM) are issued right
+    // behind the barrier of the chunk two before it -- into the buffer that barrier has just freed --, the rest in the front groups of the chunk
+    // before it; its data is waited for at that chunk's barrier.  (One chunk ahead, the last input piece had 1.3k cycles to land.)
+    constexpr int PB = (T::TS == 1 && T::TH == 32) ? 8 : 0;   // the 32x32-pixel tile only (the 96x64 and 192x128 levels: few chunks per tile, inputs from HBM); the others lose 1-2 % with it
+    static_assert(PB <= T::NA, "the back part consists of input pieces");
     {
         const DmaJob job = dma_job(dp_wtile, 0, 0, true);
-        wino_static_for<0, T::NW + T::NA>([&](auto i_c) { dma_piece(job, i_c); });
+        wino_static_for<0, T::NW + T::NA>([&](auto i_c) { dma_piece(job, dp, i_c); });
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
+    {
+        const DmaJob job = dma_job(dp_wtile, 1, 1, true);   // the back part of the first tile's chunk 1
+        wino_static_for<0, PB>([&](auto i_c) { dma_piece(job, dp, i_c); });
+    }
 
     f32x4 accv[8];   // accumulators of (cout block 1, positions 18..25); all others in a[0:255] (wino4_areg)
     WinoEpiRaw epr;
@@ -556,20 +567,27 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         constexpr bool FIRST = decltype(first_c)::value;
         const float* const Ab = smem + BUF * T::BUF_DW;
         const float* const An = smem + (BUF ^ 1) * T::BUF_DW;
-        const bool more = kc + 1 < nchunks;
-        if (!more && has_next) {   // last chunk of the tile: from here on the DMA works on the workgroup's next tile
+        const bool more = kc + 1 < nchunks, more2 = kc + 2 < nchunks;
+        if (kc == nchunks - 2 && has_next) {   // last-but-one chunk of the tile: from its barrier on the DMA works on the workgroup's next tile
             const ConvArgs& ca = wino_cold_args();
             ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
-            dp_wtile = ntile.wtile;
+            dpn_wtile = ntile.wtile;
             const WinoTileOffset nto = wino_tile_offset<T>(ca, ntile);
 #pragma unroll
-            for (int j = 0; j < T::NA; ++j) dp[j] = wino_slot_offset(geo[j], nto);
+            for (int j = 0; j < T::NA; ++j) dpn[j] = wino_slot_offset(geo[j], nto);
+        }
+        if (!more) {   // last chunk: both parts fetch the next tile
+            dp_wtile = dpn_wtile;
+#pragma unroll
+            for (int j = 0; j < T::NA; ++j) dp[j] = dpn[j];
         }
         // epilogue constants: loaded a chunk early, so that the barrier wait of the last-but-one chunk covers them and the epilogue
         // does not wait for memory (the LDS-DMA of the next tile is still in flight then)
         if (kc == nchunks - 2) epr = wino4_epilogue_load<T>(wino_cold_args(), tile.wtile, tile.n0, wave, lane);
-        const bool next_any = more || has_next;
-        const DmaJob job = dma_job(dp_wtile, more ? kc + 1 : 0, BUF ^ 1, next_any);
+        // front part: the rest of the next chunk (this tile's or, behind the last chunk, the next tile's first) into the other buffer;
+        // back part (behind the barrier): the first pieces of the chunk after that into THIS chunk's buffer, which the barrier frees
+        const DmaJob job = dma_job(dp_wtile, more ? kc + 1 : 0, BUF ^ 1, more || has_next);
+        const DmaJob jobb = dma_job(dpn_wtile, more2 ? kc + 2 : kc + 2 - nchunks, BUF, more2 || has_next);
         if constexpr ((VAR & 4) == 0) transform_head(d);
         wino_static_for<0, 18>([&](auto g_c) {
             constexpr int G = decltype(g_c)::value;
@@ -579,10 +597,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
                 // behind a tile's last chunk the wait comes after the epilogue (main loop): the first chunk of the next tile is a
                 // cold fetch, and the epilogue is the work to hide it behind
                 if constexpr ((VAR & 8) == 0) {
-                    if (more) {
-                        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of the next chunk have landed
-                        __syncthreads();                      // everyone past the LDS reads of buffer BUF and done filling the other one
-                    }
+                    // vmcnt(0): this wave's pieces of the next chunk (the next tile's first chunk behind a tile's last) have landed.  Every wave
+                    // has ISSUED its LDS reads of buffer BUF when it passes the barrier (the weights of groups 14..17 were read in groups
+                    // 10..13); they return within ~100 cycles, the first data of the back part -- issued behind two more MFMAs, fetched from
+                    // L2 or HBM -- arrives several hundred later
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    __syncthreads();   // everyone past the LDS reads of buffer BUF and done filling the other one
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -599,12 +619,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
                         constexpr int q = 2 * NPRE + 2 * (G - (NPRE - 4)) + (U == 6 ? 1 : 0);
                         load_weights(bv, Ab, wino4_pos_of(q));
                     }
-                    if constexpr ((VAR & 1) == 0 && G < 10 && (U == 1 || U == 5)) dma_piece(job, std::integral_constant<int, 2 * G + (U == 5 ? 1 : 0)>{});
+                    if constexpr ((VAR & 1) == 0 && G < 10 && (U == 1 || U == 5)) dma_piece(job, dp, std::integral_constant<int, PB + 2 * G + (U == 5 ? 1 : 0)>{});
                 } else {
+                    if constexpr ((VAR & 1) == 0 && (U == 1 || U == 5) && 2 * (G - NPRE) + (U == 5 ? 1 : 0) < PB)
+                        dma_piece(jobb, dpn, std::integral_constant<int, 2 * (G - NPRE) + (U == 5 ? 1 : 0)>{});
                     // behind the barrier: the raw patch of the next chunk (rows 0, 2, 4, 1, 3, 5) and its first weights.  Unconditional
                     // (a conditional load would keep the old contents of dn alive through the whole chunk); in a tile's last
-                    // chunk -- no barrier, the other buffer is being filled -- the values are dropped and the next tile's first
-                    // chunk is read behind the epilogue (load_first): the epilogue needs the registers
+                    // chunk the values are dropped and the next tile's first chunk is read again behind the epilogue (load_first):
+                    // the epilogue needs the registers
                     {
                         constexpr int slot = 8 * (G - NPRE) + U;           // 0..31
                         constexpr int order[6] = {0, 2, 4, 1, 3, 5};
@@ -678,9 +700,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
             wino4_epilogue<T, (VAR >> 8)>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, lane, store_plan);
         WINO4_TRACE_MARK(2);
         if (!has_next) break;
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's first chunk has landed (and this tile's stores have left)
-        WINO4_TRACE_MARK(3);
-        __syncthreads();
+        WINO4_TRACE_MARK(3);   // (no wait and no barrier here any more: the tile's last chunk waited for the next tile's first chunk at its barrier)
         WINO4_TRACE_MARK(4);
         load_first();
         WINO4_TRACE_MARK(5);
