@@ -462,10 +462,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         }
     };
 
-    // The LDS-DMA runs TWO chunks ahead of the arithmetic: the first PB pieces of a chunk (input pieces: they come from HBM) are issued right
+    // The LDS-DMA runs TWO chunks ahead of the arithmetic: the first PB pieces of a chunk (input pieces: they come from HBM; PB = 4 measured best of 2 / 4 / 8) are issued right
     // behind the barrier of the chunk two before it -- into the buffer that barrier has just freed --, the rest in the front groups of the chunk
     // before it; its data is waited for at that chunk's barrier.  (One chunk ahead, the last input piece had 1.3k cycles to land.)
-    constexpr int PB = (T::TS == 1 && T::TH == 32) ? 8 : 0;   // the 32x32-pixel tile only (the 96x64 and 192x128 levels: few chunks per tile, inputs from HBM); the others lose 1-2 % with it
+    constexpr int PB = (T::TS == 1 && T::TH == 32) ? 4 : 0;   // the 32x32-pixel tile only (the 96x64 and 192x128 levels: few chunks per tile, inputs from HBM); the others lose 1-2 % with it
     static_assert(PB <= T::NA, "the back part consists of input pieces");
     {
         const DmaJob job = dma_job(dp_wtile, 0, 0, true);
