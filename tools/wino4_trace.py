@@ -6,7 +6,8 @@ RCU_HIP_LIBRARY=reliability-challenges-uncertainty_amd/librcu_hip_ablate.so).
 
 For every named layer: where a workgroup's time goes between tiles -- the chunk loop, the epilogue, the wait for the next tile's first
 chunk (and this tile's stores), the barrier, the first fragment reads.  Ticks of s_memtime (100 MHz on gfx950), medians over all
-workgroups and waves of the tiles 0..2 of each workgroup."""
+workgroups and waves of the tiles 0..2 of each workgroup.  (Since the LDS-DMA of a tile's last chunk waits for the next tile's first chunk at its
+own barrier, nothing is waited for behind the epilogue: the `vmcnt(0)` and `barrier` rows read ~0 on the current kernel.)"""
 import ctypes
 import os
 import sys
