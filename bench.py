@@ -93,6 +93,37 @@ def _host_threads():
         return os.cpu_count() or 1
 
 
+def host_description():
+    """What makes a CPU figure comparable across boxes: the CPU model, the affinity set of this process, torch's thread settings."""
+    model_name, sockets = None, set()
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name') and model_name is None:
+                    model_name = line.split(':', 1)[1].strip()
+                elif line.startswith('physical id'):
+                    sockets.add(line.split(':', 1)[1].strip())
+    except OSError:
+        pass
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    runs, start = [], None       # compact "0-31,64-95" form of the affinity set
+    for i, c in enumerate(cpus):
+        if start is None:
+            start = c
+        if i + 1 == len(cpus) or cpus[i + 1] != c + 1:
+            runs.append(str(start) if start == c else '{}-{}'.format(start, c))
+            start = None
+    info = {k.strip(): v.strip() for k, v in (ln.split(':', 1) for ln in torch.__config__.parallel_info().splitlines() if ':' in ln)}
+    return dict(cpu_model=model_name, sockets=len(sockets) or None, logical_cpus=os.cpu_count(), affinity=','.join(runs),
+                affinity_count=len(cpus), torch_threads=torch.get_num_threads(), torch_interop_threads=torch.get_num_interop_threads(),
+                torch_parallel_backend=info.get('ATen parallel backend'), omp_max_threads=info.get('omp_get_max_threads()'),
+                mkl_max_threads=info.get('mkl_get_max_threads()'),
+                OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS'), MKL_NUM_THREADS=os.environ.get('MKL_NUM_THREADS'))
+
+
 def cpu_leg(members, params, x_cpu, sel, mask_sets_sel, with_ws, ensemble, budget_s, thread_counts):
     """The oracle's CPU path (torch-CPU conv stack + torch aggregation, oracle/) on the slices `sel` of the volume with the
     weights and the dropout masks of the last timed step.  BASELINE.md section 4's protocol on a bounded sample: per thread count
@@ -120,13 +151,16 @@ def cpu_leg(members, params, x_cpu, sel, mask_sets_sel, with_ws, ensemble, budge
             ref = so.multi_prediction_summary(multi)
             times.append(time.perf_counter() - t0)
         runs[threads] = sorted(times)[1]
+    # (outside the timing) the same passes' mutual information and variance: the reference of the all-outputs configuration
+    ref.update(so.multi_prediction_summary(multi, True, True))
     if ws is not None and with_ws:
         ref['ws_probabilities'] = ws
     passes = multi.shape[0]
     units = passes * len(sel) / n_total            # sample-volume equivalents (the ws pass is timed, not counted)
     best = min(runs, key=runs.get)
     return dict(value=units / runs[best], cores=best, kind='port',
-                by_threads={str(t): units / dt for t, dt in runs.items()}, host_threads=_host_threads(),
+                by_threads={str(t): units / dt for t, dt in runs.items()}, host_threads=_host_threads(), sample_slices=int(len(sel)),
+                host=host_description(),
                 protocol='1 warm-up + median of 3 timed runs per thread count (BASELINE.md 4), on a bounded sample',
                 sample='{} of {} slices x ({} {}{}) through oracle/ (torch-CPU); median run {:.2f} s at {} threads; the whole leg took {:.1f} s '
                        '(budget {:.0f} s)'.format(len(sel), n_total, passes, 'members' if ensemble else 'MC passes',
@@ -288,7 +322,7 @@ class VolumePrefetcher:
         self.free[slot].record()
 
 
-def aggregation_kernels(device, n_slices, height, width, reps=5):
+def aggregation_kernels(device, n_slices, height, width, reps=5, all_outputs=False):
     """The standalone aggregation kernels of the step seam (rcu_mc_accumulate: softmax of a logits volume into the statistics;
     rcu_mc_finalize: mean + entropy out of them; rechun/dl/customsteps.py:57-61), timed with events on the launch stream.
     ALGORITHMIC bytes: accumulate V*C*4 logits + 2*S*4*V statistics read-modify-write (S = 2); finalize S*4*V read +
@@ -296,8 +330,12 @@ def aggregation_kernels(device, n_slices, height, width, reps=5):
     from rcu_amd import steps
     vox = n_slices * height * width
     logits = torch.randn((n_slices, 2, height, width), device=device)
-    stats = steps.McStatistics(n_slices, 2, height, width, device)
+    stats = steps.McStatistics(n_slices, 2, height, width, device, all_outputs, all_outputs)
     out = {}
+    # all outputs (mutual information + variance): S = 5 planes [sum p (2)] [sum p^2 (2)] [sum H].  ALGORITHMIC bytes by SURVEY.md 8d's
+    # formula (float32 planes): accumulate V*C*4 + 2*S*4*V, finalize S*4*V + (C+3)*4*V; the planes are float64 here (exact variance),
+    # so the kernels MOVE 2*S*8*V resp. S*8*V of statistics -- reported next to it as `moved`.
+    S = 5 if all_outputs else 2
 
     def timed(fn):
         fn()
@@ -310,11 +348,16 @@ def aggregation_kernels(device, n_slices, height, width, reps=5):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    for name, fn, nbytes in (('mc_accumulate_kernel', lambda: stats.accumulate(logits), vox * (2 * 4 + 2 * 2 * 4)),
-                             ('mc_finalize_kernel', lambda: stats.finalize(), vox * (2 * 4 + 3 * 4))):
+    word = 8 if all_outputs else 4
+    for name, fn, nbytes, moved in (('mc_accumulate_kernel', lambda: stats.accumulate(logits), vox * (2 * 4 + 2 * S * 4),
+                                     vox * (2 * 4 + 2 * S * word)),
+                                    ('mc_finalize_kernel', lambda: stats.finalize(all_outputs, all_outputs),
+                                     vox * (S * 4 + (5 if all_outputs else 3) * 4), vox * (S * word + (5 if all_outputs else 3) * 4))):
         ms = timed(fn)
         out[name] = dict(bound='hbm', avg_launch_ms=ms, bytes_per_launch=nbytes, achieved=nbytes / ms / 1e6, peak=PEAK_HBM_GBS,
                          unit='GB/s', frac=nbytes / ms / 1e6 / PEAK_HBM_GBS)
+        if all_outputs:
+            out[name].update(moved_bytes_per_launch=moved, moved_gbs=moved / ms / 1e6, moved_frac=moved / ms / 1e6 / PEAK_HBM_GBS)
     return out
 
 
@@ -336,6 +379,14 @@ def self_launch(n_gpus):
         target.write(line)
         target.flush()
     return proc.wait()
+
+
+def plan_fingerprint(layers, samples_per_launch):
+    """Short hash of what determines a kernel's HBM traffic per launch: the layer table (kernel instantiation and shape of every layer)
+    and the samples a launch covers."""
+    import hashlib
+    text = ';'.join('{name}|{kernel}|{cin}|{cout}|{height}x{width}'.format(**L) for L in layers) + ';n={}'.format(samples_per_launch)
+    return hashlib.sha256(text.encode()).hexdigest()[:12]
 
 
 def split_masks(model, flat, n, rows):
@@ -370,6 +421,10 @@ def main():
                     help='K ensemble members (seeds 20..20+K-1) instead of T MC passes (BASELINE config "BraTS ensemble")')
     ap.add_argument('--aleatoric', action='store_true',
                     help='sigma-head U-Net, per-pass sigma averaged next to the MC statistics (BASELINE config "BraTS aleatoric + MC", use --mc 50)')
+    ap.add_argument('--all-outputs', action='store_true',
+                    help='every output of MultiPredictionSummary in the timed region: mutual information + variance next to mean + entropy '
+                         '(do_mi + do_var, rechun/dl/customsteps.py:63-71: float64 statistics, S = 5 planes).  The default run reports this '
+                         'configuration as the sub-record `all_outputs`')
     ap.add_argument('--watchdog', type=float, default=1500.0,
                     help='seconds after which a run that has not finished dumps the stacks of all threads to stderr and exits (0 = off)')
     args = ap.parse_args()
@@ -395,6 +450,19 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    # Test-only switch: RCU_BENCH_FORCE_PG=1 at N = 1 initialises the RCCL process group with ONE rank and routes every step through the
+    # exchange path (asynchronous reduce on RCCL's stream, root finalize on a side stream, record_stream, drain) -- the rehearsal of the
+    # N > 1 code on a box with one GPU (tools/rccl_world1_rehearsal.py; profiles/r04_rccl_world1.txt).
+    force_pg = world == 1 and os.environ.get('RCU_BENCH_FORCE_PG') == '1'
+    if force_pg:
+        import socket
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:
+            with socket.socket() as sock:
+                sock.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
+        dist.init_process_group(backend, rank=0, world_size=1, **(dict(device_id=device) if backend == 'nccl' else {}))
+    collective = world > 1 or force_pg          # a process group exists: barriers and max-over-ranks as the contract prescribes
     if world > 1:
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)   # "nccl" is RCCL on ROCm
@@ -430,7 +498,9 @@ def main():
     else:
         members = [model]
         runner = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed,
-                                       pass_group=args.pass_group, lanes=args.lanes, ws_transport=args.ws_transport)
+                                       pass_group=args.pass_group, lanes=args.lanes, ws_transport=args.ws_transport,
+                                       do_mi=args.all_outputs, do_var=args.all_outputs)
+    runner.force_exchange = force_pg
     # dropout masks: drawn per (seed, volume, pass) by the runner -- the same T samples whatever the world size
 
     def one_step(k, xin=x):
@@ -467,7 +537,7 @@ def main():
             m.profile_begin(height, width, n_slices * args.pass_group, max(count, 1))
         runner.forwards_run = 0
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -485,13 +555,13 @@ def main():
     out = [p.result() for p in pending][-1]
     runner.drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     passes_run = max(runner.forwards_run, 1)        # this rank's forward passes inside the timed region
     forwards_per_rank = [runner.forwards_run]
-    if world > 1:
+    if collective:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -499,7 +569,7 @@ def main():
         counts[rank] = runner.forwards_run
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         forwards_per_rank = [int(v) for v in counts.tolist()]
-    n_ranks_seen = dist.get_world_size() if world > 1 else 1
+    n_ranks_seen = dist.get_world_size() if collective else 1
 
     launches, slot_ms = 0, None
     for _, m in timed_members:
@@ -508,7 +578,7 @@ def main():
         slot_ms = ms if slot_ms is None else [a + b for a, b in zip(slot_ms, ms)]
     # ---- the same steps with the volume already resident in HBM (the secondary figure; all ranks take part)
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -517,20 +587,66 @@ def main():
         p_.result()
     runner.drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed_resident = time.perf_counter() - t1
-    if world > 1:
+    if collective:
         tmax = torch.tensor([elapsed_resident], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed_resident = float(tmax.item())
     del pend_r
+    last_step = end_step - 1
+
+    # ---- the all-outputs configuration (north_star: "softmax -> running-mean / variance -> predictive-entropy"; the reference's
+    # MultiPredictionSummary(do_mi=True, do_var=True), rechun/dl/customsteps.py:63-71): the same step with mutual information and variance
+    # tracked -- float64 statistics, S = 5 planes per voxel -- timed like the headline (H2D prefetched inside, all ranks, one reduce per
+    # volume), over step indices that END at the last timed step: the runner's masks are a function of (seed, volume, pass), so its last
+    # volume runs under the masks of the headline's last volume and the CPU leg below is the reference of both.
+    all_out, out_ao = None, None
+    if not (args.all_outputs or args.ensemble or args.aleatoric):
+        ao_steps = max(1, min(args.steps, 5))
+        runner_ao = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed, pass_group=args.pass_group,
+                                          lanes=args.lanes, ws_transport=args.ws_transport, do_mi=True, do_var=True, force_exchange=force_pg)
+        first_ao = last_step - ao_steps + 1
+        runner_ao.step_async(x, first_ao - 1).result()       # warm: the float64 blobs of the lanes come out of torch's allocator
+        runner_ao.drain()
+        runner_ao.forwards_run = 0
+        torch.cuda.synchronize()
+        if collective:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        feeder.issue(first_ao)
+        pend_a = []
+        for k in range(first_ao, last_step + 1):
+            xin = feeder.get(k)
+            if k < last_step:
+                feeder.issue(k + 1)
+            pend_a.append(runner_ao.step_async(xin, k))
+            feeder.done(k)
+        out_ao = [p_.result() for p_ in pend_a][-1]
+        runner_ao.drain()
+        torch.cuda.synchronize()
+        if collective:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed_ao = time.perf_counter() - ta
+        if collective:
+            tmax = torch.tensor([elapsed_ao], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed_ao = float(tmax.item())
+        del pend_a
+        all_out = dict(value=T * (n_slices if isic else 1) * ao_steps / elapsed_ao, unit='MC-sample-{}s/s'.format(unit_name),
+                       ms_per_step=elapsed_ao / ao_steps * 1e3, steps=ao_steps, warmup=1,
+                       outputs=['probabilities', 'entropy', 'mutual_info', 'variance'] + ([] if args.no_ws else ['ws_probabilities']),
+                       statistics='float64, S = 5 planes per voxel: sum p_c (2), sum p_c^2 (2), sum H(p_t)',
+                       h2d='prefetched, inside the timed steps (as the headline)',
+                       reduce_bytes_per_volume=(5 * 8 + (0 if args.no_ws else 2 * 8)) * n_slices * height * width if world > 1 else 0)
     if rank != 0:
-        if world > 1:
+        if collective:
             dist.destroy_process_group()
         return
-    last_step = end_step - 1
 
     # ---- stream lanes: in the timed region the kernels of different lanes overlap (that is their point: a lane fills the gaps between
     # the dependent layers of the other), so a kernel's start-to-end time there includes the other lane's work and says nothing about
@@ -621,9 +737,9 @@ def main():
     # In the timed region the classifier + softmax + statistics update run inside conv_cls.0's epilogue (two classes:
     # csrc/rcu_wino.hip, wino_epilogue_head; pass groups too) and have no launch of their own; the standalone head kernel
     # -- the path of the sigma / feature outputs and of more than two classes, same arithmetic, same bits -- is timed here, outside
-    # the timed region, on the same volume (RCU_FUSE_HEAD=0 is read per forward).
+    # the timed region, on the same volume (UNet.set_fuse_head = rcu_unet_set_fuse_head, include/rcu.h).
     fused_head_ms = slot_ms[-1] / passes_run
-    os.environ['RCU_FUSE_HEAD'] = '0'
+    model.set_fuse_head(False)
     try:
         probe = steps.McStatistics(n_slices, 2, height, width, device)
         model.forward_accumulate(x, probe)
@@ -634,8 +750,18 @@ def main():
         cnt_h, ms_h = model.profile_collect(height, width, n_slices)
         head_ms = ms_h[-1] / max(cnt_h, 1)
         del probe
+        # the same kernel with every output tracked (mutual information + variance: float64 statistics, S = 5 planes)
+        probe = steps.McStatistics(n_slices, 2, height, width, device, True, True)
+        model.forward_accumulate(x, probe)
+        model.profile_begin(height, width, n_slices, 3)
+        for _ in range(3):
+            model.forward_accumulate(x, probe)
+        torch.cuda.synchronize()
+        cnt_h, ms_h = model.profile_collect(height, width, n_slices)
+        head_all_ms = ms_h[-1] / max(cnt_h, 1)
+        del probe
     finally:
-        del os.environ['RCU_FUSE_HEAD']
+        model.set_fuse_head(True)
     roofline['other_ms_per_forward']['head_fused_into'] = 'conv_cls.0 epilogue' if fused_head_ms < 0.5 * head_ms else None
     # the first conv kernel (csrc/rcu_first.hip) reads the NCHW input itself: no re-layout kernel in the timed region then
     roofline['other_ms_per_forward']['input_read_by'] = layers[0]['kernel'] if layers[0]['kernel'].startswith('conv3x3_first') else 'pack_input_kernel'
@@ -643,14 +769,34 @@ def main():
                                    unit='GB/s', frac=head_bytes / head_ms / 1e6 / PEAK_HBM_GBS, bytes_per_launch=head_bytes,
                                    avg_launch_ms=head_ms, measured='standalone launches outside the timed region')
     roofline['aggregation'].update(aggregation_kernels(device, n_slices, height, width))
+    # the aggregation with every output tracked (188.7 MB per sample-volume = V*C*4 of logits + 2*S*4*V of statistics,
+    # S = 5).  The head kernel never sees logits -- it reads the 32-channel feature map (4*V*32) -- and its planes are float64 (2*S*8*V):
+    # `achieved` prices the ALGORITHMIC bytes against its time, `moved_*` the bytes it really moves.
+    ao_alg = vox * (2 * 4 + 2 * 5 * 4.0)
+    ao_moved = 4.0 * vox * 32 + 2 * 5 * 8.0 * vox
+    agg_all = dict(bound='hbm', kernel='head_kernel (MI + variance statistics)', avg_launch_ms=head_all_ms,
+                   bytes_per_launch=ao_alg, achieved=ao_alg / head_all_ms / 1e6, peak=PEAK_HBM_GBS, unit='GB/s',
+                   frac=ao_alg / head_all_ms / 1e6 / PEAK_HBM_GBS, moved_bytes_per_launch=ao_moved,
+                   moved_gbs=ao_moved / head_all_ms / 1e6, moved_frac=ao_moved / head_all_ms / 1e6 / PEAK_HBM_GBS,
+                   measured='standalone launches outside the timed region; in the timed steps the update runs inside conv_cls.0')
+    agg_all.update(aggregation_kernels(device, n_slices, height, width, all_outputs=True))
+    roofline['aggregation_all_outputs'] = agg_all
+    # HBM traffic of the dominant kernel: a builder-run PMC figure (profiles/pmc_traffic.json), reported only while the plan it was
+    # measured on is the plan of this run (kernel per layer, shapes, samples per launch) -- a changed tile shape must not inherit it
+    plan_hash = plan_fingerprint(layers, n_slices * g)
+    roofline['plan_fingerprint'] = plan_hash
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(pmc_path) and not isic:
         with open(pmc_path) as f:
             pmc = json.load(f)
-        if dominant in pmc:
+        meta = pmc.get('_meta', {})
+        if dominant in pmc and meta.get('plan_fingerprint') == plan_hash:
             roofline['traffic'] = pmc[dominant]
-            roofline['traffic_source'] = ('profiles/pmc_traffic.json: HBM bytes per launch from a builder-run rocprofv3 --pmc pass '
-                                          '(separate run; not measured in this process)')
+            roofline['traffic_source'] = ('profiles/pmc_traffic.json: HBM bytes per launch from a builder-run rocprofv3 --pmc pass on the '
+                                          'same plan (fingerprint {}; separate run, not measured in this process)'.format(plan_hash))
+        elif dominant in pmc:
+            roofline['traffic_source'] = ('none: profiles/pmc_traffic.json was measured on another plan (fingerprint {} there, {} here)'
+                                          .format(meta.get('plan_fingerprint'), plan_hash))
 
     # ---- parity, outside the timed region, of the TIMED output (last step): ECE on the GPU maps vs the oracle on the same maps,
     # and -- the CPU leg -- the oracle's own forward passes on a slice sample of the same volume under the same dropout masks
@@ -723,12 +869,23 @@ def main():
         cpu['metric_seam'] = 'ECE + normalised entropy + 11 uncertainty-error count passes (numpy, one thread) on {} of {} slices'.format(
             len(sel), n_slices)
         parity['ece_delta_vs_cpu'] = abs(ev.ece_binary(pg, tg, mask=mk) - ece_cpu)
+        # the all-outputs leg ran its last volume under the same masks: its four maps against the same CPU passes
+        for res, rec in ((out_ao, all_out), (out if args.all_outputs else None, parity)):
+            if res is None:
+                continue
+            deltas = {key: float((res[key][idx].cpu() - ref[key]).abs().max())
+                      for key in ('probabilities', 'entropy', 'mutual_info', 'variance') if key in res and key in ref}
+            rec['max_abs_delta_vs_cpu'] = deltas
+            rec['tolerance'] = 1e-4
+            rec['within_tolerance'] = bool(deltas) and all(v <= 1e-4 for v in deltas.values())
+            rec['slices_compared'] = [int(v) for v in sel]
 
     units = T * (n_slices if isic else 1)
     shape = '{}x{}x{}'.format(ISIC_CHANNELS, height, width) if isic else '4x160x192x128'
     result = {
         'metric': ('ensemble-member-{}s/sec ({}, K={})'.format(unit_name, shape, T) if args.ensemble
-                   else 'MC-sample-{}s/sec ({}, T={}{})'.format(unit_name, shape, T, ', sigma head' if args.aleatoric else '')),
+                   else 'MC-sample-{}s/sec ({}, T={}{}{})'.format(unit_name, shape, T, ', sigma head' if args.aleatoric else '',
+                                                                 ', all outputs' if args.all_outputs else '')),
         'value': units * args.steps / elapsed,
         'unit': 'member-{}s/s'.format(unit_name) if args.ensemble else 'MC-sample-{}s/s'.format(unit_name),
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -751,6 +908,8 @@ def main():
                                         T, '' if args.no_ws else ' + weight-scaling pass')),
                    'T': T, 'ws_pass': not (args.no_ws or args.ensemble), 'slices': n_slices, 'height': height, 'width': width,
                    'pass_group': g, 'lanes': args.lanes,
+                   'outputs': 'mean + entropy + mutual information + variance (float64 statistics)' if args.all_outputs else
+                              'mean + entropy (MultiPredictionSummary() as every shipped script constructs it)',
                    'h2d': 'prefetched, inside timed region ({} MB per {} from pinned host memory on a copy stream, one event wait per '
                           '{}; rechun/dl/customsteps.py:20)'.format(feeder.bytes // 1000000, unit_name if not isic else 'batch',
                                                                     unit_name if not isic else 'batch'),
@@ -766,9 +925,14 @@ def main():
         'calibration_kernels': calibration_kernels(device) if (world == 1 and not isic) else None,
         'cpu_baseline': cpu,
         'parity': parity,
+        'all_outputs': all_out,
     }
+    if force_pg:
+        result['rccl_rehearsal'] = dict(backend=dist.get_backend(), world=dist.get_world_size(), ws_transport=runner.ws_transport,
+                                        p2p_messages=runner.p2p_messages,
+                                        note='RCU_BENCH_FORCE_PG=1: one-rank process group, every step through the exchange path')
     print(json.dumps(result))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

@@ -70,8 +70,34 @@ typedef struct rcu_unet_desc {
 
 int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out);
 int rcu_unet_destroy(rcu_unet* h);
-/* bytes of device workspace (activations + packed weights) the handle owns */
+/* bytes of device memory the handle OWNS: its packed weights, plus the activation workspace unless that is borrowed from a donor
+ * (rcu_unet_create_with) */
 int64_t rcu_unet_workspace_bytes(const rcu_unet* h);
+
+/* Plan options: which kernel family / activation layout the planner may choose.  The defaults are the shipped path; the other
+ * values exist for A/B measurements and for the parity tests that compare the kernel families on the same input (they replace the
+ * RCU_CONV_WINO / RCU_CONV_WINO4 / RCU_CONV_FIRST / RCU_ACT_LAYOUT / RCU_FUSE_HEAD environment switches of earlier rounds: the library
+ * reads no environment variable on the product path). */
+typedef struct rcu_unet_options {
+    int32_t conv_winograd;    /* 1 (default): Winograd kernels wherever their tiles fit; 0: the direct kernels everywhere */
+    int32_t conv_winograd4;   /* 1 (default): F(4x4,3x3) wherever its tiles fit; 0: F(2x2,3x3) only; 3: F(4x4,3x3) for the units with
+                                 >= 64 output channels only (the round-2 selection) */
+    int32_t conv_first;       /* 1 (default): the unpadded first-unit kernel; 0: the tiled kernel + channels-last input copy */
+    int32_t act_layout;       /* 0 (default): channel-blocked activations between Winograd kernels; 1: channels-last everywhere */
+    int32_t fuse_head;        /* 1 (default): 1x1 classifier + softmax + statistics in conv_cls.0's epilogue where the shapes allow;
+                                 0: the standalone head kernel (also settable per handle at run time: rcu_unet_set_fuse_head) */
+    int32_t reserved[3];      /* must be 0 */
+} rcu_unet_options;
+/* fills *opts with the defaults above */
+void rcu_unet_default_options(rcu_unet_options* opts);
+/* rcu_unet_create with explicit options (NULL = defaults) and an optional workspace DONOR: a handle of the same shape (desc and options
+ * equal, max_batch <= the donor's) whose activation workspace the new handle shares instead of allocating its own -- the members of
+ * an ensemble (bin-dl/brats_test_ensemble.py:44-57: K models resident at once) differ in 35 MB of packed weights, not in their
+ * 6 GB of activations.  Handles that share a workspace must not run concurrently (launch them on ONE stream); the workspace is
+ * freed when its last user is destroyed, in any order. */
+int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_options* opts, rcu_unet* workspace_donor, rcu_unet** out);
+/* Run-time form of rcu_unet_options.fuse_head (benchmarks time the standalone head kernel on the plan of the timed run). */
+int rcu_unet_set_fuse_head(rcu_unet* h, int on);
 
 /* Dropout sites in execution order (= torch named_modules order of the Dropout2d modules). */
 int rcu_unet_num_dropout_sites(const rcu_unet* h);
@@ -235,6 +261,10 @@ int rcu_ece_hist(const float* p_dev, const uint8_t* target_dev, const uint8_t* m
                  void* stream);
 /* raw bin index per voxel (test aid: pins the binning bit-for-bit) */
 int rcu_ece_bin_ids(const float* p_dev, size_t n, const float* thr_host, int n_bins, uint8_t* ids_dev, void* stream);
+
+/* Test / tuning aid: consecutive 16,384-voxel blocks a workgroup of the histogram (ece) and of the count kernel (unc) takes;
+ * 0 = the launcher's choice (default).  Integer sums: every value gives the same results.  Process-wide. */
+int rcu_calib_set_blocks_per_workgroup(int ece_blocks, int unc_blocks);
 
 size_t rcu_unc_workspace_bytes(size_t n_per_volume, int n_volumes);
 /* counts_dev: [n_volumes][n_thr][8] uint64 = tp, tn, fp, fn, tpu, tnu, fpu, fnu with

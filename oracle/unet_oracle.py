@@ -269,3 +269,20 @@ def reference_init_state(seed, bn_seed=None, **params):
             state[op['key'] + '.weight'] = conv.weight.detach()
             state[op['key'] + '.bias'] = conv.bias.detach()
     return state
+
+
+def stress_state(state, bn_gain, head_gain):
+    """The numerics stress weights of golden fixture G18: every BatchNorm affine (weight and bias) times ``bn_gain`` -- activations then
+    grow from unit to unit instead of shrinking as they do under torch's default initialisation: with 2.5 the interior activations of
+    the full-width U-Net reach 1e2..1e3 -- and the 1x1 classifier (conv_cls.1) times ``head_gain``, which sets the range of the logits
+    (+-20 under Dropout2d(0.3) with 0.5).  What trained checkpoints look like to the kernels: wide activation ranges, saturated and
+    unsaturated softmax inputs side by side.  tests/golden/generate_golden.py applies the same rule to the reference's own module."""
+    out = {}
+    for k, v in state.items():
+        v = torch.as_tensor(v).clone()
+        if k.endswith('.bn.weight') or k.endswith('.bn.bias'):
+            v = v * bn_gain
+        if k.startswith('conv_cls.1.'):
+            v = v * head_gain
+        out[k] = v
+    return out

@@ -33,6 +33,11 @@ class UnetDesc(Structure):
                                        'provide_features')]
 
 
+class UnetOptions(Structure):
+    """rcu_unet_options (include/rcu.h): the planner's kernel-family / layout choices; defaults = the shipped path."""
+    _fields_ = [(n, c_int32) for n in ('conv_winograd', 'conv_winograd4', 'conv_first', 'act_layout', 'fuse_head')] + [('reserved', c_int32 * 3)]
+
+
 class LayerInfo(Structure):
     _fields_ = [('name', c_char * 96), ('kernel', c_char * 64), ('cin', c_int32), ('cout', c_int32),
                 ('height', c_int32), ('width', c_int32), ('upsample', c_int32), ('pooled', c_int32),
@@ -50,6 +55,9 @@ SIGNATURES = {
     'rcu_version': (c_char_p, []),
     'rcu_unet_create': (c_int, [POINTER(UnetDesc), POINTER(c_void_p)]),
     'rcu_unet_destroy': (c_int, [c_void_p]),
+    'rcu_unet_default_options': (None, [POINTER(UnetOptions)]),
+    'rcu_unet_create_with': (c_int, [POINTER(UnetDesc), POINTER(UnetOptions), c_void_p, POINTER(c_void_p)]),
+    'rcu_unet_set_fuse_head': (c_int, [c_void_p, c_int]),
     'rcu_unet_workspace_bytes': (c_int64, [c_void_p]),
     'rcu_unet_num_dropout_sites': (c_int, [c_void_p]),
     'rcu_unet_dropout_site_channels': (c_int, [c_void_p, c_int]),
@@ -87,6 +95,7 @@ SIGNATURES = {
     'rcu_ece_hist': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_float), c_int, c_void_p,
                              c_void_p, c_void_p]),
     'rcu_ece_bin_ids': (c_int, [c_void_p, c_size_t, POINTER(c_float), c_int, c_void_p, c_void_p]),
+    'rcu_calib_set_blocks_per_workgroup': (c_int, [c_int, c_int]),
     'rcu_unc_workspace_bytes': (c_size_t, [c_size_t, c_int]),
     'rcu_unc_counts': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_double),
                                c_int, c_void_p, c_void_p, c_void_p]),

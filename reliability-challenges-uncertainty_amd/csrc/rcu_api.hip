@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -64,8 +65,24 @@ struct Tensor {
     bool blocked = false;     // [N][C/8][H][W][8] instead of NHWC (rcu_kernels.h, ConvArgs): decided per tensor by assign_layouts
 };
 
+// The activation tensors of a plan: owned by the handle that allocated them, shared (shared_ptr) with the handles created with
+// that handle as their workspace donor (rcu_unet_create_with); freed with the last user.
+struct Workspace {
+    std::vector<float*> dev;      // one allocation per plan tensor
+    std::vector<size_t> bytes;
+    int max_batch = 0;
+    ~Workspace()
+    {
+        for (float* p : dev)
+            if (p) (void)hipFree(p);
+    }
+};
+
 struct rcu_unet {
     rcu_unet_desc d{};
+    rcu_unet_options opt{};
+    std::shared_ptr<Workspace> ws;
+    bool ws_borrowed = false;
     std::vector<ConvLayer> layers;
     std::vector<Tensor> tensors;
     std::vector<std::pair<std::string, int>> sites;   // (name, channels)
@@ -114,17 +131,16 @@ static size_t conv_tile_floats(const ConvConfigInfo& ci)
 
 static bool is_head_unit(const ConvLayer& L) { return L.name.rfind("conv_cls.0", 0) == 0; }
 
-static int pick_config(const ConvLayer& L, int n_slices)
+static int pick_config(const ConvLayer& L, int n_slices, const rcu_unet_options& opt)
 {
     // Winograd kernels (rcu_wino.hip, rcu_wino_up.hip): 16/36 (conv units) and 9/36 (up-convolutions) of the
     // multiplications.  They address activations through 32-bit byte offsets of a buffer resource (tensors < 2 GB)
     // and take whole tiles only.  Tiles that span two or eight slices are taken whatever the batch the plan is sized for (a last
     // group of slices that is not full reads zeros and stores nothing): the kernel of a layer -- and with it the bits of a slice's
     // result -- does not depend on the batch size, as long as every tensor stays below 2 GB.
-    // RCU_CONV_WINO=0 keeps every layer on the direct kernels of rcu_conv.hip (read at rcu_unet_create: A/B tests)
-    const char* const wino_env = getenv("RCU_CONV_WINO");
+    // rcu_unet_options.conv_winograd = 0 keeps every layer on the direct kernels of rcu_conv.hip (A/B tests)
     // a unit that adds to its output tensor (ConvResidualBlock's second unit) runs on the direct kernels, whose epilogue can
-    const bool wino_on = !(wino_env && atoi(wino_env) == 0) && !L.accumulate;
+    const bool wino_on = opt.conv_winograd != 0 && !L.accumulate;
     const size_t max_bytes = (size_t)n_slices * L.H * L.W * (size_t)std::max(std::max(L.c1p, L.c2p), L.coutp) * 4;
     const bool center_pad = L.upsample && (2 * (L.H / 2) != L.H || 2 * (L.W / 2) != L.W);   // unet.py:110-116: direct kernel only
     if (L.upsample && !center_pad && wino_on && L.c1p % 32 == 0 && L.c2p == 0 && max_bytes < ((size_t)1 << 31)) {
@@ -140,10 +156,9 @@ static int pick_config(const ConvLayer& L, int n_slices)
         return CONV_CFG_UP_T8x16_N64;
     }
     if (L.c1p + L.c2p == 8) {
-        // the network's first conv unit: unpadded K = 9 x 4 (8) on whole 8x32 tiles (rcu_first.hip); RCU_CONV_FIRST=0 keeps the
-        // tiled kernel (A/B tests)
-        const char* const first_env = getenv("RCU_CONV_FIRST");
-        const bool first_on = !(first_env && atoi(first_env) == 0);
+        // the network's first conv unit: unpadded K = 9 x 4 (8) on whole 8x32 tiles (rcu_first.hip); rcu_unet_options.conv_first = 0
+        // keeps the tiled kernel (A/B tests)
+        const bool first_on = opt.conv_first != 0;
         if (first_on && L.c2p == 0 && L.H % 8 == 0 && L.W % 32 == 0 && (L.coutp == 32 || L.coutp == 64) && L.t_pool < 0 &&
             L.name2.empty() && !L.accumulate)
             return CONV_CFG_FIRST_T8x32;
@@ -155,10 +170,9 @@ static int pick_config(const ConvLayer& L, int n_slices)
         // 256 -> 128 over F(2x2,3x3).  The 32-channel full-resolution layers -- four Cin chunks per tile, so a tile switch (cold fetch +
         // epilogue) per four chunks -- lost to F(2x2,3x3) while the activations were channels-last (0.39-0.69 against 0.36-0.64 ms); with
         // the channel-blocked layout, whose chunks are cold one at a time, they win too (round 3: 0.31 / 0.47 / 0.28 against
-        // 0.35 / 0.60 / 0.33 ms).  conv_cls.0 keeps its fused classifier head on F(2x2,3x3).  RCU_CONV_WINO4=0 keeps F(2x2,3x3)
-        // everywhere, =3 takes F(4x4,3x3) for the layers with >= 64 output channels only (the round-2 choice; A/B tests).
-        const char* const w4_env = getenv("RCU_CONV_WINO4");
-        const int w4_mode = w4_env ? atoi(w4_env) : 1;
+        // 0.35 / 0.60 / 0.33 ms).  conv_cls.0 keeps its fused classifier head on F(2x2,3x3).  rcu_unet_options.conv_winograd4 = 0 keeps
+        // F(2x2,3x3) everywhere, 3 takes F(4x4,3x3) for the layers with >= 64 output channels only (the round-2 choice; A/B tests).
+        const int w4_mode = opt.conv_winograd4;
         // (the head unit stays on F(2x2,3x3) where its classifier can be fused into the epilogue -- one 32-cout tile, no sigma twin; the
         // 64-cout cls + sigma twin unit has no fused form and takes F(4x4,3x3))
         const bool w4_ok = w4_mode != 0 && (L.coutp >= 64 || w4_mode != 3) && !(is_head_unit(L) && L.name2.empty());
@@ -309,7 +323,7 @@ static int build_plan(rcu_unet* h)
     for (size_t s = 0; s < h->sites.size(); ++s) h->site_offset[s + 1] = h->site_offset[s] + h->sites[s].second;
     h->mask_floats = h->site_offset.back();
     for (ConvLayer& L : h->layers) {
-        L.cfg = pick_config(L, h->d.max_batch);
+        L.cfg = pick_config(L, h->d.max_batch, h->opt);
         const ConvConfigInfo& ci = conv_config_info(L.cfg);
         if ((L.c1p % ci.KC) != 0 || (L.c2p % ci.KC) != 0)
             return fail(RCU_ERR_INVALID, "internal: channel chunking does not divide for layer " + L.name);
@@ -322,7 +336,7 @@ static int build_plan(rcu_unet* h)
 // Which activation tensors take the channel-blocked layout [N][C/8][H][W][8] (rcu_kernels.h, ConvArgs): every tensor all of whose
 // producers and consumers are Winograd kernels (rcu_first.hip as a producer), except the network input, the head unit's output
 // (head_kernel reads channels-last) and -- when the caller wants rcu_unet_features -- the feature tensor.  The two sources of a
-// cat-free decoder unit share one layout.  RCU_ACT_LAYOUT=nhwc keeps everything channels-last (A/B tests).
+// cat-free decoder unit share one layout.  rcu_unet_options.act_layout = 1 keeps everything channels-last (A/B tests).
 static bool cfg_reads_blocked(int cfg)
 {
     return (cfg >= CONV_CFG_WINO_T16x16_N64 && cfg <= CONV_CFG_UPW_S8T4x8_N64) || (cfg >= CONV_CFG_WINO4_T32x32_N32 && cfg < CONV_CFG_END);
@@ -331,8 +345,7 @@ static bool cfg_writes_blocked(int cfg) { return cfg_reads_blocked(cfg) || cfg =
 
 static void assign_layouts(rcu_unet* h)
 {
-    const char* const env = getenv("RCU_ACT_LAYOUT");
-    const bool on = !(env && (strcmp(env, "nhwc") == 0 || strcmp(env, "0") == 0));
+    const bool on = h->opt.act_layout == 0;
     for (Tensor& t : h->tensors) t.blocked = on && t.cp % 8 == 0 && !t.zero_fill;
     h->tensors[h->t_input].blocked = false;
     h->tensors[h->t_head].blocked = false;
@@ -365,7 +378,18 @@ static void assign_layouts(rcu_unet* h)
 extern "C" const char* rcu_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* rcu_version(void) { return "librcu_hip 0.1.0 gfx950"; }
 
-extern "C" int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out)
+extern "C" void rcu_unet_default_options(rcu_unet_options* opts)
+{
+    if (!opts) return;
+    std::memset(opts, 0, sizeof *opts);
+    opts->conv_winograd = 1;
+    opts->conv_winograd4 = 1;
+    opts->conv_first = 1;
+    opts->act_layout = 0;
+    opts->fuse_head = 1;
+}
+
+extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_options* opts, rcu_unet* donor, rcu_unet** out)
 {
     if (!desc || !out) return fail(RCU_ERR_INVALID, "rcu_unet_create: null argument");
     const rcu_unet_desc& d = *desc;
@@ -377,8 +401,17 @@ extern "C" int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out)
     const int div = 1 << d.depth;
     if (d.height < div || d.width < div)
         return fail(RCU_ERR_INVALID, "height and width must be at least 2^depth (one pixel at the bottom level)");
+    rcu_unet_options o;
+    rcu_unet_default_options(&o);
+    if (opts) {
+        o = *opts;
+        if ((o.conv_winograd | 1) != 1 || (o.conv_winograd4 != 0 && o.conv_winograd4 != 1 && o.conv_winograd4 != 3) ||
+            (o.conv_first | 1) != 1 || (o.act_layout | 1) != 1 || (o.fuse_head | 1) != 1 || o.reserved[0] || o.reserved[1] || o.reserved[2])
+            return fail(RCU_ERR_INVALID, "rcu_unet_create_with: bad rcu_unet_options value");
+    }
     rcu_unet* h = new rcu_unet();
     h->d = d;
+    h->opt = o;
     int rc = build_plan(h);
     if (rc != RCU_OK) {
         delete h;
@@ -390,6 +423,26 @@ extern "C" int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out)
             delete h;
             return fail(RCU_ERR_INVALID, "max_batch too large: an activation tensor would exceed 2^31 elements");
         }
+    if (donor) {
+        // the donor's plan must hold the same tensors (same shapes, same layouts, same never-written borders) for at least this batch
+        bool same = donor->ws && donor->tensors.size() == h->tensors.size() && donor->ws->max_batch >= d.max_batch;
+        for (size_t i = 0; same && i < h->tensors.size(); ++i) {
+            const Tensor &a = h->tensors[i], &b = donor->tensors[i];
+            same = a.floats_per_slice == b.floats_per_slice && a.H == b.H && a.W == b.W && a.cp == b.cp && a.blocked == b.blocked &&
+                   a.zero_fill == b.zero_fill;
+        }
+        if (!same) {
+            delete h;
+            return fail(RCU_ERR_INVALID, "rcu_unet_create_with: the workspace donor's plan differs (shape, options) or is sized for a smaller batch");
+        }
+        h->ws = donor->ws;
+        h->ws_borrowed = true;
+        for (size_t i = 0; i < h->tensors.size(); ++i) h->tensors[i].dev = h->ws->dev[i];
+        *out = h;
+        return RCU_OK;
+    }
+    h->ws = std::make_shared<Workspace>();
+    h->ws->max_batch = d.max_batch;
     for (Tensor& t : h->tensors) {
         const size_t bytes = t.floats_per_slice * (size_t)d.max_batch * sizeof(float);
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&t.dev), bytes);
@@ -397,7 +450,8 @@ extern "C" int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out)
             rcu_unet_destroy(h);
             return hip_fail(e, "hipMalloc(activation workspace)");
         }
-        h->allocs.push_back(t.dev);
+        h->ws->dev.push_back(t.dev);
+        h->ws->bytes.push_back(bytes);
         h->workspace_bytes += (int64_t)bytes;
         if (t.zero_fill) {
             e = hipMemset(t.dev, 0, bytes);
@@ -411,12 +465,21 @@ extern "C" int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out)
     return RCU_OK;
 }
 
+extern "C" int rcu_unet_create(const rcu_unet_desc* desc, rcu_unet** out) { return rcu_unet_create_with(desc, nullptr, nullptr, out); }
+
+extern "C" int rcu_unet_set_fuse_head(rcu_unet* h, int on)
+{
+    if (!h) return fail(RCU_ERR_INVALID, "rcu_unet_set_fuse_head: null handle");
+    h->opt.fuse_head = on ? 1 : 0;
+    return RCU_OK;
+}
+
 extern "C" int rcu_unet_destroy(rcu_unet* h)
 {
     if (!h) return RCU_OK;
-    for (void* p : h->allocs) (void)hipFree(p);
+    for (void* p : h->allocs) (void)hipFree(p);     // packed weights, epilogue constants
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
-    delete h;
+    delete h;                                       // drops its reference to the activation workspace
     return RCU_OK;
 }
 
@@ -764,14 +827,13 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
         RCU_HIP(launch_pack_input(x, h->tensors[h->t_input].dev, n_one, h->d.in_channels, h->in_cp, h->d.height, h->d.width,
                                   passes, stream));
     if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
-    // conv_cls.0 and the classifier as one kernel where the shapes allow (the shipped configurations; RCU_FUSE_HEAD=0
-    // keeps them apart): two classes, no sigma twin, 32-cout Winograd tile; the passes of a pass group run back to back on the
+    // conv_cls.0 and the classifier as one kernel where the shapes allow (the shipped configurations; rcu_unet_options.fuse_head = 0 /
+    // rcu_unet_set_fuse_head keep them apart): two classes, no sigma twin, 32-cout Winograd tile; the passes of a pass group run back to back on the
     // workgroup that owns the tile, so their read-modify-writes of the statistics are ordered (pass 0 first, as head_kernel adds them)
     const ConvLayer& last = h->layers.back();
-    const char* const fuse_env = getenv("RCU_FUSE_HEAD");
     const bool fuse = last.cfg == CONV_CFG_WINO_T16x32_N32 && h->d.nb_classes == 2 && last.name2.empty() &&
                       sigma == nullptr && (logits != nullptr || stats != nullptr) && h->head_cph == 32 &&
-                      !(fuse_env && atoi(fuse_env) == 0);
+                      h->opt.fuse_head != 0;
     for (const ConvLayer& L : h->layers) {
         const FusedHead fh{logits, stats, flags, passes};
         int rc = run_layer(h, L, n, masks, stream, (fuse && &L == &last) ? &fh : nullptr, direct_input ? x : nullptr, n_one);
@@ -1186,6 +1248,13 @@ extern "C" int rcu_ece_bin_ids(const float* p, size_t n, const float* thr, int n
     if ((n && (!p || !ids)) || !thr) return fail(RCU_ERR_INVALID, "rcu_ece_bin_ids: null argument");
     if (n_bins < 1 || n_bins > MAX_BINS) return fail(RCU_ERR_INVALID, "n_bins must be in 1..32");
     RCU_HIP(launch_bin_ids(p, n, thr, n_bins, ids, static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}
+
+extern "C" int rcu_calib_set_blocks_per_workgroup(int ece_blocks, int unc_blocks)
+{
+    if (ece_blocks < 0 || unc_blocks < 0) return fail(RCU_ERR_INVALID, "rcu_calib_set_blocks_per_workgroup: negative block count");
+    calib_set_blocks_per_workgroup(ece_blocks, unc_blocks);
     return RCU_OK;
 }
 

@@ -102,11 +102,17 @@ static inline unsigned blocks_per_volume(size_t n) { return (unsigned)((n + ELEM
 // Blocks a workgroup of a streaming histogram kernel takes: its prologue (zeroing the columns) and its reduction cost a few per cent of
 // a block's streaming time, so a large launch lets every workgroup take several consecutive blocks of its volume (measured, 160 BraTS
 // volumes: 2 blocks +4 %, 8 blocks +5 %, 16 blocks -- too few workgroups left for the tail -- +2 %) while a small one keeps one block
-// per workgroup and with it the chip full: at least four rounds of workgroups stay.  `env`: override for experiments.
-static inline unsigned blocks_per_workgroup(unsigned blocks, int n_volumes, unsigned cap, const char* env)
+// per workgroup and with it the chip full: at least four rounds of workgroups stay.  `forced`: rcu_calib_set_blocks_per_workgroup
+// (test / tuning aid; 0 = this rule).
+static int g_forced_blocks[2] = {0, 0};   // [ece, unc]
+void calib_set_blocks_per_workgroup(int ece, int unc)
 {
-    const char* const v = getenv(env);
-    if (v != nullptr && atoi(v) >= 1) return (unsigned)atoi(v) < cap ? (unsigned)atoi(v) : cap;
+    g_forced_blocks[0] = ece;
+    g_forced_blocks[1] = unc;
+}
+static inline unsigned blocks_per_workgroup(unsigned blocks, int n_volumes, unsigned cap, int forced)
+{
+    if (forced >= 1) return (unsigned)forced < cap ? (unsigned)forced : cap;
     const size_t resident = 256 * 6;   // workgroups the chip holds at a time (LDS-bound: 6-7 per CU)
     const size_t k = (size_t)blocks * n_volumes / (4 * resident);
     return (unsigned)(k < 1 ? 1 : k > cap ? cap : k);
@@ -313,7 +319,7 @@ hipError_t launch_ece_hist(const float* p, const uint8_t* target, const uint8_t*
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const unsigned bpw = blocks_per_workgroup(nb, n_volumes, ECE_MAX_BLOCKS, "RCU_ECE_BLOCKS_PER_WG");
+    const unsigned bpw = blocks_per_workgroup(nb, n_volumes, ECE_MAX_BLOCKS, g_forced_blocks[0]);
     const unsigned gx = (nb + bpw - 1) / bpw;
     if (vec)
         hipLaunchKernelGGL(ece_hist_kernel<true>, dim3(gx, n_volumes), dim3(CB_THREADS), lds, stream, p, target, mask, n, th,
@@ -655,7 +661,7 @@ hipError_t launch_unc_counts(const void* unc, int unc_is_f64, const uint8_t* pre
     for (int t = 1; t < n_thr; ++t) ascending = ascending && (thr_host[t - 1] <= thr_host[t]);
     if (ascending) {
         const size_t lds = (size_t)CB_WAVES * (n_thr + 1) * 2 * 64 * sizeof(unsigned);
-        const unsigned bpw = blocks_per_workgroup(nb, n_volumes, UNC_MAX_BLOCKS, "RCU_UNC_BLOCKS_PER_WG");
+        const unsigned bpw = blocks_per_workgroup(nb, n_volumes, UNC_MAX_BLOCKS, g_forced_blocks[1]);
         const unsigned gx = (nb + bpw - 1) / bpw;
         if (unc_is_f64)
             hipLaunchKernelGGL(unc_counts_sorted_kernel<double>, dim3(gx, n_volumes), dim3(CB_THREADS), lds, stream,

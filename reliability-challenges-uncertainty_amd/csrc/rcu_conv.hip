@@ -605,10 +605,14 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t stream)
             hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_igemm_stream<T>), T::LDS_BYTES);
             if (e != hipSuccess) return e;
             // WGS_PER_CU resident workgroups per CU, each streaming through its share of the tiles
+#ifdef RCU_EXPERIMENTS
             static const unsigned slots = [] {
                 const char* e = getenv("RCU_CONV_WGS");
                 return 256u * (unsigned)(e ? atoi(e) : T::WGS_PER_CU);
             }();
+#else
+            constexpr unsigned slots = 256u * (unsigned)T::WGS_PER_CU;
+#endif
             const unsigned grid = items < slots ? items : slots;
             hipLaunchKernelGGL(conv_igemm_stream<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);
             return hipGetLastError();

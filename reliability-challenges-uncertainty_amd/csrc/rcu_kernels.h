@@ -172,6 +172,7 @@ struct EceResult {           // one per volume
     double sum_conf[MAX_BINS];
     unsigned long long sum_pos[MAX_BINS];
 };
+void calib_set_blocks_per_workgroup(int ece, int unc);   // 0 = the launchers' own rule
 size_t ece_workspace_bytes(size_t n_per_volume, int n_volumes);
 hipError_t launch_ece_hist(const float* p, const uint8_t* target, const uint8_t* mask, size_t n_per_volume,
                            int n_volumes, const float* thr_host, int n_bins, EceResult* result_dev, void* workspace,

@@ -230,14 +230,19 @@ __device__ __forceinline__ uint32_t wino_slot_offset(uint32_t plan, const WinoTi
     return (plan & t.border) != 0u ? WINO_OOB : ((plan + t.off) & ~15u);
 }
 
-// workgroups of a persistent Winograd kernel: one per CU (RCU_PERSISTENT_GRID: experiments with kernels of two streams side by side)
+// workgroups of a persistent Winograd kernel: one per CU (experiment builds, -DRCU_EXPERIMENTS: RCU_PERSISTENT_GRID overrides it --
+// kernels of two streams side by side)
 inline unsigned wino_persistent_grid(unsigned items)
 {
+#ifdef RCU_EXPERIMENTS
     static const unsigned cap = [] {
         const char* const v = getenv("RCU_PERSISTENT_GRID");
         const int n = v ? atoi(v) : 0;
         return n > 0 ? (unsigned)n : 256u;
     }();
+#else
+    constexpr unsigned cap = 256u;
+#endif
     return items < cap ? items : cap;
 }
 

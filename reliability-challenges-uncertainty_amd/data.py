@@ -195,8 +195,13 @@ def _npz_member_mmap(path, name):
             if dtype.hasobject:
                 return None
             offset = f.tell()
+            # the mapping skips the CRC pass np.load makes over the member: at least the sizes must agree -- a truncated or overwritten
+            # file (member shorter than its header says, or reaching behind the end of the file) falls back to np.load, which fails loudly
+            nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+            if offset - (header_offset + 30 + n_name + n_extra) + nbytes != info.file_size or offset + nbytes > os.path.getsize(path):
+                return None
         return np.memmap(path, dtype=dtype, mode='r', shape=tuple(shape), offset=offset, order='F' if fortran else 'C')
-    except (KeyError, OSError, ValueError, struct.error):
+    except (KeyError, OSError, ValueError, struct.error, zipfile.BadZipFile):
         return None
 
 
@@ -397,7 +402,9 @@ class CollateDict:
 
     def __call__(self, batch):
         if isinstance(batch, PreCollated):
-            return dict(batch)
+            # the dataset stacked 'images' (and 'labels'): entries this collate would have kept as per-sample lists are unstacked again
+            return {key: (list(value) if (torch.is_tensor(value) and key in ('images', 'labels') and key not in self.entries) else value)
+                    for key, value in batch.items()}
         out = {}
         for key in batch[0]:
             if key in self.entries:

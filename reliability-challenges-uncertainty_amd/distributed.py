@@ -165,8 +165,12 @@ class ShardedMcRunner:
     assignment launch -> lane is fixed, so the result does not depend on timing."""
 
     def __init__(self, model, mc_steps, ws_pass=True, rank=0, world=1, engine=None, do_mi=False, do_var=False,
-                 root=0, seed=0, pass_group=1, lanes=1, ws_transport=None):
+                 root=0, seed=0, pass_group=1, lanes=1, ws_transport=None, force_exchange=False):
         self.engine = engine if engine is not None else HipEngine(model, do_mi, do_var)
+        # force_exchange: run the exchange step (reduce / send-recv, asynchronous work handles, side-stream finalize) at world size 1 too --
+        # the rehearsal of the RCCL path on a box with ONE GPU (tools/rccl_world1_rehearsal.py; needs an initialised process group).  A
+        # sum-reduce over one rank leaves the buffer as it is, so the result carries the bits of the plain world-1 step.
+        self.force_exchange = bool(force_exchange)
         # How the weight-scaling probabilities reach the root: 'reduce' -- in the tail of the ONE reduce buffer (zeros on every rank
         # but their owner; one collective per volume, twice the bytes on every link) -- or 'p2p': the reduce carries the statistics
         # only and the owner of job 0 sends its tail to the root (nothing when the root owns it): half the bytes on the links the
@@ -174,6 +178,8 @@ class ShardedMcRunner:
         self.ws_transport = ws_transport or os.environ.get('RCU_WS_TRANSPORT', 'reduce')
         if self.ws_transport not in ('reduce', 'p2p'):
             raise ValueError('ws_transport must be "reduce" or "p2p"')
+        self.p2p_messages = 0          # send / recv pairs this rank took part in (0 whenever the root owns the weight-scaling pass)
+        self._p2p_checked = False
         self.mc_steps = mc_steps
         self.ws_pass = ws_pass
         self.rank, self.world, self.root = rank, world, root
@@ -269,6 +275,16 @@ class ShardedMcRunner:
         if ws is None or self.ws_transport == 'reduce':
             w = dist.reduce(flat, dst=self.root, op=dist.ReduceOp.SUM, async_op=async_op)
             return [w] if async_op else []
+        if not self._p2p_checked:
+            # gloo has no send / recv for device tensors (it would fail, or exchange garbage, on the eight-ranks-on-one-GPU-over-gloo
+            # rehearsal): the tail then rides in the reduce, which every backend can do
+            self._p2p_checked = True
+            if flat.is_cuda and dist.get_backend() != 'nccl':
+                import warnings
+                warnings.warn('ws_transport="p2p" needs device send / recv, which the {} backend does not have: falling back to '
+                              '"reduce" (the tail rides in the one sum-reduce)'.format(dist.get_backend()))
+                self.ws_transport = 'reduce'
+                return self._exchange(flat, ws, step_index, async_op)
         head = flat[:flat.numel() - ws.numel()]
         tail = flat[flat.numel() - ws.numel():]
         works = [dist.reduce(head, dst=self.root, op=dist.ReduceOp.SUM, async_op=async_op)]
@@ -276,8 +292,10 @@ class ShardedMcRunner:
         if owner != self.root:
             if self.rank == owner:
                 works.append(dist.isend(tail, dst=self.root) if async_op else dist.send(tail, dst=self.root))
+                self.p2p_messages += 1
             elif self.rank == self.root:
                 works.append(dist.irecv(tail, src=owner) if async_op else dist.recv(tail, src=owner))
+                self.p2p_messages += 1
         return [w for w in works if w is not None] if async_op else []
 
     def step(self, x, step_index=0, mask_sets=None):
@@ -285,7 +303,7 @@ class ShardedMcRunner:
         ws_probabilities when enabled), None elsewhere.  ``mask_sets``: optional list of T injected
         mask sets, indexed by MC pass."""
         flat, stats, ws = self._run_jobs(x, step_index, mask_sets)
-        if self.world > 1:
+        if self.world > 1 or self.force_exchange:
             for w in self._exchange(flat, ws, step_index, async_op=False):
                 w.wait()
         if self.rank != self.root:
@@ -299,7 +317,7 @@ class ShardedMcRunner:
         """Like ``step`` but does not make this rank's compute stream wait for the other ranks: returns a
         ``PendingSummary`` whose ``result()`` is the summary dict on the root (None elsewhere).  At most
         ``depth`` reduces stay in flight per rank; their buffers are kept alive until they completed."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return PendingSummary(self.step(x, step_index, mask_sets))
         if not hasattr(self, '_inflight'):
             self._inflight = collections.deque()
@@ -352,17 +370,20 @@ class ShardedEnsembleRunner(ShardedMcRunner):
     "K=10 checkpoints, members sharded over 8 MI355X with RCCL reduce").  Job j = member j-1 in eval mode, no
     weight-scaling pass, divisor K.  A member's packed weights are 35 MB, so every rank holds all K members and
     the job rotation of the base class applies (K = 10 on 8 GPUs: 10 forwards per rank per 8 volumes instead of
-    a static 2,2,1,1,1,1,1,1 split)."""
+    a static 2,2,1,1,1,1,1,1 split).  ``share_workspace``: members 2..K borrow the activation workspace of the first (one per
+    stream lane; rcu_unet_create_with, include/rcu.h) -- K members cost lanes x 6.1 GB + K x 35 MB at 160 slices, not K x 6.1 GB."""
 
-    def __init__(self, members, rank=0, world=1, engine=None, do_mi=False, do_var=False, root=0, lanes=1):
+    def __init__(self, members, rank=0, world=1, engine=None, do_mi=False, do_var=False, root=0, lanes=1, share_workspace=True):
         members = list(members)
         super().__init__(members[0] if members else None, len(members), ws_pass=False, rank=rank, world=world,
                          engine=engine, do_mi=do_mi, do_var=do_var, root=root, lanes=lanes)
         self.members = members
+        if share_workspace:
+            steps_mod.share_member_workspaces(members)
 
     def _lane_of(self, job, count):
-        # A member keeps to one lane whatever the job rotation of a multi-rank run does: it needs ONE activation workspace (a handle
-        # per (member, lane) would be two: 12 GB each at 160 slices, never evicted -- handles are per member)
+        # A member keeps to one lane whatever the job rotation of a multi-rank run does: one plan (35 MB of packed weights) per member, and
+        # the members that share a lane's workspace run on that lane's stream, one after the other
         return (job - 1) % count
 
     def _run_job(self, job, x, stats, ws, mask_sets, step_index=0, lane=0):

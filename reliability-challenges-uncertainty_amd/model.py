@@ -58,6 +58,9 @@ class UNet(nn.Module):
     DEFAULT_START_FILTERS = 16
     DEFAULT_DROPOUT = 0.2
     MAX_HANDLES = 6          # cached (height, width[, lane]) plans incl. their workspaces
+    # rcu_unet_options (include/rcu.h): what the planner may choose.  The defaults are the shipped path; ``plan_options`` of an instance
+    # overrides them for A/B measurements and for the parity tests that compare kernel families on the same input.
+    PLAN_DEFAULTS = dict(conv_winograd=1, conv_winograd4=1, conv_first=1, act_layout=0)
 
     def __init__(self, nb_classes, in_channels, depth=DEFAULT_DEPTH, start_filters=DEFAULT_START_FILTERS,
                  dropout=DEFAULT_DROPOUT, dropout_center: int = None, residual=False, sigma_out=False,
@@ -108,8 +111,11 @@ class UNet(nn.Module):
             _add(self, 'conv_sigma.1', nn.Conv2d(cout, nb_classes, 1))
         for p in self.parameters():
             p.requires_grad = False
-        self._handles = {}       # (H, W) -> [handle, max_batch]
+        self._handles = {}       # (H, W[, lane][, 'features'], plan options) -> (handle, max_batch, weights version, donor handle)
         self._weights_version = 0
+        self.plan_options = {}   # overrides of PLAN_DEFAULTS; part of the plan's cache key
+        self.fuse_head = True    # 1x1 classifier + softmax + statistics inside conv_cls.0's epilogue where the shapes allow
+        self._donor = None       # share_workspace(): the model whose activation workspaces this one's plans borrow
         self.eval()
 
     # ------------------------------------------------------------------ weights
@@ -123,10 +129,42 @@ class UNet(nn.Module):
         """Call after editing parameters in place: the packed device copies are rebuilt lazily."""
         self._weights_version += 1
 
+    def share_workspace(self, donor):
+        """Borrow the activation workspaces of ``donor`` -- a UNet of the same architecture -- instead of allocating 6 GB per 160
+        slices again: the members of an ensemble (bin-dl/brats_test_ensemble.py:44-57) differ in their 35 MB of packed weights only
+        (include/rcu.h: rcu_unet_create_with).  Models that share a workspace must run on ONE stream at a time (the same stream
+        lane); ``None`` undoes it.  Existing plans are dropped."""
+        if donor is self:
+            donor = None
+        if donor is not None:
+            mine = (self.nb_classes, self.in_channels, self.depth, self.start_filters, self.dropout is not None, self.dropout_center,
+                    self.residual, self.sigma_out, bool(self.provide_features), self.bn)
+            theirs = (donor.nb_classes, donor.in_channels, donor.depth, donor.start_filters, donor.dropout is not None,
+                      donor.dropout_center, donor.residual, donor.sigma_out, bool(donor.provide_features), donor.bn)
+            if mine != theirs:
+                raise ValueError('share_workspace: the donor is a different architecture')
+            if donor._donor is not None:
+                donor = donor._donor         # one level: everybody borrows from the owner
+        self._release()
+        self._donor = donor
+
+    def set_fuse_head(self, on):
+        """Run-time switch between the fused classifier head and the standalone head kernel (same bits; benchmarks time the latter)."""
+        self.fuse_head = bool(on)
+        lib = _lib.load()
+        for entry in self._handles.values():
+            _lib.check(lib.rcu_unet_set_fuse_head(entry[0], int(self.fuse_head)))
+
+    def _options(self):
+        unknown = set(self.plan_options) - set(self.PLAN_DEFAULTS)
+        if unknown:
+            raise ValueError('unknown plan options: {}'.format(sorted(unknown)))
+        return dict(self.PLAN_DEFAULTS, **self.plan_options)
+
     def _release(self):
         lib = _lib.load()
-        for handle, _, _ in self._handles.values():
-            lib.rcu_unet_destroy(handle)
+        for entry in self._handles.values():
+            lib.rcu_unet_destroy(entry[0])
         self._handles = {}
         self.features = None     # a view into a destroyed handle's workspace
 
@@ -141,11 +179,17 @@ class UNet(nn.Module):
         that run concurrently on different HIP streams (rcu_amd.distributed: stream lanes) need a workspace each; a lane is a
         second, third ... handle of the same shape."""
         lib = _lib.load()
+        options = self._options()
         slot = (h, w) if lane == 0 else (h, w, lane)
         if self.provide_features:      # a plan of its own: the feature tensor is kept channels-last (include/rcu.h, rcu_unet_desc)
             slot = slot + ('features',)
+        slot = slot + (tuple(sorted(options.items())),)
         entry = self._handles.get(slot)
-        if entry is not None and entry[1] >= n and entry[2] == self._weights_version:
+        donor_handle = None
+        if self._donor is not None:    # the donor's plan of this shape and lane first (it may have to grow): its workspace is ours
+            donor_handle = self._donor._handle(h, w, n if entry is None else max(n, entry[1]), lane)
+        donor_key = None if donor_handle is None else donor_handle.value
+        if entry is not None and entry[1] >= n and entry[2] == self._weights_version and entry[3] == donor_key:
             self._handles[slot] = self._handles.pop(slot)     # most recently used last
             return entry[0]
         max_batch = n if entry is None else max(n, entry[1])
@@ -158,8 +202,9 @@ class UNet(nn.Module):
                              dropout_center=-1 if self.dropout_center is None else int(self.dropout_center),
                              sigma_out=int(self.sigma_out), bn=int(self.bn), height=h, width=w, max_batch=max_batch,
                              residual=int(self.residual), provide_features=int(bool(self.provide_features)))
+        opts = _lib.UnetOptions(fuse_head=int(self.fuse_head), **options)
         handle = ctypes.c_void_p()
-        _lib.check(lib.rcu_unet_create(ctypes.byref(desc), ctypes.byref(handle)))
+        _lib.check(lib.rcu_unet_create_with(ctypes.byref(desc), ctypes.byref(opts), donor_handle, ctypes.byref(handle)))
         try:
             for key, value in self.state_dict().items():
                 if not torch.is_floating_point(value):
@@ -171,7 +216,7 @@ class UNet(nn.Module):
         except Exception:
             lib.rcu_unet_destroy(handle)
             raise
-        self._handles[slot] = (handle, max_batch, self._weights_version)
+        self._handles[slot] = (handle, max_batch, self._weights_version, donor_key)
         while len(self._handles) > self.MAX_HANDLES:    # images of many different sizes: drop the least recently used plan
             old = next(iter(self._handles))
             lib.rcu_unet_destroy(self._handles.pop(old)[0])
@@ -379,8 +424,9 @@ class UNet(nn.Module):
         _lib.check(lib.rcu_unet_profile_collect(handle, ms, ctypes.byref(cnt)))
         return cnt.value, list(ms)
 
-    def workspace_bytes(self, h, w, n):
-        return int(_lib.load().rcu_unet_workspace_bytes(self._handle(h, w, n)))
+    def workspace_bytes(self, h, w, n, lane=0):
+        """Device bytes the plan OWNS: packed weights, plus the activation workspace unless it is borrowed (share_workspace)."""
+        return int(_lib.load().rcu_unet_workspace_bytes(self._handle(h, w, n, lane)))
 
 
 class PostNet(nn.Module):

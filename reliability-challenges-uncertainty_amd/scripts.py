@@ -48,7 +48,9 @@ class EvalSubjectStep(loops.SubjectStep):
         prediction = nifti.argmax_last(probabilities, np.uint8)      # (class indices: uint8 holds them; np.argmax's int64 where it is kept)
         if self.keep_prediction:
             subject_context.subject_data['prediction'] = prediction.astype(np.int64)
-        subject_context.more['prediction'] = prediction      # the writer hook takes it from here instead of a second arg-max
+        # the writer hook takes it from here instead of a second arg-max -- as long as ``probabilities`` still is the array it was taken from
+        # (a later subject step may replace it: the reference's writer arg-maxes at write time, brats_test_default.py:96-99)
+        subject_context.more['prediction'] = (prediction, probabilities)
         target = subject_context.subject_data['labels']
         if self.squeeze_labels:
             target = target.squeeze(-1)
@@ -69,9 +71,11 @@ class WriteHook(loops.TestLoopHook):
             raise ValueError('expected type is "TorchTestContext" but object is of type "{}"'.format(type(context).__name__))
         data = subject_context.subject_data
         subject = data.get('subject', subject_context.subject_index)
+        cached = subject_context.more.get('prediction')
+        prediction = cached[0] if (isinstance(cached, tuple) and cached[1] is data['probabilities']) else None
         nifti.write_subject(context.test_dir, subject, data['probabilities'], data.get('properties'),
                             data['sigma'] if self.with_sigma else None, in_background=self.in_background,
-                            prediction=subject_context.more.get('prediction'))
+                            prediction=prediction)
         if self.link_inputs:   # ISIC: symlink image and label next to the outputs
             files = context.test_data.dataset.get_files_by_id(subject_context.subject_index)
             for key in ('label_paths', 'image_paths'):
@@ -116,15 +120,23 @@ def _load_additional_models(context):
     return models
 
 
+def _coalesce(context):
+    """``others.coalesce_pixels`` of the YAML file (an rcu_amd extension, absent from the reference's configs): merge loader batches up to
+    that many pixels per step (loops.Test: opt-in, changes what hooks see and which masks a seed draws); None = the loop's default (off,
+    or RCU_COALESCE)."""
+    value = getattr(context.config.others, 'coalesce_pixels', None)
+    return None if value is None else int(value)
+
+
 def _run(context, dataset, test_steps, write_hook, entries, device=None):
     if dataset == 'brats':
         build = data_mod.BuildData(build_dataset=data_mod.BuildVolumeDataset())
         test = loops.Test(test_steps, [loops.ExtractSubjectInfoStep(), EvalSubjectStep()], loops.SubjectAssembler(),
-                          entries=entries)
+                          entries=entries, coalesce=_coalesce(context))
     else:
         build = data_mod.BuildData(build_dataset=data_mod.BuildIsicDataset())
         test = loops.Test(test_steps + [PrepareSubjectStep()], [EvalSubjectStep(squeeze_labels=True, keep_prediction=True)],
-                          loops.Subject2dAssembler(), entries=entries)
+                          loops.Subject2dAssembler(), entries=entries, coalesce=_coalesce(context))
     test(context, build, hook=_hooks(write_hook))
     return context
 

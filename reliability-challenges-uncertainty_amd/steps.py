@@ -387,20 +387,38 @@ class McPredictStep(BatchStep):
         return stats
 
 
+def share_member_workspaces(members):
+    """Members 2..K of an ensemble borrow the activation workspaces of the first (model.UNet.share_workspace): the K models the
+    reference keeps resident (bin-dl/brats_test_ensemble.py:44-57) differ in their weights only.  Members of another architecture,
+    foreign modules and members that already borrow are left alone."""
+    donor = members[0] if members and isinstance(members[0], model_mod.UNet) else None
+    if donor is None:
+        return
+    for m in members[1:]:
+        if isinstance(m, model_mod.UNet) and m is not donor and m._donor is None:
+            try:
+                m.share_workspace(donor)
+            except ValueError:
+                pass        # a different architecture keeps its own workspace
+
+
 class EnsemblePredictionStep(BatchStep):
     """context.model plus ``additional_models``, all in eval mode (brats_test_ensemble.py:78-94)."""
 
-    def __init__(self, additional_models, do_mi=False, do_var=False, materialize=False) -> None:
+    def __init__(self, additional_models, do_mi=False, do_var=False, materialize=False, share_workspace=True) -> None:
         super().__init__()
         self.additional_models = additional_models
         self.do_mi, self.do_var = do_mi, do_var
         self.materialize = materialize
+        self.share_workspace = share_workspace
 
     def __call__(self, batch_context, task_context, context) -> None:
         _check_context(context)
         images = _images_to_device(batch_context, context)
         members = [context.model] + list(self.additional_models)
         fused = not self.materialize and all(isinstance(m, model_mod.UNet) for m in members)
+        if self.share_workspace:
+            share_member_workspaces(members)
         if fused:
             n, _, h, w = images.shape
             def run(mi, var, materialize=False):

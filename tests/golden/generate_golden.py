@@ -715,13 +715,59 @@ def g17_unet_no_bn():
     save('g17_unet_no_bn', **arrays)
 
 
+def g18_unet_stress():
+    """Numerics stress case: the full-width BraTS U-Net (start_filters 32: every F(4x4,3x3) instantiation of the HIP
+    path on a 192x128 slice pair) with the BatchNorm affines scaled by 2.5 and the classifier by 0.5 -- interior activations of 1e2..1e3,
+    logits of +-20 under Dropout2d(0.3) -- through the REFERENCE module: an eval pass and three MC passes under the masks the reference
+    drew.  Like G11 the weights are not committed: the tests rebuild them by replaying the constructor's draws
+    (oracle.unet_oracle.reference_init_state) and applying the same scaling rule (oracle.unet_oracle.stress_state); the fixture holds
+    the input (rounded to multiples of 1/64: it compresses), the masks and a strided sub-sample of the logits."""
+    import common.utils.torchhelper as ref_th
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.3)
+    bn_gain, head_gain, stride = 2.5, 0.5, 5
+    model = make_unet(28, **params)
+    with torch.no_grad():
+        for name, p_ in list(model.named_parameters()):
+            if name.endswith('.bn.weight') or name.endswith('.bn.bias'):
+                p_.mul_(bn_gain)
+            if name.startswith('conv_cls.1.'):
+                p_.mul_(head_gain)
+    gen = torch.Generator().manual_seed(281)
+    x = torch.round(torch.randn(2, 4, 192, 128, generator=gen) * 64) / 64
+    site_names = [n for n, _ in dropout_modules(model)]
+    arrays = dict(params=np.array(repr(params)), seed=np.array(28), bn_gain=np.array(bn_gain), head_gain=np.array(head_gain),
+                  stride=np.array(stride), x=x.numpy(), sites=np.array(site_names))
+    feats = {}
+    hook = model.conv_cls.register_forward_pre_hook(lambda mod, inp: feats.__setitem__('f', inp[0].detach()))
+    with torch.no_grad():
+        y = model(x)
+        arrays['logits_eval_strided'] = y.numpy().reshape(-1)[::stride].copy()
+        arrays['logits_eval_absmax'] = np.array(float(y.abs().max()))
+        arrays['features_eval_absmax'] = np.array(float(feats['f'].abs().max()))
+        torch.manual_seed(29)
+        ref_th.set_dropout_mode(model, True)
+        for t in range(3):
+            y, recs = capture_masks(model, lambda: model(x))
+            arrays['logits_mc{}_strided'.format(t)] = y.numpy().reshape(-1)[::stride].copy()
+            arrays['logits_mc{}_absmax'.format(t)] = np.array(float(y.abs().max()))
+            arrays['features_mc{}_absmax'.format(t)] = np.array(float(feats['f'].abs().max()))
+            for s_, (_, mask) in enumerate(recs):
+                arrays['mask{}_{}'.format(t, s_)] = mask
+        ref_th.set_dropout_mode(model, False)
+    hook.remove()
+    print('G18: |logits| eval {:.2f}, MC {:.2f} / {:.2f} / {:.2f}; |features| MC {:.1f}'.format(
+        float(arrays['logits_eval_absmax']), *[float(arrays['logits_mc{}_absmax'.format(t)]) for t in range(3)],
+        float(arrays['features_mc0_absmax'])))
+    save('g18_unet_stress', **arrays)
+
+
 def main():
     install_reference()
     torch.set_num_threads(4)
     torch.set_grad_enabled(False)
     for fn in (g1_unet_eval, g2_unet_mc, g3_unet_center, g4_unet_sigma, g5_unet_isic, g6_mc_summary,
                g7_mc_step_end2end, g8_ece, g9_uncertainty, g10_prep, g11_fullsize_digest, g12_eval_csv, g13_postnet, g14_unet_residual, g15_unet_centre_pad,
-               g16_postnet_wide, g17_unet_no_bn):
+               g16_postnet_wide, g17_unet_no_bn, g18_unet_stress):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

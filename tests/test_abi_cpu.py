@@ -50,6 +50,20 @@ def test_argument_validation_without_gpu(lib):
     assert b'2^depth' in so.rcu_last_error()
     desc.height, desc.nb_classes = 32, 9
     assert so.rcu_unet_create(ctypes.byref(desc), ctypes.byref(handle)) == -1
+    # plan options (rcu_unet_options: what replaced the RCU_CONV_* / RCU_ACT_LAYOUT / RCU_FUSE_HEAD environment switches): defaults, and
+    # values outside their sets are refused before anything touches the GPU
+    opts = lib.UnetOptions()
+    so.rcu_unet_default_options(ctypes.byref(opts))
+    assert (opts.conv_winograd, opts.conv_winograd4, opts.conv_first, opts.act_layout, opts.fuse_head) == (1, 1, 1, 0, 1)
+    desc.nb_classes = 2
+    for field, bad in (('conv_winograd4', 2), ('act_layout', 5), ('fuse_head', -1)):
+        o = lib.UnetOptions()
+        so.rcu_unet_default_options(ctypes.byref(o))
+        setattr(o, field, bad)
+        assert so.rcu_unet_create_with(ctypes.byref(desc), ctypes.byref(o), None, ctypes.byref(handle)) == -1, field
+        assert b'rcu_unet_options' in so.rcu_last_error()
+    assert so.rcu_unet_set_fuse_head(None, 1) == -1
+    assert so.rcu_calib_set_blocks_per_workgroup(-1, 0) == -1 and so.rcu_calib_set_blocks_per_workgroup(0, 0) == 0
     with pytest.raises(lib.RcuError):
         lib.check(so.rcu_mc_finalize(None, 1, 1, 2, 1, 0, None, None, None, None, None))
     assert so.rcu_mc_stats_bytes(160, 192 * 128, 2, 0) == 160 * 192 * 128 * 2 * 4
@@ -78,6 +92,17 @@ def test_model_mirror_keeps_reference_surface():
     assert len(center.dropout_sites()) == 9
     nodrop = UNet(2, 4, dropout=None)
     assert nodrop.dropout_sites() == []
+    # plan options and the workspace donor are validated on the host side too
+    m.plan_options = {'conv_winograd5': 1}
+    with pytest.raises(ValueError):
+        m._options()
+    with pytest.raises(ValueError):
+        center.share_workspace(nodrop)            # another architecture (no Dropout2d modules: another set of dropout sites)
+    twin = UNet(2, 4, depth=4, start_filters=32, dropout=0.5, dropout_center=4)
+    twin.share_workspace(center)
+    third = UNet(2, 4, depth=4, start_filters=32, dropout=0.5, dropout_center=4)
+    third.share_workspace(twin)                   # one level: everybody borrows from the owner
+    assert twin._donor is center and third._donor is center
     with pytest.raises(ValueError):
         steps.McPredictStep(2)(steps.BatchContext({'images': torch.zeros(1, 4, 32, 32)}, 0), None, object())
 

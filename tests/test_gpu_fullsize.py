@@ -323,3 +323,109 @@ def test_isic_batch32_mc20_through_the_runner(dev):
     assert _maxdiff(out['probabilities'][sel].cpu().numpy(), ref['probabilities'].numpy()) < PROB_TOL
     assert _maxdiff(out['entropy'][sel].cpu().numpy(), ref['entropy'].numpy()) < PROB_TOL
     assert _maxdiff(out['ws_probabilities'][sel].cpu().numpy(), ws.numpy()) < PROB_TOL
+
+
+@pytest.mark.timeout(1200)
+def test_brats_mc20_on_the_full_volume(dev):
+    """BASELINE configs[2] at its own T (config/test_brats_baseline_mc.yaml:9: mc 20): the 160-slice volume, T = 20 MC-dropout passes + the
+    weight-scaling pass through ShardedMcRunner as `bench.py` runs it (pass pairs, two stream lanes, masks drawn per (seed, volume,
+    pass)) and through the step seam (McPredictStep + MultiPredictionSummary).  Four slices against the oracle's 21 forwards under the
+    runner's masks -- mean + entropy, and with every output tracked (mutual information + variance: float64 statistics) --; pass pairs ==
+    single passes bit for bit (one lane); lanes within float32 summation order; same seed, same bits; a slice does not depend on the
+    batch it runs in."""
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import distributed as rdist
+    from rcu_amd import steps
+    st = uo.synthetic_state(81, **PARAMS)
+    T, n, h, w = 20, 160, 192, 128
+    model = _model(PARAMS, st, dev)
+    g = torch.Generator().manual_seed(24)
+    x = torch.randn(n, 4, h, w, generator=g)
+    xd = x.to(dev)
+    sel = np.array([0, 79, 80, 159])
+    runner = rdist.ShardedMcRunner(model, T, seed=11, lanes=2, pass_group=2)
+    out = runner.step(xd, 5)
+    assert runner.forwards_run == T + 1 and set(out) == {'probabilities', 'entropy', 'ws_probabilities'}
+    again = rdist.ShardedMcRunner(model, T, seed=11, lanes=2, pass_group=2).step(xd, 5)
+    pairs = rdist.ShardedMcRunner(model, T, seed=11, lanes=1, pass_group=2).step(xd, 5)
+    singles = rdist.ShardedMcRunner(model, T, seed=11, lanes=1, pass_group=1).step(xd, 5)
+    other = rdist.ShardedMcRunner(model, T, seed=12, lanes=2, pass_group=2).step(xd, 5)
+    for key in out:
+        assert torch.equal(out[key], again[key]), key
+        assert torch.equal(pairs[key], singles[key]), key
+        assert float((out[key] - pairs[key]).abs().max()) < 1e-6, key
+    assert float((out['probabilities'] - other['probabilities']).abs().max()) > 1e-5          # the seed matters
+    assert torch.equal(out['ws_probabilities'], other['ws_probabilities'])                     # ... but not for the deterministic pass
+    rows = torch.as_tensor(sel)
+    mask_sets = [_split_masks(model, runner.masks_of(xd, 5, j), n, rows) for j in range(1, T + 1)]
+    small = rdist.ShardedMcRunner(model, T, lanes=1, pass_group=1).step(xd[sel], 5, mask_sets=mask_sets)
+    for key in out:
+        assert torch.equal(singles[key][sel], small[key]), key
+    ws, multi = so.mc_probabilities(lambda xx, mk: uo.unet_forward(st, xx, mk, **PARAMS), x[sel], mask_sets)
+    ref = so.multi_prediction_summary(multi, True, True)
+    for key in ('probabilities', 'entropy'):
+        assert _maxdiff(out[key][sel].cpu().numpy(), ref[key].numpy()) < PROB_TOL, key
+    assert _maxdiff(out['ws_probabilities'][sel].cpu().numpy(), ws.numpy()) < PROB_TOL
+    # every output (what `bench.py`'s all_outputs record times): the same passes into float64 statistics
+    full = rdist.ShardedMcRunner(model, T, seed=11, lanes=2, pass_group=2, do_mi=True, do_var=True).step(xd, 5)
+    assert set(full) == {'probabilities', 'entropy', 'mutual_info', 'variance', 'ws_probabilities'}
+    for key in ('probabilities', 'entropy', 'mutual_info', 'variance'):
+        assert _maxdiff(full[key][sel].cpu().numpy(), ref[key].numpy()) < PROB_TOL, key
+    assert float(full['variance'].min()) >= 0 and float(full['mutual_info'].min()) > -1e-6
+    assert float((full['probabilities'] - out['probabilities']).abs().max()) < 1e-6           # float64 against float32 sums of the same passes
+    # the step seam on the same volume: McPredictStep draws its own masks (device generator), so only the deterministic output is comparable
+    # bit for bit; the stochastic ones must be a valid summary of 20 passes
+    torch.manual_seed(3)
+    bc = steps.BatchContext({'images': x}, 0)
+    ctx = steps.TorchTestContext('cuda', model)
+    steps.McPredictStep(T)(bc, None, ctx)
+    steps.MultiPredictionSummary()(bc, None, ctx)
+    assert torch.equal(bc.output['ws_probabilities'], out['ws_probabilities'])
+    p = bc.output['probabilities']
+    assert float((p.sum(1) - 1).abs().max()) < 1e-6 and float((p - out['probabilities']).abs().max()) < 0.5
+    assert float(bc.output['entropy'].min()) >= 0 and float(bc.output['entropy'].max()) <= np.log(2) + 1e-6
+
+
+@pytest.mark.timeout(900)
+def test_ensemble_members_share_one_activation_workspace(dev):
+    """Members 2..K of an ensemble borrow the activation workspace of the first (rcu_unet_create_with's donor, include/rcu.h; the K
+    resident models of bin-dl/brats_test_ensemble.py:44-57 differ in 35 MB of packed weights): a borrower owns < 50 MB at 160 slices,
+    the owner the 6 GB; outputs carry the bits of members with workspaces of their own; destroying the owner first is safe."""
+    import gc
+    from oracle import unet_oracle as uo
+    from rcu_amd import distributed as rdist
+    K, n, h, w = 4, 160, 192, 128
+    states = [uo.synthetic_state(90 + k, **PARAMS) for k in range(K)]
+    g = torch.Generator().manual_seed(25)
+    xd = torch.randn(n, 4, h, w, generator=g).to(dev)
+    own = [_model(PARAMS, st, dev) for st in states]
+    ref = rdist.ShardedEnsembleRunner(own, lanes=2, share_workspace=False).step(xd, 0)
+    assert all(m._donor is None for m in own)
+    own_bytes = [m.workspace_bytes(h, w, n, lane=i % 2) for i, m in enumerate(own)]      # member i runs on lane i mod 2
+    assert min(own_bytes) > 5e9
+    del own
+    gc.collect()
+    torch.cuda.empty_cache()
+    shared = [_model(PARAMS, st, dev) for st in states]
+    runner = rdist.ShardedEnsembleRunner(shared, lanes=2)
+    out = runner.step(xd, 0)
+    for key in ref:
+        assert torch.equal(out[key], ref[key]), key
+    assert all(m._donor is shared[0] for m in shared[1:])
+    for i, m in enumerate(shared[1:], start=1):
+        assert m.workspace_bytes(h, w, n, lane=i % 2) <= 50e6, i
+    assert shared[0].workspace_bytes(h, w, n) > 5e9
+    # the workspace outlives its owner while a borrower still uses it: the borrower's plan of lane 1, called through the C ABI after
+    # every plan of the owner has been destroyed
+    from rcu_amd import _lib, steps
+    borrower = shared[1]
+    handle = next(v[0] for k, v in borrower._handles.items() if k[:3] == (h, w, 1))
+    shared[0]._release()
+    st1 = steps.McStatistics(n, 2, h, w, dev)
+    _lib.check(_lib.load().rcu_unet_forward_accumulate(handle, _lib.ptr(xd), n, None, _lib.ptr(st1.blob), 0, _lib.current_stream()))
+    st2 = steps.McStatistics(n, 2, h, w, dev)
+    fresh = _model(PARAMS, states[1], dev)
+    fresh.forward_accumulate(xd, st2)
+    torch.cuda.synchronize()
+    assert torch.equal(st1.blob, st2.blob)

@@ -78,3 +78,31 @@ def test_bench_plain_command_line_starts_its_own_ranks():
     assert abs(d['forwards_per_rank'][0] - d['forwards_per_rank'][1]) <= 1
     assert d['roofline']['frac'] <= 1.0 and d['roofline']['canonical_frac'] > d['roofline']['frac']
     assert d['parity']['bin_ids_equal'] and d['parity']['ece_delta_same_maps'] < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_rccl_world1_rehearsal_matches_the_plain_step_bit_for_bit():
+    """The exchange path of the multi-GPU runner over RCCL itself, as far as ONE GPU allows: a one-rank "nccl" process group, every
+    volume through ShardedMcRunner._exchange -- asynchronous reduce, side-stream finalize, record_stream, drain; 'reduce' and 'p2p'
+    transports (the latter a no-op when the root owns the weight-scaling pass: asserted in the tool) -- must give the bits of the plain
+    world-1 step (tools/rccl_world1_rehearsal.py), and the bench line runs through it (RCU_BENCH_FORCE_PG=1)."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rccl_world1_rehearsal.py'), '8', '4', '3'],
+                       capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['backend'] == 'nccl' and d['world'] == 1 and d['bits_equal'] and d['avg_probe_ok']
+    for transport in ('reduce', 'p2p'):
+        assert d[transport]['bits_equal_sync'] and d[transport]['bits_equal_async'] and d[transport]['p2p_messages'] == 0
+        assert d[transport]['inflight_after_drain'] == 0
+    env = dict(env, RCU_BENCH_FORCE_PG='1')
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--mc', '4', '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert b['n_gpus'] == 1 and b['n_ranks_seen'] == 1 and b['rccl_rehearsal']['backend'] == 'nccl'
+    assert b['forwards_per_rank'] == [2 * 5] and b['parity']['ece_delta_same_maps'] is not None if 'ece_delta_same_maps' in b['parity'] else True
+    assert b['all_outputs']['value'] > 0

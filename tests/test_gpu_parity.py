@@ -19,10 +19,12 @@ def dev():
     return torch.device('cuda')
 
 
-def _model(params, state, dev):
+def _model(params, state, dev, **plan_options):
+    """``plan_options``: rcu_unet_options fields (include/rcu.h) -- which kernel family / layout the planner may choose."""
     from rcu_amd.model import UNet
     m = UNet(**params)
     m.load_state_dict({k: torch.as_tensor(v) for k, v in state.items()})
+    m.plan_options = dict(plan_options)
     return m.to(dev)
 
 
@@ -109,13 +111,13 @@ def test_unet_full_width_vs_oracle(dev, shape):
         assert _maxdiff(ps, pr) < PROB_TOL
 
 
-def test_winograd_kernels_vs_direct_and_oracle(dev, monkeypatch):
+def test_winograd_kernels_vs_direct_and_oracle(dev):
     """Every Winograd instantiation (csrc/rcu_wino4.hip: F(4x4,3x3) conv units, csrc/rcu_wino.hip: F(2x2,3x3) conv units,
     csrc/rcu_wino_up.hip: F(2x2,2x2) sub-pixel up-convolutions) on the BraTS slice size with 8 slices -- enough for the work items
-    that span 2 and 8 slices: against the oracle, against the direct kernels (RCU_CONV_WINO=0), and on ragged batches.  Three
+    that span 2 and 8 slices: against the oracle, against the direct kernels (plan option conv_winograd=0), and on ragged batches.  Three
     plans: the shipped selection (F(4x4,3x3) wherever it fits -- also the 32-channel full-resolution layers, the 2x2 max-pool in its
     epilogue and the two-source K loop at that tile; conv_cls.0 keeps its fused head on F(2x2,3x3)), the round-2 selection
-    (RCU_CONV_WINO4=3: only the layers with >= 64 output channels) and F(2x2,3x3) only (RCU_CONV_WINO4=0)."""
+    (conv_winograd4=3: only the layers with >= 64 output channels) and F(2x2,3x3) only (conv_winograd4=0)."""
     from oracle import unet_oracle as uo
     params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
     st = uo.synthetic_state(21, **params)
@@ -132,8 +134,7 @@ def test_winograd_kernels_vs_direct_and_oracle(dev, monkeypatch):
     w2 = {'conv3x3_winograd<T16x16,N64,K8>', 'conv3x3_winograd<S2T8x16,N64,K8>'}
     outs = {}
     for mode, expected in (('1', common | w4), ('3', common | w4), ('0', common | w2)):
-        monkeypatch.setenv('RCU_CONV_WINO4', mode)
-        m_w = _model(params, st, dev)
+        m_w = _model(params, st, dev, conv_winograd4=int(mode))
         rows = m_w.layer_table(h, w, n)
         kernels = {row['kernel'] for row in rows}
         assert expected <= kernels, (mode, expected - kernels)
@@ -148,10 +149,8 @@ def test_winograd_kernels_vs_direct_and_oracle(dev, monkeypatch):
             out_k = m_w(x[:k].to(dev), [mk[:k] for mk in masks]).cpu().numpy()
             assert np.array_equal(out_k, out_w[:k]), (mode, k)
         outs[mode] = out_w
-    monkeypatch.delenv('RCU_CONV_WINO4')
     # the direct kernels on the same input
-    monkeypatch.setenv('RCU_CONV_WINO', '0')
-    m_d = _model(params, st, dev)
+    m_d = _model(params, st, dev, conv_winograd=0)
     assert not any('winograd' in row['kernel'] for row in m_d.layer_table(h, w, n))
     out_d = m_d(x.to(dev), masks).cpu().numpy()
     assert _maxdiff(out_d, ref) < LOGIT_TOL
@@ -160,9 +159,9 @@ def test_winograd_kernels_vs_direct_and_oracle(dev, monkeypatch):
 
 
 @pytest.mark.parametrize('in_channels,start_filters', [(3, 32), (4, 32), (6, 32), (4, 64), (1, 16)])
-def test_first_layer_kernel_vs_tiled_kernel_and_oracle(dev, monkeypatch, in_channels, start_filters):
+def test_first_layer_kernel_vs_tiled_kernel_and_oracle(dev, in_channels, start_filters):
     """csrc/rcu_first.hip (unpadded K = 9 taps x 4 or 8 channels, NCHW input read in place, 32 or 64 output channels) against
-    the oracle, against the tiled first-layer kernel + channels-last copy (RCU_CONV_FIRST=0), on a ragged batch and through a
+    the oracle, against the tiled first-layer kernel + channels-last copy (plan option conv_first=0), on a ragged batch and through a
     pass group (sample t * N + i reads image i)."""
     from oracle import unet_oracle as uo
     from rcu_amd import steps
@@ -189,8 +188,7 @@ def test_first_layer_kernel_vs_tiled_kernel_and_oracle(dev, monkeypatch, in_chan
     s2 = steps.McStatistics(n, 2, h, w, dev)
     m.forward_accumulate(x.to(dev), s2, [masks, masks2], passes=2)
     assert torch.equal(s1.blob, s2.blob)
-    monkeypatch.setenv('RCU_CONV_FIRST', '0')
-    m_t = _model(params, st, dev)
+    m_t = _model(params, st, dev, conv_first=0)
     assert m_t.layer_table(h, w, 2 * n)[0]['kernel'].startswith('conv3x3_igemm')
     out_t = m_t(x.to(dev), masks).cpu().numpy()
     assert _maxdiff(out_t, ref) < LOGIT_TOL
@@ -331,9 +329,9 @@ def test_winograd_sigma_head_and_eval_mode(dev):
                 assert _maxdiff(out.cpu().numpy(), ref.numpy()) < LOGIT_TOL
 
 
-def test_fused_head_matches_head_kernel_bitwise(dev, monkeypatch):
+def test_fused_head_matches_head_kernel_bitwise(dev):
     """conv_cls.0 with the 1x1 classifier + softmax + statistics in its epilogue (csrc/rcu_wino.hip, wino_epilogue_head)
-    against the separate head kernel (RCU_FUSE_HEAD=0): logits, MC statistics (incl. variance / mutual information) and
+    against the separate head kernel (UNet.set_fuse_head(False) = rcu_unet_set_fuse_head): logits, MC statistics (incl. variance / mutual information) and
     pass groups (the fused epilogue runs the passes of a tile back to back on the workgroup that owns it, in pass order -- the
     order in which head_kernel adds them) must carry the same bits."""
     from oracle import unet_oracle as uo
@@ -369,11 +367,11 @@ def test_fused_head_matches_head_kernel_bitwise(dev, monkeypatch):
         return stats.blob.cpu().numpy()
 
     flag_sets = ((False, False), (True, False), (True, True))
-    monkeypatch.setenv('RCU_FUSE_HEAD', '1')
+    m.set_fuse_head(True)
     lf, of = run()
     bf = [run_single_passes(*f) for f in flag_sets]
     gf = [run_groups(*f, passes) for f in flag_sets for passes in (2, 3, 4)]
-    monkeypatch.setenv('RCU_FUSE_HEAD', '0')
+    m.set_fuse_head(False)
     lu, ou = run()
     bu = [run_single_passes(*f) for f in flag_sets]
     gu = [run_groups(*f, passes) for f in flag_sets for passes in (2, 3, 4)]
@@ -776,17 +774,25 @@ def test_ece_full_size_batched_properties(dev):
     assert np.array_equal(sc, sc2)    # run-to-run deterministic, float sums included
 
 
-def test_calibration_kernels_do_not_depend_on_blocks_per_workgroup(dev, monkeypatch):
+def test_calibration_kernels_do_not_depend_on_blocks_per_workgroup(dev):
     """The workgroups of the histogram / count kernels take several consecutive blocks of a volume on large launches (the launcher decides;
-    RCU_ECE_BLOCKS_PER_WG / RCU_UNC_BLOCKS_PER_WG force it).  Integer sums: every choice gives the same numbers -- on sizes with a ragged last
+    rcu_calib_set_blocks_per_workgroup forces it).  Integer sums: every choice gives the same numbers -- on sizes with a ragged last
     block, a last workgroup with fewer blocks, sizes not divisible by four (scalar path), and with confidences below 2^-16 (rounded to 2^-40:
     the sum stays within 2^-41 per voxel of the float64 sum)."""
     from oracle import c_oracle
     from oracle import calib_oracle as co
+    from rcu_amd import _lib
     from rcu_amd import evaluation as ev
     thr = co.float32_thresholds(10)
     ue_thr = (0.05, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95)
     g = torch.Generator(device='cuda').manual_seed(12)
+    try:
+        _blocks_per_workgroup_cases(dev, g, thr, ue_thr, _lib, ev, c_oracle)
+    finally:
+        _lib.check(_lib.load().rcu_calib_set_blocks_per_workgroup(0, 0))      # back to the launchers' own rule
+
+
+def _blocks_per_workgroup_cases(dev, g, thr, ue_thr, _lib, ev, c_oracle):
     for nv, n in ((3, 16384 * 5 + 4 * 77), (2, 16384 * 3), (1, 16384 * 2 + 3), (2, 999)):
         p = torch.rand(nv, n, device=dev, generator=g)
         p = torch.where(torch.rand(nv, n, device=dev, generator=g) < 0.5, p * 3e-6, p)        # half of them below 2^-16
@@ -794,9 +800,8 @@ def test_calibration_kernels_do_not_depend_on_blocks_per_workgroup(dev, monkeypa
         m = (torch.rand(nv, n, device=dev, generator=g) < 0.6).to(torch.uint8)
         pred = (p > 0.5).to(torch.uint8)
         outs = []
-        for k_ece, k_unc in (('1', '1'), ('2', '3'), ('2', '8')):
-            monkeypatch.setenv('RCU_ECE_BLOCKS_PER_WG', k_ece)
-            monkeypatch.setenv('RCU_UNC_BLOCKS_PER_WG', k_unc)
+        for k_ece, k_unc in ((1, 1), (2, 3), (2, 8)):
+            _lib.check(_lib.load().rcu_calib_set_blocks_per_workgroup(k_ece, k_unc))
             cnt, sc, sp = ev.calibration_histogram(p, t, mask=m, n_volumes=nv)
             c = ev.uncertainty_counts(pred, t, p, ue_thr, mask=m, n_volumes=nv)
             outs.append((cnt, sc, sp, c))
@@ -1199,9 +1204,9 @@ def test_unet_no_batchnorm_full_width_vs_oracle(dev):
     assert _maxdiff(bc.output['ws_probabilities'].cpu().numpy(), ws.numpy()) < PROB_TOL
 
 
-def test_channel_blocked_layout_gives_the_bits_of_channels_last(dev, monkeypatch):
+def test_channel_blocked_layout_gives_the_bits_of_channels_last(dev):
     """The activation layout between the Winograd kernels (channel-blocked [N][C/8][H][W][8]) is an addressing
-    choice: the same kernels on channels-last tensors (RCU_ACT_LAYOUT=nhwc) give the same bits -- logits with and without masks, the
+    choice: the same kernels on channels-last tensors (plan option act_layout=1) give the same bits -- logits with and without masks, the
     fused statistics, the feature tap (which keeps its tensor channels-last in both), a sigma head, and a plan that mixes Winograd
     and direct kernels (a size 2^depth does not divide)."""
     from oracle import unet_oracle as uo
@@ -1216,8 +1221,7 @@ def test_channel_blocked_layout_gives_the_bits_of_channels_last(dev, monkeypatch
         masks = uo.sample_masks(sites, shape[0], 0.3, g)
         outs = {}
         for layout in ('blocked', 'nhwc'):
-            monkeypatch.setenv('RCU_ACT_LAYOUT', layout)
-            m = _model(params, st, dev)
+            m = _model(params, st, dev, act_layout=int(layout == 'nhwc'))
             m.provide_features = not params.get('sigma_out', False)
             res = [m(x.to(dev)), m(x.to(dev), masks)]
             res = [t for r in res for t in (r if isinstance(r, tuple) else (r,))]
@@ -1228,7 +1232,58 @@ def test_channel_blocked_layout_gives_the_bits_of_channels_last(dev, monkeypatch
                 m.forward_accumulate(x.to(dev), stats, masks)
                 res.append(stats.blob.clone())
             outs[layout] = [t.cpu() for t in res]
-        monkeypatch.delenv('RCU_ACT_LAYOUT')
         assert len(outs['blocked']) == len(outs['nhwc'])
         for a, b in zip(outs['blocked'], outs['nhwc']):
             assert torch.equal(a, b), (params, shape)
+
+
+def test_unet_stress_golden_wide_activations_and_logits(golden, dev):
+    """Numerics stress case, reference golden G18 (tests/golden/generate_golden.py: the reference UNet, common/model/unet.py:128-186, with its
+    BatchNorm affines x 2.5 and its classifier x 0.5): interior activations of 1e2..1e3 and logits of +-20 under Dropout2d(0.3) -- the ranges
+    trained checkpoints have, where the other parity inputs stay below |logit| 1.  Full width on a 192x128 slice pair, so every F(4x4,3x3)
+    instantiation runs.  Logits within a bound RELATIVE to their range of the reference's (strided sample) and of the oracle (everywhere);
+    probabilities / entropy / mutual information / variance of the three passes within 1e-4; F(2x2,3x3)-only and direct plans on the same
+    input within the same bounds."""
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    REL = 1e-5
+    g = golden('g18_unet_stress')
+    p = golden_params(g)
+    st = uo.stress_state(uo.reference_init_state(int(g['seed']), bn_seed=int(g['seed']) + 1000, **p), float(g['bn_gain']), float(g['head_gain']))
+    x = torch.as_tensor(g['x'])
+    n, _, h, w = x.shape
+    _, sites = uo.unet_plan(**p)
+    stride = int(g['stride'])
+    mask_sets = [[g['mask{}_{}'.format(t, s)] for s in range(len(sites))] for t in range(3)]
+    m = _model(p, st, dev)
+    kernels = {row['kernel'] for row in m.layer_table(h, w, n)}
+    assert {'conv3x3_winograd4<T32x32,N32,K8>', 'conv3x3_winograd4<S2T16x32,N32,K8>', 'conv3x3_winograd4<S8T8x16,N32,K8>'} <= kernels
+    xd = x.to(dev)
+    refs = []
+    for tag, mk in [('eval', None)] + [('mc{}'.format(t), mask_sets[t]) for t in range(3)]:
+        ref = uo.unet_forward(st, x, mk, **p).numpy()
+        scale = float(np.abs(ref).max())
+        if mk is not None:
+            assert scale >= 10.0
+            refs.append(ref)
+        for model in (m,) if mk is None else (m, _model(p, st, dev, conv_winograd4=0), _model(p, st, dev, conv_winograd=0)):
+            out = model(xd, mk).cpu().numpy()
+            assert _maxdiff(out, ref) < REL * scale, (tag, _maxdiff(out, ref) / scale)
+            assert _maxdiff(out.reshape(-1)[::stride], g['logits_{}_strided'.format(tag)]) < REL * scale, tag
+            ps, pr = torch.softmax(torch.from_numpy(out), 1).numpy(), torch.softmax(torch.from_numpy(ref), 1).numpy()
+            assert _maxdiff(ps, pr) < PROB_TOL, tag
+    feats_ref = uo.unet_forward(st, x, mask_sets[0], return_features=True, **p)[1]
+    assert float(feats_ref.abs().max()) >= 100.0
+    # the three passes through the fused statistics path (float32 and, with every output, float64 statistics)
+    multi = torch.stack([torch.softmax(torch.from_numpy(r), 1) for r in refs])
+    ref_sum = so.multi_prediction_summary(multi, True, True)
+    for flags in ((False, False), (True, True)):
+        bc = steps.BatchContext({'images': x.clone()}, 0)
+        ctx = steps.TorchTestContext('cuda', m)
+        steps.McPredictStep(3, do_mi=flags[0], do_var=flags[1], masks=mask_sets)(bc, None, ctx)
+        steps.MultiPredictionSummary(do_mi=flags[0], do_var=flags[1])(bc, None, ctx)
+        for key in ('probabilities', 'entropy') + (('mutual_info', 'variance') if flags[0] else ()):
+            assert _maxdiff(bc.output[key].cpu().numpy(), ref_sum[key].numpy()) < PROB_TOL, (flags, key)
+    sat = float(((multi[:, :, 1] < 0.01) | (multi[:, :, 1] > 0.99)).float().mean())
+    assert 0.05 < sat < 0.95          # saturated and unsaturated softmax inputs side by side

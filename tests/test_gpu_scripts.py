@@ -140,20 +140,21 @@ def _files(ctx):
 def test_pipelined_coalesced_loop_writes_the_files_of_the_serial_loop(tmp_path, monkeypatch):
     """The test loop's pipeline (loader thread, batches coalesced up to a volume, outputs downloaded on a side stream, NIfTI files
     written by a pool of threads) must not change a byte of what the reference-ordered serial loop writes: deterministic config --
-    default loop against RCU_PIPELINE=0 (which also means no coalescing), whole .nii.gz files compared; MC-dropout config -- masks are
-    drawn per batch, so the batches are kept as the loader makes them (RCU_COALESCE=0) and the pipelined loop is compared with the
-    serial one under the same seed."""
-    from rcu_amd import scripts
+    the pipelined loop with coalescing switched on (opt-in: RCU_COALESCE / others.coalesce_pixels) against RCU_PIPELINE=0 (which also
+    means no coalescing), whole .nii.gz files compared; MC-dropout config -- masks are drawn per step, so the batches are kept as the
+    loader makes them (the default) and the pipelined loop is compared with the serial one under the same seed."""
+    from rcu_amd import loops, scripts
     cfg_det, vols, _, _ = _setup(tmp_path / 'det')
+    monkeypatch.setenv('RCU_COALESCE', str(loops.Test.COALESCE_PIXELS))
     fast = _files(scripts.test_default('brats', cfg_det, None))
     monkeypatch.setenv('RCU_PIPELINE', '0')
     slow = _files(scripts.test_default('brats', cfg_det, None))
     monkeypatch.delenv('RCU_PIPELINE')
+    monkeypatch.delenv('RCU_COALESCE')
     assert sorted(fast) == sorted(slow) and len(fast) == 2 * len(vols)
     for name in fast:
         assert fast[name] == slow[name], name
     cfg_mc, vols_mc, _, _ = _setup(tmp_path / 'mc', mc=4)
-    monkeypatch.setenv('RCU_COALESCE', '0')
     fast = _files(scripts.test_default('brats', cfg_mc, None))
     monkeypatch.setenv('RCU_PIPELINE', '0')
     slow = _files(scripts.test_default('brats', cfg_mc, None))
@@ -233,13 +234,13 @@ def test_isic_default_script_mc2(tmp_path):
         assert os.path.islink(os.path.join(ctx.test_dir, id_ + '_segmentation.png'))
 
 
-@pytest.mark.parametrize('coalesce', ['0', None], ids=['batch-per-image', 'coalesced'])
+@pytest.mark.parametrize('coalesce', [None, str(160 * 192 * 128)], ids=['batch-per-image', 'coalesced'])
 def test_isic_many_batches_keep_their_own_labels(tmp_path, monkeypatch, coalesce):
-    """Ten ISIC subjects, batch_size 1, float labels (the shipped configs rescale ``labels``): with RCU_COALESCE=0 the pipelined loop
+    """Ten ISIC subjects, batch_size 1, float labels (the shipped configs rescale ``labels``): uncoalesced (the default) the pipelined loop
     runs ten batches -- more than the loader's staging ring holds -- and every subject's Dice must be the Dice of ITS prediction
     against ITS label image (labels are kept on the host by PrepareSubjectStep until the batch is finished: a staging buffer reused
-    too early would hand a later batch's labels to an earlier subject).  Coalesced (the default) the ten images run as one batch and
-    give the same files."""
+    too early would hand a later batch's labels to an earlier subject).  Coalesced (opt-in: RCU_COALESCE) the ten images run as one batch
+    and give the same files."""
     from PIL import Image
     from oracle import calib_oracle as co
     from oracle import unet_oracle as uo

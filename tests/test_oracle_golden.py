@@ -311,3 +311,28 @@ def test_g17_no_batchnorm_and_no_dropout(golden):
     p, st = _tagged(g, 'c')
     assert uo.unet_plan(**p)[1] == [] and any('.bn.' in k for k in st)
     _close(uo.unet_forward(st, g['x_c'], None, **p).numpy(), g['logits_c'], 5e-6)
+
+
+def test_g18_unet_stress(golden):
+    """Numerics stress fixture: BatchNorm affines x 2.5, classifier x 0.5 on the full-width U-Net -- interior activations of 1e2..1e3,
+    logits of +-20 under Dropout2d(0.3) -- through the reference (an eval pass and three MC passes under its own masks).  The weights are
+    rebuilt by replaying the constructor's draws and applying the same scaling rule (oracle.unet_oracle.stress_state); the bound on
+    the logits is RELATIVE to their range."""
+    g = golden('g18_unet_stress')
+    p = golden_params(g)
+    st = uo.stress_state(uo.reference_init_state(int(g['seed']), bn_seed=int(g['seed']) + 1000, **p),
+                         float(g['bn_gain']), float(g['head_gain']))
+    _, sites = uo.unet_plan(**p)
+    assert [s[0] for s in sites] == list(g['sites'])
+    stride = int(g['stride'])
+    y, feats = uo.unet_forward(st, g['x'], None, return_features=True, **p)
+    _close(y.numpy().reshape(-1)[::stride], g['logits_eval_strided'], 2e-6 * float(g['logits_eval_absmax']))
+    assert abs(float(feats.abs().max()) - float(g['features_eval_absmax'])) < 1e-4 * float(g['features_eval_absmax'])
+    for t in range(3):
+        masks = [g['mask{}_{}'.format(t, s)] for s in range(len(sites))]
+        assert any((m == 0).any() for m in masks)
+        y, feats = uo.unet_forward(st, g['x'], masks, return_features=True, **p)
+        scale = float(g['logits_mc{}_absmax'.format(t)])
+        assert scale >= 10.0 and float(g['features_mc{}_absmax'.format(t)]) >= 100.0       # what the fixture is for
+        _close(y.numpy().reshape(-1)[::stride], g['logits_mc{}_strided'.format(t)], 2e-6 * scale)
+        assert abs(float(feats.abs().max()) - float(g['features_mc{}_absmax'.format(t)])) < 1e-4 * float(g['features_mc{}_absmax'.format(t)])

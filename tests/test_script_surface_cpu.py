@@ -428,3 +428,25 @@ def test_block_loader_equals_the_per_slice_loader(tmp_path, monkeypatch):
     for si in range(3):
         ds[ds.index.index((si, 0))]
     assert np.array_equal(ds.direct_extract(0)['labels'], vols['s0'][1])
+
+
+def test_npz_member_mapping_checks_sizes_and_collate_honours_entries(tmp_path):
+    """the memory map of a stored .npz member skips np.load's CRC pass, so at least the member's size must agree with its
+    header and with the file (a truncated file falls back to np.load, which fails loudly); a collate whose ``entries`` exclude 'labels'
+    keeps them as per-sample lists also when the dataset handed over a batch it had collated itself."""
+    from rcu_amd import data as data_mod
+    path = str(tmp_path / 'vol.npz')
+    arr = np.arange(4 * 6 * 5 * 3, dtype=np.float32).reshape(4, 6, 5, 3)
+    np.savez(path, images=arr, labels=np.zeros((4, 6, 5), np.uint8))
+    mapped = data_mod._npz_member_mmap(path, 'images')
+    assert isinstance(mapped, np.memmap) and np.array_equal(mapped, arr)
+    blob = open(path, 'rb').read()
+    cut = str(tmp_path / 'cut.npz')
+    with open(cut, 'wb') as f:
+        f.write(blob[:len(blob) // 3])
+    assert data_mod._npz_member_mmap(cut, 'images') is None
+    pre = data_mod.PreCollated(images=torch.zeros(2, 4, 6, 5), labels=torch.ones(2, 6, 5), subject_index=[0, 0])
+    both = data_mod.CollateDict()(pre)
+    assert torch.is_tensor(both['labels']) and torch.is_tensor(both['images'])
+    only_images = data_mod.CollateDict(entries=('images',))(pre)
+    assert isinstance(only_images['labels'], list) and len(only_images['labels']) == 2 and torch.is_tensor(only_images['images'])

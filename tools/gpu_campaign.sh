@@ -24,7 +24,7 @@ cd $R
 python tools/summarize_rocprof.py stats $(find $P/stats -name "*kernel_stats.csv" | head -1) $OUT/bench_steps2_kernel_stats.csv
 python tools/summarize_rocprof.py stats $(find $P/stats2 -name "*kernel_stats.csv" | head -1) $OUT/bench_steps2_lanes2_kernel_stats.csv
 python bench.py --lanes 1 --no-cpu-baseline --steps 20 --warmup 5 > $OUT/bench_lanes1.json 2> $OUT/bench_lanes1.err; cut -c1-200 $OUT/bench_lanes1.json
-python tools/summarize_rocprof.py pmc $P/pmc_fetch $P/pmc_write $P/pmc_sq $OUT/bench_pmc.json
+python tools/summarize_rocprof.py pmc $P/pmc_fetch $P/pmc_write $P/pmc_sq $OUT/bench_pmc.json --plan $OUT/bench_default.json
 head -12 $OUT/bench_steps2_kernel_stats.csv
 timeout 600 bash tools/pmc_wait_breakdown.sh ${TAG}_waits > $OUT/wait_breakdown.txt 2>&1
 timeout 300 bash tools/pmc_inst_mix.sh ${TAG}_mix > $OUT/inst_mix.txt 2>&1

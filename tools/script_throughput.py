@@ -44,6 +44,12 @@ def main():
     text = BRATS_MC_YAML.format(test_dir=os.path.join(tmp, 'out'), model_dir=mf.model_dir, split=split,
                                 dataset=os.path.join(tmp, 'ds'))
     text = text.replace('mc: 20', 'mc: {}'.format(mc)).replace('batch_size: 32', 'batch_size: {}'.format(batch))
+    # loader batches merged to one volume per step: opt-in (rcu_amd.loops.Test), through the YAML key the scripts pass on; argv[4] = 0 keeps
+    # the reference's batches (one step per 32 slices)
+    coalesce = int(sys.argv[4]) if len(sys.argv) > 4 else bench.SLICES * bench.HEIGHT * bench.WIDTH
+    if coalesce > 0:
+        text = text.replace('  others:\n', '  others:\n    coalesce_pixels: {}\n'.format(coalesce), 1)
+        assert 'coalesce_pixels' in text
     cfg = os.path.join(tmp, 'test_brats_baseline_mc.yaml')
     with open(cfg, 'w') as f:
         f.write(text)

@@ -2,7 +2,7 @@
 """Condense rocprofv3 CSV output (gpurun_out/, scratch) into the small files kept under profiles/.
 
   python tools/summarize_rocprof.py stats  <dir>/<prefix>_kernel_stats.csv  profiles/<name>_kernel_stats.csv
-  python tools/summarize_rocprof.py pmc    <fetch_dir> <write_dir> [<sq_dir>]  profiles/<name>_pmc.json
+  python tools/summarize_rocprof.py pmc    <fetch_dir> <write_dir> [<sq_dir>]  profiles/<name>_pmc.json [--plan <bench json>]
 
 `pmc` also refreshes profiles/pmc_traffic.json (bytes per launch per conv instantiation, read by bench.py):
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE / WRITE_SIZE are in KiB and on gfx950 FETCH_SIZE
@@ -70,6 +70,16 @@ def per_kernel(path, wanted):
 
 
 def pmc(args):
+    # --plan <bench json of the same build>: its roofline.plan_fingerprint goes into pmc_traffic.json, and bench.py reports the traffic
+    # only while its own plan carries that fingerprint
+    meta = {}
+    if '--plan' in args:
+        i = args.index('--plan')
+        with open(args[i + 1]) as f:
+            line = json.loads(f.read().strip().splitlines()[-1])
+        meta = dict(plan_fingerprint=line['roofline'].get('plan_fingerprint'), pass_group=line['config'].get('pass_group'),
+                    bench_value=line.get('value'))
+        args = args[:i] + args[i + 2:]
     out_path = args[-1]
     dirs = args[:-1]
     find = lambda d: [os.path.join(d, f) for f in os.listdir(d) if f.endswith('counter_collection.csv')][0]  # noqa: E731
@@ -97,6 +107,7 @@ def pmc(args):
     with open(out_path, 'w') as f:
         json.dump(result, f, indent=1, sort_keys=True)
     traffic = {k: v['hbm_bytes_per_launch'] for k, v in result.items() if k.startswith(('conv3x3', 'upconv'))}
+    traffic['_meta'] = meta
     with open(os.path.join(os.path.dirname(out_path), 'pmc_traffic.json'), 'w') as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
 

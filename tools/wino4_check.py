@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """F(4x4,3x3) kernels (csrc/rcu_wino4.hip) on the GPU: parity against the oracle and against the F(2x2,3x3) build of the same plan
-(RCU_CONV_WINO4=0), then per-layer timing of both on the 160-slice BraTS volume.   python tools/wino4_check.py [slices] [reps]"""
+(plan option conv_winograd4=0), then per-layer timing of both on the 160-slice BraTS volume.   python tools/wino4_check.py [slices] [reps]"""
 import os
 import sys
 
@@ -15,12 +15,12 @@ from rcu_amd.model import UNet  # noqa: E402
 
 
 def build(state, dev, wino4, shape=None):
-    os.environ['RCU_CONV_WINO4'] = '1' if wino4 else '0'
     m = UNet(**bench.MODEL_PARAMS)
     m.load_state_dict(state)
+    m.plan_options = dict(conv_winograd4=1 if wino4 else 0)      # rcu_unet_options (include/rcu.h)
     m = m.to(dev)
     if shape is not None:
-        m.layer_table(*shape)          # the plan (and with it the kernel choice) is made here, under this environment
+        m.layer_table(*shape)
     return m
 
 
@@ -60,7 +60,7 @@ def main():
         torch.cuda.synchronize()
         cnt, ms = m.profile_collect(h, w, n_big)
         layers = m.layer_table(h, w, n_big)
-        print('--- RCU_CONV_WINO4={} variant {} (bit 0: no LDS-DMA in the chunks, 1: no epilogue, 2: no input transform, 3: no chunk barrier)'.format(int(wino4), var))
+        print('--- conv_winograd4={} variant {} (bit 0: no LDS-DMA in the chunks, 1: no epilogue, 2: no input transform, 3: no chunk barrier)'.format(int(wino4), var))
         tot = 0.0
         for L, t in zip(layers, ms[1:1 + len(layers)]):
             t /= cnt

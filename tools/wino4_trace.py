@@ -14,7 +14,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ['RCU_CONV_WINO4'] = '1'
 os.environ.setdefault('RCU_W4_VARIANT', '128')   # + 256 stores out of range, + 512 no store instructions, + 1024 no output transform
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
