@@ -145,6 +145,8 @@ class UNet(nn.Module):
                 raise ValueError('share_workspace: the donor is a different architecture')
             if donor._donor is not None:
                 donor = donor._donor         # one level: everybody borrows from the owner
+            if donor is self:                # (the owner asked to borrow from one of its own borrowers: it stays the owner)
+                return
         self._release()
         self._donor = donor
 

@@ -394,6 +394,8 @@ def share_member_workspaces(members):
     donor = members[0] if members and isinstance(members[0], model_mod.UNet) else None
     if donor is None:
         return
+    if donor._donor is not None:
+        donor = donor._donor         # the first member borrows already (the same models in another order): its owner lends to the rest
     for m in members[1:]:
         if isinstance(m, model_mod.UNet) and m is not donor and m._donor is None:
             try:

@@ -103,6 +103,9 @@ def test_model_mirror_keeps_reference_surface():
     third = UNet(2, 4, depth=4, start_filters=32, dropout=0.5, dropout_center=4)
     third.share_workspace(twin)                   # one level: everybody borrows from the owner
     assert twin._donor is center and third._donor is center
+    from rcu_amd.steps import share_member_workspaces
+    share_member_workspaces([third, twin, center])          # the same members in another order: the owner stays the owner
+    assert center._donor is None and twin._donor is center and third._donor is center
     with pytest.raises(ValueError):
         steps.McPredictStep(2)(steps.BatchContext({'images': torch.zeros(1, 4, 32, 32)}, 0), None, object())
 
