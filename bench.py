@@ -765,7 +765,7 @@ def main():
     roofline['other_ms_per_forward']['head_fused_into'] = 'conv_cls.0 epilogue' if fused_head_ms < 0.5 * head_ms else None
     # the first conv kernel (csrc/rcu_first.hip) reads the NCHW input itself: no re-layout kernel in the timed region then
     roofline['other_ms_per_forward']['input_read_by'] = layers[0]['kernel'] if layers[0]['kernel'].startswith('conv3x3_first') else 'pack_input_kernel'
-    roofline['aggregation'] = dict(bound='hbm', kernel='head_kernel', achieved=head_bytes / head_ms / 1e6, peak=PEAK_HBM_GBS,
+    roofline['aggregation'] = dict(bound='hbm', kernel='head_stream_kernel', achieved=head_bytes / head_ms / 1e6, peak=PEAK_HBM_GBS,
                                    unit='GB/s', frac=head_bytes / head_ms / 1e6 / PEAK_HBM_GBS, bytes_per_launch=head_bytes,
                                    avg_launch_ms=head_ms, measured='standalone launches outside the timed region')
     roofline['aggregation'].update(aggregation_kernels(device, n_slices, height, width))

@@ -2,7 +2,7 @@
 # PMC passes (FETCH_SIZE / WRITE_SIZE / SQ counters, each in a run of its own with --kernel-trace only).  The raw CSVs
 # stay in /tmp on the box; only the condensed files land in gpurun_out/$TAG/ (merged back), to be copied into profiles/.
 #   gpurun --timeout 1500 -- 'bash tools/gpu_campaign.sh r01'
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 P=/tmp/prof_$TAG
@@ -13,6 +13,14 @@ python bench.py --no-ws --no-cpu-baseline > $OUT/bench_no_ws.json 2> $OUT/bench_
 python bench.py --workload isic > $OUT/bench_isic.json 2> $OUT/bench_isic.err; cut -c1-200 $OUT/bench_isic.json
 python bench.py --ensemble 10 > $OUT/bench_ensemble10.json 2> $OUT/bench_ensemble10.err; cut -c1-200 $OUT/bench_ensemble10.json
 python bench.py --aleatoric --mc 50 --steps 4 --no-cpu-baseline > $OUT/bench_aleatoric_mc50.json 2> $OUT/bench_aleatoric_mc50.err; cut -c1-200 $OUT/bench_aleatoric_mc50.json
+# every output in the timed region (mutual information + variance: float64 statistics); the default line carries the same configuration as its `all_outputs` sub-record
+python bench.py --all-outputs --steps 20 --warmup 5 > $OUT/bench_all_outputs.json 2> $OUT/bench_all_outputs.err; cut -c1-200 $OUT/bench_all_outputs.json
+# the N > 1 exchange path over RCCL itself, as far as one GPU allows (a one-rank process group), and the bench line through it
+python tools/rccl_world1_rehearsal.py > $OUT/rccl_world1.json 2> $OUT/rccl_world1.err; cut -c1-300 $OUT/rccl_world1.json
+RCU_BENCH_FORCE_PG=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_force_pg.json 2> $OUT/bench_force_pg.err; cut -c1-200 $OUT/bench_force_pg.json
+# the N = 8 lines with all eight ranks on the one GPU over gloo (code-path runs, not throughputs): MC and -- now that members share a workspace -- the K = 10 ensemble
+RCU_BENCH_SINGLE_DEVICE=1 RCU_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_gpus8_one_device.json 2> $OUT/bench_gpus8_one_device.err; cut -c1-200 $OUT/bench_gpus8_one_device.json
+RCU_BENCH_SINGLE_DEVICE=1 RCU_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --ensemble 10 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_ens10_gpus8_one_device.json 2> $OUT/bench_ens10_gpus8_one_device.err; cut -c1-200 $OUT/bench_ens10_gpus8_one_device.json
 cd /tmp && export TMPDIR=/tmp
 # kernel times: one lane (exclusive durations, what bench.py's roofline record is taken from); then the default two lanes, whose kernels overlap
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --lanes 1 > $P/stats.log 2>&1
@@ -20,7 +28,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats2 -o bench -- py
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --lanes 1 > $P/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --lanes 1 > $P/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/pmc_sq -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --lanes 1 > $P/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/rccl -o rccl -- python3 $R/tools/rccl_world1_rehearsal.py 160 20 3 > $P/rccl.log 2>&1
 cd $R
+python tools/summarize_rocprof.py stats $(find $P/rccl -name "*kernel_stats.csv" | head -1) $OUT/rccl_world1_kernel_stats.csv
 python tools/summarize_rocprof.py stats $(find $P/stats -name "*kernel_stats.csv" | head -1) $OUT/bench_steps2_kernel_stats.csv
 python tools/summarize_rocprof.py stats $(find $P/stats2 -name "*kernel_stats.csv" | head -1) $OUT/bench_steps2_lanes2_kernel_stats.csv
 python bench.py --lanes 1 --no-cpu-baseline --steps 20 --warmup 5 > $OUT/bench_lanes1.json 2> $OUT/bench_lanes1.err; cut -c1-200 $OUT/bench_lanes1.json
@@ -29,5 +39,7 @@ head -12 $OUT/bench_steps2_kernel_stats.csv
 timeout 600 bash tools/pmc_wait_breakdown.sh ${TAG}_waits > $OUT/wait_breakdown.txt 2>&1
 timeout 300 bash tools/pmc_inst_mix.sh ${TAG}_mix > $OUT/inst_mix.txt 2>&1
 timeout 200 python tools/calib_bench.py 160 > $OUT/calib_bench.json 2>/dev/null
+timeout 200 python tools/agg_bench.py > $OUT/agg_bench.json 2>/dev/null
+timeout 600 bash tools/pmc_aggregation.sh ${TAG}_aggpmc > $OUT/aggregation_pmc.txt 2>&1
 RCU_LOOP_TIMING=1 RCU_SCRIPT_PROFILE=0 timeout 200 python tools/script_throughput.py 16 20 32 2>&1 | grep -v "Holder\|conv2d_batch\|Conv2d\|Dropout2d\|BatchNorm2d\|^ *)\|^UNet\|^model" > $OUT/script_throughput.txt
 ls -la $OUT
