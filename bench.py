@@ -454,6 +454,16 @@ def main():
     # exchange path (asynchronous reduce on RCCL's stream, root finalize on a side stream, record_stream, drain) -- the rehearsal of the
     # N > 1 code on a box with one GPU (tools/rccl_world1_rehearsal.py; profiles/r04_rccl_world1.txt).
     force_pg = world == 1 and os.environ.get('RCU_BENCH_FORCE_PG') == '1'
+    seed = 20                                   # config seed (config/test_brats_baseline_mc.yaml:6)
+    isic = args.workload == 'isic'
+    x_cpu, mask_cpu, target_cpu = make_isic_batch(seed) if isic else make_volume(seed)
+    feeder = VolumePrefetcher(x_cpu, device)
+    # The RCCL process group is initialised WITHOUT `device_id=` (the communicator is then created at the first collective, in the warm-up
+    # steps).  Measured at N = 1 through a one-rank group (round 4, profiles/r04_pg_h2d.txt): with `device_id=device` (eager creation at
+    # init_process_group) every step that overlaps a prefetched host-to-device copy runs 4 ms longer -- 166.8-168.2 against 172.5-174.3
+    # MC-sample-volumes/s, proportional to the step count, the same steps on a resident volume unaffected, GPU_MAX_HW_QUEUES and the
+    # order of the first copy irrelevant -- while the lazily created communicator costs 0.5 % (173.3-173.5).  RCU_BENCH_PG_EAGER=1: the eager form.
+    pg_kwargs = dict(device_id=device) if os.environ.get('RCU_BENCH_PG_EAGER') == '1' else {}
     if force_pg:
         import socket
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -461,11 +471,12 @@ def main():
             with socket.socket() as sock:
                 sock.bind(('127.0.0.1', 0))
                 os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
-        dist.init_process_group(backend, rank=0, world_size=1, **(dict(device_id=device) if backend == 'nccl' else {}))
+        dist.init_process_group(backend, rank=0, world_size=1, **(pg_kwargs if backend == 'nccl' else {}))
     collective = world > 1 or force_pg          # a process group exists: barriers and max-over-ranks as the contract prescribes
+    barrier_kwargs = dict(device_ids=[local_rank]) if (collective and backend == 'nccl') else {}
     if world > 1:
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)   # "nccl" is RCCL on ROCm
+            dist.init_process_group('nccl', **pg_kwargs)   # "nccl" is RCCL on ROCm; the rank's device is the current device (set_device above)
         else:
             dist.init_process_group(backend)
 
@@ -474,8 +485,6 @@ def main():
     from rcu_amd import steps
 
     T = args.mc
-    seed = 20                                   # config seed (config/test_brats_baseline_mc.yaml:6)
-    isic = args.workload == 'isic'
     params = ISIC_PARAMS if isic else MODEL_PARAMS
     n_slices, height, width = (ISIC_IMAGES, ISIC_HEIGHT, ISIC_WIDTH) if isic else (SLICES, HEIGHT, WIDTH)
     unit_name = 'image' if isic else 'volume'
@@ -484,7 +493,6 @@ def main():
     elif args.pass_group < 1:
         args.pass_group = max(1, steps.McPredictStep.GROUP_PIXELS // (n_slices * height * width))
     model = make_model(seed, device, sigma_out=args.aleatoric, params=params)
-    x_cpu, mask_cpu, target_cpu = make_isic_batch(seed) if isic else make_volume(seed)
     x = x_cpu.to(device)
     if args.ensemble:
         T = args.ensemble
@@ -520,7 +528,6 @@ def main():
         m.profile_begin(height, width, n_slices * args.pass_group, max(count, 1))
     runner.forwards_run = 0
 
-    feeder = VolumePrefetcher(x_cpu, device)
     first_step, end_step = args.warmup, args.warmup + args.steps
     resident_before = None
     if os.environ.get('RCU_BENCH_RESIDENT_FIRST') == '1' and world == 1:      # diagnostic: drift between the legs
@@ -538,13 +545,15 @@ def main():
         runner.forwards_run = 0
     torch.cuda.synchronize()
     if collective:
-        dist.barrier()
+        dist.barrier(**barrier_kwargs)
     torch.cuda.synchronize()
+    allocs_before = torch.cuda.memory_stats(device).get('num_device_alloc', 0)     # hipMalloc calls of torch's caching allocator so far
     t0 = time.perf_counter()
     # THE timed region: per volume the host-to-device copy (prefetched: volume k + 1 travels while volume k computes), the
     # weight-scaling pass, the T stochastic passes, [N > 1: the reduce] and the finalize
     feeder.issue(first_step)
     pending = []
+    host_times = [] if os.environ.get('RCU_BENCH_STEP_TIMES') == '1' else None      # diagnostic: when the host had enqueued step k
     diag = os.environ.get('RCU_BENCH_H2D_DIAG', '')      # diagnostics of the copy's cost: 'unused' = copies run, the steps read the resident volume
     for k in range(first_step, end_step):
         xin = feeder.get(k) if diag != 'nowait' else feeder.bufs[k % len(feeder.bufs)]
@@ -552,13 +561,19 @@ def main():
             feeder.issue(k + 1)
         pending.append(one_step(k, x if diag == 'unused' else xin))
         feeder.done(k)
+        if host_times is not None:
+            host_times.append(time.perf_counter() - t0)
     out = [p.result() for p in pending][-1]
     runner.drain()
     torch.cuda.synchronize()
     if collective:
-        dist.barrier()
+        dist.barrier(**barrier_kwargs)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if host_times is not None and rank == 0:
+        print('host enqueue times of the timed steps (ms): ' + ' '.join('{:.1f}'.format(v * 1e3) for v in host_times) +
+              ' | all done {:.1f}'.format(elapsed * 1e3), file=sys.stderr)
+    device_allocs_in_timed_region = torch.cuda.memory_stats(device).get('num_device_alloc', 0) - allocs_before
     passes_run = max(runner.forwards_run, 1)        # this rank's forward passes inside the timed region
     forwards_per_rank = [runner.forwards_run]
     if collective:
@@ -579,7 +594,7 @@ def main():
     # ---- the same steps with the volume already resident in HBM (the secondary figure; all ranks take part)
     torch.cuda.synchronize()
     if collective:
-        dist.barrier()
+        dist.barrier(**barrier_kwargs)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     pend_r = [one_step(k) for k in range(end_step, end_step + args.steps)]
@@ -588,7 +603,7 @@ def main():
     runner.drain()
     torch.cuda.synchronize()
     if collective:
-        dist.barrier()
+        dist.barrier(**barrier_kwargs)
     torch.cuda.synchronize()
     elapsed_resident = time.perf_counter() - t1
     if collective:
@@ -614,7 +629,7 @@ def main():
         runner_ao.forwards_run = 0
         torch.cuda.synchronize()
         if collective:
-            dist.barrier()
+            dist.barrier(**barrier_kwargs)
         torch.cuda.synchronize()
         ta = time.perf_counter()
         feeder.issue(first_ao)
@@ -629,7 +644,7 @@ def main():
         runner_ao.drain()
         torch.cuda.synchronize()
         if collective:
-            dist.barrier()
+            dist.barrier(**barrier_kwargs)
         torch.cuda.synchronize()
         elapsed_ao = time.perf_counter() - ta
         if collective:
@@ -917,6 +932,7 @@ def main():
                    'gflop_per_sample_{}'.format(unit_name): conv_flops / passes_run / 1e9 / (n_slices if isic else 1)},
         'n_ranks_seen': n_ranks_seen,
         'forwards_per_rank': forwards_per_rank,
+        'device_allocs_in_timed_region': device_allocs_in_timed_region,   # hipMalloc calls (implicit device syncs) the timed steps caused: 0 in the steady state
         'resident': dict(value=units * args.steps / elapsed_resident, ms_per_step=elapsed_resident / args.steps * 1e3, steps=args.steps,
                          ms_per_step_before_the_timed_region=resident_before,
                          note='the same steps with the volume already in HBM when the clock starts (no host-to-device copy): the '

@@ -239,9 +239,15 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
             const int yy = yy0 + 2 * i2, swz = (yy >> 1) & 1;
+#if RCU_WINO_IMAGE8
+            const int rowbase = (sl * T::SLICE_POS + yy * T::PITCH) * 8 + kq * 2;   // [slice][row][position][8 channels]
+            aA[i2] = rowbase + 8 * (x0l + swz);
+            aB[i2] = rowbase + 8 * (x0l - swz);
+#else
             const int rowbase = ((kq >> 1) * T::HALF_POS + sl * T::SLICE_POS + yy * T::PITCH) * 4 + (kq & 1) * 2;
             aA[i2] = rowbase + 4 * (x0l + swz);   // even patch columns j: pixel x0l + j sits at position x0l + j + swz
             aB[i2] = rowbase + 4 * (x0l - swz);   // odd  patch columns j: pixel x0l + j sits at position x0l + j - swz
+#endif
         }
     }
     const int b_addr = T::A_DW + (kq * T::BN + wn * 32 + 2 * m16) * 2;
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
                 // volatile: hipcc otherwise fuses pairs of these reads into ds_read2_b64, whose 16-lane groups over 32 banks
                 // conflict 2-way on this image (SQ_LDS_BANK_CONFLICT 33 % of the LDS cycles); ds_read_b64 serves 32
                 // lanes over 64 banks
-                d[4 * i + j] = *(const volatile __attribute__((address_space(3))) f32x2*)(Ab + ((j & 1) ? aB[i >> 1] : aA[i >> 1]) + (i & 1) * (T::PITCH * 4) + 4 * j);
+                d[4 * i + j] = *(const volatile __attribute__((address_space(3))) f32x2*)(Ab + ((j & 1) ? aB[i >> 1] : aA[i >> 1]) + (i & 1) * (T::PITCH * WINO_POS_DW) + WINO_POS_DW * j);
         }
         constexpr int AHEAD = 4;
         f32x4 bv[16];

@@ -182,11 +182,26 @@ __device__ __forceinline__ WinoTileId wino_tile_id(const ConvArgs& a, int item)
 // fetches by LDS-DMA; slots of zero padding / pitch padding / outside the batch point far out of range, where the
 // buffer load returns zeros.  The tile-independent part -- which (channel half, slice, halo row, pixel column) the slot
 // holds -- is packed into one register per slot at kernel start (wino_slot_geometry).
+// The LDS input image of the F(2x2,3x3) / F(2x2,2x2) kernels is [channel half][slice][halo row][position][4 channels]: the patch reads
+// (ds_read_b64: 32 lanes per cycle over 64 banks) are free of bank conflicts on it.  -DRCU_WINO_IMAGE8=1 (experiment builds) stages
+// rcu_wino4.hip's image [slice][halo row][position][8 channels] instead -- adjacent lanes of an LDS-DMA instruction fetch the two 16-byte
+// halves of one pixel's chunk, so an instruction touches 8 whole 128-byte lines of a channel-blocked tensor instead of 16 half lines --
+// at the price of 2-way conflicts on the patch reads (16 tiles x 2 channel pairs cannot fall on 16 distinct 16-byte slots without a
+// per-column half swizzle).  Measured round 4 (profiles/r04_layout_ab.txt): every one of the seven layers 0..+2.8 % SLOWER, 2.17 -> 2.19 ms
+// per pass pair, the headline unchanged: the halved L2 requests do not pay for the conflicts with two waves per SIMD.  Not the default.
+#ifndef RCU_WINO_IMAGE8
+#define RCU_WINO_IMAGE8 0
+#endif
+constexpr int WINO_POS_DW = RCU_WINO_IMAGE8 ? 8 : 4;   // dwords from one position of the input image to the next
 template <class T>
 __device__ __forceinline__ uint32_t wino_slot_geometry(int j, int wave, int lane)
 {
-    const int f = (j * T::WAVES + wave) * 64 + lane;       // position index in the LDS image
+    const int f = (j * T::WAVES + wave) * 64 + lane;       // 16-byte unit of the LDS image
+#if RCU_WINO_IMAGE8
+    const int hh = f & 1, rem = f >> 1;
+#else
     const int hh = f / T::HALF_POS, rem = f % T::HALF_POS;
+#endif
     const int s = rem / T::SLICE_POS, r2 = rem % T::SLICE_POS;
     const int yy = r2 / T::PITCH, pos = r2 % T::PITCH;
     const int x = pos ^ ((yy >> 1) & 1);                    // pixel column stored at this position

@@ -114,9 +114,15 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
             const int yy = yy0 + 2 * i2, swz = (yy >> 1) & 1;
+#if RCU_WINO_IMAGE8
+            const int rowbase = (sl * T::SLICE_POS + yy * T::PITCH) * 8 + kq * 2;   // [slice][row][position][8 channels]
+            aA[i2] = rowbase + 8 * (x0l + swz);
+            aB[i2] = rowbase + 8 * (x0l - swz);
+#else
             const int rowbase = ((kq >> 1) * T::HALF_POS + sl * T::SLICE_POS + yy * T::PITCH) * 4 + (kq & 1) * 2;
             aA[i2] = rowbase + 4 * (x0l + swz);
             aB[i2] = rowbase + 4 * (x0l - swz);
+#endif
         }
     }
     const int b_addr = T::A_DW + (kq * T::BN + wn * 32 + 2 * m16) * 2;
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 e[j] = *(const volatile __attribute__((address_space(3))) f32x2*)(Ab + ((j & 1) ? aB[ROW >> 1] : aA[ROW >> 1]) +
-                                                                                  (ROW & 1) * (T::PITCH * 4) + 4 * j);
+                                                                                  (ROW & 1) * (T::PITCH * WINO_POS_DW) + WINO_POS_DW * j);
         };
         if (pa == 0) {
             read_row(e0, std::integral_constant<int, 0>{});
