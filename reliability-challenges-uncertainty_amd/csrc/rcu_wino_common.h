@@ -188,7 +188,7 @@ __device__ __forceinline__ WinoTileId wino_tile_id(const ConvArgs& a, int item)
 // halves of one pixel's chunk, so an instruction touches 8 whole 128-byte lines of a channel-blocked tensor instead of 16 half lines --
 // at the price of 2-way conflicts on the patch reads (16 tiles x 2 channel pairs cannot fall on 16 distinct 16-byte slots without a
 // per-column half swizzle).  Measured round 4 (profiles/r04_layout_ab.txt): every one of the seven layers 0..+2.8 % SLOWER, 2.17 -> 2.19 ms
-// per pass pair, the headline unchanged: the halved L2 requests do not pay for the conflicts with two waves per SIMD.  Not the default.
+// per 160-slice forward, the headline unchanged: the halved L2 requests do not pay for the conflicts with two waves per SIMD.  Not the default.
 #ifndef RCU_WINO_IMAGE8
 #define RCU_WINO_IMAGE8 0
 #endif
