@@ -330,10 +330,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
         // LDS-DMA pieces are issued one per MFMA group below
         const bool more = kc + 1 < nchunks;
         if (!more && has_next) {   // last chunk of the tile: from here on the DMA works on the workgroup's next tile
-            const ConvArgs& ca = wino_cold_args();   // tile counts and image extents are not kept in SGPRs either
+            const WinoTileConsts ca = wino_tile_consts(wino_cold_args());   // tile counts and image extents are not kept in SGPRs either: one batch of scalar loads
             if (more_passes()) {
                 ntile = tile;
-                ntile.n0 = tile.n0 + ca.head_images;
+                ntile.n0 = tile.n0 + wino_cold_args().head_images;
             } else {
                 ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
             }

@@ -99,20 +99,25 @@ __device__ __forceinline__ WinoEpiRaw wino4_epilogue_load(const ConvArgs& a, int
     int bs, by, sb, tr, tc;
     T::block_origin(wave, bs, by);
     T::tile_of(4 * (lane >> 4), sb, tr, tc);
-    const int n = min(n0 + bs + sb, a.N - 1);
-    e.al = *reinterpret_cast<const f32x2*>(a.alpha + co);
-    e.bb = *reinterpret_cast<const f32x2*>(a.betab + co);
-    e.be = *reinterpret_cast<const f32x2*>(a.beta + co);
+    // the arguments in ONE batch of scalar loads (a wave alone on its SIMD sits out every scalar round trip: the mask branch used to fetch its
+    // own arguments behind the branch)
+    const float *alpha = a.alpha, *betab = a.betab, *beta = a.beta, *mask = a.mask, *mask2 = a.mask2;
+    int N = a.N, Cmask = a.Cmask, Cmask2 = a.Cmask2, Csplit = a.Csplit;
+    asm volatile("" : "+s"(alpha), "+s"(betab), "+s"(beta), "+s"(mask), "+s"(mask2), "+s"(N), "+s"(Cmask), "+s"(Cmask2), "+s"(Csplit));
+    const int n = min(n0 + bs + sb, N - 1);
+    e.al = *reinterpret_cast<const f32x2*>(alpha + co);
+    e.bb = *reinterpret_cast<const f32x2*>(betab + co);
+    e.be = *reinterpret_cast<const f32x2*>(beta + co);
     e.site = 0;
     e.mk[0] = e.mk[1] = 1.f;
-    if (a.mask != nullptr) {   // wave-uniform
+    if (mask != nullptr) {   // wave-uniform
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int c = co + b;
             // the fused cls + sigma head unit: output channels >= Csplit belong to the twin's dropout site (as rcu_wino_common.h)
-            const bool second = a.mask2 != nullptr && c >= a.Csplit;
-            const int cm = second ? a.Cmask2 : a.Cmask, ci = second ? c - a.Csplit : c;
-            const float* const row = second ? a.mask2 + (size_t)n * a.Cmask2 : a.mask + (size_t)n * a.Cmask;
+            const bool second = mask2 != nullptr && c >= Csplit;
+            const int cm = second ? Cmask2 : Cmask, ci = second ? c - Csplit : c;
+            const float* const row = second ? mask2 + (size_t)n * Cmask2 : mask + (size_t)n * Cmask;
             e.mk[b] = row[min(ci, cm - 1)];
             e.site |= (ci < cm ? 1 : 0) << b;
         }
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         const float* const An = smem + (BUF ^ 1) * T::BUF_DW;
         const bool more = kc + 1 < nchunks, more2 = kc + 2 < nchunks;
         if (kc == nchunks - 2 && has_next) {   // last-but-one chunk of the tile: from its barrier on the DMA works on the workgroup's next tile
-            const ConvArgs& ca = wino_cold_args();
+            const WinoTileConsts ca = wino_tile_consts(wino_cold_args());   // one batch of scalar loads, one wait
             ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
             dpn_wtile = ntile.wtile;
             const WinoTileOffset nto = wino_tile_offset<T>(ca, ntile);
@@ -597,10 +602,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
                 // behind a tile's last chunk the wait comes after the epilogue (main loop): the first chunk of the next tile is a
                 // cold fetch, and the epilogue is the work to hide it behind
                 if constexpr ((VAR & 8) == 0) {
-                    // vmcnt(0): this wave's pieces of the next chunk (the next tile's first chunk behind a tile's last) have landed.  Every wave
-                    // has ISSUED its LDS reads of buffer BUF when it passes the barrier (the weights of groups 14..17 were read in groups
-                    // 10..13); they return within ~100 cycles, the first data of the back part -- issued behind two more MFMAs, fetched from
-                    // L2 or HBM -- arrives several hundred later
+                    // vmcnt(0): this wave's pieces of the next chunk (the next tile's first chunk behind a tile's last) have landed.
+                    // INVARIANT the two-chunks-ahead LDS-DMA relies on: when a wave leaves __syncthreads(), every LDS read any wave has issued
+                    // from buffer BUF is COMPLETE -- __syncthreads() lowers to `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier` (checked in the gfx950
+                    // assembly of every in-loop barrier), and the weights of groups 14..17 were read in groups 10..13 -- so the back-part DMA issued
+                    // right behind it may overwrite BUF.  A bare __builtin_amdgcn_s_barrier() here would be a write-after-read race on BUF; if
+                    // the barrier is ever hand-rolled it needs an explicit s_waitcnt lgkmcnt(0) in front.
                     __builtin_amdgcn_s_waitcnt(0x0F70);
                     __syncthreads();   // everyone past the LDS reads of buffer BUF and done filling the other one
                 }

@@ -160,8 +160,24 @@ struct WinoTileId {
     int wtile, n0, y0, x0;
 };
 
-template <class T>
-__device__ __forceinline__ WinoTileId wino_tile_id(const ConvArgs& a, int item)
+// The kernel arguments the next-tile arithmetic needs (wino_tile_id + wino_tile_offset), fetched from the kernarg segment in ONE batch of scalar
+// loads behind one wait.  Read field by field where they were used, the compiler put a load, a wait and a branch (magic == 0 ?) in front of each of
+// the three divisions and another round trip in front of the offsets: four to five scalar-memory round trips in a row per tile, which a wave that
+// is alone on its SIMD (rcu_wino4.hip) sits out in full.
+struct WinoTileConsts {
+    int NTW_total, tiles_x, tiles_y, H, W, C1;
+    uint32_t magic_ntw, magic_tx, magic_ty, in_pix_bytes;
+};
+__device__ __forceinline__ WinoTileConsts wino_tile_consts(const ConvArgs& a)
+{
+    WinoTileConsts c{a.NTW_total, a.tiles_x, a.tiles_y, a.H, a.W, a.C1, a.magic_ntw, a.magic_tx, a.magic_ty, a.in_pix_bytes};
+    asm volatile("" : "+s"(c.NTW_total), "+s"(c.tiles_x), "+s"(c.tiles_y), "+s"(c.H), "+s"(c.W), "+s"(c.C1), "+s"(c.magic_ntw), "+s"(c.magic_tx),
+                      "+s"(c.magic_ty), "+s"(c.in_pix_bytes));
+    return c;
+}
+
+template <class T, class A>
+__device__ __forceinline__ WinoTileId wino_tile_id(const A& a, int item)
 {
     WinoTileId t;
     // item / d by multiplication with ceil(2^32 / d): exact while item * d < 2^32 (the launcher falls back to magic = 0)
@@ -229,8 +245,8 @@ __device__ __forceinline__ uint32_t wino_slot_plan(const ConvArgs& a, uint32_t g
 struct WinoTileOffset {
     uint32_t off, border;
 };
-template <class T>
-__device__ __forceinline__ WinoTileOffset wino_tile_offset(const ConvArgs& a, const WinoTileId& t)
+template <class T, class A>
+__device__ __forceinline__ WinoTileOffset wino_tile_offset(const A& a, const WinoTileId& t)
 {
     WinoTileOffset o;
     o.off = (uint32_t)t.n0 * ((uint32_t)(a.H * a.W) * (uint32_t)a.C1 * 4u) + (uint32_t)(t.y0 * a.W + t.x0) * a.in_pix_bytes;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
         const int pa = tile.wtile / a.NT;   // row parity class of this work item
         const bool more = kc + 1 < nchunks;
         if (!more && has_next) {   // last chunk of the tile: from here on the DMA works on the workgroup's next tile
-            const ConvArgs& ca = wino_cold_args();   // tile counts and image extents are not kept in SGPRs either
+            const WinoTileConsts ca = wino_tile_consts(wino_cold_args());   // tile counts and image extents are not kept in SGPRs either: one batch of scalar loads
             ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
             dp_wtile = ntile.wtile;
             const WinoTileOffset nto = wino_tile_offset<T>(ca, ntile);

@@ -450,3 +450,17 @@ def test_npz_member_mapping_checks_sizes_and_collate_honours_entries(tmp_path):
     assert torch.is_tensor(both['labels']) and torch.is_tensor(both['images'])
     only_images = data_mod.CollateDict(entries=('images',))(pre)
     assert isinstance(only_images['labels'], list) and len(only_images['labels']) == 2 and torch.is_tensor(only_images['images'])
+
+
+def test_bench_helpers_plan_fingerprint_and_host_description():
+    """bench.py reports the PMC traffic figure only for the plan it was measured on (a fingerprint of the layer table and the samples per launch)
+    and describes the host its CPU baseline ran on (VERDICT r03 weak points 8-9)."""
+    import bench
+    layers = [dict(name='a', kernel='k<1>', cin=4, cout=32, height=192, width=128), dict(name='b', kernel='k<2>', cin=32, cout=32, height=192, width=128)]
+    f = bench.plan_fingerprint(layers, 320)
+    assert f == bench.plan_fingerprint([dict(L) for L in layers], 320) and len(f) == 12
+    assert f != bench.plan_fingerprint(layers, 160)
+    assert f != bench.plan_fingerprint([dict(layers[0], kernel='k<3>'), layers[1]], 320)
+    host = bench.host_description()
+    assert host['affinity_count'] >= 1 and host['logical_cpus'] >= host['affinity_count'] and host['torch_threads'] >= 1
+    assert isinstance(host['affinity'], str) and host['affinity']

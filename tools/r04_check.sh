@@ -1,10 +1,17 @@
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r04j
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r04k
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-for m in lazy eager lazy eager; do python tools/rccl_world1_rehearsal.py 160 20 8 $m 2>/dev/null | grep '^{"backend"' | tee -a $OUT/rehearsal.jsonl | python -c "
+L=$GRAFT_REPO_ROOT/reliability-challenges-uncertainty_amd
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3
+for i in 1 2 3; do
+RCU_HIP_LIBRARY=$L/librcu_hip_prev.so python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > $OUT/prev_$i.json
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > $OUT/new_$i.json
+python - $OUT $i <<'PY'
 import json,sys
-d=json.loads(sys.stdin.read()); print(d['init'], 'plain %.2f / with copy %.2f | reduce %.2f / %.2f | p2p %.2f / %.2f | bits %s'%(d['plain_ms_per_volume'],d['plain_ms_per_volume_with_copy'],d['reduce']['ms_per_volume'],d['reduce']['ms_per_volume_with_copy'],d['p2p']['ms_per_volume'],d['p2p']['ms_per_volume_with_copy'],d['bits_equal']))"; done
-RCU_BENCH_FORCE_PG=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > $OUT/bench_force_pg.json; cut -c1-150 $OUT/bench_force_pg.json
-RCU_BENCH_FORCE_PG=1 RCU_BENCH_PG_EAGER=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > $OUT/bench_force_pg_eager.json; cut -c1-150 $OUT/bench_force_pg_eager.json
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > $OUT/bench_plain.json; cut -c1-150 $OUT/bench_plain.json
-timeout 900 python -m pytest tests/test_gpu_multirank.py -x -q -m gpu 2>&1 | tail -3
+o,i=sys.argv[1],sys.argv[2]
+a=json.load(open('%s/prev_%s.json'%(o,i))); b=json.load(open('%s/new_%s.json'%(o,i)))
+print(i,'prev %.2f (conv %.3f ms, dom %.4f ms)   new %.2f (conv %.3f ms, dom %.4f ms)'%(a['value'],a['roofline']['all_conv_kernels']['ms_per_forward'],a['roofline']['avg_launch_ms'],b['value'],b['roofline']['all_conv_kernels']['ms_per_forward'],b['roofline']['avg_launch_ms']))
+for k in a['roofline']['per_kernel']:
+    print('     %-42s %.4f -> %.4f'%(k,a['roofline']['per_kernel'][k]['ms_per_forward'],b['roofline']['per_kernel'][k]['ms_per_forward']))
+PY
+done
