@@ -16,11 +16,12 @@ python bench.py --aleatoric --mc 50 --steps 4 --no-cpu-baseline > $OUT/bench_ale
 # every output in the timed region (mutual information + variance: float64 statistics); the default line carries the same configuration as its `all_outputs` sub-record
 python bench.py --all-outputs --steps 20 --warmup 5 > $OUT/bench_all_outputs.json 2> $OUT/bench_all_outputs.err; cut -c1-200 $OUT/bench_all_outputs.json
 # the N > 1 exchange path over RCCL itself, as far as one GPU allows (a one-rank process group), and the bench line through it
-python tools/rccl_world1_rehearsal.py > $OUT/rccl_world1.json 2> $OUT/rccl_world1.err; cut -c1-300 $OUT/rccl_world1.json
-RCU_BENCH_FORCE_PG=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_force_pg.json 2> $OUT/bench_force_pg.err; cut -c1-200 $OUT/bench_force_pg.json
+for m in lazy eager; do python tools/rccl_world1_rehearsal.py 160 20 8 $m 2> $OUT/rccl_world1.err | grep '^{"backend"' >> $OUT/rccl_world1.json; done; cut -c1-300 $OUT/rccl_world1.json
+RCU_BENCH_FORCE_PG=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2> $OUT/bench_force_pg.err | grep '^{"metric"' > $OUT/bench_force_pg.json; cut -c1-200 $OUT/bench_force_pg.json
+RCU_BENCH_FORCE_PG=1 RCU_BENCH_PG_EAGER=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2> $OUT/bench_force_pg_eager.err | grep '^{"metric"' > $OUT/bench_force_pg_eager.json; cut -c1-200 $OUT/bench_force_pg_eager.json
 # the N = 8 lines with all eight ranks on the one GPU over gloo (code-path runs, not throughputs): MC and -- now that members share a workspace -- the K = 10 ensemble
-RCU_BENCH_SINGLE_DEVICE=1 RCU_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_gpus8_one_device.json 2> $OUT/bench_gpus8_one_device.err; cut -c1-200 $OUT/bench_gpus8_one_device.json
-RCU_BENCH_SINGLE_DEVICE=1 RCU_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --ensemble 10 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_ens10_gpus8_one_device.json 2> $OUT/bench_ens10_gpus8_one_device.err; cut -c1-200 $OUT/bench_ens10_gpus8_one_device.json
+RCU_BENCH_SINGLE_DEVICE=1 RCU_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 8 --warmup 2 --no-cpu-baseline 2> $OUT/bench_gpus8_one_device.err | grep '^{"metric"' > $OUT/bench_gpus8_one_device.json; cut -c1-200 $OUT/bench_gpus8_one_device.json
+RCU_BENCH_SINGLE_DEVICE=1 RCU_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --ensemble 10 --steps 8 --warmup 2 --no-cpu-baseline 2> $OUT/bench_ens10_gpus8_one_device.err | grep '^{"metric"' > $OUT/bench_ens10_gpus8_one_device.json; cut -c1-200 $OUT/bench_ens10_gpus8_one_device.json
 cd /tmp && export TMPDIR=/tmp
 # kernel times: one lane (exclusive durations, what bench.py's roofline record is taken from); then the default two lanes, whose kernels overlap
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o bench -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --lanes 1 > $P/stats.log 2>&1
