@@ -361,3 +361,41 @@ def test_eight_rank_gloo_matches_single_process_and_balances(tmp_path):
         assert max(per_rank) - min(per_rank) <= (0 if jobs % world == 0 else 1), (name, per_rank)
     # the three shapes: 21, 51 and 10 jobs per volume over 8 ranks
     assert [c['mc20'] for c in counts] == [21] * 8 and [c['mc50'] for c in counts] == [51] * 8 and [c['ens10'] for c in counts] == [10] * 8
+
+
+# ------------------------------------------------------------------------------------------------ world 1 through the exchange path
+def _w1_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from oracle import unet_oracle as uo
+    from rcu_amd.distributed import ShardedMcRunner
+    state = uo.synthetic_state(11, **W8_PARAMS)
+    x = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(9))
+    mk = lambda **kw: ShardedMcRunner(None, 6, rank=0, world=1, engine=TinyEngine(state), seed=4, pass_group=2, **kw)  # noqa: E731
+    plain = mk()
+    ok = True
+    for transport in ('reduce', 'p2p'):
+        forced = mk(force_exchange=True, ws_transport=transport)
+        ref = [plain.step(x, k) for k in range(3)]
+        pend = [forced.step_async(x, k, depth=2) for k in range(3)]          # more volumes than `depth`: the oldest is retired on the way
+        outs = [p.result() for p in pend]
+        forced.drain()
+        same = all(torch.equal(a[key], b[key]) for a, b in zip(outs, ref) for key in b) and all(set(a) == set(b) for a, b in zip(outs, ref))
+        sync = forced.step(x, 1)
+        same = same and all(torch.equal(sync[key], ref[1][key]) for key in ref[1])
+        ok = ok and same and forced.p2p_messages == 0 and len(forced._inflight) == 0 and forced.ws_owner(2) == forced.root
+    with open(out_path, 'w') as f:
+        f.write('ok' if ok else 'mismatch')
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_one_rank_group_through_the_exchange_path_gives_the_plain_step(tmp_path):
+    """`force_exchange` (the one-GPU rehearsal of the RCCL path, tools/rccl_world1_rehearsal.py) on CPU over gloo: a one-rank group, every volume
+    through `_exchange` -- asynchronous work handles, at most `depth` in flight, drain -- for both ws transports gives the bits of the plain
+    world-1 step, and the point-to-point transport sends nothing when the root owns the weight-scaling pass."""
+    out = str(tmp_path / 'w1.txt')
+    mp.spawn(_w1_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert open(out).read() == 'ok'
