@@ -51,4 +51,57 @@ __device__ __forceinline__ void accumulate_voxel(void* stats, size_t v, size_t V
     }
 }
 
+// The statistics entries of one voxel held in registers across the passes of a group: load, add pass after pass in
+// the same order and with the same operations as accumulate_voxel, store -- bit-identical to one launch per pass.
+template <int C>
+struct VoxelStats {
+    double d[2 * C + 1];
+    float f[C + 1];
+    __device__ __forceinline__ void load(const void* stats, size_t v, size_t V, int flags)
+    {
+        if (flags & MC_VAR) {
+            const double* sd = reinterpret_cast<const double*>(stats);
+#pragma unroll
+            for (int k = 0; k < 2 * C; ++k) d[k] = sd[(size_t)k * V + v];
+            d[2 * C] = (flags & MC_MI) ? sd[(size_t)(2 * C) * V + v] : 0.0;
+        } else {
+            const float* sf = reinterpret_cast<const float*>(stats);
+#pragma unroll
+            for (int k = 0; k < C; ++k) f[k] = sf[(size_t)k * V + v];
+            f[C] = (flags & MC_MI) ? sf[(size_t)C * V + v] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void add(int flags, const float (&p)[C])
+    {
+        if (flags & MC_VAR) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double pc = (double)p[c];
+                d[c] += pc;
+                d[C + c] += pc * pc;
+            }
+            if (flags & MC_MI) d[2 * C] += (double)entropy_of<C>(p);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) f[c] += p[c];
+            if (flags & MC_MI) f[C] += entropy_of<C>(p);
+        }
+    }
+    __device__ __forceinline__ void store(void* stats, size_t v, size_t V, int flags) const
+    {
+        if (flags & MC_VAR) {
+            double* sd = reinterpret_cast<double*>(stats);
+#pragma unroll
+            for (int k = 0; k < 2 * C; ++k) sd[(size_t)k * V + v] = d[k];
+            if (flags & MC_MI) sd[(size_t)(2 * C) * V + v] = d[2 * C];
+        } else {
+            float* sf = reinterpret_cast<float*>(stats);
+#pragma unroll
+            for (int k = 0; k < C; ++k) sf[(size_t)k * V + v] = f[k];
+            if (flags & MC_MI) sf[(size_t)C * V + v] = f[C];
+        }
+    }
+};
+
+
 }  // namespace rcu

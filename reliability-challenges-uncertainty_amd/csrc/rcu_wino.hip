@@ -140,6 +140,14 @@ __device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x
                                                    int x0, int wm, int wn, int lane, int tid, float* hl)
 {
     static_assert(T::TS == 1 && T::TH * T::TW == T::THREADS && T::BN == 32 && T::SW == 1, "one pixel per thread");
+    // The statistics entries of the thread's voxel are requested first: their round trip runs beside the output transform, the LDS hand-over and
+    // the dot products instead of behind the softmax -- one plane's load / add / store behind the other's, as accumulate_voxel does it, kept the
+    // whole workgroup (both waves of every SIMD are in this phase together) waiting for two memory round trips per tile.  Same operations, same bits.
+    const int gy = y0 + tid / T::TW, gx = x0 + tid % T::TW;
+    const bool inside = n0 < a.N && gy < a.H && gx < a.W;
+    const size_t hw = (size_t)gy * a.W + gx, HW = (size_t)a.H * a.W;
+    VoxelStats<2> st;
+    if (inside && a.head_stats != nullptr) st.load(a.head_stats, (size_t)nstat * HW + hw, a.head_V, a.head_flags);   // nstat: the image the sample is a pass of
     {
         const int n16 = lane & 15, g = lane >> 4;
         int bs, by, bx;
@@ -176,8 +184,7 @@ __device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x
         }
     }
     __syncthreads();
-    const int gy = y0 + tid / T::TW, gx = x0 + tid % T::TW;
-    if (n0 < a.N && gy < a.H && gx < a.W) {
+    if (inside) {
         const float* const row = hl + tid * WINO_HEAD_PITCH;
         float l[2];
 #pragma unroll
@@ -194,14 +201,14 @@ __device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x
             }
             l[c] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) + a.head_b[c];
         }
-        const size_t hw = (size_t)gy * a.W + gx, HW = (size_t)a.H * a.W;
         if (a.head_logits != nullptr) {
             a.head_logits[((size_t)n0 * 2 + 0) * HW + hw] = l[0];
             a.head_logits[((size_t)n0 * 2 + 1) * HW + hw] = l[1];
         }
         if (a.head_stats != nullptr) {
             softmax_inplace<2>(l);
-            accumulate_voxel<2>(a.head_stats, (size_t)nstat * HW + hw, a.head_V, a.head_flags, l);   // nstat: the image the sample is a pass of
+            st.add(a.head_flags, l);
+            st.store(a.head_stats, (size_t)nstat * HW + hw, a.head_V, a.head_flags);
         }
     }
 }

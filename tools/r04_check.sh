@@ -1,16 +1,17 @@
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r04l
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r04m
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-export RCU_HIP_LIBRARY=$GRAFT_REPO_ROOT/reliability-challenges-uncertainty_amd/librcu_hip_exp.so
-RCU_EXP_VERBOSE=1 RCU_EXP_STAGGER=0 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 >/dev/null | grep "^tensor" | head -40 > $OUT/addr.txt; head -12 $OUT/addr.txt
-for rep in 1 2; do
-for S in 0 4096 69632 266240 1052672 0; do
-  RCU_EXP_STAGGER=$S python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > $OUT/s_${S}_$rep.json
-  python - $OUT/s_${S}_$rep.json $S <<'PY'
+L=$GRAFT_REPO_ROOT/reliability-challenges-uncertainty_amd
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "pass_pair or mc20 or 160_slice" 2>&1 | tail -3
+for i in 1 2 3; do
+RCU_HIP_LIBRARY=$L/librcu_hip_prev.so python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > $OUT/prev_$i.json
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > $OUT/new_$i.json
+python - $OUT $i <<'PY'
 import json,sys
-d=json.load(open(sys.argv[1])); r=d['roofline']
-print('stagger %8s value %.2f resident %.2f conv %.3f ms  T32x32 %.4f  S2 %.4f S8 %.4f first %.4f up32 %.4f cls %.4f'%(sys.argv[2],d['value'],d['resident']['value'],r['all_conv_kernels']['ms_per_forward'],
-   r['per_kernel']['conv3x3_winograd4<T32x32,N32,K8>']['ms_per_forward'],r['per_kernel']['conv3x3_winograd4<S2T16x32,N32,K8>']['ms_per_forward'],r['per_kernel']['conv3x3_winograd4<S8T8x16,N32,K8>']['ms_per_forward'],
-   r['per_kernel']['conv3x3_first<T8x32,K36>']['ms_per_forward'],r['per_kernel']['upconv_winograd<T16x32,N32,K8>']['ms_per_forward'],r['per_kernel']['conv3x3_winograd<T16x32,N32,K8>']['ms_per_forward']))
+o,i=sys.argv[1],sys.argv[2]
+a=json.load(open('%s/prev_%s.json'%(o,i))); b=json.load(open('%s/new_%s.json'%(o,i)))
+k='conv3x3_winograd<T16x32,N32,K8>'
+print(i,'prev %.2f (conv %.3f ms, +head %.4f)   new %.2f (conv %.3f ms, +head %.4f)  all_out prev %.2f new %.2f'%(a['value'],a['roofline']['all_conv_kernels']['ms_per_forward'],a['roofline']['per_kernel'][k]['ms_per_forward'],b['value'],b['roofline']['all_conv_kernels']['ms_per_forward'],b['roofline']['per_kernel'][k]['ms_per_forward'],a['all_outputs']['value'],b['all_outputs']['value']))
 PY
-done; done
+done
