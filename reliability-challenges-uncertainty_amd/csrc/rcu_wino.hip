@@ -133,7 +133,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
 // 16x32-pixel x 32-channel tile goes to LDS instead of HBM ([pixel][34 floats]: conflict-free both ways), then every
 // thread takes one pixel: 1x1 conv to two logits, and either the logits (NCHW) or softmax + the MC statistics update.
 // The dot product is summed exactly as head_kernel sums it (eight 4-channel fmaf chains, pairwise tree), so a pass
-// through this epilogue and a pass through head_kernel (RCU_FUSE_HEAD=0, sigma / feature outputs) give the same bits.
+// through this epilogue and a pass through head_kernel (rcu_unet_set_fuse_head(h, 0); sigma / feature outputs) give the same bits.
 constexpr int WINO_HEAD_PITCH = 34;
 template <class T>
 __device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x4 (&acc)[2][16], const WinoEpi& ep, int n0, int nstat, int y0,
