@@ -1241,13 +1241,14 @@ def test_unet_stress_golden_wide_activations_and_logits(golden, dev):
     """Numerics stress case, reference golden G18 (tests/golden/generate_golden.py: the reference UNet, common/model/unet.py:128-186, with its
     BatchNorm affines x 2.5 and its classifier x 0.5): interior activations of 1e2..1e3 and logits of +-20 under Dropout2d(0.3) -- the ranges
     trained checkpoints have, where the other parity inputs stay below |logit| 1.  Full width on a 192x128 slice pair, so every F(4x4,3x3)
-    instantiation runs.  Logits within a bound RELATIVE to their range of the reference's (strided sample) and of the oracle (everywhere);
+    instantiation runs.  Logits within a bound RELATIVE to their range (2e-5) of the reference's (strided sample) and of the oracle (everywhere);
     probabilities / entropy / mutual information / variance of the three passes within 1e-4; F(2x2,3x3)-only and direct plans on the same
     input within the same bounds."""
     from oracle import summary_oracle as so
     from oracle import unet_oracle as uo
     from rcu_amd import steps
-    REL = 1e-5
+    REL = 2e-5      # measured (tools/stress_margin.py): 2.0e-6 (eval) / 4.2-8.4e-6 (MC passes) with F(4x4,3x3), 1.4 / 2.1-3.7e-6 with F(2x2,3x3), 1.6 / 3.9-7.3e-6 direct;
+                    # probabilities 2.7e-5 at most -- the distance to the torch-CPU oracle is float32 summation order at this dynamic range, not Winograd
     g = golden('g18_unet_stress')
     p = golden_params(g)
     st = uo.stress_state(uo.reference_init_state(int(g['seed']), bn_seed=int(g['seed']) + 1000, **p), float(g['bn_gain']), float(g['head_gain']))
