@@ -413,8 +413,9 @@ def main():
                          'their owner (rcu_amd.distributed.ShardedMcRunner)')
     ap.add_argument('--no-ws', action='store_true', help='skip the deterministic weight-scaling pass')
     ap.add_argument('--pass-group', type=int, default=0,
-                    help='MC passes of a rank per launch (N * g samples per batch); 0 = McPredictStep\'s rule, GROUP_PIXELS // (N*H*W): 2 for the '
-                         '160-slice volume, 3 for the ISIC batch')
+                    help='MC passes of a rank per launch (N * g samples per batch); 0 = McPredictStep\'s rule (steps.pass_group_size): 4 for the '
+                         '160-slice volume (2 with the sigma head), 7 for the ISIC batch; the groups of a volume are sized so that the lanes '
+                         'carry the same number of passes (steps.balanced_groups)')
     ap.add_argument('--lanes', type=int, default=2,
                     help='HIP streams a rank spreads the launches of a volume over (one workspace + statistics blob each; rcu_amd.distributed)')
     ap.add_argument('--ensemble', type=int, default=0, metavar='K',
@@ -488,11 +489,11 @@ def main():
     params = ISIC_PARAMS if isic else MODEL_PARAMS
     n_slices, height, width = (ISIC_IMAGES, ISIC_HEIGHT, ISIC_WIDTH) if isic else (SLICES, HEIGHT, WIDTH)
     unit_name = 'image' if isic else 'volume'
+    model = make_model(seed, device, sigma_out=args.aleatoric, params=params)
     if args.ensemble:
         args.pass_group = 1                     # members run one per launch (they differ in their weights)
-    elif args.pass_group < 1:
-        args.pass_group = max(1, steps.McPredictStep.GROUP_PIXELS // (n_slices * height * width))
-    model = make_model(seed, device, sigma_out=args.aleatoric, params=params)
+    elif args.pass_group < 1:                   # McPredictStep's rule: GROUP_PIXELS worth of pixels, no tensor beyond 2 GB
+        args.pass_group = steps.pass_group_size(model, n_slices, height, width, steps.McPredictStep.GROUP_PIXELS)
     x = x_cpu.to(device)
     if args.ensemble:
         T = args.ensemble

@@ -141,7 +141,9 @@ static int pick_config(const ConvLayer& L, int n_slices, const rcu_unet_options&
     // rcu_unet_options.conv_winograd = 0 keeps every layer on the direct kernels of rcu_conv.hip (A/B tests)
     // a unit that adds to its output tensor (ConvResidualBlock's second unit) runs on the direct kernels, whose epilogue can
     const bool wino_on = opt.conv_winograd != 0 && !L.accumulate;
-    const size_t max_bytes = (size_t)n_slices * L.H * L.W * (size_t)std::max(std::max(L.c1p, L.c2p), L.coutp) * 4;
+    // (an up-convolution reads the LOW-resolution grid: L.H x L.W is its output grid)
+    const size_t in_px = L.upsample ? (size_t)(L.H / 2) * (L.W / 2) : (size_t)L.H * L.W;
+    const size_t max_bytes = (size_t)n_slices * std::max(in_px * (size_t)std::max(L.c1p, L.c2p), (size_t)L.H * L.W * (size_t)L.coutp) * 4;
     const bool center_pad = L.upsample && (2 * (L.H / 2) != L.H || 2 * (L.W / 2) != L.W);   // unet.py:110-116: direct kernel only
     if (L.upsample && !center_pad && wino_on && L.c1p % 32 == 0 && L.c2p == 0 && max_bytes < ((size_t)1 << 31)) {
         const int lh = L.H / 2, lw = L.W / 2;

@@ -211,9 +211,9 @@ __global__ __launch_bounds__(CB_THREADS) void ece_hist_kernel(const float* __res
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) {
                 const size_t e = base + ((size_t)(r0 + i) * CB_THREADS + tid) * 4;
-                q[s][i] = *reinterpret_cast<const float4*>(pv + e);
-                t4[s][i] = *reinterpret_cast<const unsigned*>(tv + e);
-                m4[s][i] = mv ? *reinterpret_cast<const unsigned*>(mv + e) : 0x01010101u;
+                q[s][i] = stream_load(reinterpret_cast<const float4*>(pv + e));      // read-once streams: non-temporal (rcu_kernels.h)
+                t4[s][i] = stream_load(reinterpret_cast<const unsigned*>(tv + e));
+                m4[s][i] = mv ? stream_load(reinterpret_cast<const unsigned*>(mv + e)) : 0x01010101u;
             }
         };
         load(0, 0);
@@ -429,12 +429,12 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_kernel(const U* __restr
 // and the base counts are the column sums.  Writes the same partial layout as the general kernel.
 __device__ __forceinline__ void load4(const float* src, float (&q)[4])
 {
-    const float4 v = *reinterpret_cast<const float4*>(src);
+    const float4 v = stream_load(reinterpret_cast<const float4*>(src));
     q[0] = v.x, q[1] = v.y, q[2] = v.z, q[3] = v.w;
 }
 __device__ __forceinline__ void load4(const double* src, double (&q)[4])
 {
-    const double2 a = *reinterpret_cast<const double2*>(src), b = *reinterpret_cast<const double2*>(src + 2);
+    const double2 a = stream_load(reinterpret_cast<const double2*>(src)), b = stream_load(reinterpret_cast<const double2*>(src + 2));
     q[0] = a.x, q[1] = a.y, q[2] = b.x, q[3] = b.y;
 }
 
@@ -517,9 +517,9 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
             for (int i = 0; i < BATCH; ++i) {
                 const size_t e = base + ((size_t)(r0 + i) * CB_THREADS + tid) * 4;
                 load4(uv + e, q[s][i]);
-                p4[s][i] = *reinterpret_cast<const unsigned*>(pv + e);
-                t4[s][i] = *reinterpret_cast<const unsigned*>(tv + e);
-                m4[s][i] = mv ? *reinterpret_cast<const unsigned*>(mv + e) : 0x01010101u;
+                p4[s][i] = stream_load(reinterpret_cast<const unsigned*>(pv + e));
+                t4[s][i] = stream_load(reinterpret_cast<const unsigned*>(tv + e));
+                m4[s][i] = mv ? stream_load(reinterpret_cast<const unsigned*>(mv + e)) : 0x01010101u;
             }
         };
         load(0, 0);

@@ -115,6 +115,41 @@ hipError_t launch_upconv_wino(int cfg, const ConvArgs& a, hipStream_t stream);
 hipError_t launch_conv_wino4(int cfg, const ConvArgs& a, hipStream_t stream);
 hipError_t launch_conv_first(const ConvArgs& a, hipStream_t stream);
 
+// Loads of data a kernel reads exactly once (activation / logits / probability / label streams of the per-voxel kernels): non-temporal, so that the
+// stream does not push the lines that ARE reused -- statistics planes that are read-modify-written, weights -- out of L2 and the memory-side cache.
+// Measured round 4 (profiles/r04_nt_loads.txt): head kernel 116 -> 98 us (0.61 -> 0.72 of the HBM peak), ece_hist / unc_counts 0.72 / 0.74 -> 0.79 /
+// 0.82.  NOT for the conv kernels' input staging (their input was written by the previous kernel and neighbouring tiles re-read its halo: +4..5 %
+// time with nt there) and NOT for mc_accumulate / mc_finalize (their logits and statistics were written by the kernel before them and one volume's
+// worth sits in the 256 MB memory-side cache: finalize 13.3 -> 15.3 us with nt).  -DRCU_STREAM_NT=0: plain loads everywhere.
+#ifndef RCU_STREAM_NT
+#define RCU_STREAM_NT 1
+#endif
+#if defined(__HIPCC__)
+template <class V>
+__device__ __forceinline__ V stream_load_as(const void* p)
+{
+#if RCU_STREAM_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+#else
+    return *reinterpret_cast<const V*>(p);
+#endif
+}
+__device__ __forceinline__ float stream_load(const float* p) { return stream_load_as<float>(p); }
+__device__ __forceinline__ unsigned stream_load(const unsigned* p) { return stream_load_as<unsigned>(p); }
+__device__ __forceinline__ float4 stream_load(const float4* p)
+{
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 v = stream_load_as<v4>(p);
+    return float4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ double2 stream_load(const double2* p)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const v2 v = stream_load_as<v2>(p);
+    return double2{v.x, v.y};
+}
+#endif
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: set once per (kernel, device), so that one
 // process driving several GPUs gets it on every one of them.
 hipError_t set_max_dynamic_lds(const void* kernel, int bytes);

@@ -75,7 +75,7 @@ __device__ __forceinline__ void head_dot8(const float* __restrict__ row, const f
                                           float (&acc)[C])
 {
     for (int seg = 0; seg < cph; seg += 32) {
-        const float4 x = *reinterpret_cast<const float4*>(row + seg + sub * 4);
+        const float4 x = stream_load(reinterpret_cast<const float4*>(row + seg + sub * 4));
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float4 wv = *reinterpret_cast<const float4*>(w + c * cph + seg + sub * 4);
@@ -109,8 +109,8 @@ __device__ __forceinline__ void head_load32(const HeadArgs& a, const float* __re
     for (int round = 0; round < 8; ++round) {
         const size_t v = v0 + round * 8 + grp;
         const float* row = act + (v < a.V ? v : a.V - 1) * a.CP;      // (a voxel behind the end reads the last one and is zeroed in the sums)
-        t.xa[round] = *reinterpret_cast<const float4*>(row + sub * 4);
-        if constexpr (SIG) t.xs[round] = *reinterpret_cast<const float4*>(row + 32 + sub * 4);
+        t.xa[round] = stream_load(reinterpret_cast<const float4*>(row + sub * 4));      // read once: non-temporal (rcu_kernels.h)
+        if constexpr (SIG) t.xs[round] = stream_load(reinterpret_cast<const float4*>(row + 32 + sub * 4));
     }
 }
 template <int C, bool SIG>
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(PW_THREADS) void mc_accumulate4_kernel(const float4
     const uint32_t n = i / HW4, q = i - n * HW4;
     float4 x[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) x[c] = in[(size_t)(n * C + c) * HW4 + q];
+    for (int c = 0; c < C; ++c) x[c] = in[(size_t)(n * C + c) * HW4 + q];      // plain loads: see stream_load (rcu_kernels.h)
     float p[4][C];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

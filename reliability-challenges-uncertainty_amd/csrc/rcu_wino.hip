@@ -310,10 +310,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
             if (job.active && ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES)) {
                 if (job.first)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16,
-                                                             dp[j], job.cb, 0, 0);
+                                                             dp[j], job.cb, 0, RCU_DMA_IN_AUX);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16,
-                                                             dp[j], job.cb, 0, 0);
+                                                             dp[j], job.cb, 0, RCU_DMA_IN_AUX);
             }
         }
     };

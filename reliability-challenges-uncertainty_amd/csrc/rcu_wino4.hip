@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
             constexpr int j = I;
             if ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(job.rs, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16, off[j],
-                                                         job.cb, 0, 0);
+                                                         job.cb, 0, RCU_DMA_IN_AUX);
         } else if constexpr (I < T::NW + T::NA) {
             constexpr int k = I - T::NA;
             if ((k + 1) * T::WAVES <= T::W_PIECES || k * T::WAVES + wave < T::W_PIECES)

@@ -13,6 +13,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// Cache policy of the LDS-DMA loads of INPUT activations (the aux immediate of buffer_load ... lds: 1 sc0, 2 nt, 16 sc1).  0 = cached; experiment builds set
+// it (profiles/r04_nt_loads.txt).
+#ifndef RCU_DMA_IN_AUX
+#define RCU_DMA_IN_AUX 0
+#endif
+
 // Exchange with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2].
 __device__ __forceinline__ float wino_swap_adjacent(float v)
 {

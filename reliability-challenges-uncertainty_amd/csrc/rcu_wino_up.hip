@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
             constexpr int j = I - T::NW;
             if (job.active && ((j + 1) * T::WAVES <= T::A_PIECES || j * T::WAVES + wave < T::A_PIECES))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(uintptr_t)(lds_base + job.lb + (j * T::WAVES + wave) * 1024), 16, dp[j],
-                                                         job.cb, 0, 0);
+                                                         job.cb, 0, RCU_DMA_IN_AUX);
         }
     };
 

@@ -236,9 +236,13 @@ class ShardedMcRunner:
         lanes.begin(stats, lambda: self.engine.side_statistics(x), inputs=(x,), first=step_index if self.world > 1 else 0)
         on_lane = lanes.run
 
+        # group sizes of this rank's MC passes: rounds of one group per lane (steps.balanced_groups), so that the lanes carry the same load
+        sizes = steps_mod.balanced_groups(sum(1 for j in jobs if j != 0), self.pass_group, lanes.count)
         i = 0
         while i < len(jobs):
-            group = [j for j in jobs[i:i + self.pass_group] if j != 0] if jobs[i] != 0 else []
+            group = [j for j in jobs[i:i + sizes[0]] if j != 0] if jobs[i] != 0 else []
+            if group:
+                sizes.pop(0)
             if len(group) > 1:     # consecutive MC passes of this rank as one batch of N * g samples
                 def run_group(st, lane, group=group):
                     if mask_sets is None:

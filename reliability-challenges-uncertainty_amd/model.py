@@ -225,6 +225,13 @@ class UNet(nn.Module):
             self.features = None
         return handle
 
+    def max_group_samples(self, h, w):
+        """Largest batch of h x w images whose every activation tensor stays below the 2 GB that the Winograd kernels' 32-bit buffer offsets
+        reach (csrc/rcu_api.hip pick_config: beyond it a layer falls back to the direct kernels -- correct, but slower).  The widest
+        full-resolution tensor has ``start_filters`` channels (twice that for the classifier + sigma twin unit)."""
+        widest = max(8, self.start_filters * (2 if self.sigma_out else 1))
+        return max(1, ((1 << 31) - 1) // (int(h) * int(w) * 4 * widest))
+
     def reserve(self, h, w, n, lane=0):
         """Make the plan and the activation workspace for batches of up to ``n`` images of h x w now (a step that knows it will run pass
         groups of n * g samples calls this before its first, smaller forward: one plan instead of a small one that is replaced)."""

@@ -225,6 +225,30 @@ class StreamLanes:
         self._stats = self._stats[:1]
 
 
+def balanced_groups(count, group, lanes):
+    """Sizes of the pass groups ``count`` MC passes run in, at most ``group`` passes each, for launches that take ``lanes`` stream lanes in
+    turn: rounds of one group per lane, every group of a round the same size, the last rounds smaller instead of a full group for one
+    lane and nothing for the other -- T = 20 in groups of 4 on two lanes is 4 4 | 4 4 | 2 2 (10 passes per lane), not 4 4 | 4 4 | 4
+    (12 against 8: the lanes fill each other's gaps only while both have work).  One lane, or a group size that divides count / lanes:
+    plain groups of ``group``."""
+    group, lanes, left, sizes = max(1, int(group)), max(1, int(lanes)), int(count), []
+    while left > 0:
+        for k in range(lanes):         # one round: lane k takes its share of what the lanes from k on still have to run
+            if left <= 0:
+                break
+            sizes.append(min(group, -(-left // (lanes - k))))
+            left -= sizes[-1]
+    return sizes
+
+
+def pass_group_size(model, n, h, w, group_pixels):
+    """MC passes per launch for batches of n images of h x w: ``group_pixels`` worth of pixels, and no tensor of the plan beyond the 2 GB
+    the Winograd kernels address (model.UNet.max_group_samples)."""
+    g = max(1, int(group_pixels) // (n * h * w))
+    cap = getattr(model, 'max_group_samples', None)
+    return g if cap is None else max(1, min(g, cap(h, w) // n))
+
+
 def merge_statistics(stats, side):
     """Add the statistics of a side lane into ``stats`` (plain sums, include/rcu.h rcu_mc_*)."""
     stats.blob.add_(side.blob)
@@ -280,12 +304,12 @@ class McPredictStep(BatchStep):
     first, customsteps.py:22-25)."""
 
     # A forward pass fills the GPU from about 160 BraTS slices (3.9 M pixels) on, and the deep levels of the U-Net -- few, long
-    # work items per launch -- only from twice that (their last round of workgroups is 75-88 % full at 160 slices); the shipped
-    # configs use batch_size 32.  The T passes of a batch are independent, so the fused path runs them in groups of
-    # g = GROUP_PIXELS // (N*H*W) as one batch of N * g samples (include/rcu.h: rcu_unet_forward_accumulate_passes)
-    # -- same statistics bit for bit; the workspace grows to that of a 320-slice batch (12 GB of the 288), not beyond, and
-    # every tensor stays below the 2 GB the kernels' 32-bit buffer offsets reach.
-    GROUP_PIXELS = 2 * 160 * 192 * 128
+    # work items per launch -- only from two to four times that (their last round of workgroups is 75-88 % full at 160 slices, 94 % at
+    # 320, full at 640); the shipped configs use batch_size 32.  The T passes of a batch are independent, so the fused path runs them in
+    # groups of g = GROUP_PIXELS // (N*H*W) as one batch of N * g samples (include/rcu.h: rcu_unet_forward_accumulate_passes) -- same
+    # statistics bit for bit; the workspace grows to that of a 640-slice batch (12 GB per lane of the 288), not beyond, and
+    # pass_group_size keeps every tensor below the 2 GB the kernels' 32-bit buffer offsets reach (640 BraTS slices x 32 channels: 2.01e9 bytes).
+    GROUP_PIXELS = 4 * 160 * 192 * 128
     LANES = max(1, int(os.environ.get('RCU_STREAM_LANES', '2')))   # HIP streams the pass groups of a batch alternate over (StreamLanes)
 
     def __init__(self, mc_steps, do_mi=False, do_var=False, materialize=False, masks=None, ws_pass=True,
@@ -306,7 +330,7 @@ class McPredictStep(BatchStep):
 
         if isinstance(model, model_mod.UNet) and not self.materialize:     # the plan for the pass groups, before the smaller first forward
             n, _, h, w = images.shape
-            model.reserve(h, w, n * min(self.mc_steps, max(1, self.group_pixels // (n * h * w))))
+            model.reserve(h, w, n * min(self.mc_steps, pass_group_size(model, n, h, w, self.group_pixels)))
         fused = not self.materialize and isinstance(model, model_mod.UNet)
         if self.ws_pass and not fused:
             batch_context.output['ws_probabilities'] = softmax(model(images))
@@ -338,14 +362,14 @@ class McPredictStep(BatchStep):
         dev = images.device
         rng_state = torch.cuda.get_rng_state(dev) if (self.masks is None and dev.type == 'cuda') else None
         stats = McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var)
-        group = max(1, self.group_pixels // (n * h * w))
+        group = pass_group_size(model, n, h, w, self.group_pixels)
         lanes = StreamLanes(dev, min(self.lanes, -(-self.mc_steps // group)))
+        sizes = balanced_groups(self.mc_steps, group, lanes.count)
         lanes.begin(stats, lambda: McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var), inputs=(images,))
         if before is not None:
             before()                   # (the weight-scaling pass, on the caller's stream)
         i = 0
-        while i < self.mc_steps:       # masks are drawn (host side: in launch order, whatever the lane) inside forward_accumulate
-            g = min(group, self.mc_steps - i)
+        for g in sizes:                # masks are drawn (host side: in launch order, whatever the lane) inside forward_accumulate
             if g == 1:
                 lanes.run(lambda st, lane, i=i: model.forward_accumulate(images, st, None if self.masks is None else self.masks[i], lane=lane))
             else:
@@ -364,8 +388,7 @@ class McPredictStep(BatchStep):
                     return self._fused_passes(model, images, mi, var)
                 probs = []
                 t = 0
-                while t < self.mc_steps:             # the same draws as the fused path makes: one per pass group
-                    g = min(group, self.mc_steps - t)
+                for g in sizes:                      # the same draws as the fused path makes: one per pass group
                     if self.masks is not None:
                         sets = self.masks[t:t + g]
                     elif g == 1:
@@ -548,12 +571,11 @@ class AleatoricMcPredictStep(BatchStep):
             stats = fresh()
             sigma_sum = stats.sigma_sum
             # pass groups and stream lanes as in McPredictStep: g passes per launch, launches alternating over two HIP streams
-            group = max(1, McPredictStep.GROUP_PIXELS // (n * h * w))
+            group = pass_group_size(model, n, h, w, McPredictStep.GROUP_PIXELS)
             lanes = StreamLanes(dev, min(McPredictStep.LANES, -(-self.mc_steps // group)))
             lanes.begin(stats, fresh, inputs=(images,))
             i = 0
-            while i < self.mc_steps:
-                g = min(group, self.mc_steps - i)
+            for g in balanced_groups(self.mc_steps, group, lanes.count):
                 masks = None if self.masks is None else (self.masks[i] if g == 1 else self.masks[i:i + g])
                 lanes.run(lambda st, lane, masks=masks, g=g: model.forward_accumulate_sigma(images, st, st.sigma_sum, masks, self.is_log_sigma,
                                                                                          lane=lane, passes=g))

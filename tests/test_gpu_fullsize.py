@@ -116,10 +116,10 @@ def test_real_data_shapes_full_width_vs_oracle(dev, cin, n, h, w):
 
 @pytest.mark.timeout(900)
 def test_pass_pair_of_the_full_volume_is_bit_identical_to_single_passes(dev):
-    """The headline path runs the MC passes of a 160-slice volume two per launch (320 samples: the 48x32 / 24x16 / 12x8 levels
-    then fill their last round of workgroups): rcu_unet_forward_accumulate_passes at N = 160 must give exactly the statistics of
-    two single-pass launches under the same masks, through McPredictStep too (its default GROUP_PIXELS pairs the passes; its default two
-    stream lanes change the summation order only)."""
+    """The headline path runs the MC passes of a 160-slice volume four (round 2-3: two) per launch (640 samples: the 48x32 / 24x16 / 12x8
+    levels then fill their last round of workgroups; every tensor still below 2 GB): rcu_unet_forward_accumulate_passes at N = 160 must give
+    exactly the statistics of single-pass launches under the same masks -- in pairs and in fours -- through McPredictStep too (its default
+    GROUP_PIXELS takes four passes per launch; its default two stream lanes change the summation order only)."""
     from oracle import unet_oracle as uo
     from rcu_amd import steps
     st = uo.synthetic_state(35, **PARAMS)
@@ -127,21 +127,28 @@ def test_pass_pair_of_the_full_volume_is_bit_identical_to_single_passes(dev):
     n, h, w = 160, 192, 128
     x = torch.randn(n, 4, h, w, generator=g).to(dev)
     _, sites = uo.unet_plan(**PARAMS)
-    mask_sets = [uo.sample_masks(sites, n, 0.3, g) for _ in range(4)]
+    mask_sets = [uo.sample_masks(sites, n, 0.3, g) for _ in range(8)]
     model = _model(PARAMS, st, dev)
     single = steps.McStatistics(n, 2, h, w, dev, do_mi=True)
     for ms in mask_sets:
         model.forward_accumulate(x, single, ms)
     paired = steps.McStatistics(n, 2, h, w, dev, do_mi=True)
-    model.forward_accumulate(x, paired, mask_sets[:2], passes=2)
-    model.forward_accumulate(x, paired, mask_sets[2:], passes=2)
+    for k in range(0, 8, 2):
+        model.forward_accumulate(x, paired, mask_sets[k:k + 2], passes=2)
     assert torch.equal(single.blob, paired.blob)
-    assert steps.McPredictStep.GROUP_PIXELS // (n * h * w) == 2
+    fours = steps.McStatistics(n, 2, h, w, dev, do_mi=True)
+    model.forward_accumulate(x, fours, mask_sets[:4], passes=4)
+    model.forward_accumulate(x, fours, mask_sets[4:], passes=4)
+    assert torch.equal(single.blob, fours.blob)
+    # no layer of the 640-sample plan has left the Winograd kernels (an up-convolution reads the LOW-resolution grid: 1.0 GB, not 3 GB)
+    assert not [r['kernel'] for r in model.layer_table(h, w, 4 * n) if 'igemm' in r['kernel']]
+    assert steps.pass_group_size(model, n, h, w, steps.McPredictStep.GROUP_PIXELS) == 4
+    assert steps.balanced_groups(8, 4, 2) == [4, 4]
     ctx = steps.TorchTestContext('cuda', model)
     outs = []
     for group_pixels, lanes in ((0, 1), (None, 1), (None, 2), (None, 2)):
         bc = steps.BatchContext({'images': x}, 0)
-        steps.McPredictStep(4, do_mi=True, masks=mask_sets, group_pixels=group_pixels, lanes=lanes)(bc, None, ctx)
+        steps.McPredictStep(8, do_mi=True, masks=mask_sets, group_pixels=group_pixels, lanes=lanes)(bc, None, ctx)
         steps.MultiPredictionSummary(do_mi=True)(bc, None, ctx)
         outs.append(bc.output)
     for key in ('probabilities', 'entropy', 'mutual_info', 'ws_probabilities'):
@@ -300,8 +307,8 @@ def test_isic_batch32_mc20_through_the_runner(dev):
     g = torch.Generator().manual_seed(23)
     x = torch.rand(n, 3, h, w, generator=g)
     xd = x.to(dev)
-    group = steps.McPredictStep.GROUP_PIXELS // (n * h * w)
-    assert group == 3
+    group = steps.pass_group_size(model, n, h, w, steps.McPredictStep.GROUP_PIXELS)
+    assert group == 7                                # 224 samples: 1.88 GB for the widest tensor; two lanes run 7 7 | 3 3
     sel = np.array([0, 31])
     runner = rdist.ShardedMcRunner(model, T, seed=9, lanes=2, pass_group=group)
     out = runner.step(xd, 2)

@@ -464,3 +464,34 @@ def test_bench_helpers_plan_fingerprint_and_host_description():
     host = bench.host_description()
     assert host['affinity_count'] >= 1 and host['logical_cpus'] >= host['affinity_count'] and host['torch_threads'] >= 1
     assert isinstance(host['affinity'], str) and host['affinity']
+
+
+def test_pass_groups_are_balanced_over_the_lanes_and_capped_by_the_2gb_tensor_bound():
+    """steps.balanced_groups: rounds of one group per lane, so both lanes carry the same passes; steps.pass_group_size: GROUP_PIXELS worth of
+    pixels, and no activation tensor beyond the 2 GB the Winograd kernels address (model.UNet.max_group_samples)."""
+    from rcu_amd import model as model_mod
+    from rcu_amd import steps
+    assert steps.balanced_groups(20, 4, 2) == [4, 4, 4, 4, 2, 2]
+    assert steps.balanced_groups(20, 2, 2) == [2] * 10
+    assert steps.balanced_groups(20, 4, 1) == [4] * 5
+    assert steps.balanced_groups(20, 7, 2) == [7, 7, 3, 3]
+    assert steps.balanced_groups(3, 2, 2) == [2, 1]
+    assert steps.balanced_groups(50, 2, 2) == [2] * 24 + [1, 1]
+    assert steps.balanced_groups(0, 4, 2) == []
+    for count in range(1, 40):
+        for group in (1, 2, 3, 4, 7):
+            for lanes in (1, 2, 3):
+                sizes = steps.balanced_groups(count, group, lanes)
+                assert sum(sizes) == count and max(sizes) <= group and min(sizes) >= 1
+                loads = [sum(sizes[k::lanes]) for k in range(lanes)]
+                assert max(loads) - min(loads) <= 1, (count, group, lanes, sizes)
+    brats = model_mod.UNet(2, 4, 4, 32, 0.05)
+    assert brats.max_group_samples(192, 128) == 682
+    assert steps.pass_group_size(brats, 160, 192, 128, steps.McPredictStep.GROUP_PIXELS) == 4
+    assert steps.pass_group_size(brats, 32, 192, 128, steps.McPredictStep.GROUP_PIXELS) == 20
+    assert steps.pass_group_size(brats, 160, 192, 128, 0) == 1
+    sigma = model_mod.UNet(2, 4, 4, 32, 0.05, sigma_out=True)
+    assert steps.pass_group_size(sigma, 160, 192, 128, steps.McPredictStep.GROUP_PIXELS) == 2
+    isic = model_mod.UNet(2, 3, 4, 32, 0.05)
+    assert steps.pass_group_size(isic, 32, 256, 256, steps.McPredictStep.GROUP_PIXELS) == 7
+    assert steps.pass_group_size(object(), 32, 256, 256, steps.McPredictStep.GROUP_PIXELS) == 7       # a foreign module: the pixel rule alone

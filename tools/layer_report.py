@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-layer timing of the BraTS-shaped forward (HIP events between kernels): python tools/layer_report.py [forwards]"""
+"""Per-layer timing of the BraTS-shaped forward (HIP events between kernels): python tools/layer_report.py [forwards] [samples per launch, default 160]"""
 import os
 import sys
 
@@ -15,7 +15,8 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else bench.SLICES
     dev = torch.device('cuda')
     model = bench.make_model(20, dev)
-    x = bench.make_volume(20)[0][:n].to(dev)
+    x = bench.make_volume(20)[0]
+    x = x.repeat((n + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:n].to(dev)          # more samples than slices: the volume again (a pass group's batch)
     from rcu_amd import steps
     steps.set_dropout_mode(model, True)
     for _ in range(2):

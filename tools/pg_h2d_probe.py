@@ -62,7 +62,7 @@ def main():
     x_cpu = bench.make_volume(20)[0]
     x = x_cpu.to(dev)
     feeder = bench.VolumePrefetcher(x_cpu, dev)
-    kw = dict(seed=20, pass_group=2, lanes=2)
+    kw = dict(seed=20, pass_group=4, lanes=2)
     out = {}
 
     def run(tag, **extra):

@@ -35,6 +35,7 @@ import torch.distributed as dist  # noqa: E402
 
 import bench  # noqa: E402
 from rcu_amd import distributed as rdist  # noqa: E402
+from rcu_amd import steps as rsteps  # noqa: E402
 
 
 def main():
@@ -56,7 +57,7 @@ def main():
     x_cpu = bench.make_volume(20, n)[0]
     x = x_cpu.to(dev)
     feeder = bench.VolumePrefetcher(x_cpu, dev)
-    group = max(1, min(2, (2 * 160 * 192 * 128) // (n * bench.HEIGHT * bench.WIDTH)))
+    group = rsteps.pass_group_size(model, n, bench.HEIGHT, bench.WIDTH, rsteps.McPredictStep.GROUP_PIXELS)
     kw = dict(seed=20, pass_group=group, lanes=2)
     plain = rdist.ShardedMcRunner(model, T, **kw)
     record = dict(backend=dist.get_backend(), world=dist.get_world_size(), init='eager (device_id=)' if eager else 'lazy', slices=n, T=T, steps=steps,
