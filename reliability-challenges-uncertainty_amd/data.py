@@ -18,6 +18,7 @@ import glob
 import json
 import os
 import threading
+import warnings
 
 import numpy as np
 import torch
@@ -306,12 +307,20 @@ class VolumeDataset(torch_data.Dataset):
 
         def collated(k):
             shape = (n,) + tuple(blocks[k][0].shape[1:])
-            dst = np.empty(shape, dtype=blocks[k][0].dtype)          # one (transposing) copy per block, straight out of the file mapping
+            dst = torch.from_numpy(np.empty(shape, dtype=blocks[k][0].dtype))
             at = 0
-            for blk in blocks[k]:
-                dst[at:at + blk.shape[0]] = blk
+            for blk in blocks[k]:       # one (transposing) copy per block, straight out of the file mapping
+                piece = dst[at:at + blk.shape[0]]
+                if blk.nbytes >= (1 << 20) and all(s_ >= 0 for s_ in blk.strides):
+                    # a large channel-last -> channel-first copy: torch splits it over its intra-op threads (numpy's runs on this one
+                    # thread: 12 ms for a batch of 32 BraTS slices, beside the loader's other work for it)
+                    with warnings.catch_warnings():
+                        warnings.simplefilter('ignore', UserWarning)      # (a view of the read-only file mapping: only read here)
+                        piece.copy_(torch.from_numpy(blk))
+                else:
+                    piece.numpy()[...] = blk
                 at += blk.shape[0]
-            return torch.from_numpy(dst)
+            return dst
 
         out['images'] = collated('images')            # (the key order of the per-slice samples: images, the index entries, labels)
         out.update(meta)

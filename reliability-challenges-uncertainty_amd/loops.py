@@ -10,6 +10,7 @@ Mirrors
 The loop hands every kept output entry to the assembler channel-last as numpy (loops.py:214-220), exactly
 like the reference, so writer hooks and subject steps see the same arrays.
 """
+import collections
 import contextlib
 import csv
 import logging
@@ -367,6 +368,7 @@ class _Staged:
         self.tensor = torch.empty(shape, dtype=dtype, pin_memory=True)
         self.event = None
         self.busy = False
+        self.released = 0        # order of the releases (the worker waits for the oldest one when none has completed)
 
 
 def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
@@ -392,10 +394,19 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
         if ring_key not in ring and len(ring) >= 4:        # batches of many shapes: drop the oldest shape's buffers (those still
             ring.pop(next(iter(ring)))                     # in flight stay alive through the batches that hold them)
         bufs = ring.setdefault(ring_key, [])
+        t_a = time.perf_counter()
         with cond:
             while True:
                 free = [b for b in bufs if not b.busy]
-                if free or len(bufs) < depth + 3:      # depth queued + one being filled + one with the consumer + one in flight
+                # a released buffer may still be read by its host-to-device copy, which is queued behind the kernels of the batches
+                # before it (up to Test.MAX_INFLIGHT of them): take one whose copy has completed; failing that grow the ring; failing
+                # that wait for the buffer that was released first
+                ready = [b for b in free if b.event is None or b.event.query()]
+                if ready or len(bufs) < depth + 3:     # depth queued + one being filled + one with the consumer + one in flight
+                    free = ready
+                    break
+                if free:
+                    free = [min(free, key=lambda b: b.released)]
                     break
                 cond.wait(0.05)
                 if stop.is_set():
@@ -406,13 +417,18 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
                 buf = _Staged(shape, pieces[0].dtype)
                 bufs.append(buf)
             buf.busy = True
+        t_b = time.perf_counter()
         if buf.event is not None:
             buf.event.synchronize()                    # the copy that read this buffer last has finished
             buf.event = None
+        t_c = time.perf_counter()
         at = 0
         for t in pieces:
             buf.tensor[at:at + t.shape[0]].copy_(t)
             at += t.shape[0]
+        spent['ring'] += t_b - t_a
+        spent['sync'] += t_c - t_b
+        spent['copy'] += time.perf_counter() - t_c
         return buf
 
     def put(entry):
@@ -425,7 +441,7 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
         return False
 
     timing = os.environ.get('RCU_LOOP_TIMING') == '1'
-    spent = {'load': 0.0, 'stage': 0.0, 'items': 0}
+    spent = {'load': 0.0, 'stage': 0.0, 'items': 0, 'ring': 0.0, 'sync': 0.0, 'copy': 0.0}
 
     def timed_iter():
         it = iter(iterable)
@@ -474,13 +490,15 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
                 if not put((item, held, None)):
                     return
             if timing:
-                logging.info('loader thread: {items} items, {load:.3f} s loading + collating, {stage:.3f} s merging + staging'.format(**spent))
+                logging.info('loader thread: {items} items, {load:.3f} s loading + collating, {stage:.3f} s merging + staging (waiting for a staging buffer {ring:.3f} s, for its last copy {sync:.3f} s, copying {copy:.3f} s)'.format(**spent))
             put((done, [], None))
         except BaseException as exc:  # noqa: BLE001 - re-raised in the consumer
             put((done, [], exc))
 
     thread = threading.Thread(target=worker, daemon=True, name='rcu-loader')
     thread.start()
+
+    released = [0]
 
     def releaser(held):
         def release():
@@ -494,6 +512,8 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
                 for buf in held:
                     buf.event = event
                     buf.busy = False
+                    released[0] += 1
+                    buf.released = released[0]
                 cond.notify_all()
             held.clear()
         return release
@@ -565,9 +585,15 @@ def _with_last_flag(iterable):
 
 
 class Test:
-    """``pipelined`` (default: on for a CUDA device, ``RCU_PIPELINE=0`` switches it off): batch k + 1 is loaded and its GPU work
+    """``pipelined`` (default: on for a CUDA device, ``RCU_PIPELINE=0`` switches it off): the next batches are loaded and their GPU work
     enqueued while the outputs of batch k come to the host, so "batch k + 1 start" fires before "subjects of batch k" / "batch k
     end"; with ``pipelined=False`` every callback comes in the reference's order (loops.py:176-235).
+    How far the loop runs ahead: until ``INFLIGHT_PIXELS`` (two BraTS volumes) worth of batches is enqueued behind the batch being finished,
+    at most ``MAX_INFLIGHT`` batches.  One batch ahead (rounds 2-3) hides the host's work on a batch behind the next batch's kernels only
+    when batches are volume-sized: with the shipped ``batch_size: 32`` a batch is 24 ms of GPU work, and the batch that completes a subject
+    costs the host 100-190 ms (assembly, the metric seam, argmax, hand-over to the NIfTI writers; tools/loop_timeline.py) -- the GPU idled
+    a third of the time; ten batches ahead keep it busy (0.185-0.192 -> 0.133-0.149 s per subject, tools/script_throughput.py 16 20 32 0;
+    0.12 with coalescing, which also makes the launches volume-sized).
     ``coalesce`` (pipelined only; OPT-IN: the constructor argument, the YAML key ``others.coalesce_pixels`` the scripts pass on, or
     ``RCU_COALESCE``; default 0 = off, as the reference, whose loop never regroups batches): consecutive loader batches are merged up to
     that many samples x height x width before the steps run -- ``COALESCE_PIXELS`` = one BraTS volume, 160 x 192 x 128, is what fills
@@ -576,9 +602,11 @@ class Test:
     the MERGED batch (fewer ``on_test_batch_*`` calls, renumbered ``batch_index``, fewer ``batch_metrics`` entries); the Dropout2d masks
     of a stochastic step are drawn per step, so for a given seed MC / aleatoric outputs differ from the uncoalesced run's (another
     sample of the same distribution; deterministic steps give the same files byte for byte); and the activation workspace grows to that
-    of the merged batch times the pass group (12 GB for two passes of 160 slices instead of 2.4 GB for 32)."""
+    of the merged batch times the pass group (24 GB per lane for four passes of 160 slices)."""
     __test__ = False
     COALESCE_PIXELS = 160 * 192 * 128
+    INFLIGHT_PIXELS = 2 * 160 * 192 * 128
+    MAX_INFLIGHT = 12
 
     def __init__(self, steps: list, subject_steps: list = None, subject_assembler=None, entries: tuple = None,
                  convert_fn=tensor_to_numpy, pipelined=None, coalesce=None):
@@ -619,23 +647,34 @@ class Test:
             coalesce = self.coalesce if self.coalesce is not None else int(os.environ.get('RCU_COALESCE', 0))
             if coalesce > 0:
                 loader = coalesced(loader, coalesce, lazy=True)
-        waiting = None
-        batches = prefetch(loader, pin=pipelined)
+        inflight = collections.deque()        # (batch context, download, pixels, download slot) of the batches whose GPU work is enqueued
+        free_slots, slots = [], 0             # download slots (a set of pinned buffers each): taken per batch, back when it is finished
+
+        def finish_oldest():
+            batch_context, download, _, slot = inflight.popleft()
+            self._finish_batch(batch_context, download, task_context, context, hook)
+            free_slots.append(slot)
+
+        batches = prefetch(loader, depth=self.MAX_INFLIGHT if pipelined else 2, pin=pipelined)
         try:
             for i, ((batch, release), last) in enumerate(_with_last_flag(batches)):
                 batch_context = BatchContext(batch, i)
                 batch_context.more['last_batch'] = last
                 hook.on_test_batch_start(batch_context, task_context, context)
-                download = self._run_steps(batch_context, task_context, context, side, i & 1)
+                if free_slots:
+                    slot = free_slots.pop()
+                else:
+                    slot, slots = slots, slots + 1
+                download = self._run_steps(batch_context, task_context, context, side, slot)
                 release()                     # the step's host-to-device copies are enqueued: the staging buffers may go back
-                if waiting is not None:
-                    self._finish_batch(*waiting, task_context, context, hook)
-                waiting = (batch_context, download)
-                if not pipelined:
-                    self._finish_batch(*waiting, task_context, context, hook)
-                    waiting = None
-            if waiting is not None:
-                self._finish_batch(*waiting, task_context, context, hook)
+                # (pixels of the batch = the measure of its GPU work the run-ahead is budgeted in; a batch without an image tensor counts as a full budget)
+                inflight.append((batch_context, download, _batch_pixels(batch) or self.INFLIGHT_PIXELS, slot))
+                # finish the oldest batch once enough work is enqueued behind it to cover the host's share of finishing it
+                while inflight and (not pipelined or len(inflight) > self.MAX_INFLIGHT or
+                                    (len(inflight) > 1 and sum(e[2] for e in inflight) - inflight[0][2] >= self.INFLIGHT_PIXELS)):
+                    finish_oldest()
+            while inflight:
+                finish_oldest()
         finally:
             batches.close()                   # stops the loader thread, also when a step or a hook raised
         hook.on_test_end(task_context, context)

@@ -76,7 +76,10 @@ def _check_context(context):
 
 def set_dropout_mode(model, is_train=True):
     """common/utils/torchhelper.py:44-50: toggles only the Dropout modules; BatchNorm stays in eval."""
-    for m in model.modules():
+    # (model.UNet keeps the list of its Dropout2d modules -- its module tree is fixed after construction: no walk over 150 modules four
+    # times per batch)
+    sites = getattr(model, '_site_modules', None) if isinstance(model, model_mod.UNet) else None
+    for m in (model.modules() if sites is None else sites):
         if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d, torch.nn.Dropout3d)):
             if is_train:
                 m.train()
@@ -363,7 +366,8 @@ class McPredictStep(BatchStep):
         rng_state = torch.cuda.get_rng_state(dev) if (self.masks is None and dev.type == 'cuda') else None
         stats = McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var)
         group = pass_group_size(model, n, h, w, self.group_pixels)
-        lanes = StreamLanes(dev, min(self.lanes, -(-self.mc_steps // group)))
+        # (every lane gets work whenever there are two passes: T = 20 on batches of 32 slices is 10 | 10 on two lanes, not one launch of 20 on one)
+        lanes = StreamLanes(dev, min(self.lanes, self.mc_steps))
         sizes = balanced_groups(self.mc_steps, group, lanes.count)
         lanes.begin(stats, lambda: McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var), inputs=(images,))
         if before is not None:
@@ -572,7 +576,7 @@ class AleatoricMcPredictStep(BatchStep):
             sigma_sum = stats.sigma_sum
             # pass groups and stream lanes as in McPredictStep: g passes per launch, launches alternating over two HIP streams
             group = pass_group_size(model, n, h, w, McPredictStep.GROUP_PIXELS)
-            lanes = StreamLanes(dev, min(McPredictStep.LANES, -(-self.mc_steps // group)))
+            lanes = StreamLanes(dev, min(McPredictStep.LANES, self.mc_steps))
             lanes.begin(stats, fresh, inputs=(images,))
             i = 0
             for g in balanced_groups(self.mc_steps, group, lanes.count):
