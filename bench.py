@@ -322,7 +322,7 @@ class VolumePrefetcher:
         self.free[slot].record()
 
 
-def aggregation_kernels(device, n_slices, height, width, reps=5, all_outputs=False):
+def aggregation_kernels(device, n_slices, height, width, reps=30, all_outputs=False):
     """The standalone aggregation kernels of the step seam (rcu_mc_accumulate: softmax of a logits volume into the statistics;
     rcu_mc_finalize: mean + entropy out of them; rechun/dl/customsteps.py:57-61), timed with events on the launch stream.
     ALGORITHMIC bytes: accumulate V*C*4 logits + 2*S*4*V statistics read-modify-write (S = 2); finalize S*4*V read +
@@ -337,7 +337,8 @@ def aggregation_kernels(device, n_slices, height, width, reps=5, all_outputs=Fal
     # so the kernels MOVE 2*S*8*V resp. S*8*V of statistics -- reported next to it as `moved`.
     S = 5 if all_outputs else 2
 
-    def timed(fn):
+    def timed(fn):      # (30 launches: the first one waits ~10 us for the host's enqueue, a sixth of these kernels' time if only 5 share it)
+        fn()
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
