@@ -161,6 +161,30 @@ def test_pipelined_coalesced_loop_writes_the_files_of_the_serial_loop(tmp_path, 
     assert len(fast) == 2 * len(vols_mc)
     for name in fast:
         assert fast[name] == slow[name], name
+    # thirteen batches of one slice: the loop runs Test.MAX_INFLIGHT batches ahead of the one it finishes (download slots and staging
+    # buffers in rotation, subjects completed while later batches are enqueued) -- still the serial loop's bytes
+    monkeypatch.delenv('RCU_PIPELINE')
+    cfg_one, vols_one, _, _ = _setup(tmp_path / 'one', mc=3)
+    with open(cfg_one) as f:
+        text = f.read()
+    assert 'batch_size: 4' in text
+    with open(cfg_one, 'w') as f:
+        f.write(text.replace('batch_size: 4', 'batch_size: 1'))
+    inflight = []
+    inner = loops.Test._finish_batch
+
+    def counting(self, batch_context, *args):
+        inflight.append(batch_context.batch_index)
+        return inner(self, batch_context, *args)
+
+    monkeypatch.setattr(loops.Test, '_finish_batch', counting)
+    fast = _files(scripts.test_default('brats', cfg_one, None))
+    assert inflight == sorted(inflight) and len(inflight) == 13          # finished in order, every batch once
+    monkeypatch.setenv('RCU_PIPELINE', '0')
+    slow = _files(scripts.test_default('brats', cfg_one, None))
+    assert len(fast) == 2 * len(vols_one)
+    for name in fast:
+        assert fast[name] == slow[name], name
 
 
 ISIC_MC_YAML = """
