@@ -333,7 +333,8 @@ class McPredictStep(BatchStep):
 
         if isinstance(model, model_mod.UNet) and not self.materialize:     # the plan for the pass groups, before the smaller first forward
             n, _, h, w = images.shape
-            model.reserve(h, w, n * min(self.mc_steps, pass_group_size(model, n, h, w, self.group_pixels)))
+            sizes = balanced_groups(self.mc_steps, pass_group_size(model, n, h, w, self.group_pixels), min(self.lanes, max(self.mc_steps, 1)))
+            model.reserve(h, w, n * max(sizes + [1]))     # the largest launch the passes will make (T = 20 on 32 slices: 10 | 10, not 20)
         fused = not self.materialize and isinstance(model, model_mod.UNet)
         if self.ws_pass and not fused:
             batch_context.output['ws_probabilities'] = softmax(model(images))
@@ -367,7 +368,7 @@ class McPredictStep(BatchStep):
         stats = McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var)
         group = pass_group_size(model, n, h, w, self.group_pixels)
         # (every lane gets work whenever there are two passes: T = 20 on batches of 32 slices is 10 | 10 on two lanes, not one launch of 20 on one)
-        lanes = StreamLanes(dev, min(self.lanes, self.mc_steps))
+        lanes = StreamLanes(dev, min(self.lanes, max(self.mc_steps, 1)))
         sizes = balanced_groups(self.mc_steps, group, lanes.count)
         lanes.begin(stats, lambda: McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var), inputs=(images,))
         if before is not None:
