@@ -1281,3 +1281,28 @@ extern "C" int rcu_normalised_entropy(const float* p_fg, size_t n, double* out64
     RCU_HIP(launch_norm_entropy(p_fg, n, out64, out32, static_cast<hipStream_t>(stream)));
     return RCU_OK;
 }
+
+#ifdef RCU_EXPERIMENTS
+// Experiment builds only (tools/cu_contention_probe.py): `wgs` workgroups that each need a CU of their own (96 KB of LDS) and hold it for `usec`
+// microseconds -- a stand-in for a collective's kernel running beside the persistent conv kernels on an 8-GPU node.
+namespace rcu {
+__global__ __launch_bounds__(256) void hog_kernel(unsigned long long ticks, float* sink)
+{
+    extern __shared__ float hog_lds[];
+    hog_lds[threadIdx.x] = (float)threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (sink && hog_lds[threadIdx.x] < 0.f) sink[0] = 1.f;
+}
+}  // namespace rcu
+extern "C" __attribute__((visibility("default"))) int rcu_debug_hog(int wgs, int usec, void* stream)
+{
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rcu::hog_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        once = true;
+    }
+    hipLaunchKernelGGL(rcu::hog_kernel, dim3(wgs), dim3(256), 96 * 1024, (hipStream_t)stream, (unsigned long long)usec * 100ull, (float*)nullptr);
+    return (int)hipGetLastError();
+}
+#endif
