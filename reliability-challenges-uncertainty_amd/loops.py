@@ -571,6 +571,18 @@ class _Download:
         return {k: v.numpy() for k, v in self.arrays.items()}
 
 
+def _finish_oldest_now(pixels, pipelined, budget, max_inflight):
+    """The test loop's run-ahead rule.  ``pixels``: samples x height x width of the batches whose GPU work is enqueued, oldest first.  The oldest
+    is finished (its outputs awaited, its subjects assembled / evaluated / written) once the batches enqueued BEHIND it are worth ``budget``
+    pixels -- the GPU then has work for as long as the host spends on that batch -- or more than ``max_inflight`` batches are enqueued; the plain
+    loop finishes every batch at once."""
+    if not pixels:
+        return False
+    if not pipelined or len(pixels) > max_inflight:
+        return True
+    return len(pixels) > 1 and sum(pixels[1:]) >= budget
+
+
 def _with_last_flag(iterable):
     """(item, is_last) pairs: one item of lookahead."""
     it = iter(iterable)
@@ -589,7 +601,7 @@ class Test:
     enqueued while the outputs of batch k come to the host, so "batch k + 1 start" fires before "subjects of batch k" / "batch k
     end"; with ``pipelined=False`` every callback comes in the reference's order (loops.py:176-235).
     How far the loop runs ahead: until ``INFLIGHT_PIXELS`` (two BraTS volumes) worth of batches is enqueued behind the batch being finished,
-    at most ``MAX_INFLIGHT`` batches.  One batch ahead (rounds 2-3) hides the host's work on a batch behind the next batch's kernels only
+    at most ``MAX_INFLIGHT`` batches (two volume-sized batches, ten of 32 slices).  One batch ahead (rounds 2-3) hides the host's work on a batch behind the next batch's kernels only
     when batches are volume-sized: with the shipped ``batch_size: 32`` a batch is 24 ms of GPU work, and the batch that completes a subject
     costs the host 100-190 ms (assembly, the metric seam, argmax, hand-over to the NIfTI writers; tools/loop_timeline.py) -- the GPU idled
     a third of the time; ten batches ahead keep it busy (0.185-0.192 -> 0.133-0.149 s per subject, tools/script_throughput.py 16 20 32 0;
@@ -670,8 +682,7 @@ class Test:
                 # (pixels of the batch = the measure of its GPU work the run-ahead is budgeted in; a batch without an image tensor counts as a full budget)
                 inflight.append((batch_context, download, _batch_pixels(batch) or self.INFLIGHT_PIXELS, slot))
                 # finish the oldest batch once enough work is enqueued behind it to cover the host's share of finishing it
-                while inflight and (not pipelined or len(inflight) > self.MAX_INFLIGHT or
-                                    (len(inflight) > 1 and sum(e[2] for e in inflight) - inflight[0][2] >= self.INFLIGHT_PIXELS)):
+                while _finish_oldest_now([e[2] for e in inflight], pipelined, self.INFLIGHT_PIXELS, self.MAX_INFLIGHT):
                     finish_oldest()
             while inflight:
                 finish_oldest()

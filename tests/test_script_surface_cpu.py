@@ -495,3 +495,29 @@ def test_pass_groups_are_balanced_over_the_lanes_and_capped_by_the_2gb_tensor_bo
     isic = model_mod.UNet(2, 3, 4, 32, 0.05)
     assert steps.pass_group_size(isic, 32, 256, 256, steps.McPredictStep.GROUP_PIXELS) == 7
     assert steps.pass_group_size(object(), 32, 256, 256, steps.McPredictStep.GROUP_PIXELS) == 7       # a foreign module: the pixel rule alone
+
+
+def test_the_test_loop_runs_ahead_by_a_pixel_budget():
+    """loops._finish_oldest_now: two volume-sized batches stay enqueued behind the one being finished, ten of the shipped batches of 32 slices
+    (two volumes' worth of pixels), tiny batches are capped by MAX_INFLIGHT, the plain loop finishes every batch at once."""
+    from rcu_amd import loops
+    budget, cap = loops.Test.INFLIGHT_PIXELS, loops.Test.MAX_INFLIGHT
+    volume, batch32, one = 160 * 192 * 128, 32 * 192 * 128, 32 * 32
+
+    def steady_depth(px):
+        inflight, deepest = [], 0
+        for _ in range(100):
+            inflight.append(px)
+            while loops._finish_oldest_now(inflight, True, budget, cap):
+                inflight.pop(0)
+            deepest = max(deepest, len(inflight))
+        return deepest
+
+    assert budget == 2 * volume
+    assert steady_depth(volume) == 2            # volume-sized batches: two enqueued while the one before them is finished
+    assert steady_depth(batch32) == 10
+    assert steady_depth(one) == cap
+    assert not loops._finish_oldest_now([], True, budget, cap)
+    assert not loops._finish_oldest_now([one], True, budget, cap)
+    assert loops._finish_oldest_now([one], False, budget, cap)
+    assert loops._finish_oldest_now([volume, volume, volume], True, budget, cap)
