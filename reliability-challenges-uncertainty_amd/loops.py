@@ -604,7 +604,7 @@ class Test:
     at most ``MAX_INFLIGHT`` batches (two volume-sized batches, ten of 32 slices).  One batch ahead (rounds 2-3) hides the host's work on a batch behind the next batch's kernels only
     when batches are volume-sized: with the shipped ``batch_size: 32`` a batch is 24 ms of GPU work, and the batch that completes a subject
     costs the host 100-190 ms (assembly, the metric seam, argmax, hand-over to the NIfTI writers; tools/loop_timeline.py) -- the GPU idled
-    a third of the time; ten batches ahead keep it busy (0.185-0.192 -> 0.133-0.149 s per subject, tools/script_throughput.py 16 20 32 0;
+    a third of the time; ten batches ahead keep it busy (0.185-0.192 -> 0.133-0.155 s per subject, tools/script_throughput.py 16 20 32 0;
     0.12 with coalescing, which also makes the launches volume-sized).
     ``coalesce`` (pipelined only; OPT-IN: the constructor argument, the YAML key ``others.coalesce_pixels`` the scripts pass on, or
     ``RCU_COALESCE``; default 0 = off, as the reference, whose loop never regroups batches): consecutive loader batches are merged up to
