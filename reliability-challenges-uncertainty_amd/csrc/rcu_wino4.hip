@@ -756,7 +756,11 @@ static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
         case 1: return launch_wino4_var<T, 1>(a, stream);
         case 2: return launch_wino4_var<T, 2>(a, stream);
         case 3: return launch_wino4_var<T, 3>(a, stream);
+        case 4: return launch_wino4_var<T, 4>(a, stream);
+        case 5: return launch_wino4_var<T, 5>(a, stream);
+        case 6: return launch_wino4_var<T, 6>(a, stream);
         case 7: return launch_wino4_var<T, 7>(a, stream);
+        case 8: return launch_wino4_var<T, 8>(a, stream);
         case 11: return launch_wino4_var<T, 11>(a, stream);
         case 15: return launch_wino4_var<T, 15>(a, stream);
         case 16: return launch_wino4_var<T, 16>(a, stream);
