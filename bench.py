@@ -443,6 +443,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints its version banner to file descriptor 1 when the
+    # communicator is created): from here on descriptor 1 is this process's stderr, and the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
     # Test-only switches for a box with ONE GPU (RCCL refuses two ranks per device): all ranks on device 0 over gloo.
@@ -949,7 +954,8 @@ def main():
         result['rccl_rehearsal'] = dict(backend=dist.get_backend(), world=dist.get_world_size(), ws_transport=runner.ws_transport,
                                         p2p_messages=runner.p2p_messages,
                                         note='RCU_BENCH_FORCE_PG=1: one-rank process group, every step through the exchange path')
-    print(json.dumps(result))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(result) + '\n').encode())
     if collective:
         dist.destroy_process_group()
 
