@@ -210,11 +210,19 @@ int rcu_postnet_forward(rcu_postnet* h, const float* features_dev, int channel_p
 #define RCU_MC_MI 1           /* also track sum_t H(p_t)  -> mutual_info available */
 #define RCU_MC_VAR 2          /* statistics in float64 incl. sum p^2 -> variance available */
 #define RCU_MC_INPUT_PROBS 4  /* rcu_mc_accumulate input is already softmax-ed */
+#define RCU_MC_EXACT 8        /* statistics in float64, every addend rounded to a multiple of 2^-40 first: all additions are exact */
+#define RCU_MC_EXACT_MAX_PASSES 2048
 
 /* Size of the statistics blob for n*hw voxels.  Layout: planes over voxel v = n_idx*hw + pix;
- * without RCU_MC_VAR float32 planes [sum p_c (C)] [sum H (if MI)]; with RCU_MC_VAR float64 planes
- * [sum p_c (C)] [sum p_c^2 (C)] [sum H (if MI)].  The blob is plain additive: partial blobs of
- * disjoint pass subsets are merged by element-wise addition (one RCCL sum-reduce). */
+ * with neither RCU_MC_VAR nor RCU_MC_EXACT float32 planes [sum p_c (C)] [sum H (if MI)]; with either, float64 planes
+ * [sum p_c (C)] [sum p_c^2 (C) (if VAR)] [sum H (if MI)].  The blob is plain additive: partial blobs of
+ * disjoint pass subsets are merged by element-wise addition (one RCCL sum-reduce).
+ * RCU_MC_EXACT (what the predict steps of the product use): an addend x (a pass's p_c, p_c^2 or entropy, all <= log 8) enters as
+ * (x + 6144.0) - 6144.0 in float64, i.e. rounded to the nearest multiple of 2^-40; sums of such multiples below 2^13 are exactly
+ * representable, so every addition -- in a kernel, between stream lanes, in the collective -- is exact and the merged statistics of
+ * up to RCU_MC_EXACT_MAX_PASSES passes do not depend on the order, the pass groups, the lanes, the number of ranks or the
+ * collective's reduction tree: a run on 8 GPUs writes the bytes a run on one GPU writes.  Cost against the reference's float32
+ * mean: |delta p| <= 2^-41 per pass on probabilities below 2^-17. */
 size_t rcu_mc_stats_bytes(size_t n, size_t hw, int nb_classes, int flags);
 int rcu_mc_begin(void* stats_dev, size_t n, size_t hw, int nb_classes, int flags, void* stream);
 /* in_dev: [n][C][hw] logits (softmax applied here) or probabilities (RCU_MC_INPUT_PROBS). */

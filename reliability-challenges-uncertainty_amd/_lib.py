@@ -15,6 +15,8 @@ LIB_PATH = os.environ.get('RCU_HIP_LIBRARY') or os.path.join(PKG_DIR, 'librcu_hi
 RCU_MC_MI = 1
 RCU_MC_VAR = 2
 RCU_MC_INPUT_PROBS = 4
+RCU_MC_EXACT = 8
+RCU_MC_EXACT_MAX_PASSES = 2048
 RCU_MAX_BINS = 32
 RCU_MAX_THRESHOLDS = 16
 

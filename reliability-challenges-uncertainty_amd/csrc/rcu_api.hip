@@ -908,7 +908,7 @@ extern "C" int rcu_unet_forward_accumulate(rcu_unet* h, const float* x_dev, int 
                                            int flags, void* stream)
 {
     if (!stats_dev) return fail(RCU_ERR_INVALID, "rcu_unet_forward_accumulate: null stats");
-    return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR),
+    return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR | RCU_MC_EXACT),
                         static_cast<hipStream_t>(stream));
 }
 
@@ -916,7 +916,7 @@ extern "C" int rcu_unet_forward_accumulate_sigma(rcu_unet* h, const float* x_dev
                                                  int flags, float* sigma_sum_dev, int is_log_sigma, void* stream)
 {
     if (!stats_dev || !sigma_sum_dev) return fail(RCU_ERR_INVALID, "rcu_unet_forward_accumulate_sigma: null stats / sigma sum");
-    return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR),
+    return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR | RCU_MC_EXACT),
                         static_cast<hipStream_t>(stream), 1, sigma_sum_dev, is_log_sigma ? 1 : 0);
 }
 
@@ -924,7 +924,7 @@ extern "C" int rcu_unet_forward_accumulate_sigma_passes(rcu_unet* h, const float
                                                         void* stats_dev, int flags, float* sigma_sum_dev, int is_log_sigma, void* stream)
 {
     if (!stats_dev || !sigma_sum_dev) return fail(RCU_ERR_INVALID, "rcu_unet_forward_accumulate_sigma_passes: null stats / sigma sum");
-    return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR),
+    return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR | RCU_MC_EXACT),
                         static_cast<hipStream_t>(stream), passes, sigma_sum_dev, is_log_sigma ? 1 : 0);
 }
 
@@ -1089,7 +1089,7 @@ extern "C" int rcu_unet_forward_accumulate_passes(rcu_unet* h, const float* x_de
                                                   void* stats_dev, int flags, void* stream)
 {
     if (!stats_dev) return fail(RCU_ERR_INVALID, "rcu_unet_forward_accumulate_passes: null stats");
-    return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR),
+    return forward_impl(h, x_dev, n, masks_dev, nullptr, nullptr, stats_dev, flags & (RCU_MC_MI | RCU_MC_VAR | RCU_MC_EXACT),
                         static_cast<hipStream_t>(stream), passes);
 }
 
@@ -1148,7 +1148,7 @@ extern "C" size_t rcu_mc_stats_bytes(size_t n, size_t hw, int C, int flags)
 {
     const size_t V = n * hw;
     const size_t mi = (flags & RCU_MC_MI) ? 1 : 0;
-    if (flags & RCU_MC_VAR) return V * (2 * (size_t)C + mi) * sizeof(double);
+    if (flags & (RCU_MC_VAR | RCU_MC_EXACT)) return V * ((size_t)C + ((flags & RCU_MC_VAR) ? (size_t)C : 0) + mi) * sizeof(double);
     return V * ((size_t)C + mi) * sizeof(float);
 }
 
@@ -1177,6 +1177,8 @@ extern "C" int rcu_mc_finalize(const void* stats, size_t n, size_t hw, int C, in
     if (T < 1) return fail(RCU_ERR_INVALID, "rcu_mc_finalize: T must be >= 1");
     if (mi && !(flags & RCU_MC_MI)) return fail(RCU_ERR_INVALID, "mutual_info requested without RCU_MC_MI statistics");
     if (var && !(flags & RCU_MC_VAR)) return fail(RCU_ERR_INVALID, "variance requested without RCU_MC_VAR statistics");
+    if ((flags & RCU_MC_EXACT) && T > RCU_MC_EXACT_MAX_PASSES)
+        return fail(RCU_ERR_INVALID, "RCU_MC_EXACT statistics hold at most 2048 passes (sums of multiples of 2^-40 below 2^13)");
     if (n * hw == 0) return RCU_OK;
     RCU_HIP(launch_mc_finalize(stats, C, n, hw, T, flags, mean, entropy, mi, var, static_cast<hipStream_t>(stream)));
     return RCU_OK;

@@ -161,11 +161,13 @@ hipError_t launch_pack_input(const float* x_nchw, float* out_nhwc, int N, int C,
                              hipStream_t stream);
 
 // MC statistics blob: planes over the voxel index v = n*HW + hw.
-//   flags & RCU_MC_VAR == 0 : float planes  [sum_p[0..C-1]] [sum_H if MI]
-//   flags & RCU_MC_VAR != 0 : double planes [sum_p[0..C-1]] [sum_p^2[0..C-1]] [sum_H if MI]
+//   neither RCU_MC_VAR nor RCU_MC_EXACT : float planes  [sum_p[0..C-1]] [sum_H if MI]
+//   RCU_MC_VAR and / or RCU_MC_EXACT    : double planes [sum_p[0..C-1]] [sum_p^2[0..C-1] if VAR] [sum_H if MI]
+//   RCU_MC_EXACT: the addends are rounded to multiples of 2^-40 first, which makes every addition exact (rcu_head_common.h)
 constexpr int MC_MI = 1;
 constexpr int MC_VAR = 2;
 constexpr int MC_INPUT_PROBS = 4;   // accumulate: input already holds probabilities (ensemble seam)
+constexpr int MC_EXACT = 8;
 constexpr int MAX_CLASSES = 8;
 
 struct HeadArgs {

@@ -398,31 +398,7 @@ __global__ __launch_bounds__(PW_THREADS) void mc_accumulate4_kernel(const float4
         for (int c = 0; c < C; ++c) p[k][c] = reinterpret_cast<const float*>(&x[c])[k];
         if (!(flags & MC_INPUT_PROBS)) softmax_inplace<C>(p[k]);
     }
-    if (flags & MC_VAR) {
-        double2* sd = reinterpret_cast<double2*>(stats);      // plane k: [V] doubles = [2 V4] double2
-        const size_t P2 = 2 * (size_t)V4;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                double2 a = sd[(size_t)c * P2 + 2 * (size_t)i + h], b = sd[(size_t)(C + c) * P2 + 2 * (size_t)i + h];
-                const double p0 = (double)p[2 * h][c], p1 = (double)p[2 * h + 1][c];
-                a.x += p0; a.y += p1;
-                b.x += p0 * p0; b.y += p1 * p1;
-                sd[(size_t)c * P2 + 2 * (size_t)i + h] = a;
-                sd[(size_t)(C + c) * P2 + 2 * (size_t)i + h] = b;
-            }
-        }
-        if (flags & MC_MI) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                double2 e = sd[(size_t)(2 * C) * P2 + 2 * (size_t)i + h];
-                e.x += (double)entropy_of<C>(p[2 * h]);
-                e.y += (double)entropy_of<C>(p[2 * h + 1]);
-                sd[(size_t)(2 * C) * P2 + 2 * (size_t)i + h] = e;
-            }
-        }
-    } else {
+    {      // float32 planes only (launch_mc_accumulate sends float64 statistics to the one-voxel kernel)
         float4* sf = reinterpret_cast<float4*>(stats);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -443,7 +419,7 @@ hipError_t launch_mc_accumulate(const float* in, void* stats, int C, size_t N, s
     const size_t V = N * HW;
     // (float64 statistics -- 80 bytes of read-modify-write per voxel -- run as fast or faster one voxel per thread: measured 0.84 / 0.73 of
     // the HBM peak on one / four volumes against 0.83 / 0.67 with four voxels per thread; profiles/r04_aggregation.txt)
-    if (!(flags & MC_VAR) && vec4_ok(HW, V, {in, stats})) {
+    if (!(flags & (MC_VAR | MC_EXACT)) && vec4_ok(HW, V, {in, stats})) {
         RCU_DISPATCH_C(C, hipLaunchKernelGGL(mc_accumulate4_kernel<C_>, dim3(grid_for(V / 4)), dim3(PW_THREADS), 0, stream,
                                              reinterpret_cast<const float4*>(in), stats, (uint32_t)(HW / 4), (uint32_t)(V / 4), flags));
         return hipGetLastError();
@@ -464,17 +440,20 @@ __global__ __launch_bounds__(PW_THREADS) void mc_finalize_kernel(const void* sta
     const size_t n = v / HW, hw = v % HW;
     float p[C];
     float sum_h = 0.f;
-    if (flags & MC_VAR) {
+    if (mc_is_f64(flags)) {
         const double* sd = reinterpret_cast<const double*>(stats);
         double vsum = 0.0;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const double s = sd[(size_t)c * V + v], q = sd[(size_t)(C + c) * V + v];
+            const double s = sd[(size_t)c * V + v];
             p[c] = (float)(s / (double)T);
-            vsum += (q - s * s / (double)T) / (double)(T - 1);   // unbiased, as torch.var (customsteps.py:70)
+            if (flags & MC_VAR) {
+                const double q = sd[(size_t)(C + c) * V + v];
+                vsum += (q - s * s / (double)T) / (double)(T - 1);   // unbiased, as torch.var (customsteps.py:70)
+            }
         }
-        if (var != nullptr) var[v] = (float)(vsum / (double)C);
-        if (flags & MC_MI) sum_h = (float)sd[(size_t)(2 * C) * V + v];
+        if (var != nullptr && (flags & MC_VAR)) var[v] = (float)(vsum / (double)C);
+        if (flags & MC_MI) sum_h = (float)sd[(size_t)mc_h_plane(flags, C) * V + v];
     } else {
         const float* sf = reinterpret_cast<const float*>(stats);
 #pragma unroll
@@ -499,7 +478,7 @@ __global__ __launch_bounds__(PW_THREADS) void mc_finalize4_kernel(const void* st
     if (i >= V4) return;
     const uint32_t n = i / HW4, q = i - n * HW4;
     float p[4][C], sum_h[4] = {0.f, 0.f, 0.f, 0.f}, vr[4] = {0.f, 0.f, 0.f, 0.f};
-    if (flags & MC_VAR) {
+    if (mc_is_f64(flags)) {
         const double2* sd = reinterpret_cast<const double2*>(stats);
         const size_t P2 = 2 * (size_t)V4;
         double vsum[4] = {0.0, 0.0, 0.0, 0.0};
@@ -507,11 +486,14 @@ __global__ __launch_bounds__(PW_THREADS) void mc_finalize4_kernel(const void* st
         for (int c = 0; c < C; ++c) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const double2 s2 = sd[(size_t)c * P2 + 2 * (size_t)i + h], q2 = sd[(size_t)(C + c) * P2 + 2 * (size_t)i + h];
+                const double2 s2 = sd[(size_t)c * P2 + 2 * (size_t)i + h];
                 p[2 * h][c] = (float)(s2.x / (double)T);
                 p[2 * h + 1][c] = (float)(s2.y / (double)T);
-                vsum[2 * h] += (q2.x - s2.x * s2.x / (double)T) / (double)(T - 1);   // unbiased, as torch.var (customsteps.py:70)
-                vsum[2 * h + 1] += (q2.y - s2.y * s2.y / (double)T) / (double)(T - 1);
+                if (flags & MC_VAR) {
+                    const double2 q2 = sd[(size_t)(C + c) * P2 + 2 * (size_t)i + h];
+                    vsum[2 * h] += (q2.x - s2.x * s2.x / (double)T) / (double)(T - 1);   // unbiased, as torch.var (customsteps.py:70)
+                    vsum[2 * h + 1] += (q2.y - s2.y * s2.y / (double)T) / (double)(T - 1);
+                }
             }
         }
 #pragma unroll
@@ -519,7 +501,7 @@ __global__ __launch_bounds__(PW_THREADS) void mc_finalize4_kernel(const void* st
         if (flags & MC_MI) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const double2 e = sd[(size_t)(2 * C) * P2 + 2 * (size_t)i + h];
+                const double2 e = sd[(size_t)mc_h_plane(flags, C) * P2 + 2 * (size_t)i + h];
                 sum_h[2 * h] = (float)e.x;
                 sum_h[2 * h + 1] = (float)e.y;
             }

@@ -26,6 +26,11 @@ import torch.utils.data as torch_data
 
 from . import nifti
 
+# The block loader copies out of read-only file mappings through torch.from_numpy (it only reads them); torch warns about the non-writable
+# array once per process.  One targeted process-wide filter, installed at import: warnings.catch_warnings() around the copy is not
+# thread-safe (it swaps the global filter list) and that copy runs on the loader thread beside the main thread's own warnings.
+warnings.filterwarnings('ignore', message='The given NumPy array is not writable', category=UserWarning)
+
 
 # ------------------------------------------------------------------------------------ transforms
 # Every transform also has a ``batched`` form that takes a dict of BLOCKS (``[n, ...]`` arrays: n consecutive samples) and gives, per
@@ -209,8 +214,9 @@ def _npz_member_mmap(path, name):
 class VolumeDataset(torch_data.Dataset):
     """One sample = one slice (axis 0) of one subject; subjects in sorted order, optionally a subset."""
 
-    def __init__(self, dataset_dir, transform=None, subject_subset=None, slice_categories=('images',)):
+    def __init__(self, dataset_dir, transform=None, subject_subset=None, slice_categories=('images',), block_loader=True):
         self.slice_categories = tuple(slice_categories)
+        self.block_loader = bool(block_loader)      # False: the per-slice path (one __getitem__ per sample) instead of block extraction
         if str(dataset_dir).endswith(('.h5', '.hdf5')):
             raise ValueError('"{}": pymia HDF5 datasets cannot be read in this environment (no h5py / pymia); export the '
                              'volumes with rcu_amd.data.write_volume(<dir>, subject, images, labels) and point '
@@ -282,7 +288,7 @@ class VolumeDataset(torch_data.Dataset):
         """A loader batch at once (torch's DataLoader calls this with the batch's indices when it exists): runs of consecutive
         slices of one subject are taken from the volume as blocks and go through the batched forms of the transforms -> a
         ``PreCollated`` batch, equal entry for entry to what CollateDict makes of the per-slice samples."""
-        if not getattr(self.transform, 'batchable', False) or os.environ.get('RCU_BLOCK_LOADER', '1') == '0':
+        if not getattr(self.transform, 'batchable', False) or not self.block_loader:
             return [self[i] for i in indices]
         keys = ('images', 'labels') if 'labels' in self.slice_categories else ('images',)
         blocks = {k: [] for k in keys}
@@ -314,9 +320,7 @@ class VolumeDataset(torch_data.Dataset):
                 if blk.nbytes >= (1 << 20) and all(s_ >= 0 for s_ in blk.strides):
                     # a large channel-last -> channel-first copy: torch splits it over its intra-op threads (numpy's runs on this one
                     # thread: 12 ms for a batch of 32 BraTS slices, beside the loader's other work for it)
-                    with warnings.catch_warnings():
-                        warnings.simplefilter('ignore', UserWarning)      # (a view of the read-only file mapping: only read here)
-                        piece.copy_(torch.from_numpy(blk))
+                    piece.copy_(torch.from_numpy(blk))      # (a view of the read-only file mapping, only read here: see the filter at the top)
                 else:
                     piece.numpy()[...] = blk
                 at += blk.shape[0]

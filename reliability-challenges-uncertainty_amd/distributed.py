@@ -15,6 +15,11 @@ across consecutive volumes.  To let it do so the ranks must not meet at every vo
 issues the reduce on RCCL's own stream, finalises on a side stream of the root and hands back a
 ``PendingSummary``; the compute stream of every rank goes straight on to its share of the next
 volume (T+1 = 21 jobs on 8 GPUs: 21 forward passes per rank per 8 volumes instead of 3 per volume).
+
+Behind the drop-in scripts: ``ShardedMcPredictStep`` / ``ShardedEnsemblePredictionStep`` are the ``BatchStep`` forms of the runners;
+``rcu_amd.scripts`` picks them when the script runs under ``python -m torch.distributed.run`` (``world_from_env``): every rank iterates
+the same loader, the root alone assembles, evaluates and writes.  Masks are a function of (seed, batch, pass) and the statistics are
+exact sums (rcu_amd.steps.McStatistics), so the files an N-rank run writes are the files the one-process run writes, byte for byte.
 """
 import collections
 import os
@@ -28,9 +33,16 @@ from . import steps as steps_mod
 class HipEngine:
     """The product engine: fused forward + softmax + accumulate on librcu_hip."""
 
-    def __init__(self, model, do_mi=False, do_var=False):
+    def __init__(self, model, do_mi=False, do_var=False, exact=True):
         self.model = model
         self.do_mi, self.do_var = do_mi, do_var
+        # exact sums (rcu_amd.steps.McStatistics, include/rcu.h RCU_MC_EXACT): float64 planes whose additions are all exact -- the merged
+        # statistics carry the same bits for every world size, job rotation, lane count and reduction tree of the collective
+        self.exact = bool(exact)
+
+    def _statistics(self, x, blob=None):
+        n, _, h, w = x.shape
+        return steps_mod.McStatistics(n, self.model.nb_classes, h, w, x.device, self.do_mi, self.do_var, blob=blob, exact=self.exact)
 
     def buffers(self, x, with_ws):
         """-> (flat reduce buffer, statistics object living in its head, ws tensor or None): the weight-scaling
@@ -38,11 +50,11 @@ class HipEngine:
         value is exact in float64, and a sum with the other ranks' zeros is too), so a volume is always one collective."""
         n, _, h, w = x.shape
         c = self.model.nb_classes
-        dtype = torch.float64 if self.do_var else torch.float32
-        n_stats = steps_mod.McStatistics.blob_elements(n, c, h * w, self.do_mi, self.do_var)
+        dtype = steps_mod.McStatistics.dtype_of(self.do_var, self.exact)
+        n_stats = steps_mod.McStatistics.blob_elements(n, c, h * w, self.do_mi, self.do_var, self.exact)
         n_ws = n * c * h * w if with_ws else 0
         flat = torch.empty(n_stats + n_ws, device=x.device, dtype=dtype)
-        stats = steps_mod.McStatistics(n, c, h, w, x.device, self.do_mi, self.do_var, blob=flat[:n_stats])
+        stats = self._statistics(x, flat[:n_stats])
         ws = None
         if with_ws:
             ws = flat[n_stats:].view(n, c, h, w)
@@ -77,8 +89,7 @@ class HipEngine:
 
     def side_statistics(self, x):
         """Fresh (zeroed) statistics for a stream lane of its own; ``merge`` adds them into the volume's statistics."""
-        n, _, h, w = x.shape
-        return steps_mod.McStatistics(n, self.model.nb_classes, h, w, x.device, self.do_mi, self.do_var)
+        return self._statistics(x)
 
     def merge(self, stats, side):
         stats.blob.add_(side.blob)          # plain sums (include/rcu.h, rcu_mc_*)
@@ -96,7 +107,8 @@ class AleatoricHipEngine(HipEngine):
     flat = [statistics | sigma sum [n,C,H,W] | ws probabilities | ws sigma]."""
 
     def __init__(self, model, is_log_sigma=False, do_mi=False):
-        super().__init__(model, do_mi, False)
+        # float32 statistics: the sigma sums share the buffer (unbounded addends: no exact form), one dtype per collective
+        super().__init__(model, do_mi, False, exact=False)
         if not getattr(model, 'sigma_out', False):
             raise ValueError('AleatoricHipEngine needs a model built with sigma_out=True')
         self.is_log_sigma = is_log_sigma
@@ -146,9 +158,7 @@ class AleatoricHipEngine(HipEngine):
         return {'ws_probabilities': ws[0], 'ws_sigma': ws[1]}
 
 
-def job_seed(seed, step_index, job):
-    """Seed of the dropout masks of MC pass ``job`` of volume ``step_index``: a function of (seed, volume, pass) only."""
-    return (int(seed) * 1000003 + int(step_index) * 10007 + int(job)) % (2 ** 63 - 1)
+job_seed = steps_mod.job_seed      # seed of the dropout masks of MC pass ``job`` of volume ``step_index``: a function of (seed, volume, pass) only
 
 
 class ShardedMcRunner:
@@ -165,8 +175,8 @@ class ShardedMcRunner:
     assignment launch -> lane is fixed, so the result does not depend on timing."""
 
     def __init__(self, model, mc_steps, ws_pass=True, rank=0, world=1, engine=None, do_mi=False, do_var=False,
-                 root=0, seed=0, pass_group=1, lanes=1, ws_transport=None, force_exchange=False):
-        self.engine = engine if engine is not None else HipEngine(model, do_mi, do_var)
+                 root=0, seed=0, pass_group=1, lanes=1, ws_transport=None, force_exchange=False, exact=True):
+        self.engine = engine if engine is not None else HipEngine(model, do_mi, do_var, exact)
         # force_exchange: run the exchange step (reduce / send-recv, asynchronous work handles, side-stream finalize) at world size 1 too --
         # the rehearsal of the RCCL path on a box with ONE GPU (tools/rccl_world1_rehearsal.py; needs an initialised process group).  A
         # sum-reduce over one rank leaves the buffer as it is, so the result carries the bits of the plain world-1 step.
@@ -174,8 +184,8 @@ class ShardedMcRunner:
         # How the weight-scaling probabilities reach the root: 'reduce' -- in the tail of the ONE reduce buffer (zeros on every rank
         # but their owner; one collective per volume, twice the bytes on every link) -- or 'p2p': the reduce carries the statistics
         # only and the owner of job 0 sends its tail to the root (nothing when the root owns it): half the bytes on the links the
-        # send does not use.  RCU_WS_TRANSPORT overrides the default.
-        self.ws_transport = ws_transport or os.environ.get('RCU_WS_TRANSPORT', 'reduce')
+        # send does not use.
+        self.ws_transport = ws_transport or 'reduce'
         if self.ws_transport not in ('reduce', 'p2p'):
             raise ValueError('ws_transport must be "reduce" or "p2p"')
         self.p2p_messages = 0          # send / recv pairs this rank took part in (0 whenever the root owns the weight-scaling pass)
@@ -352,6 +362,26 @@ class ShardedMcRunner:
         self._inflight.append(pending)
         return pending
 
+    def reduce_async(self, x, step_index=0, mask_sets=None, depth=2):
+        """The step-seam form: this rank's jobs of the batch and the exchange, WITHOUT the finalize.  Root -> (merged statistics with
+        ``count`` = T, dict of the weight-scaling outputs or None): the calling stream waits for the collective, so
+        ``MultiPredictionSummary`` finalises them like the statistics of a one-process step.  Other ranks -> (None, None): the collective
+        stays in flight (at most ``depth`` per rank, their buffers kept alive) while the rank goes on to the next batch."""
+        if not hasattr(self, '_inflight'):
+            self._inflight = collections.deque()
+        while len(self._inflight) >= depth:
+            self._inflight.popleft().retire()
+        flat, stats, ws = self._run_jobs(x, step_index, mask_sets)
+        works = self._exchange(flat, ws, step_index, async_op=True) if (self.world > 1 or self.force_exchange) else []
+        if self.rank != self.root:
+            self._inflight.append(PendingSummary(None, works=works, keep=(flat, ws)))
+            return None, None
+        for w in works:
+            w.wait()            # RCCL: the current stream waits for the collective's stream; gloo: the host does
+        stats.count = self.mc_steps
+        stats.keep = flat       # the statistics are a view into the reduce buffer
+        return stats, (self._ws_outputs(ws) if ws is not None else None)
+
     def drain(self):
         """Retire every reduce still in flight (call before destroying the process group)."""
         while getattr(self, '_inflight', None):
@@ -377,10 +407,11 @@ class ShardedEnsembleRunner(ShardedMcRunner):
     a static 2,2,1,1,1,1,1,1 split).  ``share_workspace``: members 2..K borrow the activation workspace of the first (one per
     stream lane; rcu_unet_create_with, include/rcu.h) -- K members cost lanes x 6.1 GB + K x 35 MB at 160 slices, not K x 6.1 GB."""
 
-    def __init__(self, members, rank=0, world=1, engine=None, do_mi=False, do_var=False, root=0, lanes=1, share_workspace=True):
+    def __init__(self, members, rank=0, world=1, engine=None, do_mi=False, do_var=False, root=0, lanes=1, share_workspace=True,
+                 exact=True):
         members = list(members)
         super().__init__(members[0] if members else None, len(members), ws_pass=False, rank=rank, world=world,
-                         engine=engine, do_mi=do_mi, do_var=do_var, root=root, lanes=lanes)
+                         engine=engine, do_mi=do_mi, do_var=do_var, root=root, lanes=lanes, exact=exact)
         self.members = members
         if share_workspace:
             steps_mod.share_member_workspaces(members)
@@ -421,3 +452,143 @@ class PendingSummary:
     def result(self):
         self.retire()
         return self.value
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the runners as batch steps of the drop-in scripts
+# ------------------------------------------------------------------------------------------------------------------------------
+class World:
+    """This process's place in a ``torch.distributed.run`` launch (RANK / WORLD_SIZE / LOCAL_RANK)."""
+
+    def __init__(self, rank=0, world=1, local_rank=0, device='cuda', backend=None):
+        self.rank, self.world, self.local_rank, self.device, self.backend = rank, world, local_rank, device, backend
+
+    @property
+    def is_root(self):
+        return self.rank == 0
+
+
+def world_from_env(device='cuda', backend=None):
+    """-> ``World``.  With WORLD_SIZE > 1 in the environment (a ``python -m torch.distributed.run`` launch) the process group is
+    initialised here: ``nccl`` (= RCCL over xGMI) with one GPU per rank -- the rank's device is ``cuda:LOCAL_RANK`` -- or, when the node
+    has fewer GPUs than ranks (the two-ranks-on-one-GPU rehearsal of the tests), ``gloo`` with every rank on the visible devices in turn.
+    Without WORLD_SIZE: rank 0 of a world of one, no process group."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return World(device=device)
+    rank, local = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    n_dev = torch.cuda.device_count()
+    if str(device).startswith('cuda'):
+        if n_dev < 1:
+            raise RuntimeError('rcu_amd needs a GPU (librcu_hip); there is no CPU fallback')
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+        if backend is None:
+            backend = 'nccl' if n_dev >= local_world else 'gloo'
+        device = 'cuda:{}'.format(local % n_dev)
+        torch.cuda.set_device(torch.device(device))
+    elif backend is None:
+        backend = 'gloo'
+    if not dist.is_initialized():
+        # (no device_id=: the communicator is created at the first collective; eager creation costs 2-3.5 % per step on this image, DESIGN.md 4)
+        dist.init_process_group(backend)
+    return World(rank, world, local, device, backend)
+
+
+class _ShardedStepBase(steps_mod.BatchStep):
+    """What the sharded predict steps share: a runner per model, bounded run-ahead, the root's hand-over to MultiPredictionSummary."""
+    MAX_AHEAD = 3       # batches a rank's host may enqueue ahead of its GPU (the buffers of every batch in flight stay allocated)
+
+    def __init__(self, world, do_mi, do_var, lanes, exact, engine_factory=None):
+        super().__init__()
+        self.rank, self.world = world.rank, world.world
+        self.engine_factory = engine_factory      # tests: model -> engine (the CPU tests of the step seam run an oracle-backed engine)
+        self.do_mi, self.do_var = do_mi, do_var
+        self.lanes = steps_mod.McPredictStep.LANES if lanes is None else max(1, int(lanes))
+        self.exact = bool(exact)
+        self._runner, self._runner_key = None, None
+        self._events = collections.deque()
+        self._batches = 0
+
+    def _engine(self, model):
+        return None if self.engine_factory is None else self.engine_factory(model)
+
+    def finish(self):
+        """Retire the collectives still in flight (before the process group goes away)."""
+        if self._runner is not None:
+            self._runner.drain()
+            import logging
+            logging.info('rank {} of {}: {} forward passes in {} batches'.format(self.rank, self.world, self._runner.forwards_run, self._batches))
+        self._events.clear()
+
+    def _throttle(self, device):
+        if device.type != 'cuda':
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events.append(ev)
+        while len(self._events) > self.MAX_AHEAD:
+            self._events.popleft().synchronize()
+
+    def _hand_over(self, batch_context, runner, x, step_index, mask_sets=None):
+        """This rank's jobs of the batch + the exchange.  Root: the merged statistics go under ``multi_probabilities`` (the compute stream
+        waits for the collective), the weight-scaling probabilities under ``ws_probabilities``; other ranks: ``None`` there
+        (MultiPredictionSummary then has nothing to do) and the reduce stays in flight behind the next batch's passes."""
+        stats, ws = runner.reduce_async(x, step_index, mask_sets)
+        self._batches += 1
+        batch_context.output['multi_probabilities'] = stats
+        if ws is not None:
+            batch_context.output.update(ws)
+        self._throttle(x.device)
+
+
+class ShardedMcPredictStep(_ShardedStepBase):
+    """``McPredictStep`` with the T stochastic passes (and the weight-scaling pass) of every batch sharded over the ranks of the process
+    group (``ShardedMcRunner``): rechun/dl/customsteps.py:10-39 behind bin-dl/brats_test_default.py:39,46-54 on N GPUs.  Every rank calls
+    the step with the SAME batch; the root's batch context receives what ``McPredictStep`` leaves there."""
+
+    def __init__(self, mc_steps, world, do_mi=False, do_var=False, masks=None, ws_pass=True, group_pixels=None, lanes=None, seed=0,
+                 exact=True, ws_transport=None, engine_factory=None) -> None:
+        super().__init__(world, do_mi, do_var, lanes, exact, engine_factory)
+        if seed is None:
+            raise ValueError('a sharded MC step needs a seed: the masks of a pass must not depend on the rank that runs it')
+        self.mc_steps, self.masks, self.ws_pass, self.seed = mc_steps, masks, ws_pass, seed
+        self.group_pixels = steps_mod.McPredictStep.GROUP_PIXELS if group_pixels is None else group_pixels
+        self.ws_transport = ws_transport
+
+    def __call__(self, batch_context, task_context, context) -> None:
+        steps_mod._check_context(context)
+        images = steps_mod._images_to_device(batch_context, context)
+        model = context.model
+        n, _, h, w = images.shape
+        group = steps_mod.pass_group_size(model, n, h, w, self.group_pixels)
+        group = max(1, min(group, self.mc_steps))
+        key = (id(model), group)
+        if self._runner_key != key:
+            self._runner = ShardedMcRunner(model, self.mc_steps, ws_pass=self.ws_pass, rank=self.rank, world=self.world, do_mi=self.do_mi,
+                                           do_var=self.do_var, seed=self.seed, pass_group=group, lanes=self.lanes,
+                                           ws_transport=self.ws_transport, exact=self.exact, engine=self._engine(model))
+            self._runner_key = key
+        self._hand_over(batch_context, self._runner, images, batch_context.batch_index, self.masks)
+
+
+class ShardedEnsemblePredictionStep(_ShardedStepBase):
+    """``EnsemblePredictionStep`` (bin-dl/brats_test_ensemble.py:72-94) with the K members of every batch sharded over the ranks
+    (``ShardedEnsembleRunner``: every rank holds all members -- 107 MB of packed weights each, one shared workspace per lane)."""
+
+    def __init__(self, additional_models, world, do_mi=False, do_var=False, lanes=None, exact=True, share_workspace=True,
+                 engine_factory=None) -> None:
+        super().__init__(world, do_mi, do_var, lanes, exact, engine_factory)
+        self.additional_models = additional_models
+        self.share_workspace = share_workspace
+
+    def __call__(self, batch_context, task_context, context) -> None:
+        steps_mod._check_context(context)
+        images = steps_mod._images_to_device(batch_context, context)
+        members = [context.model] + list(self.additional_models)
+        key = tuple(id(m) for m in members)
+        if self._runner_key != key:
+            self._runner = ShardedEnsembleRunner(members, rank=self.rank, world=self.world, do_mi=self.do_mi, do_var=self.do_var,
+                                                 lanes=min(self.lanes, len(members)), share_workspace=self.share_workspace, exact=self.exact,
+                                                 engine=self._engine(members[0]))
+            self._runner_key = key
+        self._hand_over(batch_context, self._runner, images, batch_context.batch_index)

@@ -65,6 +65,7 @@ class TorchTestContext(steps_mod.TorchTestContext):
 
     def __init__(self, device_str: str = 'cuda'):
         super().__init__(device_str)
+        self.writes_output = True      # False on the ranks other than the root of a sharded run (rcu_amd.scripts._context): no test directory, no log file
         self.config = None
         self.test_id = self.test_dir = self.log_file = ''
         self.model_files = None
@@ -83,12 +84,16 @@ class TorchTestContext(steps_mod.TorchTestContext):
         self.model_files = mgt.ModelFiles.from_model_dir(self.config.model_dir)
 
     def setup_directory(self):
+        if not self.writes_output:
+            return
         os.makedirs(self.test_dir, exist_ok=True)
         cfg.save(os.path.join(self.test_dir, 'config' + os.path.splitext(self.config_file_path)[1]), self.config)
         if self.config.split:
             shutil.copy(self.config.split, os.path.join(self.test_dir, os.path.basename(self.config.split)))
 
     def setup_logging(self):
+        if not self.writes_output:
+            return
         handler = logging.FileHandler(self.log_file)
         handler.setFormatter(logging.Formatter('%(asctime)s - %(filename)s:%(funcName)s %(levelname)s: %(message)s'))
         logging.getLogger().addHandler(handler)
@@ -371,13 +376,14 @@ class _Staged:
         self.released = 0        # order of the releases (the worker waits for the oldest one when none has completed)
 
 
-def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
+def prefetch(iterable, depth=2, pin=False, pin_entries=('images',), timing=False):
     """Iterate ``iterable`` from a background thread, ``depth`` items ahead: the loader's work for the next batches (file reads,
     decompression -- zlib and numpy release the GIL -- transforms, collation) overlaps the GPU work of the current one.  ``pin``:
     the ``pin_entries`` of a dict batch (the tensors a step copies to the device) are staged in pinned host memory there too, so
     that the step's host-to-device copy is asynchronous.  Yields ``(item, release)``: call ``release()`` once the copies of the
     item's pinned entries have been ENQUEUED (it records a CUDA event; the buffer is not written again before that event has
     completed).  Entries the steps keep on the host (labels) are never staged: they are the loader's own tensors.
+    ``timing``: the worker logs where its time went when the iterable is exhausted (tools/loop_timeline.py).
     Closing the generator (or an exception in the consumer) stops the worker."""
     import queue
     import threading
@@ -440,7 +446,6 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',)):
                 continue
         return False
 
-    timing = os.environ.get('RCU_LOOP_TIMING') == '1'
     spent = {'load': 0.0, 'stage': 0.0, 'items': 0, 'ring': 0.0, 'sync': 0.0, 'copy': 0.0}
 
     def timed_iter():
@@ -597,17 +602,21 @@ def _with_last_flag(iterable):
 
 
 class Test:
-    """``pipelined`` (default: on for a CUDA device, ``RCU_PIPELINE=0`` switches it off): the next batches are loaded and their GPU work
+    """``pipelined`` (default: on for a CUDA device; the constructor argument, or the YAML key ``others.pipelined`` the scripts pass on,
+    switches it off): the next batches are loaded and their GPU work
     enqueued while the outputs of batch k come to the host, so "batch k + 1 start" fires before "subjects of batch k" / "batch k
     end"; with ``pipelined=False`` every callback comes in the reference's order (loops.py:176-235).
     How far the loop runs ahead: until ``INFLIGHT_PIXELS`` (two BraTS volumes) worth of batches is enqueued behind the batch being finished,
-    at most ``MAX_INFLIGHT`` batches (two volume-sized batches, ten of 32 slices).  One batch ahead (rounds 2-3) hides the host's work on a batch behind the next batch's kernels only
+    at most ``MAX_INFLIGHT`` batches (two volume-sized batches, ten of 32 slices; ``max_inflight`` / ``inflight_pixels`` of the constructor --
+    YAML ``others.max_inflight`` -- bound it for memory-constrained runs: 1 = one batch ahead).  Output entries a run does not keep
+    (``entries``) are dropped from the batch context as soon as the kept ones are on their way to the host, so a batch in flight holds its
+    kept entries only.  One batch ahead (rounds 2-3) hides the host's work on a batch behind the next batch's kernels only
     when batches are volume-sized: with the shipped ``batch_size: 32`` a batch is 24 ms of GPU work, and the batch that completes a subject
     costs the host 100-190 ms (assembly, the metric seam, argmax, hand-over to the NIfTI writers; tools/loop_timeline.py) -- the GPU idled
     a third of the time; ten batches ahead keep it busy (0.185-0.192 -> 0.133-0.155 s per subject, tools/script_throughput.py 16 20 32 0;
     0.12 with coalescing, which also makes the launches volume-sized).
-    ``coalesce`` (pipelined only; OPT-IN: the constructor argument, the YAML key ``others.coalesce_pixels`` the scripts pass on, or
-    ``RCU_COALESCE``; default 0 = off, as the reference, whose loop never regroups batches): consecutive loader batches are merged up to
+    ``coalesce`` (OPT-IN: the constructor argument or the YAML key ``others.coalesce_pixels`` the scripts pass on;
+    default 0 = off, as the reference, whose loop never regroups batches): consecutive loader batches are merged up to
     that many samples x height x width before the steps run -- ``COALESCE_PIXELS`` = one BraTS volume, 160 x 192 x 128, is what fills
     the GPU (five batches of the shipped ``batch_size: 32`` become one step of 160 slices: the kernels' small levels run 1.3-2x faster
     per slice).  What it changes, which is why it is not a default: the YAML batch_size no longer is the step's batch; steps and hooks see
@@ -621,7 +630,7 @@ class Test:
     MAX_INFLIGHT = 12
 
     def __init__(self, steps: list, subject_steps: list = None, subject_assembler=None, entries: tuple = None,
-                 convert_fn=tensor_to_numpy, pipelined=None, coalesce=None):
+                 convert_fn=tensor_to_numpy, pipelined=None, coalesce=None, max_inflight=None, inflight_pixels=None, loader_timing=False):
         self.steps = steps
         self.subject_steps = subject_steps or []
         self.subject_assembler = subject_assembler
@@ -629,6 +638,9 @@ class Test:
         self.convert_fn = convert_fn
         self.pipelined = pipelined
         self.coalesce = coalesce
+        self.max_inflight = self.MAX_INFLIGHT if max_inflight is None else max(1, int(max_inflight))
+        self.inflight_pixels = self.INFLIGHT_PIXELS if inflight_pixels is None else max(1, int(inflight_pixels))
+        self.loader_timing = bool(loader_timing)
 
     def __call__(self, context, build_test, hook: TestLoopHook = TestLoopHook()):
         hook.on_startup()
@@ -647,18 +659,15 @@ class Test:
         # batch k come to the host -- and its subjects are assembled, evaluated and written -- while batch k + 1 computes.  Per
         # batch the order of the callbacks is the reference's (batch start, steps, subject start / steps / end, batch end); only
         # "batch k + 1 start" now comes before "subjects of batch k".  A custom convert_fn or a CPU device keeps the plain order.
-        pipelined = self.pipelined
-        if pipelined is None:
-            pipelined = os.environ.get('RCU_PIPELINE', '1') != '0'
+        pipelined = True if self.pipelined is None else self.pipelined
         pipelined = bool(pipelined) and (self.convert_fn is tensor_to_numpy and self.subject_assembler is not None and
                                          getattr(context.device, 'type', 'cpu') == 'cuda')
         side = torch.cuda.Stream(device=context.device) if pipelined else None
         self._subject_stream = torch.cuda.Stream(device=context.device) if pipelined else None
         loader = task_context.data.loader
-        if pipelined:
-            coalesce = self.coalesce if self.coalesce is not None else int(os.environ.get('RCU_COALESCE', 0))
-            if coalesce > 0:
-                loader = coalesced(loader, coalesce, lazy=True)
+        coalesce = int(self.coalesce or 0)
+        if coalesce > 0 and getattr(context.device, 'type', 'cpu') == 'cuda':
+            loader = coalesced(loader, coalesce, lazy=pipelined)
         inflight = collections.deque()        # (batch context, download, pixels, download slot) of the batches whose GPU work is enqueued
         free_slots, slots = [], 0             # download slots (a set of pinned buffers each): taken per batch, back when it is finished
 
@@ -667,7 +676,7 @@ class Test:
             self._finish_batch(batch_context, download, task_context, context, hook)
             free_slots.append(slot)
 
-        batches = prefetch(loader, depth=self.MAX_INFLIGHT if pipelined else 2, pin=pipelined)
+        batches = prefetch(loader, depth=self.max_inflight if pipelined else 2, pin=pipelined, timing=self.loader_timing)
         try:
             for i, ((batch, release), last) in enumerate(_with_last_flag(batches)):
                 batch_context = BatchContext(batch, i)
@@ -680,9 +689,9 @@ class Test:
                 download = self._run_steps(batch_context, task_context, context, side, slot)
                 release()                     # the step's host-to-device copies are enqueued: the staging buffers may go back
                 # (pixels of the batch = the measure of its GPU work the run-ahead is budgeted in; a batch without an image tensor counts as a full budget)
-                inflight.append((batch_context, download, _batch_pixels(batch) or self.INFLIGHT_PIXELS, slot))
+                inflight.append((batch_context, download, _batch_pixels(batch) or self.inflight_pixels, slot))
                 # finish the oldest batch once enough work is enqueued behind it to cover the host's share of finishing it
-                while _finish_oldest_now([e[2] for e in inflight], pipelined, self.INFLIGHT_PIXELS, self.MAX_INFLIGHT):
+                while _finish_oldest_now([e[2] for e in inflight], pipelined, self.inflight_pixels, self.max_inflight):
                     finish_oldest()
             while inflight:
                 finish_oldest()
@@ -702,7 +711,12 @@ class Test:
             task_context.history.add(batch_context.metrics, 'batch_metrics')
         if side is None or self.subject_assembler is None:
             return None
-        return _Download(self._kept(batch_context), side, slot)
+        kept = self._kept(batch_context)
+        download = _Download(kept, side, slot)
+        # up to max_inflight batches are enqueued before this one is finished: the entries nobody keeps must not stay on the GPU that long
+        batch_context.output = {key: value for key, value in batch_context.output.items()
+                                if key in kept or not (isinstance(value, torch.Tensor) and value.is_cuda)}
+        return download
 
     def _finish_batch(self, batch_context, download, task_context, context, hook):
         if self.subject_assembler is not None:

@@ -17,6 +17,7 @@ import os
 import numpy as np
 
 from . import data as data_mod
+from . import distributed as rdist
 from . import evalrun
 from . import evaluation as ev
 from . import loops
@@ -93,15 +94,41 @@ class PrepareSubjectStep(steps.BatchStep):
         batch_context.output['labels'] = batch_context.input['labels'].unsqueeze(1)   # isic_test_default.py:62-66
 
 
-def _default_steps(context):
+def _other(context, key, default=None):
+    """A key of the YAML file's free-form ``others`` (rcu_amd extensions, absent from the reference's configs: coalesce_pixels, pipelined,
+    max_inflight, stream_lanes, device_metrics)."""
+    return getattr(context.config.others, key, default)
+
+
+def _mask_seed(context, world):
+    """Seed of the per-(batch, pass) Dropout2d masks: the YAML file's ``seed`` (the reference seeds torch with it,
+    common/trainloop/loops.py:183-185).  Without one a one-process run draws from the device generator; a sharded run agrees on a
+    random seed (the masks of a pass must not depend on the rank that runs it)."""
+    seed = context.config.seed
+    if seed is None and world.world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.randint(2 ** 31 - 1, (1,), dtype=torch.int64)
+        if world.backend == 'nccl':
+            t = t.to(world.device)
+        dist.broadcast(t, src=0)
+        seed = int(t.item())
+    return seed
+
+
+def _default_steps(context, world):
     if hasattr(context.config.others, 'mc'):
-        return [steps.McPredictStep(context.config.others.mc), steps.MultiPredictionSummary()]
+        lanes = _other(context, 'stream_lanes')
+        if world.world > 1:     # the T + 1 passes of every batch sharded over the ranks, one sum-reduce per batch (rcu_amd.distributed)
+            return [rdist.ShardedMcPredictStep(context.config.others.mc, world, seed=_mask_seed(context, world), lanes=lanes),
+                    steps.MultiPredictionSummary()]
+        return [steps.McPredictStep(context.config.others.mc, seed=_mask_seed(context, world), lanes=lanes), steps.MultiPredictionSummary()]
     return [steps.SegmentationPredictStep(do_probs=True)]
 
 
-def _hooks(write_hook):
-    return loops.ReducedComposeTestLoopHook([loops.ConsoleTestLogHook(), loops.WriteTestMetricsCsvHook('metrics.csv'),
-                                             write_hook])
+def _hooks(write_hook, context=None):
+    hooks = [loops.ConsoleTestLogHook(), loops.WriteTestMetricsCsvHook('metrics.csv'), write_hook]
+    return loops.ReducedComposeTestLoopHook(hooks)
 
 
 def _load_additional_models(context):
@@ -120,47 +147,85 @@ def _load_additional_models(context):
     return models
 
 
-def _coalesce(context):
-    """``others.coalesce_pixels`` of the YAML file (an rcu_amd extension, absent from the reference's configs): merge loader batches up to
-    that many pixels per step (loops.Test: opt-in, changes what hooks see and which masks a seed draws); None = the loop's default (off,
-    or RCU_COALESCE)."""
-    value = getattr(context.config.others, 'coalesce_pixels', None)
-    return None if value is None else int(value)
+def _loop_options(context):
+    """Test-loop options from the YAML file's ``others`` (rcu_amd extensions): ``coalesce_pixels`` -- merge loader batches up to that many
+    pixels per step (loops.Test: opt-in, changes what hooks see and which masks a seed draws; two BraTS volumes, 7864320, keep the
+    launches of an 8-GPU run at 640 samples) --, ``pipelined: false`` (the reference's callback order), ``max_inflight``,
+    ``loader_timing: true`` (the loader thread logs where its time went)."""
+    value = _other(context, 'coalesce_pixels')
+    return dict(coalesce=None if value is None else int(value), pipelined=_other(context, 'pipelined'),
+                max_inflight=_other(context, 'max_inflight'), loader_timing=bool(_other(context, 'loader_timing', False)))
 
 
-def _run(context, dataset, test_steps, write_hook, entries, device=None):
-    if dataset == 'brats':
-        build = data_mod.BuildData(build_dataset=data_mod.BuildVolumeDataset())
+def _context(device, config_file):
+    """-> (context, world): under ``python -m torch.distributed.run`` every rank gets its own GPU (rcu_amd.distributed.world_from_env) and
+    only rank 0 creates the test directory, logs, assembles, evaluates and writes."""
+    world = rdist.world_from_env(device)
+    context = loops.TorchTestContext(world.device)
+    context.writes_output = world.is_root
+    context.load_from_config(config_file)
+    return context, world
+
+
+def _run(context, dataset, test_steps, write_hook, entries, world=None):
+    world = world if world is not None else rdist.World()
+    sharded = [s_ for s_ in test_steps if isinstance(s_, rdist._ShardedStepBase)]
+    if world.world > 1 and not sharded:
+        # one deterministic forward pass per batch: nothing to shard over samples -- the run is rank 0's, the other ranks leave at once
+        if not world.is_root:
+            logging.info('rank {}: this configuration has one forward pass per batch, nothing to shard; rank 0 runs it'.format(world.rank))
+            return context
+    build = data_mod.BuildData(build_dataset=data_mod.BuildVolumeDataset() if dataset == 'brats' else data_mod.BuildIsicDataset())
+    options = _loop_options(context)
+    if dataset != 'brats':
+        test_steps = test_steps + [PrepareSubjectStep()]
+    if not world.is_root:
+        # a rank other than the root of a sharded run: the same loader and the same batch steps, nothing assembled, evaluated or written
+        # (the same coalescing: every rank must see the root's batches -- batch indices seed the masks, shapes size the collective)
+        test = loops.Test(test_steps, [], None, entries=(), coalesce=options['coalesce'], pipelined=False)
+        hook = loops.TestLoopHook()
+    elif dataset == 'brats':
         test = loops.Test(test_steps, [loops.ExtractSubjectInfoStep(), EvalSubjectStep()], loops.SubjectAssembler(),
-                          entries=entries, coalesce=_coalesce(context))
+                          entries=entries, **options)
+        hook = _hooks(write_hook, context)
     else:
-        build = data_mod.BuildData(build_dataset=data_mod.BuildIsicDataset())
-        test = loops.Test(test_steps + [PrepareSubjectStep()], [EvalSubjectStep(squeeze_labels=True, keep_prediction=True)],
-                          loops.Subject2dAssembler(), entries=entries, coalesce=_coalesce(context))
-    test(context, build, hook=_hooks(write_hook))
+        test = loops.Test(test_steps, [EvalSubjectStep(squeeze_labels=True, keep_prediction=True)],
+                          loops.Subject2dAssembler(), entries=entries, **options)
+        hook = _hooks(write_hook, context)
+    try:
+        test(context, build, hook=hook)
+    finally:
+        if world.world > 1:
+            import torch
+            import torch.distributed as dist
+            for s_ in sharded:
+                s_.finish()
+            torch.cuda.synchronize()
+            dist.barrier()           # no rank leaves (and frees what a collective still reads) before the root has the last batch
     return context
 
 
 def test_default(dataset, config_file=None, config_id=None, device='cuda'):
-    context = loops.TorchTestContext(device)
-    context.load_from_config(config_file or _config_path(dataset, config_id))
+    context, world = _context(device, config_file or _config_path(dataset, config_id))
     entries = ('probabilities',) if dataset == 'brats' else None
-    return _run(context, dataset, _default_steps(context), WriteHook(link_inputs=dataset == 'isic'), entries)
+    return _run(context, dataset, _default_steps(context, world), WriteHook(link_inputs=dataset == 'isic'), entries, world)
 
 
 def test_ensemble(dataset, config_file=None, device='cuda'):
-    context = loops.TorchTestContext(device)
-    context.load_from_config(config_file or os.path.join(CONFIG_DIR, 'test_{}_ensemble.yaml'.format(dataset)))
+    context, world = _context(device, config_file or os.path.join(CONFIG_DIR, 'test_{}_ensemble.yaml'.format(dataset)))
     members = _load_additional_models(context)
-    test_steps = [steps.EnsemblePredictionStep(members), steps.MultiPredictionSummary()]
-    return _run(context, dataset, test_steps, WriteHook(link_inputs=dataset == 'isic'), None)
+    lanes = _other(context, 'stream_lanes')
+    if world.world > 1:     # the K members of every batch sharded over the ranks (bin-dl/brats_test_ensemble.py:44-59 on N GPUs)
+        test_steps = [rdist.ShardedEnsemblePredictionStep(members, world, lanes=lanes), steps.MultiPredictionSummary()]
+    else:
+        test_steps = [steps.EnsemblePredictionStep(members, lanes=lanes), steps.MultiPredictionSummary()]
+    return _run(context, dataset, test_steps, WriteHook(link_inputs=dataset == 'isic'), None, world)
 
 
 def test_aleatoric(dataset, config_file=None, device='cuda'):
-    context = loops.TorchTestContext(device)
-    context.load_from_config(config_file or os.path.join(CONFIG_DIR, 'test_{}_aleatoric.yaml'.format(dataset)))
+    context, world = _context(device, config_file or os.path.join(CONFIG_DIR, 'test_{}_aleatoric.yaml'.format(dataset)))
     return _run(context, dataset, [steps.AleatoricPredictStep()], WriteHook(with_sigma=True, link_inputs=dataset == 'isic'),
-                None)
+                None, world)
 
 
 # ------------------------------------------------------------------------------- auxiliary networks

@@ -21,7 +21,6 @@ sums, updated by the fused forward+softmax+accumulate kernel) under ``multi_prob
 """
 import abc
 import logging
-import os
 
 import torch
 
@@ -87,17 +86,25 @@ def set_dropout_mode(model, is_train=True):
                 m.eval()
 
 
+def job_seed(seed, step_index, job):
+    """Seed of the dropout masks of MC pass ``job`` (1..T) of batch / volume ``step_index``: a function of (seed, batch, pass) only -- not
+    of the pass groups, the stream lanes, the rank that runs the pass or the number of ranks."""
+    return (int(seed) * 1000003 + int(step_index) * 10007 + int(job)) % (2 ** 63 - 1)
+
+
 class McStatistics:
     """Per-voxel sufficient statistics of the passes seen so far (the ``stats`` blob of include/rcu.h).
     Plain additive: blobs of disjoint pass subsets merge by ``+`` (one RCCL sum-reduce, see
-    rcu_amd.distributed)."""
+    rcu_amd.distributed).  ``exact`` (RCU_MC_EXACT; what the predict steps use): float64 planes whose addends are rounded to multiples
+    of 2^-40 first -- every addition is then exact, so the sums (and everything finalised from them) carry the same bits whatever the order of
+    the passes, the pass groups, the stream lanes, the ranks and the collective's reduction tree."""
 
-    def __init__(self, n, nb_classes, height, width, device, do_mi=False, do_var=False, blob=None):
+    def __init__(self, n, nb_classes, height, width, device, do_mi=False, do_var=False, blob=None, exact=False):
         self.n, self.nb_classes, self.height, self.width = n, nb_classes, height, width
         self.hw = height * width
-        self.flags = (_lib.RCU_MC_MI if do_mi else 0) | (_lib.RCU_MC_VAR if do_var else 0)
-        elems = self.blob_elements(n, nb_classes, self.hw, do_mi, do_var)
-        dtype = torch.float64 if do_var else torch.float32
+        self.flags = self.flags_of(do_mi, do_var, exact)
+        elems = self.blob_elements(n, nb_classes, self.hw, do_mi, do_var, exact)
+        dtype = self.dtype_of(do_var, exact)
         if blob is None:
             blob = torch.empty(elems, device=device, dtype=dtype)
         elif blob.numel() != elems or blob.dtype != dtype or not blob.is_contiguous():
@@ -111,9 +118,21 @@ class McStatistics:
                                             _lib.current_stream()))
 
     @staticmethod
-    def blob_elements(n, nb_classes, hw, do_mi=False, do_var=False):
-        flags = (_lib.RCU_MC_MI if do_mi else 0) | (_lib.RCU_MC_VAR if do_var else 0)
-        return _lib.load().rcu_mc_stats_bytes(n, hw, nb_classes, flags) // (8 if do_var else 4)
+    def flags_of(do_mi=False, do_var=False, exact=False):
+        return (_lib.RCU_MC_MI if do_mi else 0) | (_lib.RCU_MC_VAR if do_var else 0) | (_lib.RCU_MC_EXACT if exact else 0)
+
+    @staticmethod
+    def dtype_of(do_var=False, exact=False):
+        return torch.float64 if (do_var or exact) else torch.float32
+
+    @staticmethod
+    def blob_elements(n, nb_classes, hw, do_mi=False, do_var=False, exact=False):
+        flags = McStatistics.flags_of(do_mi, do_var, exact)
+        return _lib.load().rcu_mc_stats_bytes(n, hw, nb_classes, flags) // (8 if (do_var or exact) else 4)
+
+    @property
+    def exact(self):
+        return bool(self.flags & _lib.RCU_MC_EXACT)
 
     @property
     def do_mi(self):
@@ -304,7 +323,13 @@ class SegmentationPredictStep(BatchStep):
 
 class McPredictStep(BatchStep):
     """T stochastic passes (plus the deterministic 'weight scaling' pass the reference always runs
-    first, customsteps.py:22-25)."""
+    first, customsteps.py:22-25).
+    ``seed``: the Dropout2d masks of pass j of batch k are drawn from a generator seeded with ``job_seed(seed, k, j)`` (k =
+    ``batch_context.batch_index``) instead of the device's default generator: the T samples of a batch are then a function of (seed,
+    batch, pass) alone -- the same whatever the pass groups and stream lanes, and the same when the passes are sharded over several GPUs
+    (rcu_amd.distributed.ShardedMcPredictStep).  The drop-in scripts pass the YAML file's ``seed``.
+    ``exact`` (default): the statistics are exact sums (McStatistics), so that ``MultiPredictionSummary``'s outputs do not depend on
+    how the passes were grouped, laned or sharded either; ``exact=False`` keeps float32 sums (float64 with ``do_var``)."""
 
     # A forward pass fills the GPU from about 160 BraTS slices (3.9 M pixels) on, and the deep levels of the U-Net -- few, long
     # work items per launch -- only from two to four times that (their last round of workgroups is 75-88 % full at 160 slices, 94 % at
@@ -313,10 +338,10 @@ class McPredictStep(BatchStep):
     # statistics bit for bit; the workspace grows to that of a 640-slice batch (12 GB per lane of the 288), not beyond, and
     # pass_group_size keeps every tensor below the 2 GB the kernels' 32-bit buffer offsets reach (640 BraTS slices x 32 channels: 2.01e9 bytes).
     GROUP_PIXELS = 4 * 160 * 192 * 128
-    LANES = max(1, int(os.environ.get('RCU_STREAM_LANES', '2')))   # HIP streams the pass groups of a batch alternate over (StreamLanes)
+    LANES = 2      # HIP streams the pass groups of a batch alternate over (StreamLanes); the ``lanes`` argument overrides it
 
     def __init__(self, mc_steps, do_mi=False, do_var=False, materialize=False, masks=None, ws_pass=True,
-                 group_pixels=None, lanes=None) -> None:
+                 group_pixels=None, lanes=None, seed=None, exact=True) -> None:
         super().__init__()
         self.mc_steps = mc_steps
         self.do_mi, self.do_var = do_mi, do_var
@@ -324,12 +349,35 @@ class McPredictStep(BatchStep):
         self.masks = masks          # optional: list (one per pass) of mask sets to inject instead of sampling
         self.ws_pass = ws_pass
         self.group_pixels = self.GROUP_PIXELS if group_pixels is None else group_pixels
-        self.lanes = self.LANES if lanes is None else lanes
+        self.lanes = self.LANES if lanes is None else max(1, int(lanes))
+        self.seed = seed
+        self.exact = bool(exact)
+        self._generators = {}
+
+    def _seeded_masks(self, model, images, batch_index, job):
+        """The mask tensor of MC pass ``job`` (1..T) of batch ``batch_index`` under ``self.seed`` (dropout mode is on)."""
+        dev = images.device
+        gen = self._generators.get(dev)
+        if gen is None:
+            gen = self._generators[dev] = torch.Generator(device=dev)
+        gen.manual_seed(job_seed(self.seed, batch_index, job))
+        return model.sample_masks(images.shape[0], dev, generator=gen)
+
+    def _launch_masks(self, model, images, batch_index, first, count):
+        """``masks`` argument of the launch that runs the passes first .. first + count - 1 (0-based): injected sets, seeded draws, or
+        None = drawn inside the launch from the device's default generator."""
+        if self.masks is not None:
+            return self.masks[first] if count == 1 else self.masks[first:first + count]
+        if self.seed is None:
+            return None
+        sets = [self._seeded_masks(model, images, batch_index, j + 1) for j in range(first, first + count)]
+        return sets[0] if count == 1 else sets
 
     def __call__(self, batch_context, task_context, context) -> None:
         _check_context(context)
         images = _images_to_device(batch_context, context)
         model = context.model
+        k = batch_context.batch_index
 
         if isinstance(model, model_mod.UNet) and not self.materialize:     # the plan for the pass groups, before the smaller first forward
             n, _, h, w = images.shape
@@ -349,37 +397,41 @@ class McPredictStep(BatchStep):
             if not fused:
                 probs = []
                 for i in range(self.mc_steps):
-                    logits = model(images) if self.masks is None else model(images, self.masks[i])
+                    masks = self._launch_masks(model, images, k, i, 1) if isinstance(model, model_mod.UNet) else None
+                    logits = model(images) if masks is None else model(images, masks)
                     probs.append(softmax(logits))
                 batch_context.output['multi_probabilities'] = torch.stack(probs)
             else:
-                batch_context.output['multi_probabilities'] = self._fused_passes(model, images, self.do_mi, self.do_var,
+                batch_context.output['multi_probabilities'] = self._fused_passes(model, images, self.do_mi, self.do_var, k,
                                                                                  before=ws_pass if self.ws_pass else None)
         finally:
             set_dropout_mode(model, is_train=False)   # reset to eval for the next batch (customsteps.py:39)
 
-    def _fused_passes(self, model, images, do_mi, do_var, before=None):
+    def _fused_passes(self, model, images, do_mi, do_var, batch_index=0, before=None):
         """The T passes into per-voxel statistics (dropout mode is on).  The statistics carry a recipe that replays the passes
-        -- same images, same masks: the device generator is put back to where the sampling started -- so that
-        ``MultiPredictionSummary(do_mi / do_var)`` decides alone which outputs exist, as in the reference (customsteps.py:44-48)."""
+        -- same images, same masks (seeded: the same draws again; unseeded: the device generator is put back to where the sampling
+        started) -- so that ``MultiPredictionSummary(do_mi / do_var)`` decides alone which outputs exist, as in the reference
+        (customsteps.py:44-48)."""
         n, _, h, w = images.shape
         dev = images.device
-        rng_state = torch.cuda.get_rng_state(dev) if (self.masks is None and dev.type == 'cuda') else None
-        stats = McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var)
+        unseeded = self.masks is None and self.seed is None
+        rng_state = torch.cuda.get_rng_state(dev) if (unseeded and dev.type == 'cuda') else None
+
+        def fresh():
+            return McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var, exact=self.exact)
+
+        stats = fresh()
         group = pass_group_size(model, n, h, w, self.group_pixels)
         # (every lane gets work whenever there are two passes: T = 20 on batches of 32 slices is 10 | 10 on two lanes, not one launch of 20 on one)
         lanes = StreamLanes(dev, min(self.lanes, max(self.mc_steps, 1)))
         sizes = balanced_groups(self.mc_steps, group, lanes.count)
-        lanes.begin(stats, lambda: McStatistics(n, model.nb_classes, h, w, dev, do_mi, do_var), inputs=(images,))
+        lanes.begin(stats, fresh, inputs=(images,))
         if before is not None:
             before()                   # (the weight-scaling pass, on the caller's stream)
         i = 0
-        for g in sizes:                # masks are drawn (host side: in launch order, whatever the lane) inside forward_accumulate
-            if g == 1:
-                lanes.run(lambda st, lane, i=i: model.forward_accumulate(images, st, None if self.masks is None else self.masks[i], lane=lane))
-            else:
-                lanes.run(lambda st, lane, i=i, g=g: model.forward_accumulate(images, st, None if self.masks is None else self.masks[i:i + g],
-                                                                           passes=g, lane=lane))
+        for g in sizes:                # unseeded masks are drawn (host side: in launch order, whatever the lane) inside forward_accumulate
+            masks = self._launch_masks(model, images, batch_index, i, g)
+            lanes.run(lambda st, lane, masks=masks, g=g: model.forward_accumulate(images, st, masks, passes=g, lane=lane))
             i += g
         lanes.end(merge_statistics)
 
@@ -390,12 +442,12 @@ class McPredictStep(BatchStep):
             set_dropout_mode(model, is_train=True)
             try:
                 if not materialize:
-                    return self._fused_passes(model, images, mi, var)
+                    return self._fused_passes(model, images, mi, var, batch_index)
                 probs = []
                 t = 0
                 for g in sizes:                      # the same draws as the fused path makes: one per pass group
-                    if self.masks is not None:
-                        sets = self.masks[t:t + g]
+                    if not unseeded:
+                        sets = [self._launch_masks(model, images, batch_index, j, 1) for j in range(t, t + g)]
                     elif g == 1:
                         sets = [None]
                     else:                            # rows [site][pass * n + i]: split the group's draw into its passes
@@ -435,12 +487,15 @@ def share_member_workspaces(members):
 class EnsemblePredictionStep(BatchStep):
     """context.model plus ``additional_models``, all in eval mode (brats_test_ensemble.py:78-94)."""
 
-    def __init__(self, additional_models, do_mi=False, do_var=False, materialize=False, share_workspace=True) -> None:
+    def __init__(self, additional_models, do_mi=False, do_var=False, materialize=False, share_workspace=True, lanes=None,
+                 exact=True) -> None:
         super().__init__()
         self.additional_models = additional_models
         self.do_mi, self.do_var = do_mi, do_var
         self.materialize = materialize
         self.share_workspace = share_workspace
+        self.lanes = McPredictStep.LANES if lanes is None else max(1, int(lanes))
+        self.exact = bool(exact)       # exact sums (McStatistics): the member order / lanes / ranks do not change the bits
 
     def __call__(self, batch_context, task_context, context) -> None:
         _check_context(context)
@@ -454,9 +509,10 @@ class EnsemblePredictionStep(BatchStep):
             def run(mi, var, materialize=False):
                 if materialize:
                     return torch.stack([softmax(m(images)) for m in members])
-                st = McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var)
-                lanes = StreamLanes(images.device, min(McPredictStep.LANES, len(members)))
-                lanes.begin(st, lambda: McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var), inputs=(images,))
+                st = McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var, exact=self.exact)
+                lanes = StreamLanes(images.device, min(self.lanes, len(members)))
+                lanes.begin(st, lambda: McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var, exact=self.exact),
+                            inputs=(images,))
                 for m in members:      # (a member keeps to its lane from batch to batch: one workspace per member)
                     lanes.run(lambda s_, lane, m=m: m.forward_accumulate(images, s_, lane=lane))
                 lanes.end(merge_statistics)
@@ -481,6 +537,8 @@ class MultiPredictionSummary(BatchStep):
             multi = batch_context.output.pop('multi_probabilities')
         else:
             multi = batch_context.output['multi_probabilities']
+        if multi is None:      # a rank other than the root of a sharded predict step (rcu_amd.distributed): the root alone has the merged statistics
+            return
         if isinstance(multi, McStatistics):
             stats = multi
             if (self.do_mi and not stats.do_mi) or (self.do_var and not stats.do_var):
@@ -498,7 +556,8 @@ class MultiPredictionSummary(BatchStep):
                 stats = stats.recipe(self.do_mi or stats.do_mi, self.do_var or stats.do_var)
         else:
             t, n, c, h, w = multi.shape
-            stats = McStatistics(n, c, h, w, multi.device, self.do_mi, self.do_var)
+            # (exact sums: a materialised stack gives the bits the fused statistics of the same passes give)
+            stats = McStatistics(n, c, h, w, multi.device, self.do_mi, self.do_var, exact=t <= _lib.RCU_MC_EXACT_MAX_PASSES)
             for i in range(t):
                 stats.accumulate(multi[i], is_probabilities=True)
         out = stats.finalize(self.do_mi, self.do_var)
@@ -539,13 +598,15 @@ class AleatoricMcPredictStep(BatchStep):
     (AleatoricPredictStep, brats_test_aleatoric.py:66-69) is averaged over the passes -> ``sigma`` [N, C, H, W].  The
     deterministic pass that McPredictStep runs first gives ``ws_probabilities`` and ``ws_sigma``."""
 
-    def __init__(self, mc_steps, is_log_sigma=False, do_mi=False, do_var=False, masks=None, ws_pass=True) -> None:
+    def __init__(self, mc_steps, is_log_sigma=False, do_mi=False, do_var=False, masks=None, ws_pass=True, lanes=None, exact=True) -> None:
         super().__init__()
         self.mc_steps = mc_steps
         self.is_log_sigma = is_log_sigma
         self.do_mi, self.do_var = do_mi, do_var
         self.masks = masks
         self.ws_pass = ws_pass
+        self.lanes = McPredictStep.LANES if lanes is None else max(1, int(lanes))
+        self.exact = bool(exact)       # the probability statistics; the sigma sums stay float32 (unbounded addends)
 
     def __call__(self, batch_context, task_context, context) -> None:
         _check_context(context)
@@ -569,7 +630,7 @@ class AleatoricMcPredictStep(BatchStep):
             dev = images.device
 
             def fresh():
-                st = McStatistics(n, c, h, w, dev, self.do_mi, self.do_var)
+                st = McStatistics(n, c, h, w, dev, self.do_mi, self.do_var, exact=self.exact)
                 st.sigma_sum = torch.zeros((n, c, h, w), device=dev, dtype=torch.float32)
                 return st
 
@@ -577,7 +638,7 @@ class AleatoricMcPredictStep(BatchStep):
             sigma_sum = stats.sigma_sum
             # pass groups and stream lanes as in McPredictStep: g passes per launch, launches alternating over two HIP streams
             group = pass_group_size(model, n, h, w, McPredictStep.GROUP_PIXELS)
-            lanes = StreamLanes(dev, min(McPredictStep.LANES, self.mc_steps))
+            lanes = StreamLanes(dev, min(self.lanes, self.mc_steps))
             lanes.begin(stats, fresh, inputs=(images,))
             i = 0
             for g in balanced_groups(self.mc_steps, group, lanes.count):

@@ -176,6 +176,72 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+class OracleExactEngine(OracleEngine):
+    """The exact statistics of the product engine (include/rcu.h RCU_MC_EXACT) restated on the CPU: float64 sums of addends rounded to
+    multiples of 2^-40, (x + 6144) - 6144 -- every addition exact, so the merged sums cannot depend on the world size."""
+
+    def buffers(self, x, with_ws):
+        n, _, h, w = x.shape
+        c = PARAMS['nb_classes']
+        flat = torch.zeros(n * c * h * w * (2 if with_ws else 1), dtype=torch.float64)
+        stats = flat[:n * c * h * w].view(n, c, h, w)
+        ws = flat[n * c * h * w:].view(n, c, h, w) if with_ws else None
+        return flat, stats, ws
+
+    def mc_pass(self, x, stats, masks=None, passes=1):
+        for ms in ([masks] if passes == 1 else masks):
+            p = torch.softmax(self.uo.unet_forward(self.state, x, ms, **PARAMS), 1).double()
+            stats += (p + 6144.0) - 6144.0
+
+
+def _step_worker(rank, world, port, out_dir):
+    """The step seam of the scripts: ShardedMcPredictStep + MultiPredictionSummary called by every rank with the same batches."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from rcu_amd import steps
+    from rcu_amd.distributed import ShardedMcPredictStep, World
+    torch.set_num_threads(2)
+    state, x, _ = _inputs()
+    step = ShardedMcPredictStep(T, World(rank, world, rank, 'cpu', 'gloo'), seed=5, engine_factory=lambda model: OracleExactEngine(state),
+                                group_pixels=2 * x.shape[0] * 32 * 32)
+    ctx = steps.TorchTestContext('cpu', None)
+    for k in range(3):
+        bc = steps.BatchContext({'images': x + 0.1 * k}, k)
+        step(bc, None, ctx)
+        multi = bc.output['multi_probabilities']
+        if rank == 0:
+            assert multi.count == T and bc.output['ws_probabilities'].shape == x[:, :2].shape
+            np.savez(os.path.join(out_dir, 'w{}_batch{}.npz'.format(world, k)), sums=multi.numpy(), ws=bc.output['ws_probabilities'].numpy())
+        else:
+            assert multi is None and 'ws_probabilities' not in bc.output
+            steps.MultiPredictionSummary()(bc, None, ctx)          # nothing to finalise off the root: no outputs, no error
+            assert bc.output == {}
+    step.finish()
+    assert step._runner.forwards_run == sum(len(step._runner.jobs_of(k, rank)) for k in range(3))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_batch_step_hands_the_root_the_bits_of_the_one_process_step(tmp_path):
+    """rcu_amd.distributed.ShardedMcPredictStep over gloo, two ranks, three batches: the root's ``multi_probabilities`` are the merged
+    statistics -- with exact sums, the very bits the one-process step leaves there -- the other rank gets None; masks come from
+    (seed, batch, pass), so no mask set is injected."""
+    mp.spawn(_step_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    _step_worker(0, 1, 0, str(tmp_path))
+    for k in range(3):
+        two, one = np.load(os.path.join(str(tmp_path), 'w2_batch{}.npz'.format(k))), np.load(os.path.join(str(tmp_path), 'w1_batch{}.npz'.format(k)))
+        assert np.array_equal(two['sums'].view(np.uint64), one['sums'].view(np.uint64))
+        assert np.array_equal(two['ws'], one['ws'])
+        scaled = one['sums'] * 2.0 ** 40
+        assert np.array_equal(scaled, np.round(scaled)) and one['sums'].max() <= T
+    a, b = np.load(os.path.join(str(tmp_path), 'w1_batch0.npz'))['sums'], np.load(os.path.join(str(tmp_path), 'w1_batch1.npz'))['sums']
+    assert not np.array_equal(a, b)
+
+
 class PendingNow:
     def __init__(self, value):
         self.value = value

@@ -106,3 +106,68 @@ def test_rccl_world1_rehearsal_matches_the_plain_step_bit_for_bit():
     assert b['n_gpus'] == 1 and b['n_ranks_seen'] == 1 and b['rccl_rehearsal']['backend'] == 'nccl'
     assert b['forwards_per_rank'] == [2 * 5] and b['parity']['ece_delta_same_maps'] is not None if 'ece_delta_same_maps' in b['parity'] else True
     assert b['all_outputs']['value'] > 0
+
+
+def _script_setup(tmp_path, seeds=(20,), mc=6):
+    """Two small BraTS-like subjects, model dir(s) + checkpoint(s), split and two YAML files that differ in their test_dir only."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import test_gpu_scripts as tgs
+    cfg, vols, _, _ = tgs._setup(tmp_path, mc=mc if len(seeds) == 1 else None, seeds=seeds)
+    with open(cfg) as f:
+        text = f.read()
+    cfgs = []
+    for tag in ('one', 'two'):
+        path = str(tmp_path / 'cfg_{}.yaml'.format(tag))
+        with open(path, 'w') as f:
+            f.write(text.replace(str(tmp_path / 'out'), str(tmp_path / 'out_{}'.format(tag))))
+        cfgs.append(path)
+    return cfgs, vols
+
+
+def _written(out_root):
+    import glob
+    dirs = glob.glob(os.path.join(out_root, '*'))
+    assert len(dirs) == 1, dirs
+    files = {os.path.basename(f): open(f, 'rb').read() for f in sorted(glob.glob(os.path.join(dirs[0], '*')))
+             if f.endswith(('.nii.gz', 'metrics.csv'))}
+    return files
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize('script,seeds', [('brats_test_default.py', (20,)), ('brats_test_ensemble.py', (20, 21, 22))], ids=['mc', 'ensemble'])
+def test_drop_in_script_under_torch_distributed_run_writes_the_one_process_files(tmp_path, script, seeds):
+    """`python -m torch.distributed.run --nproc-per-node 2 bin-dl/brats_test_default.py -config_file ...` (both ranks on the one GPU of the
+    test box: the scripts fall back to gloo when the node has fewer GPUs than ranks) shards the MC passes / ensemble members of every batch
+    over the two ranks behind the unchanged script surface and must write, byte for byte, the .nii.gz files and the metrics.csv of the plain
+    one-process run of the same script under the same YAML file: masks are a function of (seed, batch, pass), statistics are exact sums."""
+    (cfg_one, cfg_two), vols = _script_setup(tmp_path, seeds=seeds)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    path = os.path.join(ROOT, 'bin-dl', script)
+    r1 = subprocess.run([sys.executable, path, '-config_file', cfg_one], capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    for attempt in range(2):          # (gloo's loopback rendezvous has been seen to hang once with three processes on one GPU: one retry)
+        import shutil
+        shutil.rmtree(str(tmp_path / 'out_two'), ignore_errors=True)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port()), path, '-config_file', cfg_two]
+        try:
+            r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+        except subprocess.TimeoutExpired:
+            continue
+        if r2.returncode == 0:
+            break
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    one, two = _written(str(tmp_path / 'out_one')), _written(str(tmp_path / 'out_two'))
+    assert sorted(one) == sorted(two) and len(one) == 2 * len(vols) + 1
+    for name in one:
+        assert one[name] == two[name], name
+    # both ranks worked: the sharded steps report their share when the run ends
+    import re
+    shares = {int(m.group(1)): (int(m.group(2)), int(m.group(3)))
+              for m in re.finditer(r'rank (\d) of 2: (\d+) forward passes in (\d+) batches', r2.stdout + r2.stderr)}
+    assert sorted(shares) == [0, 1], (r2.stdout[-1500:], r2.stderr[-1500:])
+    batches = shares[0][1]
+    jobs = batches * (len(seeds) if len(seeds) > 1 else 6 + 1)         # K members, or T = 6 passes + the weight-scaling pass, per batch
+    assert shares[1][1] == batches and shares[0][0] + shares[1][0] == jobs and abs(shares[0][0] - shares[1][0]) <= 1

@@ -1288,3 +1288,110 @@ def test_unet_stress_golden_wide_activations_and_logits(golden, dev):
             assert _maxdiff(bc.output[key].cpu().numpy(), ref_sum[key].numpy()) < PROB_TOL, (flags, key)
     sat = float(((multi[:, :, 1] < 0.01) | (multi[:, :, 1] > 0.99)).float().mean())
     assert 0.05 < sat < 0.95          # saturated and unsaturated softmax inputs side by side
+
+
+# ---------------------------------------------------------------------------------- exact statistics (RCU_MC_EXACT)
+def _quantise(x):
+    """include/rcu.h RCU_MC_EXACT: an addend enters as (x + 6144) - 6144 in float64 = rounded to the nearest multiple of 2^-40."""
+    x = np.asarray(x, dtype=np.float64)
+    return (x + 6144.0) - 6144.0
+
+
+def test_exact_statistics_are_sums_of_quantised_addends_in_any_order(dev):
+    """The exact statistics hold, bit for bit, the float64 sums of the quantised float32 probabilities (and their squares and entropies) --
+    whatever the order the passes were added in; values far below 2^-40 and exact 0 / 1 included."""
+    from rcu_amd import steps
+    n, c, h, w, T = 2, 2, 16, 24, 9
+    rng = np.random.RandomState(5)
+    p1 = rng.rand(T, n, 1, h, w).astype(np.float32)
+    p1[0, 0, 0, :4] = [[1e-30, 3e-13, 2.0 ** -41, 1.5 * 2.0 ** -41] * 6]     # below / at half the quantum: 0, 0, ties-to-even, rounds up
+    p1[1, 0, 0, 0, :3] = [0.0, 1.0, np.float32(1.0) - np.float32(2.0 ** -24)]
+    probs = np.concatenate([1 - p1, p1], axis=2).astype(np.float32)           # [T, n, 2, h, w]
+    assert _quantise(2.0 ** -41) == 0.0 and _quantise(1.5 * 2.0 ** -41) == 2.0 ** -40 and _quantise(3e-13) == 0.0
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ent = -np.sum(np.where(probs > 0, probs * np.log(probs), 0).astype(np.float32), axis=2, dtype=np.float32)
+    blobs = []
+    for order in (range(T), reversed(range(T)), rng.permutation(T)):
+        st = steps.McStatistics(n, c, h, w, dev, do_mi=False, do_var=True, exact=True)
+        for t in order:
+            st.accumulate(torch.from_numpy(probs[t]).to(dev), is_probabilities=True)
+        blobs.append(st.blob.cpu().numpy().copy())
+        assert st.blob.dtype == torch.float64 and st.exact
+    assert all(np.array_equal(blobs[0].view(np.uint64), b.view(np.uint64)) for b in blobs[1:])
+    planes = blobs[0].reshape(2 * c, n, h * w)
+    want_p = _quantise(probs).sum(0)                                          # [n, c, h, w]; exact sums: any order
+    want_q = _quantise(probs.astype(np.float64) ** 2).sum(0)
+    for k in range(c):
+        assert np.array_equal(planes[k], want_p[:, k].reshape(n, -1))
+        assert np.array_equal(planes[c + k], want_q[:, k].reshape(n, -1))
+    # without the squares: planes [sum p_c] [sum H]; the device's logf differs from numpy's in the last ulp, so H is checked for its
+    # quantum (a multiple of 2^-40) and its value
+    st = steps.McStatistics(n, c, h, w, dev, do_mi=True, do_var=False, exact=True)
+    for t in range(T):
+        st.accumulate(torch.from_numpy(probs[t]).to(dev), is_probabilities=True)
+    planes = st.blob.cpu().numpy().reshape(c + 1, n, h * w)
+    assert st.blob.numel() == (c + 1) * n * h * w
+    for k in range(c):
+        assert np.array_equal(planes[k], want_p[:, k].reshape(n, -1))
+    scaled = planes[c] * 2.0 ** 40
+    assert np.array_equal(scaled, np.round(scaled))
+    assert np.max(np.abs(planes[c] - ent.astype(np.float64).sum(0).reshape(n, -1))) < 1e-5
+    out = st.finalize(do_mi=True)
+    mean = (want_p / T).astype(np.float32)
+    assert np.array_equal(out['probabilities'].cpu().numpy(), mean)
+    # the pass limit of the exact form is part of the contract
+    from rcu_amd import _lib
+    with pytest.raises(_lib.RcuError):
+        st.finalize(count=_lib.RCU_MC_EXACT_MAX_PASSES + 1)
+
+
+def test_exact_statistics_do_not_depend_on_groups_lanes_or_the_materialised_stack(dev):
+    """McPredictStep's outputs under a seed: the same bits for every pass grouping, one or two stream lanes, and for the materialised
+    [T, N, C, H, W] stack summed by MultiPredictionSummary -- masks are a function of (seed, batch, pass), the sums are exact."""
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    from rcu_amd.model import UNet
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=8, dropout=0.3)
+    model = UNet(**params)
+    model.load_state_dict(uo.synthetic_state(3, **params))
+    model = model.to(dev)
+    n, h, w, T = 3, 48, 32, 7
+    x = torch.randn(n, 4, h, w, generator=torch.Generator().manual_seed(1)).to(dev)
+    model.reserve(h, w, n * 4)      # one plan for every grouping (bit-identity of a pass is a property of a plan)
+    ctx = steps.TorchTestContext('cuda', model)
+    outs = []
+    for kwargs in (dict(group_pixels=0, lanes=1), dict(group_pixels=0, lanes=2), dict(group_pixels=4 * n * h * w, lanes=2),
+                   dict(group_pixels=3 * n * h * w, lanes=1), dict(materialize=True)):
+        bc = steps.BatchContext({'images': x}, 5)
+        steps.McPredictStep(T, do_mi=True, do_var=True, seed=20, **kwargs)(bc, None, ctx)
+        steps.MultiPredictionSummary(do_mi=True, do_var=True)(bc, None, ctx)
+        outs.append(bc.output)
+    for o in outs[1:]:
+        for key in ('probabilities', 'entropy', 'mutual_info', 'variance', 'ws_probabilities'):
+            assert torch.equal(outs[0][key], o[key]), key
+    # another batch index: other masks
+    bc = steps.BatchContext({'images': x}, 6)
+    steps.McPredictStep(T, seed=20)(bc, None, ctx)
+    steps.MultiPredictionSummary()(bc, None, ctx)
+    assert not torch.equal(bc.output['probabilities'], outs[0]['probabilities'])
+    assert torch.equal(bc.output['ws_probabilities'], outs[0]['ws_probabilities'])
+    # the summary may ask for more than the step tracked: the replay draws the same seeded masks
+    bc = steps.BatchContext({'images': x}, 5)
+    steps.McPredictStep(T, seed=20)(bc, None, ctx)
+    steps.MultiPredictionSummary(do_mi=True, do_var=True)(bc, None, ctx)
+    for key in ('probabilities', 'entropy', 'mutual_info', 'variance'):
+        assert torch.equal(outs[0][key], bc.output[key]), key
+    # against the oracle under the same masks (float32 sums there): within the float32 noise of T additions
+    from oracle import summary_oracle as so
+    step = steps.McPredictStep(T, seed=20)
+    steps.set_dropout_mode(model, True)
+    masks = [step._seeded_masks(model, x, 5, j) for j in range(1, T + 1)]
+    steps.set_dropout_mode(model, False)
+    sites = model.dropout_sites()
+    mask_sets = [[m.cpu() for m in torch.split(ms, [n * c_ for _, c_ in sites])] for ms in masks]
+    mask_sets = [[m.view(n, -1) for m in ms] for ms in mask_sets]
+    state = {k: v.cpu() for k, v in model.state_dict().items()}
+    ws, multi = so.mc_probabilities(lambda xx, m: uo.unet_forward(state, xx, m, **params), x.cpu(), mask_sets)
+    ref = so.multi_prediction_summary(multi, True, True)
+    for key, v in ref.items():
+        assert _maxdiff(outs[0][key].cpu(), v) < 2e-6, key

@@ -137,33 +137,52 @@ def _files(ctx):
     return {os.path.basename(f): open(f, 'rb').read() for f in sorted(glob.glob(os.path.join(ctx.test_dir, '*.nii.gz')))}
 
 
+def _with_others(cfg_path, suffix, **others):
+    """A copy of the YAML file with keys added to (None: removed from) ``config.others`` -- the rcu_amd loop options ride there."""
+    import yaml
+    with open(cfg_path) as f:
+        doc = yaml.safe_load(f)
+    cur = dict(doc['config'].get('others') or {})
+    for k, v in others.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = v
+    doc['config']['others'] = cur
+    out = cfg_path.replace('.yaml', '_{}.yaml'.format(suffix))
+    with open(out, 'w') as f:
+        yaml.safe_dump(doc, f)
+    return out
+
+
 def test_pipelined_coalesced_loop_writes_the_files_of_the_serial_loop(tmp_path, monkeypatch):
     """The test loop's pipeline (loader thread, batches coalesced up to a volume, outputs downloaded on a side stream, NIfTI files
     written by a pool of threads) must not change a byte of what the reference-ordered serial loop writes: deterministic config --
-    the pipelined loop with coalescing switched on (opt-in: RCU_COALESCE / others.coalesce_pixels) against RCU_PIPELINE=0 (which also
-    means no coalescing), whole .nii.gz files compared; MC-dropout config -- masks are drawn per step, so the batches are kept as the
+    the pipelined loop with coalescing switched on (opt-in: others.coalesce_pixels) against ``others.pipelined: false`` without
+    coalescing, whole .nii.gz files compared; MC-dropout config -- masks are drawn per step, so the batches are kept as the
     loader makes them (the default) and the pipelined loop is compared with the serial one under the same seed."""
     from rcu_amd import loops, scripts
     cfg_det, vols, _, _ = _setup(tmp_path / 'det')
-    monkeypatch.setenv('RCU_COALESCE', str(loops.Test.COALESCE_PIXELS))
-    fast = _files(scripts.test_default('brats', cfg_det, None))
-    monkeypatch.setenv('RCU_PIPELINE', '0')
-    slow = _files(scripts.test_default('brats', cfg_det, None))
-    monkeypatch.delenv('RCU_PIPELINE')
-    monkeypatch.delenv('RCU_COALESCE')
+    fast = _files(scripts.test_default('brats', _with_others(cfg_det, 'fast', coalesce_pixels=loops.Test.COALESCE_PIXELS), None))
+    slow = _files(scripts.test_default('brats', _with_others(cfg_det, 'slow', pipelined=False), None))
     assert sorted(fast) == sorted(slow) and len(fast) == 2 * len(vols)
     for name in fast:
         assert fast[name] == slow[name], name
     cfg_mc, vols_mc, _, _ = _setup(tmp_path / 'mc', mc=4)
     fast = _files(scripts.test_default('brats', cfg_mc, None))
-    monkeypatch.setenv('RCU_PIPELINE', '0')
-    slow = _files(scripts.test_default('brats', cfg_mc, None))
+    slow = _files(scripts.test_default('brats', _with_others(cfg_mc, 'slow', pipelined=False), None))
     assert len(fast) == 2 * len(vols_mc)
     for name in fast:
         assert fast[name] == slow[name], name
+    # the MC files do not depend on the stream lanes either (exact statistics, masks a function of (seed, batch, pass)) ...
+    one_lane = _files(scripts.test_default('brats', _with_others(cfg_mc, 'lane1', stream_lanes=1), None))
+    for name in fast:
+        assert fast[name] == one_lane[name], name
+    # ... but coalescing renumbers the batches: another sample of the same distribution
+    merged = _files(scripts.test_default('brats', _with_others(cfg_mc, 'merged', coalesce_pixels=loops.Test.COALESCE_PIXELS), None))
+    assert any(fast[name] != merged[name] for name in fast)
     # thirteen batches of one slice: the loop runs Test.MAX_INFLIGHT batches ahead of the one it finishes (download slots and staging
     # buffers in rotation, subjects completed while later batches are enqueued) -- still the serial loop's bytes
-    monkeypatch.delenv('RCU_PIPELINE')
     cfg_one, vols_one, _, _ = _setup(tmp_path / 'one', mc=3)
     with open(cfg_one) as f:
         text = f.read()
@@ -180,8 +199,7 @@ def test_pipelined_coalesced_loop_writes_the_files_of_the_serial_loop(tmp_path, 
     monkeypatch.setattr(loops.Test, '_finish_batch', counting)
     fast = _files(scripts.test_default('brats', cfg_one, None))
     assert inflight == sorted(inflight) and len(inflight) == 13          # finished in order, every batch once
-    monkeypatch.setenv('RCU_PIPELINE', '0')
-    slow = _files(scripts.test_default('brats', cfg_one, None))
+    slow = _files(scripts.test_default('brats', _with_others(cfg_one, 'slow', pipelined=False), None))
     assert len(fast) == 2 * len(vols_one)
     for name in fast:
         assert fast[name] == slow[name], name
@@ -263,15 +281,13 @@ def test_isic_many_batches_keep_their_own_labels(tmp_path, monkeypatch, coalesce
     """Ten ISIC subjects, batch_size 1, float labels (the shipped configs rescale ``labels``): uncoalesced (the default) the pipelined loop
     runs ten batches -- more than the loader's staging ring holds -- and every subject's Dice must be the Dice of ITS prediction
     against ITS label image (labels are kept on the host by PrepareSubjectStep until the batch is finished: a staging buffer reused
-    too early would hand a later batch's labels to an earlier subject).  Coalesced (opt-in: RCU_COALESCE) the ten images run as one batch
-    and give the same files."""
+    too early would hand a later batch's labels to an earlier subject).  Coalesced (opt-in: others.coalesce_pixels) the ten images run as
+    one batch and give the same files."""
     from PIL import Image
     from oracle import calib_oracle as co
     from oracle import unet_oracle as uo
     from rcu_amd import management as mgt
     from rcu_amd import nifti, scripts
-    if coalesce is not None:
-        monkeypatch.setenv('RCU_COALESCE', coalesce)
     params = dict(nb_classes=2, in_channels=3, depth=4, start_filters=8, dropout=0.05)
     prefix = tmp_path / 'isic_many' / 'ISIC-2017_Test_v2'
     img_dir, lab_dir = str(prefix) + '_Data', str(prefix) + '_Part1_GroundTruth'
@@ -292,6 +308,8 @@ def test_isic_many_batches_keep_their_own_labels(tmp_path, monkeypatch, coalesce
     cfg_path = str(tmp_path / 'test_isic_baseline_mc.yaml')
     with open(cfg_path, 'w') as f:
         f.write(ISIC_MC_YAML.format(test_dir=str(tmp_path / 'out'), model_dir=mf.model_dir, dataset=str(prefix)))
+    if coalesce is not None:
+        cfg_path = _with_others(cfg_path, 'coalesced', coalesce_pixels=int(coalesce))
     ctx = scripts.test_default('isic', cfg_path, None)
     rows = {r['subject']: r for r in csv.DictReader(open(os.path.join(ctx.test_dir, 'metrics.csv')))}
     assert sorted(rows) == ids

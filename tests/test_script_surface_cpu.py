@@ -407,9 +407,9 @@ def test_block_loader_equals_the_per_slice_loader(tmp_path, monkeypatch):
     for categories in (('images',), ('images', 'labels')):
         ds = data_mod.VolumeDataset(root, transform(), slice_categories=categories)
         fast = list(torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=data_mod.CollateDict()))
-        monkeypatch.setenv('RCU_BLOCK_LOADER', '0')
+        ds.block_loader = False
         slow = list(torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=data_mod.CollateDict()))
-        monkeypatch.delenv('RCU_BLOCK_LOADER')
+        ds.block_loader = True
         assert len(fast) == len(slow) == 4                       # 15 slices: batches straddle the subjects
         for a, b in zip(fast, slow):
             assert list(a.keys()) == list(b.keys())

@@ -43,7 +43,7 @@ timeout 200 python tools/calib_bench.py 160 > $OUT/calib_bench.json 2>/dev/null
 timeout 200 python tools/agg_bench.py > $OUT/agg_bench.json 2>/dev/null
 timeout 600 bash tools/pmc_aggregation.sh ${TAG}_aggpmc > $OUT/aggregation_pmc.txt 2>&1
 RCU_SCRIPT_PROFILE=0 timeout 200 python tools/script_throughput.py 16 20 32 > /dev/null 2>&1    # (a first run on a fresh box pages the interpreter, the NIfTI writers' zlib ... in: 0.12-0.16 s per subject; the recorded run is the second)
-RCU_LOOP_TIMING=1 RCU_SCRIPT_PROFILE=0 timeout 200 python tools/script_throughput.py 16 20 32 2>&1 | grep -v "Holder\|conv2d_batch\|Conv2d\|Dropout2d\|BatchNorm2d\|^ *)\|^UNet\|^model" > $OUT/script_throughput.txt
+RCU_SCRIPT_PROFILE=0 timeout 200 python tools/script_throughput.py 16 20 32 3932160 timing 2>&1 | grep -v "Holder\|conv2d_batch\|Conv2d\|Dropout2d\|BatchNorm2d\|^ *)\|^UNet\|^model" > $OUT/script_throughput.txt
 # the shipped batch_size: 32 as it is (no coalescing): the loop's run-ahead (rcu_amd.loops.Test.INFLIGHT_PIXELS) is what keeps the GPU busy there
-RCU_LOOP_TIMING=1 RCU_SCRIPT_PROFILE=0 timeout 200 python tools/script_throughput.py 16 20 32 0 2>&1 | grep -v "Holder\|conv2d_batch\|Conv2d\|Dropout2d\|BatchNorm2d\|^ *)\|^UNet\|^model" > $OUT/script_throughput_batch32.txt
+RCU_SCRIPT_PROFILE=0 timeout 200 python tools/script_throughput.py 16 20 32 0 timing 2>&1 | grep -v "Holder\|conv2d_batch\|Conv2d\|Dropout2d\|BatchNorm2d\|^ *)\|^UNet\|^model" > $OUT/script_throughput_batch32.txt
 ls -la $OUT

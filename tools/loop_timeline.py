@@ -24,6 +24,7 @@ def wrap(cls, name):
 wrap(loops.Test, '_run_steps'); wrap(loops.Test, '_finish_batch'); wrap(loops._Download, 'wait')
 _pf = loops.prefetch
 def timed_prefetch(*a, **k):
+    k['timing'] = True      # the loader thread logs where its time went
     it = _pf(*a, **k)
     while True:
         t = time.perf_counter()
@@ -34,7 +35,6 @@ def timed_prefetch(*a, **k):
         log.append(('next(loader)', t - T0, time.perf_counter() - t))
         yield item
 loops.prefetch = timed_prefetch
-os.environ['RCU_LOOP_TIMING'] = '1'
 import script_throughput
 sys.argv = ['x', sys.argv[1] if len(sys.argv) > 1 else '8', '20', '32', '0']
 script_throughput.main()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end wall time of the drop-in brats_test_default script (YAML -> dataset -> Test loop -> NIfTI + metrics) on
-full-size synthetic subjects, with a cProfile breakdown of the host side: python tools/script_throughput.py [subjects] [mc]"""
+full-size synthetic subjects, with a cProfile breakdown of the host side:
+    python tools/script_throughput.py [subjects] [mc] [batch_size] [coalesce_pixels, 0 = off] [timing: the loader thread logs its time split]"""
 import cProfile
 import json
 import os
@@ -50,6 +51,8 @@ def main():
     if coalesce > 0:
         text = text.replace('  others:\n', '  others:\n    coalesce_pixels: {}\n'.format(coalesce), 1)
         assert 'coalesce_pixels' in text
+    if len(sys.argv) > 5 and sys.argv[5] == 'timing':
+        text = text.replace('  others:\n', '  others:\n    loader_timing: true\n', 1)
     cfg = os.path.join(tmp, 'test_brats_baseline_mc.yaml')
     with open(cfg, 'w') as f:
         f.write(text)
