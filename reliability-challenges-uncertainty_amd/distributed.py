@@ -61,6 +61,12 @@ class HipEngine:
             ws.zero_()
         return flat, stats, ws
 
+    def reserve(self, x, mc_steps, group, lanes):
+        """The canonical plans of the batch (rcu_amd.steps.reserve_canonical_plans): the bits of a pass must not depend on which launches
+        THIS rank happens to make."""
+        n, _, h, w = x.shape
+        steps_mod.reserve_canonical_plans(self.model, n, h, w, mc_steps, group, lanes)
+
     def ws_pass(self, x, ws_out):
         steps_mod.set_dropout_mode(self.model, False)
         if ws_out.dtype == torch.float32 and ws_out.is_contiguous():
@@ -199,6 +205,7 @@ class ShardedMcRunner:
         self.lanes = max(1, int(lanes))
         self._generator = None
         self.forwards_run = 0          # launches of this rank (a pass group counts its passes)
+        self.reserve_plans = True      # (the ensemble runner: every launch is one member on n samples, nothing to make canonical)
 
     def masks_of(self, x, step_index, job):
         """The device mask tensor MC pass ``job`` (1..T) of volume ``step_index`` runs under (None without a seed / an engine
@@ -243,6 +250,8 @@ class ShardedMcRunner:
         jobs = self.jobs_of(step_index, self.rank)
         # stream lanes (rcu_amd.steps.StreamLanes): lane 0 = the caller's stream and the volume's statistics
         lanes = steps_mod.StreamLanes(x.device, self.lanes if (x.is_cuda and hasattr(self.engine, 'side_statistics')) else 1)
+        if hasattr(self.engine, 'reserve') and self.reserve_plans:
+            self.engine.reserve(x, self.mc_steps, self.pass_group, lanes.count)
         lanes.begin(stats, lambda: self.engine.side_statistics(x), inputs=(x,), first=step_index if self.world > 1 else 0)
         on_lane = lanes.run
 
@@ -413,6 +422,7 @@ class ShardedEnsembleRunner(ShardedMcRunner):
         super().__init__(members[0] if members else None, len(members), ws_pass=False, rank=rank, world=world,
                          engine=engine, do_mi=do_mi, do_var=do_var, root=root, lanes=lanes, exact=exact)
         self.members = members
+        self.reserve_plans = False
         if share_workspace:
             steps_mod.share_member_workspaces(members)
 

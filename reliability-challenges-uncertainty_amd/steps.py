@@ -271,6 +271,15 @@ def pass_group_size(model, n, h, w, group_pixels):
     return g if cap is None else max(1, min(g, cap(h, w) // n))
 
 
+def reserve_canonical_plans(model, n, h, w, mc_steps, group, lanes):
+    """Plans (and workspaces) of ``model`` for batches of n images of h x w whose T = ``mc_steps`` passes run up to ``group`` per launch, on
+    ``lanes`` stream lanes: all sized for n * min(group, T) samples, whatever launches this process will really make."""
+    plan = n * max(1, min(int(group), max(int(mc_steps), 1)))
+    for lane in range(max(1, int(lanes))):
+        model.reserve(h, w, plan, lane)
+    return plan
+
+
 def merge_statistics(stats, side):
     """Add the statistics of a side lane into ``stats`` (plain sums, include/rcu.h rcu_mc_*)."""
     stats.blob.add_(side.blob)
@@ -379,10 +388,13 @@ class McPredictStep(BatchStep):
         model = context.model
         k = batch_context.batch_index
 
-        if isinstance(model, model_mod.UNet) and not self.materialize:     # the plan for the pass groups, before the smaller first forward
+        if isinstance(model, model_mod.UNet):
+            # The CANONICAL plan of the batch, on every lane, before the first forward: which kernel a layer gets depends on the batch its plan
+            # is sized for, and a pass's bits are a property of the plan -- so every way of running the T passes (any grouping, one lane or
+            # two, fused or materialised, one process or the ranks of rcu_amd.distributed) sizes its plans for the same n * min(group, T).
             n, _, h, w = images.shape
-            sizes = balanced_groups(self.mc_steps, pass_group_size(model, n, h, w, self.group_pixels), min(self.lanes, max(self.mc_steps, 1)))
-            model.reserve(h, w, n * max(sizes + [1]))     # the largest launch the passes will make (T = 20 on 32 slices: 10 | 10, not 20)
+            reserve_canonical_plans(model, n, h, w, self.mc_steps, pass_group_size(model, n, h, w, self.group_pixels),
+                                    1 if self.materialize else min(self.lanes, max(self.mc_steps, 1)))
         fused = not self.materialize and isinstance(model, model_mod.UNet)
         if self.ws_pass and not fused:
             batch_context.output['ws_probabilities'] = softmax(model(images))

@@ -1357,7 +1357,10 @@ def test_exact_statistics_do_not_depend_on_groups_lanes_or_the_materialised_stac
     model = model.to(dev)
     n, h, w, T = 3, 48, 32, 7
     x = torch.randn(n, 4, h, w, generator=torch.Generator().manual_seed(1)).to(dev)
-    model.reserve(h, w, n * 4)      # one plan for every grouping (bit-identity of a pass is a property of a plan)
+    # one plan for every grouping: a pass's bits are a property of the plan, and a step sizes its (canonical) plans for n * min(group, T)
+    # -- equal for equal group_pixels, whatever the lanes; across different group_pixels the plans are made equal here, up front
+    for lane in (0, 1):
+        model.reserve(h, w, n * T, lane)
     ctx = steps.TorchTestContext('cuda', model)
     outs = []
     for kwargs in (dict(group_pixels=0, lanes=1), dict(group_pixels=0, lanes=2), dict(group_pixels=4 * n * h * w, lanes=2),
