@@ -19,6 +19,8 @@ if __name__ == '__main__':
     parser.add_argument('--gt_dir', type=str, default=None, help='BraTS training tree / ISIC dataset prefix '
                         '(default: directories.BRATS_ORIG_DATA_DIR / ISIC_PREPROCESSED_TEST_DATA_DIR)')
     parser.add_argument('--out_dir', type=str, default=None, help='default: directories.EVAL_DIR')
+    parser.add_argument('--batch_subjects', type=int, default=8, help='rcu_amd: subjects of a probability-map run evaluated per GPU launch')
+    parser.add_argument('--plain', action='store_true', help='rcu_amd: the reference\'s subject-by-subject, action-by-action loop for every run')
     args = parser.parse_args()
     from rcu_amd import directories as dirs
     from rcu_amd import scripts
@@ -38,4 +40,4 @@ if __name__ == '__main__':
                          'entry in rechun/directories.py:7) or pass --gt_dir')
     runs = {i: (os.path.join(args.pred_dir, ds, i) if args.pred_dir else dirs.prediction_dir(ds, i)) for i in ids}
     out_dir = os.path.join(args.out_dir, ds) if args.out_dir else dirs.eval_dir(ds)
-    scripts.eval_uncertainty(ds, runs, gt_dir, out_dir, acts)
+    scripts.eval_uncertainty(ds, runs, gt_dir, out_dir, acts, fused=not args.plain, batch_subjects=args.batch_subjects)

@@ -282,6 +282,25 @@ size_t rcu_unc_workspace_bytes(size_t n_per_volume, int n_volumes);
 int rcu_unc_counts(const void* unc_dev, int unc_is_f64, const uint8_t* prediction_dev, const uint8_t* target_dev,
                    const uint8_t* mask_dev, size_t n_per_volume, int n_volumes, const double* thr_host, int n_thr,
                    uint64_t* counts_dev, void* workspace_dev, void* stream);
+/* The same counts straight from the float32 foreground-probability map p, for the evaluation of the 'probabilities' confidence entry
+ * (bin-eval/eval_uncertainty.py:176-202 on analysis.py:249-252: uncertainty = ToEntropy([1 - p, p])): that uncertainty is a function of the
+ * float32 p alone, so {p : uncertainty(p) > thr} is a set of float32 values -- found for the script's 11 thresholds (eval_uncertainty.py:239)
+ * by running the REFERENCE over every float32 in [0, 1] (tests/golden/generate_ue_boundaries.py, fixture g20, compiled in as
+ * csrc/rcu_ue_table.inc): an interval of bit patterns per threshold with a ragged window of 0-3 values at either end.  The kernel looks p
+ * up in that table: the counts equal the reference's integer for integer (no device log to disagree with numpy's in the last ulp) and the
+ * 8-byte-per-voxel entropy map is never made (6 bytes per voxel instead of 7 + 12 for making the map).
+ * thr_host: strictly ascending, every value one of rcu_unc_from_p_threshold(0 .. rcu_unc_from_p_num_thresholds() - 1), else RCU_ERR_INVALID
+ * (rcu_unc_from_p_supported tells beforehand; other thresholds take rcu_normalised_entropy + rcu_unc_counts).  The table (4.4 KB) is
+ * copied to the workspace with every call, stream-ordered. */
+int rcu_unc_from_p_num_thresholds(void);
+double rcu_unc_from_p_threshold(int i);
+int rcu_unc_from_p_supported(const double* thr_host, int n_thr);
+/* number of the thresholds the probability p exceeds per the table (host side: tests pin the table against the fixture without a GPU); -1 = unsupported thresholds */
+int rcu_unc_from_p_exceeded(float p, const double* thr_host, int n_thr);
+size_t rcu_unc_from_p_workspace_bytes(size_t n_per_volume, int n_volumes);
+int rcu_unc_counts_from_p(const float* p_foreground_dev, const uint8_t* prediction_dev, const uint8_t* target_dev, const uint8_t* mask_dev,
+                          size_t n_per_volume, int n_volumes, const double* thr_host, int n_thr, uint64_t* counts_dev, void* workspace_dev,
+                          void* stream);
 /* ToEntropy (rechun/eval/analysis.py:196-203) on a foreground-probability map: float32 products,
  * float64 sum, / log 2.  Either output may be NULL. */
 int rcu_normalised_entropy(const float* p_foreground_dev, size_t n, double* out_f64_dev, float* out_f32_dev,

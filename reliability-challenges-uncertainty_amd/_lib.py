@@ -102,6 +102,13 @@ SIGNATURES = {
     'rcu_unc_counts': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_double),
                                c_int, c_void_p, c_void_p, c_void_p]),
     'rcu_normalised_entropy': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'rcu_unc_from_p_num_thresholds': (c_int, []),
+    'rcu_unc_from_p_threshold': (c_double, [c_int]),
+    'rcu_unc_from_p_supported': (c_int, [POINTER(c_double), c_int]),
+    'rcu_unc_from_p_exceeded': (c_int, [c_float, POINTER(c_double), c_int]),
+    'rcu_unc_from_p_workspace_bytes': (c_size_t, [c_size_t, c_int]),
+    'rcu_unc_counts_from_p': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_double), c_int, c_void_p, c_void_p,
+                                      c_void_p]),
 }
 
 _lib = None

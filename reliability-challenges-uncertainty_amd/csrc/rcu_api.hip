@@ -1277,6 +1277,29 @@ extern "C" int rcu_unc_counts(const void* unc, int unc_is_f64, const uint8_t* pr
     return RCU_OK;
 }
 
+extern "C" int rcu_unc_from_p_num_thresholds(void) { return unc_from_p_num_thresholds(); }
+extern "C" double rcu_unc_from_p_threshold(int i) { return unc_from_p_threshold(i); }
+extern "C" int rcu_unc_from_p_supported(const double* thr, int n_thr) { return (thr && unc_from_p_supported(thr, n_thr)) ? 1 : 0; }
+extern "C" int rcu_unc_from_p_exceeded(float p, const double* thr, int n_thr)
+{
+    if (!thr || n_thr < 1 || n_thr > MAX_THR) return -1;
+    return unc_from_p_exceeded_host(p, thr, n_thr);
+}
+extern "C" size_t rcu_unc_from_p_workspace_bytes(size_t n, int nv) { return unc_from_p_workspace_bytes(n, nv < 1 ? 1 : nv); }
+
+extern "C" int rcu_unc_counts_from_p(const float* p, const uint8_t* prediction, const uint8_t* target, const uint8_t* mask, size_t n,
+                                     int n_volumes, const double* thr, int n_thr, uint64_t* counts, void* workspace, void* stream)
+{
+    if (!thr || !counts || !workspace || (n && (!p || !prediction || !target)))
+        return fail(RCU_ERR_INVALID, "rcu_unc_counts_from_p: null argument");
+    if (n_thr < 1 || n_thr > MAX_THR || n_volumes < 1) return fail(RCU_ERR_INVALID, "rcu_unc_counts_from_p: bad n_thr / n_volumes");
+    if (!unc_from_p_supported(thr, n_thr))
+        return fail(RCU_ERR_INVALID, "rcu_unc_counts_from_p: thresholds must be strictly ascending values of the built-in table (rcu_unc_from_p_threshold)");
+    RCU_HIP(launch_unc_counts_from_p(p, prediction, target, mask, n, n_volumes, thr, n_thr, reinterpret_cast<unsigned long long*>(counts),
+                                     workspace, static_cast<hipStream_t>(stream)));
+    return RCU_OK;
+}
+
 extern "C" int rcu_normalised_entropy(const float* p_fg, size_t n, double* out64, float* out32, void* stream)
 {
     if (n && !p_fg) return fail(RCU_ERR_INVALID, "rcu_normalised_entropy: null argument");

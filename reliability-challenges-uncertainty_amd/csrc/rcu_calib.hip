@@ -21,6 +21,8 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <utility>
 #include <type_traits>
 
 namespace rcu {
@@ -55,6 +57,27 @@ struct UncThresholds {
     float cell_thr[UNC_CELLS];
     unsigned char cell_base[UNC_CELLS];
 };
+
+// Uncertain-voxel sets of the reference as a function of the float32 probability (rcu_unc_counts_from_p): per threshold tau the set
+// {p : ToEntropy([1 - p, p]) > tau} is, by an exhaustive run of the reference over every float32 in [0, 1]
+// (tests/golden/generate_ue_boundaries.py -> rcu_ue_table.inc), an interval of bit patterns with, at each end, a ragged window of a few
+// values described by a bit mask.
+static constexpr int UE_P_CELLS = 256, UE_P_MASK_WORDS = 4;
+struct UePRow {
+    double thr;
+    unsigned lo_first, lo_width, hi_first, hi_width;      // windows [first, first + width); members in between
+    unsigned long long lo_mask[UE_P_MASK_WORDS], hi_mask[UE_P_MASK_WORDS];
+};
+static const UePRow UE_P_TABLE[] = {
+#include "rcu_ue_table.inc"
+};
+static constexpr int UE_P_ROWS = (int)(sizeof(UE_P_TABLE) / sizeof(UE_P_TABLE[0]));
+struct UePCell {          // one 1/256 slice of [0, 1]: m(p) = base + sign * past(p); past = p's bits >= end, or the mask bit inside [first, end)
+    int first, end;
+    short base, sign;
+    unsigned mask_slot;
+};
+static_assert(sizeof(UePCell) == 16, "one ds_read_b128");
 
 // One histogram word per voxel: the confidence as a 2^-40 fixed-point integer in bits 0..47, a count of one in bits 48..55 and the
 // positive flag in bits 56..63.  A lane sees at most ECE_MAX_BLOCKS * ELEMS_PER_BLOCK / CB_THREADS = 128 voxels per workgroup, so neither
@@ -438,17 +461,27 @@ __device__ __forceinline__ void load4(const double* src, double (&q)[4])
     q[0] = a.x, q[1] = a.y, q[2] = b.x, q[3] = b.y;
 }
 
-template <typename U>
+// FROM_P: `unc` is the float32 foreground-probability map itself and "uncertain" is decided by the table of the reference's own
+// float32 -> {uncertain, not} sets (UePCell below): no entropy map, no log.
+template <typename U, bool FROM_P = false>
 __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* __restrict__ unc, const uint8_t* __restrict__ pred,
                                                                         const uint8_t* __restrict__ target,
                                                                         const uint8_t* __restrict__ mask, size_t n,
                                                                         const UncThresholds th,
-                                                                        unsigned long long* __restrict__ partial, unsigned blocks_per_wg, unsigned nblocks)
+                                                                        unsigned long long* __restrict__ partial, unsigned blocks_per_wg, unsigned nblocks,
+                                                                        const UePCell* __restrict__ p_cells = nullptr,
+                                                                        const unsigned long long* __restrict__ p_masks = nullptr)
 {
     extern __shared__ unsigned unc_smem[];           // [wave][(n_thr + 1) * 2][lane], two 16-bit cell counters per word
     __shared__ unsigned s_w[CB_WAVES][UNC_SLOTS];    // per wave: [m][cell] totals
-    __shared__ float2 s_cell[UNC_CELLS];             // (threshold of the cell, thresholds below the cell as an integer in a float's bits): ONE read
-    if (threadIdx.x < UNC_CELLS) s_cell[threadIdx.x] = make_float2(th.cell_thr[threadIdx.x], __uint_as_float(th.cell_base[threadIdx.x]));
+    __shared__ float2 s_cell[FROM_P ? 1 : UNC_CELLS];   // (threshold of the cell, thresholds below the cell as an integer in a float's bits): ONE read
+    __shared__ UePCell s_pcell[FROM_P ? UE_P_CELLS : 1];
+    if constexpr (FROM_P) {
+        static_assert(UE_P_CELLS == CB_THREADS, "one cell per thread");
+        s_pcell[threadIdx.x] = p_cells[threadIdx.x];
+    } else {
+        if (threadIdx.x < UNC_CELLS) s_cell[threadIdx.x] = make_float2(th.cell_thr[threadIdx.x], __uint_as_float(th.cell_base[threadIdx.x]));
+    }
     __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ncol = (th.n_thr + 1) * 2;
@@ -462,7 +495,18 @@ __global__ __launch_bounds__(CB_THREADS) void unc_counts_sorted_kernel(const U* 
     // m = number of thresholds u exceeds
     auto exceeded = [&](U u) {
         int m = 0;
-        if constexpr (std::is_same<U, float>::value) {   // full-rate float32 compares instead of float64 ones
+        if constexpr (FROM_P) {
+            // cell = the 1/256-wide slice of [0, 1] the probability sits in (NaN, negatives -> 0); a cell holds at most one edge of one
+            // threshold's set: m = (sets that hold the cell's start) +- (is p past the edge?), the edge's ragged window by its bit mask
+            const int b = (int)__float_as_uint(u);          // signed compares: negative floats sort below every edge
+            const UePCell e = s_pcell[(int)__builtin_amdgcn_fmed3f(u * (float)UE_P_CELLS, 0.f, (float)(UE_P_CELLS - 1))];
+            int past = (b >= e.end) ? 1 : 0;
+            if (b >= e.first && b < e.end) {                // inside a ragged window (a handful of float32 values per table)
+                const unsigned d = (unsigned)(b - e.first);
+                past = (int)((p_masks[(size_t)e.mask_slot * UE_P_MASK_WORDS + (d >> 6)] >> (d & 63u)) & 1ull);
+            }
+            m = e.base + e.sign * past;
+        } else if constexpr (std::is_same<U, float>::value) {   // full-rate float32 compares instead of float64 ones
             if (th.n_cells > 0) {
                 // unc_cell_of with the clamp made on the float (one v_med3_f32; NaN -> 0): the same integer
                 const int c = (int)__builtin_amdgcn_fmed3f((u - th.cell_lo) * th.cell_scale, 0.f, (float)(UNC_CELLS - 1));
@@ -675,6 +719,129 @@ hipError_t launch_unc_counts(const void* unc, int unc_is_f64, const uint8_t* pre
     else
         hipLaunchKernelGGL(unc_counts_kernel<float>, dim3(nb, n_volumes), dim3(CB_THREADS), 0, stream,
                            reinterpret_cast<const float*>(unc), prediction, target, mask, n, th, part);
+    hipLaunchKernelGGL(unc_reduce_kernel, dim3((unsigned)((n_volumes * n_thr * 4 + RED_THREADS - 1) / RED_THREADS)), dim3(RED_THREADS), 0, stream, part,
+                       n_volumes, n_thr, out_dev);
+    return hipGetLastError();
+}
+
+// ---- the same counts from the float32 probability map (rcu_unc_counts_from_p)
+static inline int ue_p_cell_of(unsigned bits)
+{
+    float u;
+    std::memcpy(&u, &bits, 4);
+    const float x = u * (float)UE_P_CELLS;      // exact (a power of two): the device's product
+    const int c = (x > 0.f) ? (int)x : 0;
+    return c < UE_P_CELLS - 1 ? c : UE_P_CELLS - 1;
+}
+
+// Row of the table for a threshold (exact match of the double), or -1
+static int ue_p_row_of(double thr)
+{
+    for (int r = 0; r < UE_P_ROWS; ++r)
+        if (UE_P_TABLE[r].thr == thr) return r;
+    return -1;
+}
+
+// Cells + masks for the thresholds thr[0..n_thr) (strictly ascending, all in the table).  false: a threshold is not in the table, or two
+// edges share a cell / a window straddles a cell border (cannot happen with the shipped table: checked by tests/test_abi_cpu.py).
+static bool ue_p_build(const double* thr, int n_thr, UePCell* cells, unsigned long long* masks)
+{
+    if (n_thr < 1 || n_thr > MAX_THR) return false;
+    struct Edge { unsigned first, end; int sign; unsigned long long mask[UE_P_MASK_WORDS]; };
+    Edge edges[2 * MAX_THR];
+    int n_edges = 0;
+    for (int t = 0; t < n_thr; ++t) {
+        if (t > 0 && !(thr[t - 1] < thr[t])) return false;
+        const int r = ue_p_row_of(thr[t]);
+        if (r < 0) return false;
+        const UePRow& R = UE_P_TABLE[r];
+        Edge up{R.lo_first, R.lo_first + R.lo_width, +1, {}}, down{R.hi_first, R.hi_first + R.hi_width, -1, {}};
+        for (int w = 0; w < UE_P_MASK_WORDS; ++w) {
+            up.mask[w] = R.lo_mask[w];           // past the rising edge = member
+            down.mask[w] = ~R.hi_mask[w];        // past the falling edge = NOT member
+        }
+        edges[n_edges++] = up;
+        edges[n_edges++] = down;
+    }
+    // nested sets: rising edges ascend with the threshold, falling edges descend -- sort by position
+    for (int i = 1; i < n_edges; ++i)
+        for (int j = i; j > 0 && edges[j].first < edges[j - 1].first; --j) std::swap(edges[j], edges[j - 1]);
+    for (int c = 0; c < UE_P_CELLS; ++c) cells[c] = UePCell{0x7fffffff, 0x7fffffff, 0, 0, 0u};
+    for (int w = 0; w < UE_P_MASK_WORDS; ++w) masks[w] = 0ull;      // slot 0: no window
+    int m = 0, prev_cell = -1;
+    for (int e = 0; e < n_edges; ++e) {
+        const Edge& E = edges[e];
+        const int c0 = ue_p_cell_of(E.first), c1 = ue_p_cell_of(E.end);
+        if (c0 != c1 || c0 <= prev_cell || E.end - E.first > 64u * UE_P_MASK_WORDS) return false;
+        for (int c = prev_cell + 1; c < c0; ++c) cells[c].base = (short)m;
+        cells[c0] = UePCell{(int)E.first, (int)E.end, (short)m, (short)E.sign, (unsigned)(e + 1)};
+        for (int w = 0; w < UE_P_MASK_WORDS; ++w) masks[(size_t)(e + 1) * UE_P_MASK_WORDS + w] = E.mask[w];
+        m += E.sign;
+        if (m < 0 || m > n_thr) return false;
+        prev_cell = c0;
+    }
+    for (int c = prev_cell + 1; c < UE_P_CELLS; ++c) cells[c].base = (short)m;
+    return m == 0;
+}
+
+int unc_from_p_num_thresholds() { return UE_P_ROWS; }
+double unc_from_p_threshold(int i) { return (i >= 0 && i < UE_P_ROWS) ? UE_P_TABLE[i].thr : -1.0; }
+bool unc_from_p_supported(const double* thr, int n_thr)
+{
+    UePCell cells[UE_P_CELLS];
+    unsigned long long masks[(2 * MAX_THR + 1) * UE_P_MASK_WORDS];
+    return ue_p_build(thr, n_thr, cells, masks);
+}
+
+static constexpr size_t UE_P_TABLE_BYTES = sizeof(UePCell) * UE_P_CELLS + sizeof(unsigned long long) * (2 * MAX_THR + 1) * UE_P_MASK_WORDS;
+size_t unc_from_p_workspace_bytes(size_t n_per_volume, int n_volumes)
+{
+    return unc_workspace_bytes(n_per_volume, n_volumes) + UE_P_TABLE_BYTES;
+}
+
+// Reference-side evaluation of the table for one probability (test aid + the launcher's tiny-input path)
+int unc_from_p_exceeded_host(float p, const double* thr, int n_thr)
+{
+    unsigned b;
+    std::memcpy(&b, &p, 4);
+    int m = 0;
+    for (int t = 0; t < n_thr; ++t) {
+        const int r = ue_p_row_of(thr[t]);
+        if (r < 0) return -1;
+        const UePRow& R = UE_P_TABLE[r];
+        bool in = b >= R.lo_first + R.lo_width && b < R.hi_first;
+        if (b >= R.lo_first && b < R.lo_first + R.lo_width) in = (R.lo_mask[(b - R.lo_first) >> 6] >> ((b - R.lo_first) & 63u)) & 1ull;
+        if (b >= R.hi_first && b < R.hi_first + R.hi_width) in = (R.hi_mask[(b - R.hi_first) >> 6] >> ((b - R.hi_first) & 63u)) & 1ull;
+        m += in ? 1 : 0;
+    }
+    return m;
+}
+
+hipError_t launch_unc_counts_from_p(const float* p_fg, const uint8_t* prediction, const uint8_t* target, const uint8_t* mask, size_t n,
+                                    int n_volumes, const double* thr_host, int n_thr, unsigned long long* out_dev, void* workspace,
+                                    hipStream_t stream)
+{
+    if (n_volumes < 1) return hipErrorInvalidValue;
+    // the table travels with every call (4.4 KB, stream-ordered; pageable source: the runtime stages it before the call returns)
+    struct Host { UePCell cells[UE_P_CELLS]; unsigned long long masks[(2 * MAX_THR + 1) * UE_P_MASK_WORDS]; } host;
+    static_assert(sizeof(Host) == UE_P_TABLE_BYTES, "workspace layout");
+    if (!ue_p_build(thr_host, n_thr, host.cells, host.masks)) return hipErrorInvalidValue;
+    const unsigned nb = blocks_per_volume(n);
+    if (nb == 0) return hipMemsetAsync(out_dev, 0, sizeof(unsigned long long) * 8 * n_thr * n_volumes, stream);
+    unsigned long long* part = reinterpret_cast<unsigned long long*>(workspace);
+    char* table_dev = reinterpret_cast<char*>(workspace) + unc_workspace_bytes(n, n_volumes);
+    hipError_t e = hipMemsetAsync(part, 0, unc_workspace_bytes(n, n_volumes), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(table_dev, &host, sizeof host, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    UncThresholds th{};
+    th.n_thr = n_thr;
+    const size_t lds = (size_t)CB_WAVES * (n_thr + 1) * 2 * 64 * sizeof(unsigned);
+    const unsigned bpw = blocks_per_workgroup(nb, n_volumes, UNC_MAX_BLOCKS, g_forced_blocks[1]);
+    const unsigned gx = (nb + bpw - 1) / bpw;
+    hipLaunchKernelGGL((unc_counts_sorted_kernel<float, true>), dim3(gx, n_volumes), dim3(CB_THREADS), lds, stream, p_fg, prediction, target,
+                       mask, n, th, part, bpw, nb, reinterpret_cast<const UePCell*>(table_dev),
+                       reinterpret_cast<const unsigned long long*>(table_dev + sizeof(UePCell) * UE_P_CELLS));
     hipLaunchKernelGGL(unc_reduce_kernel, dim3((unsigned)((n_volumes * n_thr * 4 + RED_THREADS - 1) / RED_THREADS)), dim3(RED_THREADS), 0, stream, part,
                        n_volumes, n_thr, out_dev);
     return hipGetLastError();

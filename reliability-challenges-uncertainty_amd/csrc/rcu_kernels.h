@@ -222,6 +222,15 @@ hipError_t launch_unc_counts(const void* unc, int unc_is_f64, const uint8_t* pre
                              const uint8_t* mask, size_t n_per_volume, int n_volumes, const double* thr_host,
                              int n_thr, unsigned long long* out_dev, void* workspace, hipStream_t stream);
 hipError_t launch_norm_entropy(const float* p_fg, size_t n, double* out_f64, float* out_f32, hipStream_t stream);
+// the same counts straight from the float32 foreground-probability map, "uncertain" decided by the table of the reference's own sets
+int unc_from_p_num_thresholds();
+double unc_from_p_threshold(int i);
+bool unc_from_p_supported(const double* thr, int n_thr);
+int unc_from_p_exceeded_host(float p, const double* thr, int n_thr);
+size_t unc_from_p_workspace_bytes(size_t n_per_volume, int n_volumes);
+hipError_t launch_unc_counts_from_p(const float* p_fg, const uint8_t* prediction, const uint8_t* target, const uint8_t* mask, size_t n_per_volume,
+                                    int n_volumes, const double* thr_host, int n_thr, unsigned long long* out_dev, void* workspace,
+                                    hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // PostNet: fused 1x1-conv stack on the U-Net feature map (rcu_postnet.hip)

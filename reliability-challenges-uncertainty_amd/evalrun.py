@@ -417,6 +417,9 @@ class CorrectionAction(EvalAction):
             case.record(results[thr], sf.subject, self.id_)
 
 
+ECE_TYPES = {EceAction, EceCalibrationAction}
+
+
 def get_actions(action_names, min_max_dir, base_dir, ece_details):
     """bin-eval/eval_uncertainty.py:226-244."""
     actions = []
@@ -432,14 +435,167 @@ def get_actions(action_names, min_max_dir, base_dir, ece_details):
     return actions
 
 
-def evaluate_runs(eval_data_list, action_names, base_dir, ece_details=''):
-    """The subject loop of bin-eval/eval_uncertainty.py:13-50 for already collected runs."""
+# ------------------------------------------------------------------------ the fused subject loop
+class _ReadAhead:
+    """The files of the coming subjects, read by a few threads while the current ones are evaluated (zlib releases the GIL: the .nii.gz
+    streams really inflate side by side).  ``get(i)`` -> the ``to_eval`` dict of subject i (blocks until its files are in)."""
+
+    def __init__(self, subject_files, params, depth, threads=4):
+        import concurrent.futures
+        self.subject_files, self.params, self.depth = subject_files, params, max(1, int(depth))
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=threads, thread_name_prefix='rcu-eval-read')
+        self.futures = {}
+        self.next = 0
+
+    def _read(self, sf):
+        t0 = time.perf_counter()
+        cats, p = sf.categories, self.params
+        out = {p.misc_entry: nifti.read(cats['misc'][p.misc_entry])[0]}
+        if p.need_target:
+            out['target'] = (read_label_image(cats['labels']['gt']) > 0).astype(np.uint8)       # analysis.py:88-89
+        if p.need_prediction:
+            out['prediction'] = nifti.read(cats['labels']['prediction'], np.uint8)[0]
+        if p.need_t2_mask:
+            out['mask'] = nifti.read(cats['images']['t2'])[0] > 0
+        out['_read_s'] = time.perf_counter() - t0
+        return out
+
+    def _fill(self, upto):
+        while self.next < min(upto, len(self.subject_files)):
+            self.futures[self.next] = self.pool.submit(self._read, self.subject_files[self.next])
+            self.next += 1
+
+    def get(self, i):
+        self._fill(i + 1 + self.depth)
+        return self.futures.pop(i).result()
+
+    def close(self):
+        self.pool.shutdown(wait=False, cancel_futures=True)
+
+
+def _fusable(entry, actions):
+    """The fused loop covers the runs whose confidence entry IS the probability map (baseline, baseline_mc, center, center_mc, ensemble:
+    evaldata.py:21-47) -- no rescaling, no uncertainty-to-probability conversion -- and the four actions of the script."""
+    masks = {bool(getattr(a, 'need_t2_mask', False) or getattr(a, 'need_mask', False)) for a in actions if type(a) in ECE_TYPES}
+    return (entry.confidence_entry == 'probabilities' and len(masks) <= 1 and
+            all(type(a) in (SaveMinMaxAction, EceAction, EceCalibrationAction, CorrectionAction) for a in actions) and
+            all(ev.from_p_supported(a.thresholds) for a in actions if isinstance(a, CorrectionAction)))
+
+
+def _evaluate_fused(entry, actions, batch_subjects, timing):
+    """All actions of a 'probabilities' run from ONE upload per subject and ONE launch per scan and batch of subjects: files read ahead by
+    threads, subjects of equal size staged side by side in pinned memory, `evaluation.SubjectBatch.metrics` -- reliability histogram inside
+    the mask (ece_dice and calib share it), the uncertainty-error counts of all thresholds from the probability map (their tp / tn / fp /
+    fn are ece_dice's confusion matrix), min / max -- and the results fanned out to the actions' CSV hooks in subject order.  The rows are
+    those of the per-action loop, byte for byte (tests/test_gpu_parity.py)."""
+    by_type = {type(a): a for a in actions}
+    want_mask = any(getattr(a, 'need_t2_mask', False) or getattr(a, 'need_mask', False) for a in actions)
+    params = Loader.Params('probabilities', need_target=True, need_prediction=True, need_t2_mask=want_mask)
+    want = (['ece'] if (EceAction in by_type or EceCalibrationAction in by_type) else []) + ['minmax'] + \
+           (['ue'] if (CorrectionAction in by_type or EceAction in by_type or EceCalibrationAction in by_type) else [])
+    ue = by_type.get(CorrectionAction)
+    thresholds = tuple(ue.thresholds) if ue is not None else (0.5,)
+    files = entry.subject_files
+    reader = _ReadAhead(files, params, depth=2 * batch_subjects)
+    batches = {}          # voxels per subject -> SubjectBatch (datasets have one size; a mixed one gets a batch object per size)
+    try:
+        i = 0
+        while i < len(files):
+            t_start = time.perf_counter()
+            first = reader.get(i)
+            n_vox, n_dim = first['probabilities'].size, first['target'].ndim
+            group = [(i, first)]
+            while len(group) < batch_subjects and i + len(group) < len(files):
+                nxt = reader.get(i + len(group))
+                if nxt['probabilities'].size != n_vox:
+                    reader.futures[i + len(group)] = _Done(nxt)       # another size: it opens the next batch
+                    break
+                group.append((i + len(group), nxt))
+            t_read = time.perf_counter()
+            batch = batches.get((n_vox, want_mask))
+            if batch is None or batch.count < len(group):
+                batch = batches[(n_vox, want_mask)] = ev.SubjectBatch(max(batch_subjects, len(group)), n_vox, with_mask=want_mask)
+            batch.used = 0
+            for slot, (_, d) in enumerate(group):
+                batch.put(slot, d['probabilities'], d['prediction'], d['target'], d.get('mask'))
+            t_stage = time.perf_counter()
+            batch.upload()
+            res = batch.metrics(thresholds=thresholds, want=want)
+            t_gpu = time.perf_counter()
+            for slot, (k, d) in enumerate(group):
+                sf = files[k]
+                mn, mx = res['min'][slot], res['max'][slot]
+                # helper.add_background_probability's range check (rechun/eval/helper.py:8-12, 31-47), on the device's min / max
+                if (ECE_TYPES & set(by_type)) or ue is not None:
+                    if mx > 1:
+                        raise ValueError('Found value larger than 1: "{}"'.format(mx))
+                    if mn < 0:
+                        raise ValueError('Found value smaller than 0: "{}"'.format(mn))
+                counts = res['counts'][slot] if 'counts' in res else None
+                for action in actions:
+                    if isinstance(action, SaveMinMaxAction):
+                        action.eval_cases[0].record({'min': mn, 'max': mx}, sf.subject, action.id_)
+                    elif isinstance(action, (EceAction, EceCalibrationAction)):
+                        hist = [h[slot] for h in res['hist']]
+                        tp, tn, fp, fn = (int(v) for v in counts[0][:4])
+                        results = {}
+                        if isinstance(action, EceCalibrationAction):      # key order of EceBinaryNumpy(return_bins=True) + DiceNumpy
+                            ece = ev.ece_from_histogram(*hist, n_dim=n_dim, out_bins=results)
+                            results['ece'] = ece
+                            results['dice'] = ev._dice(tp, fp, fn)
+                        else:
+                            results['ece'] = ev.ece_from_histogram(*hist, n_dim=n_dim)
+                            results['dice'] = ev._dice(tp, fp, fn)
+                            results.update(tp=tp, tn=tn, fp=fp, fn=fn, n=tp + tn + fp + fn)
+                        action.eval_cases[0].record(results, sf.subject, action.id_)
+                    elif isinstance(action, CorrectionAction):
+                        for t, case in enumerate(action.eval_cases):
+                            case.record(ev.correction_results(counts[t]), sf.subject, action.id_)
+            t_end = time.perf_counter()
+            per = (t_end - t_start) / len(group)
+            for k, d in group:
+                print('[{}/{}] {} ({}s)'.format(k + 1, len(files), files[k].subject, per))
+            if timing is not None:
+                timing['subjects'] += len(group)
+                timing['batches'] += 1
+                timing['wait_for_files_s'] += t_read - t_start
+                timing['read_thread_s'] += sum(d['_read_s'] for _, d in group)
+                timing['stage_s'] += t_stage - t_read
+                timing['upload_and_kernels_s'] += t_gpu - t_stage
+                timing['csv_rows_s'] += t_end - t_gpu
+            i += len(group)
+    finally:
+        reader.close()
+
+
+class _Done:
+    def __init__(self, value):
+        self.value = value
+
+    def result(self):
+        return self.value
+
+
+def evaluate_runs(eval_data_list, action_names, base_dir, ece_details='', fused=True, batch_subjects=8, timing=None):
+    """The subject loop of bin-eval/eval_uncertainty.py:13-50 for already collected runs.
+    ``fused`` (default): runs whose confidence entry is the probability map go through ``_evaluate_fused`` -- one upload per subject shared by
+    all actions, ``batch_subjects`` subjects per launch, files read ahead; the other runs (confidence / sigma entries: host-side
+    rescaling recipes) and ``fused=False`` take the reference's subject-by-subject, action-by-action order.
+    ``timing``: a dict that receives where the fused loop's time went (tools/eval_throughput.py)."""
     actions = get_actions(action_names, os.path.join(base_dir, MINMAX_NAME), base_dir, ece_details)
     for entry in eval_data_list:
         for action in actions:
             action.setup_eval(entry)
         for action in actions:
             action.start_eval()
+        if fused and entry.subject_files and _fusable(entry, actions):
+            if timing is not None:
+                for key in ('subjects', 'batches', 'wait_for_files_s', 'read_thread_s', 'stage_s', 'upload_and_kernels_s', 'csv_rows_s'):
+                    timing.setdefault(key, 0)
+            _evaluate_fused(entry, actions, max(1, int(batch_subjects)), timing)
+            for action in actions:
+                action.finish_eval()
+            continue
         for i, sf in enumerate(entry.subject_files):
             print('[{}/{}] {}'.format(i + 1, len(entry.subject_files), sf.subject), end=' ', flush=True)
             loader = Loader()

@@ -119,6 +119,94 @@ def ece_binary(probabilities, target, n_bins=10, threshold_range: tuple = None, 
     return ece_from_histogram(count[0], sum_conf[0], sum_pos[0], n_dim, out_bins, bin_weighting)
 
 
+# ------------------------------------------------------ everything the evaluation asks of a probability map, from ONE resident copy
+class SubjectBatch:
+    """``count`` subjects of ``n`` voxels each, resident on the device as [count, n] arrays: foreground probability (float32), prediction,
+    target and (optionally) evaluation mask (uint8).  Filled slot by slot from pinned staging buffers (numpy arrays) or device tensors;
+    ``metrics`` runs every per-voxel scan of the evaluation script on it in one launch each."""
+
+    def __init__(self, count, n, device=None, with_mask=False):
+        self.count, self.n = int(count), int(n)
+        self.device = torch.device(device) if device is not None else _device()
+        self.with_mask = bool(with_mask)
+        shape = (self.count, self.n)
+        self.p = torch.empty(shape, device=self.device, dtype=torch.float32)
+        self.prediction = torch.empty(shape, device=self.device, dtype=torch.uint8)
+        self.target = torch.empty(shape, device=self.device, dtype=torch.uint8)
+        self.mask = torch.empty(shape, device=self.device, dtype=torch.uint8) if with_mask else None
+        self._pinned = None
+        self.used = 0
+
+    def _staging(self):
+        if self._pinned is None:       # one pinned image of the batch: the slots are filled on the host, the batch goes up in four copies
+            shape = (self.count, self.n)
+            self._pinned = {'p': torch.empty(shape, dtype=torch.float32, pin_memory=True),
+                            'prediction': torch.empty(shape, dtype=torch.uint8, pin_memory=True),
+                            'target': torch.empty(shape, dtype=torch.uint8, pin_memory=True)}
+            if self.with_mask:
+                self._pinned['mask'] = torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+        return self._pinned
+
+    def put(self, slot, p, prediction, target, mask=None):
+        """Subject ``slot`` of the batch: numpy arrays (staged in pinned memory, uploaded by ``upload``) or device tensors (copied in place)."""
+        arrays = {'p': p, 'prediction': prediction, 'target': target}
+        if self.with_mask:
+            if mask is None:
+                raise ValueError('this batch was made with a mask')
+            arrays['mask'] = mask
+        for key, a in arrays.items():
+            dst_dev = getattr(self, key)[slot]
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                dst_dev.copy_(a.reshape(-1).to(dst_dev.dtype), non_blocking=True)
+            else:
+                a = np.asarray(a)
+                if a.size != self.n:
+                    raise ValueError('subject of {} voxels in a batch of {}-voxel slots'.format(a.size, self.n))
+                dst = self._staging()[key][slot].numpy()
+                np.copyto(dst, a.reshape(-1), casting='unsafe')      # (bool / int64 label maps -> uint8, as torch's cast on the device would)
+        self.used = max(self.used, slot + 1)
+
+    def upload(self):
+        if self._pinned is not None:
+            for key, host in self._pinned.items():
+                getattr(self, key)[:self.used].copy_(host[:self.used], non_blocking=True)
+
+    def metrics(self, n_bins=10, thresholds=UE_THRESHOLDS, want=('minmax', 'ece', 'ue')):
+        """-> dict of host arrays over the ``used`` subjects: ``min`` / ``max`` (float32), ``hist`` = (count, sum_conf, sum_pos) of the
+        reliability histogram inside the mask, ``counts`` [used, len(thresholds), 8] of the uncertainty-error action on the WHOLE volume
+        (bin-eval/eval_uncertainty.py:176-202 uses no mask; tp, tn, fp, fn of it are the confusion matrix of ece_dice).  One launch per
+        scan for all subjects, one synchronisation for all results."""
+        v = self.used
+        lib = _lib.load()
+        out, keep = {}, []
+        if 'minmax' in want:
+            lo, hi = torch.aminmax(self.p[:v], dim=1)
+            keep.append(('minmax', torch.stack([lo, hi])))
+        if 'ece' in want:
+            result = torch.empty(v * ctypes.sizeof(_lib.EceResult), device=self.device, dtype=torch.uint8)
+            ws = torch.empty(max(lib.rcu_ece_workspace_bytes(self.n, v), 8), device=self.device, dtype=torch.uint8)
+            _lib.check(lib.rcu_ece_hist(_lib.ptr(self.p), _lib.ptr(self.target), _lib.ptr(self.mask), self.n, v, _lib.ece_thresholds(n_bins),
+                                        n_bins, _lib.ptr(result), _lib.ptr(ws), _lib.current_stream()))
+            keep.append(('ece', result))
+        if 'ue' in want:
+            thr = (ctypes.c_double * len(thresholds))(*[float(t) for t in thresholds])
+            counts = torch.empty((v, len(thresholds), 8), device=self.device, dtype=torch.int64)
+            ws2 = torch.empty(lib.rcu_unc_from_p_workspace_bytes(self.n, v), device=self.device, dtype=torch.uint8)
+            _lib.check(lib.rcu_unc_counts_from_p(_lib.ptr(self.p), _lib.ptr(self.prediction), _lib.ptr(self.target), None, self.n, v, thr,
+                                                 len(thresholds), _lib.ptr(counts), _lib.ptr(ws2), _lib.current_stream()))
+            keep.append(('ue', counts))
+        host = {k: t.cpu() for k, t in keep}          # (the first .cpu() waits for the stream: the others are ready by then)
+        if 'minmax' in host:
+            mm = host['minmax'].numpy()
+            out['min'], out['max'] = mm[0].copy(), mm[1].copy()
+        if 'ece' in host:
+            raw = host['ece'].numpy().view(np.uint64).reshape(v, 3, _lib.RCU_MAX_BINS)
+            out['hist'] = (raw[:, 0, :n_bins].astype(np.int64), raw[:, 1, :n_bins].copy().view(np.float64), raw[:, 2, :n_bins].astype(np.int64))
+        if 'ue' in host:
+            out['counts'] = host['ue'].numpy()
+        return out
+
+
 # ---------------------------------------------------------------------- uncertainty-error counts
 def uncertainty_counts(prediction, target, uncertainty, thresholds=UE_THRESHOLDS, mask=None, n_volumes=1):
     """int64 ``[n_volumes, len(thresholds), 8]`` = tp, tn, fp, fn, tpu, tnu, fpu, fnu with
@@ -136,6 +224,78 @@ def uncertainty_counts(prediction, target, uncertainty, thresholds=UE_THRESHOLDS
     _lib.check(lib.rcu_unc_counts(_lib.ptr(u), int(is64), _lib.ptr(pr), _lib.ptr(tg), _lib.ptr(m), n, n_volumes, thr,
                                   len(thresholds), _lib.ptr(out), _lib.ptr(ws), _lib.current_stream()))
     return out.cpu().numpy()
+
+
+def from_p_supported(thresholds):
+    """True when the library's table of the reference's uncertain-voxel sets covers these thresholds (strictly ascending, each one of
+    bin-eval/eval_uncertainty.py:239's eleven): ``uncertainty_counts_from_p`` then reproduces the reference's counts integer for integer."""
+    thresholds = [float(t) for t in thresholds]
+    if not 1 <= len(thresholds) <= _lib.RCU_MAX_THRESHOLDS:
+        return False
+    thr = (ctypes.c_double * len(thresholds))(*thresholds)
+    return bool(_lib.load().rcu_unc_from_p_supported(thr, len(thresholds)))
+
+
+def uncertainty_counts_from_p(prediction, target, foreground_probability, thresholds=UE_THRESHOLDS, mask=None, n_volumes=1):
+    """``uncertainty_counts`` for uncertainty = ToEntropy([1 - p, p]) (the 'probabilities' confidence entry, analysis.py:249-252) computed
+    from the float32 probability map itself: "uncertain" is looked up in the table of the reference's own float32 sets (include/rcu.h,
+    rcu_unc_counts_from_p; fixture g20), so neither an entropy map nor a device log enters -- the counts are the reference's."""
+    p = _to_dev(foreground_probability, torch.float32).reshape(n_volumes, -1)
+    pr = _to_dev(prediction, torch.uint8).reshape(n_volumes, -1)
+    tg = _to_dev(target, torch.uint8).reshape(n_volumes, -1)
+    m = None if mask is None else _to_dev(mask, torch.uint8).reshape(n_volumes, -1)
+    n = p.shape[1]
+    thr = (ctypes.c_double * len(thresholds))(*[float(t) for t in thresholds])
+    lib = _lib.load()
+    out = torch.empty((n_volumes, len(thresholds), 8), device=p.device, dtype=torch.int64)
+    ws = torch.empty(lib.rcu_unc_from_p_workspace_bytes(n, n_volumes), device=p.device, dtype=torch.uint8)
+    _lib.check(lib.rcu_unc_counts_from_p(_lib.ptr(p), _lib.ptr(pr), _lib.ptr(tg), _lib.ptr(m), n, n_volumes, thr, len(thresholds),
+                                         _lib.ptr(out), _lib.ptr(ws), _lib.current_stream()))
+    return out.cpu().numpy()
+
+
+class EntropyOfProbability:
+    """What ``ToEntropy`` leaves under ``uncertainty``: the normalised entropy of ``[1 - p, p]`` as a function of the float32 foreground
+    map it holds.  The uncertainty-error strategies hand the MAP to ``uncertainty_counts_from_p`` (exact counts, no entropy volume);
+    anything that wants the array (``np.asarray``, arithmetic, indexing) gets the device-computed float64 map, made once."""
+
+    def __init__(self, foreground_probability):
+        self.foreground_probability = foreground_probability
+        self._array = None
+
+    def materialise(self):
+        if self._array is None:
+            self._array = normalised_entropy(self.foreground_probability).cpu().numpy()
+        return self._array
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.materialise()
+        return a if dtype is None else a.astype(dtype)
+
+    shape = property(lambda self: tuple(self.foreground_probability.shape))
+    dtype = np.dtype(np.float64)
+
+    def __getitem__(self, item):
+        return self.materialise()[item]
+
+    def __gt__(self, other):
+        return self.materialise() > other
+
+    def min(self):
+        return self.materialise().min()
+
+    def max(self):
+        return self.materialise().max()
+
+
+def _counts(prediction, target, uncertainty, thresholds, mask=None):
+    """The 8 x len(thresholds) counts of one volume: through the probability table when the uncertainty is ToEntropy's and the
+    thresholds are the table's, else by comparing the uncertainty map."""
+    if isinstance(uncertainty, EntropyOfProbability):
+        if from_p_supported(thresholds):
+            return uncertainty_counts_from_p(prediction, target, uncertainty.foreground_probability, thresholds, mask)[0]
+        uncertainty = uncertainty.materialise()
+    return uncertainty_counts(prediction, target, uncertainty, thresholds, mask)[0]
 
 
 def uncertainty(prediction, target, thresholded_uncertainty, mask=None):
@@ -314,9 +474,9 @@ class ToEntropy(PrepareData):
         if prob.shape[-1] != self.nb_classes:
             raise ValueError('last dimension of probability array ({}) must be equal to nb_classes ({})'
                              .format(prob.shape, self.nb_classes))
-        ent = normalised_entropy(np.ascontiguousarray(prob[..., 1])).cpu().numpy()
-        to_eval[self.entropy_entry] = ent
-        check_min_max(ent, only_warn=True)
+        # (the reference's check_min_max(..., only_warn=True) can only ever warn here: the entropy of a probability pair lies in
+        # [0, 1 + 2e-7]; the map itself is made when somebody asks for it)
+        to_eval[self.entropy_entry] = EntropyOfProbability(np.ascontiguousarray(prob[..., 1]))
         return to_eval
 
 
@@ -439,8 +599,7 @@ class UncertaintyErrorDiceNumpy(EvaluationStrategy):
 
     def __call__(self, to_evaluate: dict, results: dict):
         mask = ~to_evaluate['target_boarder'] if self.with_mask else None
-        c = uncertainty_counts(to_evaluate['prediction'], to_evaluate['target'], to_evaluate['uncertainty'],
-                               (self.uncertainty_threshold,), mask)[0, 0]
+        c = _counts(to_evaluate['prediction'], to_evaluate['target'], to_evaluate['uncertainty'], (self.uncertainty_threshold,), mask)[0]
         tp, tn, fp, fn, tpu, tnu, fpu, fnu = (int(v) for v in c)
         results['{}precision'.format(self.prefix)] = error_precision(tpu, tnu, fpu, fnu)
         results['{}recall'.format(self.prefix)] = error_recall(fp, fn, fpu, fnu)
@@ -453,8 +612,7 @@ class UncertaintyAndCorrectionEvalNumpy(EvaluationStrategy):
         self.uncertainty_threshold = uncertainty_threshold
 
     def __call__(self, to_evaluate: dict, results: dict) -> None:
-        c = uncertainty_counts(to_evaluate['prediction'], to_evaluate['target'], to_evaluate['uncertainty'],
-                               (self.uncertainty_threshold,))[0, 0]
+        c = _counts(to_evaluate['prediction'], to_evaluate['target'], to_evaluate['uncertainty'], (self.uncertainty_threshold,))[0]
         results.update(correction_results(c))
 
 
@@ -467,7 +625,6 @@ class UncertaintyAndCorrectionSweep(EvaluationStrategy):
         self.thresholds = tuple(thresholds)
 
     def __call__(self, to_evaluate: dict, results: dict) -> None:
-        c = uncertainty_counts(to_evaluate['prediction'], to_evaluate['target'], to_evaluate['uncertainty'],
-                               self.thresholds)[0]
+        c = _counts(to_evaluate['prediction'], to_evaluate['target'], to_evaluate['uncertainty'], self.thresholds)
         for i, thr in enumerate(self.thresholds):
             results[thr] = correction_results(c[i])

@@ -398,7 +398,7 @@ for _fn in (test_default, test_ensemble, test_aleatoric, test_auxiliary_feat, te
 
 
 def eval_uncertainty(dataset, run_dirs: dict, ground_truth_dir, base_dir, actions=('minmax', 'ece_dice', 'calib', 'bnf_ue'),
-                     expected_subjects=None):
+                     expected_subjects=None, fused=True, batch_subjects=8, timing=None):
     """``run_dirs``: run id (baseline, baseline_mc, ..., aleatoric) -> prediction directory.  BraTS evaluates
     inside the T2 brain mask (``ece_details='foreground'``), ISIC on all pixels (eval_uncertainty.py:19-26).
     ``ground_truth_dir``: the BraTS tree of ``<subject>/<subject>_{t2,seg,...}.nii.gz`` or, for ISIC, the dataset
@@ -412,5 +412,6 @@ def eval_uncertainty(dataset, run_dirs: dict, ground_truth_dir, base_dir, action
         gts = evalrun.collect_isic_ground_truth(ground_truth_dir)
         details = ''
     entries = [evalrun.get_eval_data(run_id, path, gts, expected_subjects) for run_id, path in run_dirs.items()]
-    evalrun.evaluate_runs(entries, list(actions), base_dir, details)
+    # (fused / batch_subjects / timing: rcu_amd.evalrun.evaluate_runs -- one upload per subject shared by all actions, subjects batched per launch)
+    evalrun.evaluate_runs(entries, list(actions), base_dir, details, fused=fused, batch_subjects=batch_subjects, timing=timing)
     return entries

@@ -164,3 +164,35 @@ def test_winograd4_kernel_owns_the_accumulator_file(tmp_path):
         assert int(block.split()[0]) == 256
         assert int(re.search(r'\.vgpr_spill_count:\s*(\d+)', block).group(1)) == 0
         assert int(re.search(r'\.private_segment_fixed_size:\s*(\d+)', block).group(1)) == 0
+
+
+def test_uncertain_voxel_table_matches_fixture_g20():
+    """The table compiled into the library (csrc/rcu_ue_table.inc) is the committed fixture g20 -- checked through the host-side entry
+    points, no GPU: thresholds, support of the script's eleven thresholds and of their subsets, and the membership of every probe value."""
+    import ctypes
+    import numpy as np
+    from conftest import load_golden
+    from rcu_amd import _lib
+    lib = _lib.load()
+    g = load_golden('g20_ue_boundaries')
+    thr = [float(t) for t in g['thresholds']]
+    assert lib.rcu_unc_from_p_num_thresholds() == len(thr) == 11
+    assert [lib.rcu_unc_from_p_threshold(i) for i in range(11)] == thr and lib.rcu_unc_from_p_threshold(11) == -1.0
+    arr = (ctypes.c_double * 11)(*thr)
+    assert lib.rcu_unc_from_p_supported(arr, 11) == 1
+    for sub in ([0.5], [0.05, 0.95], thr[3:8]):
+        assert lib.rcu_unc_from_p_supported((ctypes.c_double * len(sub))(*sub), len(sub)) == 1
+    for bad in ([0.25], [0.5, 0.3], [0.5, 0.5]):
+        assert lib.rcu_unc_from_p_supported((ctypes.c_double * len(bad))(*bad), len(bad)) == 0
+    member = g['probe_member'].sum(0)
+    got = [lib.rcu_unc_from_p_exceeded(float(v), arr, 11) for v in g['probe_bits'].view(np.float32)]
+    assert got == [int(m) for m in member]
+    one = (ctypes.c_double * 1)(0.95)
+    assert [lib.rcu_unc_from_p_exceeded(float(v), one, 1) for v in g['probe_bits'].view(np.float32)] == [int(m) for m in g['probe_member'][10]]
+    # the report stored with the fixture: every float32 in [0, 1] was run through the reference; only the 0.95 threshold has ragged windows
+    assert int(g['values_scanned']) == 0x3F800000 + 1
+    assert list(g['lo_width']) == [0] * 10 + [3] and list(g['hi_width']) == [0] * 10 + [2]
+    with open(os.path.join(ROOT, 'reliability-challenges-uncertainty_amd', 'csrc', 'rcu_ue_table.inc')) as f:
+        text = f.read()
+    for k in range(11):
+        assert '0x{:08x}u, {}u, 0x{:08x}u, {}u'.format(int(g['lo_first'][k]), int(g['lo_width'][k]), int(g['hi_first_false'][k]), int(g['hi_width'][k])) in text

@@ -830,13 +830,28 @@ def test_uncertainty_counts_golden(golden, dev):
         assert [res['dice'], res['recall'], res['precision']] == list(g['derived'][i])
     tpl = ev.uncertainty(g['prediction'], g['target'], g['uncertainty'] > 0.3)
     assert list(tpl) == list(g['counts'][3])
-    # device entropy vs the reference's float64 map: float tolerance; counts from it may only differ on
-    # voxels whose entropy sits within that tolerance of a threshold
-    ent = ev.normalised_entropy(g['p']).cpu().numpy()
+    # end to end from the float32 probability map (round 5): "uncertain" looked up in the table of the reference's own float32 sets
+    # (fixture g20): the reference's counts, integer for integer -- no device log, no entropy map
+    assert ev.from_p_supported(tuple(g['thresholds']))
+    c2 = ev.uncertainty_counts_from_p(g['prediction'], g['target'], g['p'], tuple(g['thresholds']))[0]
+    assert np.array_equal(c2, g['counts'])
+    c3 = ev.uncertainty_counts_from_p(g['prediction'], g['target'], g['p'], (0.5,), mask=g['mask'])[0, 0]
+    assert list(c3) == list(g['masked_counts_thr05'])
+    # ... which is what the preparation recipe + the sweep of the bnf_ue action run (ToEntropy leaves an EntropyOfProbability)
+    prep, _ = ev.get_uncertainty_preparation('probabilities', 'run')
+    to_eval = prep({'probabilities': g['p'].copy(), 'prediction': g['prediction'], 'target': g['target']})
+    assert isinstance(to_eval['uncertainty'], ev.EntropyOfProbability)
+    res = {}
+    ev.UncertaintyAndCorrectionSweep()(to_eval, res)
+    for i, t in enumerate(ev.UE_THRESHOLDS):
+        assert [res[t][k] for k in ('tp', 'tn', 'fp', 'fn', 'tpu', 'tnu', 'fpu', 'fnu')] == list(g['counts'][i])
+    res = {}
+    ev.UncertaintyErrorDiceNumpy(0.3)(to_eval, res)
+    assert [res['dice'], res['recall'], res['precision']] == list(g['derived'][3])
+    # thresholds outside the table take the entropy map (device logf: float tolerance on the map)
+    assert not ev.from_p_supported((0.25,)) and not ev.from_p_supported((0.5, 0.3))
+    ent = np.asarray(to_eval['uncertainty'])
     assert ent.dtype == np.float64 and _maxdiff(ent, g['uncertainty']) < 1e-6
-    c2 = ev.uncertainty_counts(g['prediction'], g['target'], ent, tuple(g['thresholds']))[0]
-    near = sum(int(np.sum(np.abs(g['uncertainty'] - t) < 1e-6)) for t in g['thresholds'])
-    assert np.abs(c2 - g['counts']).sum() <= 2 * near
     res = {}
     ev.UncertaintyAndCorrectionSweep()({'prediction': g['prediction'], 'target': g['target'],
                                         'uncertainty': g['uncertainty']}, res)
@@ -1024,12 +1039,34 @@ def test_eval_driver_csvs_against_oracle(dev, tmp_path):
             p, pred, tgt, _ = truth[r['subject_name']]
             unc = co.normalised_entropy(co.add_background_probability(p))
             ref = co.correction_metrics(co.uncertainty_counts(pred.astype(bool), tgt.astype(bool), unc > thr))
-            near = int(np.sum(np.abs(unc - thr) < 1e-6))        # device logf vs numpy log: last-ulp ties only
-            for k in ('tp', 'tn', 'fp', 'fn'):
+            for k in ('tp', 'tn', 'fp', 'fn', 'tpu', 'tnu', 'fpu', 'fnu'):      # exact: the probability table, not a device log (fixture g20)
                 assert int(r[k]) == ref[k]
-            for k in ('tpu', 'tnu', 'fpu', 'fnu'):
-                assert abs(int(r[k]) - ref[k]) <= near
             assert set(r) >= {'corrected_dice', 'corrected_accuracy', 'corrected_add_dice', 'dice_benefit_correct'}
+    # the fused loop (one upload per subject shared by all actions, subjects batched per launch, files read ahead: the default) writes the
+    # bytes of the reference-ordered loop (subject by subject, action by action), whatever the batch size -- all 15 CSV files
+    import glob
+    import os
+
+    def all_csv(root):
+        return {os.path.relpath(f, root): open(f, 'rb').read() for f in sorted(glob.glob(os.path.join(root, '**', '*.csv'), recursive=True))}
+
+    fused = all_csv(str(base))
+    assert len(fused) == 1 + 1 + 1 + 11
+    for tag, kwargs in (('plain', dict(fused=False)), ('one', dict(batch_subjects=1))):
+        other = tmp_path / ('eval_' + tag)
+        timing = {}
+        evalrun.evaluate_runs([entry], ['minmax', 'ece_dice', 'calib', 'bnf_ue'], str(other), 'foreground', timing=timing, **kwargs)
+        assert all_csv(str(other)) == fused, tag
+        assert (timing.get('subjects'), timing.get('batches')) == ((None, None) if tag == 'plain' else (2, 2))
+    # subsets of the actions, and no mask (the ISIC form of the script)
+    for actions, details in ((['ece_dice'], 'foreground'), (['bnf_ue'], ''), (['minmax', 'calib'], '')):
+        a, b = tmp_path / 'sub_a', tmp_path / 'sub_b'
+        import shutil
+        shutil.rmtree(str(a), ignore_errors=True)
+        shutil.rmtree(str(b), ignore_errors=True)
+        evalrun.evaluate_runs([entry], actions, str(a), details)
+        evalrun.evaluate_runs([entry], actions, str(b), details, fused=False)
+        assert all_csv(str(a)) == all_csv(str(b)) and len(all_csv(str(a))) >= 1, actions
 
 
 def test_pass_groups_bit_identical_to_single_passes(dev):
@@ -1398,3 +1435,49 @@ def test_exact_statistics_do_not_depend_on_groups_lanes_or_the_materialised_stac
     ref = so.multi_prediction_summary(multi, True, True)
     for key, v in ref.items():
         assert _maxdiff(outs[0][key].cpu(), v) < 2e-6, key
+
+
+def test_uncertain_voxel_sets_of_the_reference_g20(golden, dev):
+    """rcu_unc_counts_from_p against fixture g20 (the reference run over every float32 in [0, 1]): on the probe vector -- every value of
+    the ragged windows, 40 neighbours on either side of every edge, 0, 0.5, 1 and their neighbours -- the kernel must call exactly the
+    reference's voxels uncertain, for all eleven thresholds at once, for subsets, per volume of a batch, and with a mask."""
+    from rcu_amd import evaluation as ev
+    g = golden('g20_ue_boundaries')
+    p = g['probe_bits'].view(np.float32)
+    member = g['probe_member'].astype(bool)                     # [11, n]
+    thr = tuple(float(t) for t in g['thresholds'])
+    assert thr == ev.UE_THRESHOLDS and int(g['values_scanned']) == 0x3F800000 + 1
+    rng = np.random.RandomState(7)
+    pred = (rng.rand(p.size) > 0.5).astype(np.uint8)
+    tgt = (rng.rand(p.size) > 0.5).astype(np.uint8)
+
+    def reference(sel, rows):
+        out = np.zeros((len(rows), 8), np.int64)
+        for i, r in enumerate(rows):
+            u = member[r]
+            for k, (a, b) in enumerate(((1, 1), (0, 0), (1, 0), (0, 1))):          # tp, tn, fp, fn: (prediction, target)
+                cell = sel & (pred == a) & (tgt == b)
+                out[i, k], out[i, 4 + k] = cell.sum(), (cell & u).sum()
+        return out
+
+    every = np.ones(p.size, bool)
+    assert np.array_equal(ev.uncertainty_counts_from_p(pred, tgt, p, thr)[0], reference(every, range(11)))
+    mask = rng.rand(p.size) > 0.4
+    assert np.array_equal(ev.uncertainty_counts_from_p(pred, tgt, p, thr, mask=mask)[0], reference(mask, range(11)))
+    rows = [0, 4, 9, 10]
+    assert np.array_equal(ev.uncertainty_counts_from_p(pred, tgt, p, [thr[r] for r in rows])[0], reference(every, rows))
+    assert np.array_equal(ev.uncertainty_counts_from_p(pred, tgt, p, (0.95,))[0], reference(every, [10]))
+    # a batch of volumes in one launch: 4 volumes of a quarter each (ragged length: the scalar tail path), and a long one (the vector path)
+    q = p.size // 4
+    got = ev.uncertainty_counts_from_p(pred[:4 * q], tgt[:4 * q], p[:4 * q], thr, n_volumes=4)
+    for v in range(4):
+        sel = np.zeros(p.size, bool)
+        sel[v * q:(v + 1) * q] = True
+        assert np.array_equal(got[v], reference(sel, range(11)))
+    reps = 40
+    big = ev.uncertainty_counts_from_p(np.tile(pred, reps), np.tile(tgt, reps), np.tile(p, reps), thr)[0]
+    assert np.array_equal(big, reps * reference(every, range(11)))
+    # values a probability map cannot hold count as not uncertain (the reference rejects them before it gets here)
+    odd = np.array([-0.0, -1.0, 2.0, np.nan, np.inf, -np.inf], np.float32)
+    c = ev.uncertainty_counts_from_p(np.zeros(6, np.uint8), np.zeros(6, np.uint8), odd, thr)[0]
+    assert np.array_equal(c[:, 4:], np.zeros((11, 4), np.int64)) and np.all(c[:, 1] == 6)

@@ -131,6 +131,12 @@ def test_brats_ensemble_and_aleatoric_then_eval(tmp_path):
     assert len(glob.glob(str(tmp_path / 'eval' / 'uncertainty' / 'eval_uncertainty_ensemble_th*.csv'))) == 11
     rows = list(csv.DictReader(open(str(tmp_path / 'eval' / 'ece_foreground' / 'eval_ece_ensemble.csv'))))
     assert [r['subject_name'] for r in rows] == sorted(vols) and all(0 <= float(r['ece']) <= 1 for r in rows)
+    # subjects of two sizes (6 and 7 slices): the fused loop batches equal sizes only -- still the bytes of the subject-by-subject loop
+    scripts.eval_uncertainty('brats', {'ensemble': ctx.test_dir}, str(tmp_path / 'gt'), str(tmp_path / 'eval_plain'), fused=False)
+    a = {os.path.relpath(f, str(tmp_path / 'eval')): open(f, 'rb').read() for f in glob.glob(str(tmp_path / 'eval' / '**' / '*.csv'), recursive=True)}
+    b = {os.path.relpath(f, str(tmp_path / 'eval_plain')): open(f, 'rb').read()
+         for f in glob.glob(str(tmp_path / 'eval_plain' / '**' / '*.csv'), recursive=True)}
+    assert a == b and len(a) == 14
 
 
 def _files(ctx):
