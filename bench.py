@@ -242,12 +242,15 @@ def cpu_probe_slices(member, params, x_cpu, passes_total, budget_s, thread_count
 
 
 def calibration_kernels(device, volumes=160, reps=5):
-    """ECE histogram and uncertainty-error counts over a test-split sized batch (160 BraTS volumes, as
-    bin-eval/eval_uncertainty.py processes them), timed with events on the launch stream.  ALGORITHMIC bytes per
-    voxel: 4 (confidence / uncertainty f32) + 1 (target) + 1 (mask) for the histogram, + 1 (prediction) for the
-    counts."""
+    """ECE histogram and uncertainty-error counts, timed with events on the launch stream, at two batch sizes: `volumes` = a test-split
+    sized batch (160 BraTS volumes: the roofline figure) and the batch the PRODUCT issues -- `rcu_amd.evalrun.evaluate_runs` evaluates
+    `batch_subjects` = 8 subjects per launch by default (bin-eval/eval_uncertainty.py --batch_subjects).  ALGORITHMIC bytes per voxel
+    (SURVEY.md 8d): 4 (probability f32) + 1 (target) + 1 (mask) for the histogram; 4 + 1 (prediction) + 1 (target) for the counts, which
+    the product takes straight from the probability map (rcu_unc_counts_from_p, no mask in the bnf_ue action); the map-thresholding
+    form rcu_unc_counts (float32 uncertainty + prediction + target + mask, 7 bytes) is timed next to it."""
     import ctypes
     from rcu_amd import _lib
+    from rcu_amd import evalrun
     lib = _lib.load()
     n = SLICES * HEIGHT * WIDTH
     g = torch.Generator(device=device).manual_seed(5)
@@ -256,7 +259,9 @@ def calibration_kernels(device, volumes=160, reps=5):
     m = (torch.rand((volumes, n), device=device, generator=g) < 0.4).to(torch.uint8)      # brain mask share
     pred = (p > 0.5).to(torch.uint8)
     stream = _lib.current_stream()
-    out = {}
+    import inspect
+    product_batch = inspect.signature(evalrun.evaluate_runs).parameters['batch_subjects'].default
+    out = {'product_batch_subjects': product_batch}
 
     def timed(fn):
         fn()
@@ -270,21 +275,31 @@ def calibration_kernels(device, volumes=160, reps=5):
         return e0.elapsed_time(e1) / reps
 
     thr = _lib.ece_thresholds(10)
-    res = torch.empty(volumes * ctypes.sizeof(_lib.EceResult), device=device, dtype=torch.uint8)
-    ws = torch.empty(max(lib.rcu_ece_workspace_bytes(n, volumes), 8), device=device, dtype=torch.uint8)
-    ms = timed(lambda: _lib.check(lib.rcu_ece_hist(_lib.ptr(p), _lib.ptr(t), _lib.ptr(m), n, volumes, thr, 10,
-                                                   _lib.ptr(res), _lib.ptr(ws), stream)))
-    nbytes = volumes * n * 6
-    out['ece_hist'] = dict(bound='hbm', ms=ms, achieved=nbytes / ms / 1e6, peak=PEAK_HBM_GBS, unit='GB/s',
-                           frac=nbytes / ms / 1e6 / PEAK_HBM_GBS, bytes=nbytes, volumes=volumes)
     ue = (ctypes.c_double * 11)(*([0.05] + [0.1 * k for k in range(1, 10)] + [0.95]))   # bin-eval/eval_uncertainty.py:239
-    cnt = torch.empty((volumes, 11, 8), device=device, dtype=torch.int64)
-    ws2 = torch.empty(max(lib.rcu_unc_workspace_bytes(n, volumes), 8), device=device, dtype=torch.uint8)
-    ms = timed(lambda: _lib.check(lib.rcu_unc_counts(_lib.ptr(p), 0, _lib.ptr(pred), _lib.ptr(t), _lib.ptr(m), n, volumes,
-                                                     ue, 11, _lib.ptr(cnt), _lib.ptr(ws2), stream)))
-    nbytes = volumes * n * 7
-    out['unc_counts'] = dict(bound='hbm', ms=ms, achieved=nbytes / ms / 1e6, peak=PEAK_HBM_GBS, unit='GB/s',
-                             frac=nbytes / ms / 1e6 / PEAK_HBM_GBS, bytes=nbytes, volumes=volumes, thresholds=11)
+    ue_table = (ctypes.c_double * 11)(*[lib.rcu_unc_from_p_threshold(i) for i in range(11)])
+    for nv, suffix in ((volumes, ''), (product_batch, '_product_batch')):
+        res = torch.empty(nv * ctypes.sizeof(_lib.EceResult), device=device, dtype=torch.uint8)
+        ws = torch.empty(max(lib.rcu_ece_workspace_bytes(n, nv), 8), device=device, dtype=torch.uint8)
+        ms = timed(lambda: _lib.check(lib.rcu_ece_hist(_lib.ptr(p), _lib.ptr(t), _lib.ptr(m), n, nv, thr, 10, _lib.ptr(res), _lib.ptr(ws), stream)))
+        nbytes = nv * n * 6
+        out['ece_hist' + suffix] = dict(bound='hbm', ms=ms, achieved=nbytes / ms / 1e6, peak=PEAK_HBM_GBS, unit='GB/s',
+                                        frac=nbytes / ms / 1e6 / PEAK_HBM_GBS, bytes=nbytes, volumes=nv)
+        cnt = torch.empty((nv, 11, 8), device=device, dtype=torch.int64)
+        ws3 = torch.empty(lib.rcu_unc_from_p_workspace_bytes(n, nv), device=device, dtype=torch.uint8)
+        ms = timed(lambda: _lib.check(lib.rcu_unc_counts_from_p(_lib.ptr(p), _lib.ptr(pred), _lib.ptr(t), None, n, nv, ue_table, 11,
+                                                                _lib.ptr(cnt), _lib.ptr(ws3), stream)))
+        nbytes = nv * n * 6
+        out['unc_counts_from_p' + suffix] = dict(bound='hbm', ms=ms, achieved=nbytes / ms / 1e6, peak=PEAK_HBM_GBS, unit='GB/s',
+                                                 frac=nbytes / ms / 1e6 / PEAK_HBM_GBS, bytes=nbytes, volumes=nv, thresholds=11,
+                                                 what='the product path: counts from the float32 probability map (table of the reference\'s sets)')
+        if not suffix:
+            ws2 = torch.empty(max(lib.rcu_unc_workspace_bytes(n, nv), 8), device=device, dtype=torch.uint8)
+            ms = timed(lambda: _lib.check(lib.rcu_unc_counts(_lib.ptr(p), 0, _lib.ptr(pred), _lib.ptr(t), _lib.ptr(m), n, nv,
+                                                             ue, 11, _lib.ptr(cnt), _lib.ptr(ws2), stream)))
+            nbytes = nv * n * 7
+            out['unc_counts'] = dict(bound='hbm', ms=ms, achieved=nbytes / ms / 1e6, peak=PEAK_HBM_GBS, unit='GB/s',
+                                     frac=nbytes / ms / 1e6 / PEAK_HBM_GBS, bytes=nbytes, volumes=nv, thresholds=11,
+                                     what='thresholding an uncertainty map (confidence / sigma runs)')
     return out
 
 
@@ -320,6 +335,28 @@ class VolumePrefetcher:
         slot = k % len(self.bufs)
         self.free[slot] = torch.cuda.Event()
         self.free[slot].record()
+
+
+def device_identity(device, rank):
+    """What tells two GPUs of a node apart: the HIP device's UUID and PCI address, next to the rank's environment."""
+    props = torch.cuda.get_device_properties(device)
+    uuid = getattr(props, 'uuid', None)
+    return dict(rank=rank, local_rank=int(os.environ.get('LOCAL_RANK', '0')), device_index=device.index, name=props.name,
+                uuid=str(uuid) if uuid is not None else None,
+                pci=('{:04x}:{:02x}:{:02x}'.format(getattr(props, 'pci_domain_id', 0), getattr(props, 'pci_bus_id', 0), getattr(props, 'pci_device_id', 0))
+                     if hasattr(props, 'pci_bus_id') else None),
+                hip_visible_devices=os.environ.get('HIP_VISIBLE_DEVICES'), rocr_visible_devices=os.environ.get('ROCR_VISIBLE_DEVICES'))
+
+
+def volumes_per_step(world, jobs_per_volume, pass_group):
+    """Consecutive volumes a rank takes as one batch.  T + 1 jobs per volume over `world` ranks leave a rank jobs / world passes per volume;
+    while that is at least a full pass group (4 passes of 160 slices = 640 samples per launch) volumes run one by one, below it a rank's
+    passes of v volumes run as groups of pass_group / v passes over 160 v slices -- the same 640-sample launches (measured on one GPU with
+    rank 0's exact job list: tools/rank_share_of_world.py, profiles/r05_rank_share_of_8.json)."""
+    v = 1
+    while v < pass_group and jobs_per_volume * v < world * pass_group:
+        v *= 2
+    return v
 
 
 def aggregation_kernels(device, n_slices, height, width, reps=30, all_outputs=False):
@@ -427,6 +464,9 @@ def main():
                     help='every output of MultiPredictionSummary in the timed region: mutual information + variance next to mean + entropy '
                          '(do_mi + do_var, rechun/dl/customsteps.py:63-71: float64 statistics, S = 5 planes).  The default run reports this '
                          'configuration as the sub-record `all_outputs`')
+    ap.add_argument('--volumes-per-step', type=int, default=0,
+                    help='consecutive volumes a rank takes as ONE batch of 160 v slices, its passes of them in one launch (0 = the rule of '
+                         'volumes_per_step(): 1 while a rank\'s share of a volume fills 640-sample launches, 2 at 8 ranks)')
     ap.add_argument('--watchdog', type=float, default=1500.0,
                     help='seconds after which a run that has not finished dumps the stacks of all threads to stderr and exits (0 = off)')
     args = ap.parse_args()
@@ -516,153 +556,152 @@ def main():
                                        pass_group=args.pass_group, lanes=args.lanes, ws_transport=args.ws_transport,
                                        do_mi=args.all_outputs, do_var=args.all_outputs)
     runner.force_exchange = force_pg
-    # dropout masks: drawn per (seed, volume, pass) by the runner -- the same T samples whatever the world size
+    # dropout masks: drawn per (seed, step, pass) by the runner -- the same T samples whatever the world size
+    # Volumes per runner step: a rank of a large world takes v consecutive volumes as one batch of n_slices * v slices and groups
+    # pass_group / v passes of it per launch -- the launches keep the size they have on one GPU (volumes_per_step above); `--steps K` stays
+    # the number of VOLUMES: K // v steps of v volumes and K % v single ones.
+    samples_per_launch = n_slices * args.pass_group
+    v_step = args.volumes_per_step if args.volumes_per_step > 0 else volumes_per_step(world, runner.jobs_per_step, args.pass_group)
+    if args.ensemble:
+        v_step = 1
+    runner.group_samples = samples_per_launch if not args.ensemble else None
+    x_by_size = {1: x}
+    feeders = {1: feeder}
+    if v_step > 1:
+        x_cpu_v = torch.cat([x_cpu] * v_step)
+        x_by_size[v_step] = x_cpu_v.to(device)
+        feeders[v_step] = VolumePrefetcher(x_cpu_v, device)
 
-    def one_step(k, xin=x):
-        # N>1: the reduce runs on RCCL's stream and the root finalises on a side stream, so the ranks'
-        # compute streams do not meet at every volume (rcu_amd.distributed.ShardedMcRunner.step_async)
-        return runner.step_async(xin, k)
+    def chunks(count):
+        return [v_step] * (count // v_step) + [1] * (count % v_step)
 
-    for k in range(args.warmup):
-        one_step(k).result()
+    step_counter = [0]
+
+    def run_volumes(run, count, fed=True):
+        """`count` volumes through runner `run` in chunks; fed: every chunk comes from pinned host memory on the copy stream (prefetched one
+        chunk ahead), else the chunks read the resident device copies.  -> (pending summaries, their step indices, their sizes)"""
+        sizes = chunks(count)
+        idx = list(range(step_counter[0], step_counter[0] + len(sizes)))
+        step_counter[0] += len(sizes)
+        if fed and sizes:
+            feeders[sizes[0]].issue(idx[0])
+        pend = []
+        for i, (k, size) in enumerate(zip(idx, sizes)):
+            xin = feeders[size].get(k) if fed else x_by_size[size]
+            if fed and i + 1 < len(sizes):
+                feeders[sizes[i + 1]].issue(idx[i + 1])
+            # N>1: the reduce runs on RCCL's stream and the root finalises on a side stream, so the ranks' compute streams do not meet at
+            # every step (rcu_amd.distributed.ShardedMcRunner.step_async)
+            pend.append(run.step_async(xin, k))
+            if fed:
+                feeders[size].done(k)
+        return pend, idx, sizes
+
+    def bracket():
+        torch.cuda.synchronize()
+        if collective:
+            dist.barrier(**barrier_kwargs)
+        torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        if not collective:
+            return seconds
+        tmax = torch.tensor([seconds], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
+    for p_ in run_volumes(runner, args.warmup, fed=False)[0]:
+        p_.result()
     # per-kernel HIP events for this rank's forwards inside the timed region (per member in ensemble mode)
-    my_jobs = [j for k in range(args.warmup, args.warmup + args.steps) for j in runner.jobs_of(k, rank)]
+    timed_sizes = chunks(args.steps)
+    timed_idx = list(range(step_counter[0], step_counter[0] + len(timed_sizes)))
+    my_jobs = [j for k in timed_idx for j in runner.jobs_of(k, rank)]
     # (ensemble members keep to one stream lane: a member of a side lane never runs on its lane-0 handle -- which is the one these
     # calls create and time -- so it is left alone here: 6 GB of workspace per member that nobody would use)
     timed_members = [(i, m) for i, m in enumerate(members) if not (args.ensemble and args.lanes > 1 and i % args.lanes != 0)]
     for i, m in timed_members:
         count = sum(1 for j in my_jobs if j - 1 == i) if args.ensemble else len(my_jobs)
-        m.profile_begin(height, width, n_slices * args.pass_group, max(count, 1))
+        m.profile_begin(height, width, samples_per_launch, max(count, 1))
     runner.forwards_run = 0
 
-    first_step, end_step = args.warmup, args.warmup + args.steps
-    resident_before = None
-    if os.environ.get('RCU_BENCH_RESIDENT_FIRST') == '1' and world == 1:      # diagnostic: drift between the legs
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        for k in range(1000, 1000 + args.steps):
-            one_step(k).result()
-        torch.cuda.synchronize()
-        resident_before = (time.perf_counter() - tb) / args.steps * 1e3
-        for _, m in timed_members:
-            m.profile_collect(height, width, n_slices * args.pass_group)
-        for i, m in timed_members:
-            count = sum(1 for j in my_jobs if j - 1 == i) if args.ensemble else len(my_jobs)
-            m.profile_begin(height, width, n_slices * args.pass_group, max(count, 1))
-        runner.forwards_run = 0
-    torch.cuda.synchronize()
-    if collective:
-        dist.barrier(**barrier_kwargs)
-    torch.cuda.synchronize()
+    bracket()
     allocs_before = torch.cuda.memory_stats(device).get('num_device_alloc', 0)     # hipMalloc calls of torch's caching allocator so far
     t0 = time.perf_counter()
-    # THE timed region: per volume the host-to-device copy (prefetched: volume k + 1 travels while volume k computes), the
+    # THE timed region: per volume the host-to-device copy (prefetched: the next chunk travels while this one computes), the
     # weight-scaling pass, the T stochastic passes, [N > 1: the reduce] and the finalize
-    feeder.issue(first_step)
-    pending = []
-    host_times = [] if os.environ.get('RCU_BENCH_STEP_TIMES') == '1' else None      # diagnostic: when the host had enqueued step k
-    diag = os.environ.get('RCU_BENCH_H2D_DIAG', '')      # diagnostics of the copy's cost: 'unused' = copies run, the steps read the resident volume
-    for k in range(first_step, end_step):
-        xin = feeder.get(k) if diag != 'nowait' else feeder.bufs[k % len(feeder.bufs)]
-        if k + 1 < end_step:
-            feeder.issue(k + 1)
-        pending.append(one_step(k, x if diag == 'unused' else xin))
-        feeder.done(k)
-        if host_times is not None:
-            host_times.append(time.perf_counter() - t0)
-    out = [p.result() for p in pending][-1]
+    pending, timed_idx, timed_sizes = run_volumes(runner, args.steps)
+    out = [p_.result() for p_ in pending][-1]
     runner.drain()
-    torch.cuda.synchronize()
-    if collective:
-        dist.barrier(**barrier_kwargs)
-    torch.cuda.synchronize()
+    bracket()
     elapsed = time.perf_counter() - t0
-    if host_times is not None and rank == 0:
-        print('host enqueue times of the timed steps (ms): ' + ' '.join('{:.1f}'.format(v * 1e3) for v in host_times) +
-              ' | all done {:.1f}'.format(elapsed * 1e3), file=sys.stderr)
     device_allocs_in_timed_region = torch.cuda.memory_stats(device).get('num_device_alloc', 0) - allocs_before
-    passes_run = max(runner.forwards_run, 1)        # this rank's forward passes inside the timed region
-    forwards_per_rank = [runner.forwards_run]
+    last_step, last_size = timed_idx[-1], timed_sizes[-1]
+    if out is not None and last_size > 1:       # the first volume of the last chunk stands for it in the parity leg
+        out = {k_: v_[:n_slices] for k_, v_ in out.items()}
+    # forward passes in units of one volume (a job of a v-volume chunk is v of them)
+    weight = {k: sz for k, sz in zip(timed_idx, timed_sizes)}
+    forwards_this_rank = sum(weight[k] * len(runner.jobs_of(k, rank)) for k in timed_idx)
+    passes_run = max(forwards_this_rank, 1)         # this rank's forward passes inside the timed region
+    forwards_per_rank = [forwards_this_rank]
+    devices_seen = None
+    elapsed = max_over_ranks(elapsed)
     if collective:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
         counts = torch.zeros(world, device=device, dtype=torch.int64)
-        counts[rank] = runner.forwards_run
+        counts[rank] = forwards_this_rank
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         forwards_per_rank = [int(v) for v in counts.tolist()]
+        # which GPUs the ranks ran on: all-gathered identities (the driver checks that N ranks mean N distinct devices)
+        devices_seen = [None] * dist.get_world_size()
+        dist.all_gather_object(devices_seen, device_identity(device, rank))
+    else:
+        devices_seen = [device_identity(device, rank)]
     n_ranks_seen = dist.get_world_size() if collective else 1
 
     launches, slot_ms = 0, None
     for _, m in timed_members:
-        cnt, ms = m.profile_collect(height, width, n_slices * args.pass_group)
+        cnt, ms = m.profile_collect(height, width, samples_per_launch)
         launches += cnt
         slot_ms = ms if slot_ms is None else [a + b for a, b in zip(slot_ms, ms)]
     # ---- the same steps with the volume already resident in HBM (the secondary figure; all ranks take part)
-    torch.cuda.synchronize()
-    if collective:
-        dist.barrier(**barrier_kwargs)
-    torch.cuda.synchronize()
+    bracket()
     t1 = time.perf_counter()
-    pend_r = [one_step(k) for k in range(end_step, end_step + args.steps)]
-    for p_ in pend_r:
+    for p_ in run_volumes(runner, args.steps, fed=False)[0]:
         p_.result()
     runner.drain()
-    torch.cuda.synchronize()
-    if collective:
-        dist.barrier(**barrier_kwargs)
-    torch.cuda.synchronize()
-    elapsed_resident = time.perf_counter() - t1
-    if collective:
-        tmax = torch.tensor([elapsed_resident], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed_resident = float(tmax.item())
-    del pend_r
-    last_step = end_step - 1
+    bracket()
+    elapsed_resident = max_over_ranks(time.perf_counter() - t1)
 
     # ---- the all-outputs configuration (north_star: "softmax -> running-mean / variance -> predictive-entropy"; the reference's
     # MultiPredictionSummary(do_mi=True, do_var=True), rechun/dl/customsteps.py:63-71): the same step with mutual information and variance
-    # tracked -- float64 statistics, S = 5 planes per voxel -- timed like the headline (H2D prefetched inside, all ranks, one reduce per
-    # volume), over step indices that END at the last timed step: the runner's masks are a function of (seed, volume, pass), so its last
+    # tracked -- exact float64 statistics, S = 5 planes per voxel -- timed like the headline (H2D prefetched inside, all ranks, one reduce per
+    # step), over the SAME step indices as the headline's timed region: the runner's masks are a function of (seed, step, pass), so its last
     # volume runs under the masks of the headline's last volume and the CPU leg below is the reference of both.
     all_out, out_ao = None, None
     if not (args.all_outputs or args.ensemble or args.aleatoric):
-        ao_steps = max(1, min(args.steps, 5))
+        ao_volumes = sum(timed_sizes[-min(len(timed_sizes), 5):])
         runner_ao = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed, pass_group=args.pass_group,
                                           lanes=args.lanes, ws_transport=args.ws_transport, do_mi=True, do_var=True, force_exchange=force_pg)
-        first_ao = last_step - ao_steps + 1
-        runner_ao.step_async(x, first_ao - 1).result()       # warm: the float64 blobs of the lanes come out of torch's allocator
+        runner_ao.group_samples = samples_per_launch
+        runner_ao.step_async(x, last_step + 1000).result()       # warm: the float64 blobs of the lanes come out of torch's allocator
         runner_ao.drain()
-        runner_ao.forwards_run = 0
-        torch.cuda.synchronize()
-        if collective:
-            dist.barrier(**barrier_kwargs)
-        torch.cuda.synchronize()
+        saved = step_counter[0]
+        step_counter[0] = timed_idx[-min(len(timed_sizes), 5)]
+        bracket()
         ta = time.perf_counter()
-        feeder.issue(first_ao)
-        pend_a = []
-        for k in range(first_ao, last_step + 1):
-            xin = feeder.get(k)
-            if k < last_step:
-                feeder.issue(k + 1)
-            pend_a.append(runner_ao.step_async(xin, k))
-            feeder.done(k)
+        pend_a, idx_a, sizes_a = run_volumes(runner_ao, ao_volumes)
         out_ao = [p_.result() for p_ in pend_a][-1]
         runner_ao.drain()
-        torch.cuda.synchronize()
-        if collective:
-            dist.barrier(**barrier_kwargs)
-        torch.cuda.synchronize()
-        elapsed_ao = time.perf_counter() - ta
-        if collective:
-            tmax = torch.tensor([elapsed_ao], device=device, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed_ao = float(tmax.item())
+        bracket()
+        elapsed_ao = max_over_ranks(time.perf_counter() - ta)
+        assert idx_a[-1] == last_step and sizes_a[-1] == last_size
+        step_counter[0] = saved
+        if out_ao is not None and last_size > 1:
+            out_ao = {k_: v_[:n_slices] for k_, v_ in out_ao.items()}
         del pend_a
-        all_out = dict(value=T * (n_slices if isic else 1) * ao_steps / elapsed_ao, unit='MC-sample-{}s/s'.format(unit_name),
-                       ms_per_step=elapsed_ao / ao_steps * 1e3, steps=ao_steps, warmup=1,
+        all_out = dict(value=T * (n_slices if isic else 1) * ao_volumes / elapsed_ao, unit='MC-sample-{}s/s'.format(unit_name),
+                       ms_per_step=elapsed_ao / ao_volumes * 1e3, steps=ao_volumes, warmup=1,
                        outputs=['probabilities', 'entropy', 'mutual_info', 'variance'] + ([] if args.no_ws else ['ws_probabilities']),
-                       statistics='float64, S = 5 planes per voxel: sum p_c (2), sum p_c^2 (2), sum H(p_t)',
+                       statistics='exact float64 sums, S = 5 planes per voxel: sum p_c (2), sum p_c^2 (2), sum H(p_t)',
                        h2d='prefetched, inside the timed steps (as the headline)',
                        reduce_bytes_per_volume=(5 * 8 + (0 if args.no_ws else 2 * 8)) * n_slices * height * width if world > 1 else 0)
     if rank != 0:
@@ -690,7 +729,7 @@ def main():
         else:
             serial = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, seed=seed, pass_group=args.pass_group, lanes=1)
         serial_steps = max(1, min(args.steps, 2))
-        first = end_step + args.steps + 8
+        first = step_counter[0] + 1008
         serial.step(x, first - 1)                     # warm (the lane-0 workspace is the one the timed region used)
         serial_jobs = [j for k in range(first, first + serial_steps) for j in serial.jobs_of(k, 0)]
         for i, m in enumerate(members):
@@ -833,28 +872,19 @@ def main():
         parity['ece_delta_same_maps'] = abs(ece_gpu - ece_oracle)
         parity['bin_ids_equal'] = bool(np.array_equal(ev.bin_ids(p_np), co.bin_ids(p_np.reshape(-1))))
     if not args.no_cpu_baseline:
-        # the uncertainty-error counts (bnf_ue action: 11 thresholds, numpyfunctions.py:86-107) of the TIMED output: (i) on the same
-        # device-computed normalised entropy map the GPU counts must equal the C oracle's, integer for integer; (ii) against the
-        # oracle's own numpy entropy (ToEntropy, analysis.py:189-203: numpy's log differs from the device's in the last ulp) the counts
-        # may differ by at most the voxels whose two entropies fall on different sides of a threshold -- the tie census
+        # the uncertainty-error counts (bnf_ue action: 11 thresholds, numpyfunctions.py:86-107) of the TIMED output, straight from the float32
+        # probability map (rcu_unc_counts_from_p: "uncertain" looked up in the table of the reference's own float32 sets, fixture g20) against
+        # the oracle's counts on ITS numpy entropy (ToEntropy, analysis.py:189-203): integer for integer -- no tie census any more
         from oracle import c_oracle
         thr_ue = list(ev.UE_THRESHOLDS)
-        u_dev = ev.normalised_entropy(p_fg, as_float64=True)
-        got = ev.uncertainty_counts(pred, target_cpu, u_dev, thresholds=thr_ue, mask=mask_cpu)[0].astype(np.int64)
+        got = ev.uncertainty_counts_from_p(pred, target_cpu, p_fg, thresholds=thr_ue, mask=mask_cpu)[0].astype(np.int64)
         pred_np, tg_np, mk_np = pred.cpu().numpy(), target_cpu.numpy(), mask_cpu.numpy().astype(np.uint8)
-        u_dev_np = u_dev.cpu().numpy()
-        same = c_oracle.unc_counts(u_dev_np, pred_np, tg_np, mk_np, thr_ue).astype(np.int64)
         u_np = co.normalised_entropy(np.stack([1 - p_np, p_np], -1))
         ref_counts = c_oracle.unc_counts(u_np, pred_np, tg_np, mk_np, thr_ue).astype(np.int64)
-        inside = mk_np.reshape(-1) != 0
-        ties = [int(np.count_nonzero(((u_dev_np.reshape(-1) > t) != (u_np.reshape(-1) > t)) & inside)) for t in thr_ue]
-        delta = np.abs(got - ref_counts)
-        parity['ue_counts_equal'] = bool(np.array_equal(got, same))
-        parity['ue_tie_voxels'] = ties
-        parity['ue_max_count_delta_vs_numpy_entropy'] = [int(v) for v in delta.max(axis=1)]
-        parity['ue_counts_within_ties'] = bool(all(int(delta[i].max()) <= ties[i] for i in range(len(thr_ue))))
-        parity['ue_max_abs_dentropy'] = float(np.max(np.abs(u_dev_np - u_np)))
-        parity['ue_voxels'] = int(np.count_nonzero(inside))
+        parity['ue_counts_equal'] = bool(np.array_equal(got, ref_counts))
+        parity['ue_counts_of'] = 'rcu_unc_counts_from_p on the timed probability map vs the C oracle on the numpy entropy of the same map'
+        parity['ue_max_count_delta'] = int(np.abs(got - ref_counts).max())
+        parity['ue_voxels'] = int(np.count_nonzero(mk_np))
     if not args.no_cpu_baseline and world == 1 and not args.aleatoric:     # the CPU leg: rank 0 at N=1 only
         passes_total = T + (0 if (args.ensemble or args.no_ws) else 1)
         thread_counts, thread_probes = cpu_thread_counts(params, height, width)
@@ -929,7 +959,7 @@ def main():
                                 .format('aleatoric + MC' if args.aleatoric else 'baseline_mc', ', sigma_out' if args.aleatoric else '',
                                         T, '' if args.no_ws else ' + weight-scaling pass')),
                    'T': T, 'ws_pass': not (args.no_ws or args.ensemble), 'slices': n_slices, 'height': height, 'width': width,
-                   'pass_group': g, 'lanes': args.lanes,
+                   'pass_group': g, 'lanes': args.lanes, 'volumes_per_step': v_step, 'samples_per_launch': samples_per_launch,
                    'outputs': 'mean + entropy + mutual information + variance (float64 statistics)' if args.all_outputs else
                               'mean + entropy (MultiPredictionSummary() as every shipped script constructs it)',
                    'h2d': 'prefetched, inside timed region ({} MB per {} from pinned host memory on a copy stream, one event wait per '
@@ -938,10 +968,11 @@ def main():
                    'sharding': 'passes over ranks, one RCCL sum-reduce of the statistics per step' if world > 1 else 'none',
                    'gflop_per_sample_{}'.format(unit_name): conv_flops / passes_run / 1e9 / (n_slices if isic else 1)},
         'n_ranks_seen': n_ranks_seen,
+        'devices': devices_seen,
+        'distinct_devices': len({(d_['uuid'], d_['pci'], d_['device_index']) for d_ in devices_seen}),
         'forwards_per_rank': forwards_per_rank,
         'device_allocs_in_timed_region': device_allocs_in_timed_region,   # hipMalloc calls (implicit device syncs) the timed steps caused: 0 in the steady state
         'resident': dict(value=units * args.steps / elapsed_resident, ms_per_step=elapsed_resident / args.steps * 1e3, steps=args.steps,
-                         ms_per_step_before_the_timed_region=resident_before,
                          note='the same steps with the volume already in HBM when the clock starts (no host-to-device copy): the '
                               'secondary figure; `value` has the prefetched copy inside'),
         'roofline': roofline,

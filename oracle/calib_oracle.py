@@ -128,8 +128,10 @@ def error_precision(tpu, tnu, fpu, fnu):
     return (fnu + fpu) / den
 
 
-# --- pymia 0.2.1 ConfusionMatrix / DiceCoefficient / Accuracy: PARITY UNPINNED (package absent; restated
-# from the call sites nf.py:128-151: counts over ==1 / ==0, Dice 2tp/(2tp+fp+fn), accuracy (tp+tn)/n).
+# --- pymia 0.2.1 ConfusionMatrix / DiceCoefficient / Accuracy (package absent; restated from the call sites nf.py:128-151 and pymia's
+# published algorithm: counts over ==1 / ==0, Dice 2tp/(2tp+fp+fn) -- 1 when there is no foreground at all --, accuracy (tp+tn)/n).
+# Pinned against an independent third party: fixture g19 = scikit-learn's confusion_matrix / f1_score / accuracy_score on the same
+# label pairs (tests/test_oracle_golden.py); only the 0 / 0 Dice convention rests on pymia's source alone.
 
 def confusion_counts(prediction, target):
     prediction = np.asarray(prediction)

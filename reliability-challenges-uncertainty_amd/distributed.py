@@ -202,6 +202,9 @@ class ShardedMcRunner:
         self.jobs_per_step = mc_steps + (1 if ws_pass else 0)
         self.seed = seed
         self.pass_group = max(1, int(pass_group))
+        # group_samples (optional attribute): samples per launch instead of passes per launch -- a step over a batch of n images then groups
+        # group_samples // n passes (a runner that is handed one volume or several consecutive ones keeps its launches the same size)
+        self.group_samples = None
         self.lanes = max(1, int(lanes))
         self._generator = None
         self.forwards_run = 0          # launches of this rank (a pass group counts its passes)
@@ -250,13 +253,14 @@ class ShardedMcRunner:
         jobs = self.jobs_of(step_index, self.rank)
         # stream lanes (rcu_amd.steps.StreamLanes): lane 0 = the caller's stream and the volume's statistics
         lanes = steps_mod.StreamLanes(x.device, self.lanes if (x.is_cuda and hasattr(self.engine, 'side_statistics')) else 1)
+        pass_group = self.pass_group if self.group_samples is None else max(1, int(self.group_samples) // int(x.shape[0]))
         if hasattr(self.engine, 'reserve') and self.reserve_plans:
-            self.engine.reserve(x, self.mc_steps, self.pass_group, lanes.count)
+            self.engine.reserve(x, self.mc_steps, pass_group, lanes.count)
         lanes.begin(stats, lambda: self.engine.side_statistics(x), inputs=(x,), first=step_index if self.world > 1 else 0)
         on_lane = lanes.run
 
         # group sizes of this rank's MC passes: rounds of one group per lane (steps.balanced_groups), so that the lanes carry the same load
-        sizes = steps_mod.balanced_groups(sum(1 for j in jobs if j != 0), self.pass_group, lanes.count)
+        sizes = steps_mod.balanced_groups(sum(1 for j in jobs if j != 0), pass_group, lanes.count)
         i = 0
         while i < len(jobs):
             group = [j for j in jobs[i:i + sizes[0]] if j != 0] if jobs[i] != 0 else []

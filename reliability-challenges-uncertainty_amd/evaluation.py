@@ -323,8 +323,9 @@ def error_precision(tpu, tnu, fpu, fnu):
     return (fnu + fpu) / (fnu + fpu + tpu + tnu)
 
 
-# pymia 0.2.1 ConfusionMatrix / DiceCoefficient / Accuracy are absent from the reference tree: restated from
-# the call sites (numpyfunctions.py:128-151) -- parity unpinned.
+# pymia 0.2.1 ConfusionMatrix / DiceCoefficient / Accuracy are absent from the reference tree: restated from the call sites
+# (numpyfunctions.py:128-151) and pinned against scikit-learn's confusion_matrix / f1_score / accuracy_score (fixture g19); the 0 / 0
+# Dice (no foreground in prediction and target) is 1, pymia's convention.
 def confusion_matrx(prediction, target):
     c = uncertainty_counts(prediction, target, _zeros_like_map(prediction), thresholds=(0.5,))[0, 0]
     tp, tn, fp, fn = (int(v) for v in c[:4])

@@ -441,9 +441,11 @@ class McPredictStep(BatchStep):
         if before is not None:
             before()                   # (the weight-scaling pass, on the caller's stream)
         i = 0
-        for g in sizes:                # unseeded masks are drawn (host side: in launch order, whatever the lane) inside forward_accumulate
-            masks = self._launch_masks(model, images, batch_index, i, g)
-            lanes.run(lambda st, lane, masks=masks, g=g: model.forward_accumulate(images, st, masks, passes=g, lane=lane))
+        for g in sizes:
+            # the masks are drawn INSIDE the launch, i.e. on the lane's stream -- the stream that reads them (seeded: from the step's generator;
+            # unseeded: by forward_accumulate from the device's, in launch order whatever the lane)
+            lanes.run(lambda st, lane, i=i, g=g: model.forward_accumulate(images, st, self._launch_masks(model, images, batch_index, i, g),
+                                                                       passes=g, lane=lane))
             i += g
         lanes.end(merge_statistics)
 

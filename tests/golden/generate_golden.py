@@ -761,13 +761,61 @@ def g18_unet_stress():
     save('g18_unet_stress', **arrays)
 
 
+def g19_confusion_third_party():
+    """a17: Dice / confusion matrix / accuracy.  The reference gets them from pymia 0.2.1 (common/evalutation/numpyfunctions.py:128-151),
+    which is absent here -- so this fixture pins the restatement against an INDEPENDENT third party instead: scikit-learn's
+    confusion_matrix / f1_score / accuracy_score on the same label pairs (for two classes the Dice coefficient of the foreground IS the
+    binary F1 score).  The one convention neither can decide is 0 / 0 (no foreground in prediction and target): sklearn reports what
+    ``zero_division`` says; pymia 0.2.1's DiceCoefficient.calculate returns 1 there (published source) -- both variants are stored."""
+    import warnings
+    from sklearn.metrics import accuracy_score, confusion_matrix, f1_score
+    rng = np.random.RandomState(29)
+    cases = {}
+    shape = (5, 12, 10)
+    cases['random_a'] = ((rng.rand(*shape) < 0.3).astype(np.uint8), (rng.rand(*shape) < 0.35).astype(np.uint8))
+    t = (rng.rand(*shape) < 0.2).astype(np.uint8)
+    noisy = t.copy()
+    flip = rng.rand(*shape) < 0.05
+    noisy[flip] = 1 - noisy[flip]
+    cases['random_overlapping'] = (noisy, t)
+    cases['identical'] = (t.copy(), t.copy())
+    cases['all_background'] = (np.zeros(shape, np.uint8), np.zeros(shape, np.uint8))
+    cases['all_foreground'] = (np.ones(shape, np.uint8), np.ones(shape, np.uint8))
+    cases['prediction_empty'] = (np.zeros(shape, np.uint8), t.copy())
+    cases['target_empty'] = (t.copy(), np.zeros(shape, np.uint8))
+    a = np.zeros(shape, np.uint8)
+    b = np.zeros(shape, np.uint8)
+    a[:2] = 1
+    b[3:] = 1
+    cases['empty_intersection'] = (a, b)
+    cases['inverted'] = (1 - t, t.copy())
+    cases['isic_2d'] = ((rng.rand(64, 48) < 0.4).astype(np.uint8), (rng.rand(64, 48) < 0.4).astype(np.uint8))
+    arrays = {'names': np.array(sorted(cases))}
+    for name in sorted(cases):
+        pred, tgt = cases[name]
+        tn, fp, fn, tp = confusion_matrix(tgt.ravel(), pred.ravel(), labels=[0, 1]).ravel()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            f1_zero = f1_score(tgt.ravel(), pred.ravel(), zero_division=0.0)
+            f1_one = f1_score(tgt.ravel(), pred.ravel(), zero_division=1.0)
+        arrays[name + '::prediction'] = pred
+        arrays[name + '::target'] = tgt
+        arrays[name + '::counts_tp_tn_fp_fn_n'] = np.array([tp, tn, fp, fn, pred.size], dtype=np.int64)
+        arrays[name + '::f1_zero_division_0'] = np.array(f1_zero, dtype=np.float64)
+        arrays[name + '::f1_zero_division_1'] = np.array(f1_one, dtype=np.float64)
+        arrays[name + '::accuracy'] = np.array(accuracy_score(tgt.ravel(), pred.ravel()), dtype=np.float64)
+    import sklearn
+    arrays['sklearn_version'] = np.array(sklearn.__version__)
+    save('g19_confusion_third_party', **arrays)
+
+
 def main():
     install_reference()
     torch.set_num_threads(4)
     torch.set_grad_enabled(False)
     for fn in (g1_unet_eval, g2_unet_mc, g3_unet_center, g4_unet_sigma, g5_unet_isic, g6_mc_summary,
                g7_mc_step_end2end, g8_ece, g9_uncertainty, g10_prep, g11_fullsize_digest, g12_eval_csv, g13_postnet, g14_unet_residual, g15_unet_centre_pad,
-               g16_postnet_wide, g17_unet_no_bn, g18_unet_stress):
+               g16_postnet_wide, g17_unet_no_bn, g18_unet_stress, g19_confusion_third_party):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

@@ -1481,3 +1481,18 @@ def test_uncertain_voxel_sets_of_the_reference_g20(golden, dev):
     odd = np.array([-0.0, -1.0, 2.0, np.nan, np.inf, -np.inf], np.float32)
     c = ev.uncertainty_counts_from_p(np.zeros(6, np.uint8), np.zeros(6, np.uint8), odd, thr)[0]
     assert np.array_equal(c[:, 4:], np.zeros((11, 4), np.int64)) and np.all(c[:, 1] == 6)
+
+
+def test_confusion_dice_accuracy_against_sklearn_g19(golden, dev):
+    """a17 on the GPU path (evaluation.confusion_matrx / dice / accuracy: the counts kernel) against scikit-learn's numbers (fixture g19)."""
+    from rcu_amd import evaluation as ev
+    g = golden('g19_confusion_third_party')
+    for name in g['names']:
+        name = str(name)
+        pred, tgt = g[name + '::prediction'], g[name + '::target']
+        assert list(ev.confusion_matrx(pred, tgt)) == list(g[name + '::counts_tp_tn_fp_fn_n']), name
+        assert abs(ev.dice(pred, tgt) - float(g[name + '::f1_zero_division_1'])) < 1e-15, name
+        assert abs(ev.accuracy(pred, tgt) - float(g[name + '::accuracy'])) < 1e-15, name
+        res = {}
+        ev.ComposeEvaluation([ev.DiceNumpy(), ev.ConfusionMatrix()])({'prediction': pred, 'target': tgt}, res)
+        assert [res[k] for k in ('tp', 'tn', 'fp', 'fn', 'n')] == list(g[name + '::counts_tp_tn_fp_fn_n'])

@@ -336,3 +336,24 @@ def test_g18_unet_stress(golden):
         assert scale >= 10.0 and float(g['features_mc{}_absmax'.format(t)]) >= 100.0       # what the fixture is for
         _close(y.numpy().reshape(-1)[::stride], g['logits_mc{}_strided'.format(t)], 2e-6 * scale)
         assert abs(float(feats.abs().max()) - float(g['features_mc{}_absmax'.format(t)])) < 1e-4 * float(g['features_mc{}_absmax'.format(t)])
+
+
+def test_confusion_dice_accuracy_against_sklearn_g19(golden):
+    """a17: pymia's ConfusionMatrix / DiceCoefficient / Accuracy are absent, so the restatement is pinned against an independent
+    third party -- fixture g19 holds scikit-learn's confusion_matrix / f1_score / accuracy_score for random, degenerate and 2D label pairs.
+    The one case no third party decides is 0 / 0 (no foreground anywhere): pymia 0.2.1 returns Dice 1 there, which is sklearn's
+    zero_division=1 variant."""
+    from oracle import calib_oracle as co
+    g = golden('g19_confusion_third_party')
+    for name in g['names']:
+        name = str(name)
+        pred, tgt = g[name + '::prediction'], g[name + '::target']
+        tp, tn, fp, fn, n = co.confusion_counts(pred, tgt)
+        assert [tp, tn, fp, fn, n] == list(g[name + '::counts_tp_tn_fp_fn_n']), name
+        dice = co.dice_from_counts(tp, fp, fn)
+        assert abs(dice - float(g[name + '::f1_zero_division_1'])) < 1e-15, name
+        if 2 * tp + fp + fn > 0:
+            assert abs(dice - float(g[name + '::f1_zero_division_0'])) < 1e-15, name
+        else:
+            assert dice == 1.0 and float(g[name + '::f1_zero_division_0']) == 0.0          # the convention case
+        assert abs(co.accuracy_from_counts(tp, tn, n) - float(g[name + '::accuracy'])) < 1e-15, name

@@ -15,4 +15,4 @@ for path in sys.argv[1:]:
     print('{}: {:.2f} {} (resident {}) | {:.2f} ms/step | lanes {} group {} | dominant {} frac {:.3f} avg launch {:.4f} ms | conv {:.3f} ms/forward frac {:.3f} | dp {} bins {}'.format(
         path, d['value'], d['unit'], None if res is None else round(res, 2), d['ms_per_step'], d['config'].get('lanes'), d['config'].get('pass_group'), r['kernel'], r['frac'], r['avg_launch_ms'],
         r['all_conv_kernels']['ms_per_forward'], r['all_conv_kernels']['frac'], par.get('max_abs_dprobabilities_vs_cpu'), par.get('bin_ids_equal')) +
-          ' | ue equal {} within ties {}'.format(par.get('ue_counts_equal'), par.get('ue_counts_within_ties')))
+          ' | ue counts equal {} (max delta {})'.format(par.get('ue_counts_equal'), par.get('ue_max_count_delta')))
