@@ -414,6 +414,9 @@ extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_op
     rcu_unet* h = new rcu_unet();
     h->d = d;
     h->opt = o;
+    // A borrower is planned for the DONOR's batch: the planner's choices (kernel family per layer, tensor layouts) depend on max_batch, and
+    // two plans that share one workspace must agree on every tensor -- identical by construction instead of by luck
+    if (donor && donor->ws && donor->ws->max_batch >= d.max_batch) h->d.max_batch = donor->ws->max_batch;
     int rc = build_plan(h);
     if (rc != RCU_OK) {
         delete h;
@@ -421,7 +424,7 @@ extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_op
     }
     // 32-bit element offsets inside the conv kernel
     for (const Tensor& t : h->tensors)
-        if (t.floats_per_slice * (size_t)d.max_batch >= (size_t)1 << 31) {
+        if (t.floats_per_slice * (size_t)h->d.max_batch >= (size_t)1 << 31) {
             delete h;
             return fail(RCU_ERR_INVALID, "max_batch too large: an activation tensor would exceed 2^31 elements");
         }

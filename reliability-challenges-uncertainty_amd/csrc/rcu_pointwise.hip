@@ -452,7 +452,7 @@ __global__ __launch_bounds__(PW_THREADS) void mc_finalize_kernel(const void* sta
                 vsum += (q - s * s / (double)T) / (double)(T - 1);   // unbiased, as torch.var (customsteps.py:70)
             }
         }
-        if (var != nullptr && (flags & MC_VAR)) var[v] = (float)(vsum / (double)C);
+        if (var != nullptr && (flags & MC_VAR)) var[v] = (float)fmax(vsum / (double)C, 0.0);      // (sum p^2 - (sum p)^2 / T can round a hair below 0 where all passes agree)
         if (flags & MC_MI) sum_h = (float)sd[(size_t)mc_h_plane(flags, C) * V + v];
     } else {
         const float* sf = reinterpret_cast<const float*>(stats);
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(PW_THREADS) void mc_finalize4_kernel(const void* st
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) vr[k] = (float)(vsum[k] / (double)C);
+        for (int k = 0; k < 4; ++k) vr[k] = (float)fmax(vsum[k] / (double)C, 0.0);
         if (flags & MC_MI) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {

@@ -482,19 +482,57 @@ def _fusable(entry, actions):
             all(ev.from_p_supported(a.thresholds) for a in actions if isinstance(a, CorrectionAction)))
 
 
+def metrics_wanted(actions):
+    """(`want` of evaluation.SubjectBatch.metrics, thresholds of the uncertainty-error counts, whether the ECE actions use a mask) for a
+    list of actions on a probability-map run."""
+    by_type = {type(a): a for a in actions}
+    want = (['ece'] if (ECE_TYPES & set(by_type)) else []) + ['minmax'] + \
+           (['ue'] if (CorrectionAction in by_type or (ECE_TYPES & set(by_type))) else [])
+    ue = by_type.get(CorrectionAction)
+    want_mask = any(getattr(a, 'need_t2_mask', False) or getattr(a, 'need_mask', False) for a in actions)
+    return want, (tuple(ue.thresholds) if ue is not None else (0.5,)), want_mask
+
+
+def record_subject(actions, subject, res, slot, n_dim):
+    """Fan the metrics of subject ``slot`` of a `SubjectBatch.metrics` result out to the actions' CSV hooks -- the rows (keys, key order,
+    value types) the per-action strategies of the reference-ordered loop produce."""
+    mn, mx = res['min'][slot], res['max'][slot]
+    # helper.add_background_probability's range check (rechun/eval/helper.py:8-12, 31-47), on the device's min / max
+    if any(not isinstance(a, SaveMinMaxAction) for a in actions):
+        if mx > 1:
+            raise ValueError('Found value larger than 1: "{}"'.format(mx))
+        if mn < 0:
+            raise ValueError('Found value smaller than 0: "{}"'.format(mn))
+    counts = res['counts'][slot] if 'counts' in res else None
+    for action in actions:
+        if isinstance(action, SaveMinMaxAction):
+            action.eval_cases[0].record({'min': mn, 'max': mx}, subject, action.id_)
+        elif isinstance(action, (EceAction, EceCalibrationAction)):
+            hist = [h[slot] for h in res['hist']]
+            tp, tn, fp, fn = (int(v) for v in counts[0][:4])
+            results = {}
+            if isinstance(action, EceCalibrationAction):      # key order of EceBinaryNumpy(return_bins=True) + DiceNumpy
+                ece = ev.ece_from_histogram(*hist, n_dim=n_dim, out_bins=results)
+                results['ece'] = ece
+                results['dice'] = ev._dice(tp, fp, fn)
+            else:
+                results['ece'] = ev.ece_from_histogram(*hist, n_dim=n_dim)
+                results['dice'] = ev._dice(tp, fp, fn)
+                results.update(tp=tp, tn=tn, fp=fp, fn=fn, n=tp + tn + fp + fn)
+            action.eval_cases[0].record(results, subject, action.id_)
+        elif isinstance(action, CorrectionAction):
+            for t, case in enumerate(action.eval_cases):
+                case.record(ev.correction_results(counts[t]), subject, action.id_)
+
+
 def _evaluate_fused(entry, actions, batch_subjects, timing):
     """All actions of a 'probabilities' run from ONE upload per subject and ONE launch per scan and batch of subjects: files read ahead by
     threads, subjects of equal size staged side by side in pinned memory, `evaluation.SubjectBatch.metrics` -- reliability histogram inside
     the mask (ece_dice and calib share it), the uncertainty-error counts of all thresholds from the probability map (their tp / tn / fp /
     fn are ece_dice's confusion matrix), min / max -- and the results fanned out to the actions' CSV hooks in subject order.  The rows are
     those of the per-action loop, byte for byte (tests/test_gpu_parity.py)."""
-    by_type = {type(a): a for a in actions}
-    want_mask = any(getattr(a, 'need_t2_mask', False) or getattr(a, 'need_mask', False) for a in actions)
+    want, thresholds, want_mask = metrics_wanted(actions)
     params = Loader.Params('probabilities', need_target=True, need_prediction=True, need_t2_mask=want_mask)
-    want = (['ece'] if (EceAction in by_type or EceCalibrationAction in by_type) else []) + ['minmax'] + \
-           (['ue'] if (CorrectionAction in by_type or EceAction in by_type or EceCalibrationAction in by_type) else [])
-    ue = by_type.get(CorrectionAction)
-    thresholds = tuple(ue.thresholds) if ue is not None else (0.5,)
     files = entry.subject_files
     reader = _ReadAhead(files, params, depth=2 * batch_subjects)
     batches = {}          # voxels per subject -> SubjectBatch (datasets have one size; a mixed one gets a batch object per size)
@@ -523,34 +561,7 @@ def _evaluate_fused(entry, actions, batch_subjects, timing):
             res = batch.metrics(thresholds=thresholds, want=want)
             t_gpu = time.perf_counter()
             for slot, (k, d) in enumerate(group):
-                sf = files[k]
-                mn, mx = res['min'][slot], res['max'][slot]
-                # helper.add_background_probability's range check (rechun/eval/helper.py:8-12, 31-47), on the device's min / max
-                if (ECE_TYPES & set(by_type)) or ue is not None:
-                    if mx > 1:
-                        raise ValueError('Found value larger than 1: "{}"'.format(mx))
-                    if mn < 0:
-                        raise ValueError('Found value smaller than 0: "{}"'.format(mn))
-                counts = res['counts'][slot] if 'counts' in res else None
-                for action in actions:
-                    if isinstance(action, SaveMinMaxAction):
-                        action.eval_cases[0].record({'min': mn, 'max': mx}, sf.subject, action.id_)
-                    elif isinstance(action, (EceAction, EceCalibrationAction)):
-                        hist = [h[slot] for h in res['hist']]
-                        tp, tn, fp, fn = (int(v) for v in counts[0][:4])
-                        results = {}
-                        if isinstance(action, EceCalibrationAction):      # key order of EceBinaryNumpy(return_bins=True) + DiceNumpy
-                            ece = ev.ece_from_histogram(*hist, n_dim=n_dim, out_bins=results)
-                            results['ece'] = ece
-                            results['dice'] = ev._dice(tp, fp, fn)
-                        else:
-                            results['ece'] = ev.ece_from_histogram(*hist, n_dim=n_dim)
-                            results['dice'] = ev._dice(tp, fp, fn)
-                            results.update(tp=tp, tn=tn, fp=fp, fn=fn, n=tp + tn + fp + fn)
-                        action.eval_cases[0].record(results, sf.subject, action.id_)
-                    elif isinstance(action, CorrectionAction):
-                        for t, case in enumerate(action.eval_cases):
-                            case.record(ev.correction_results(counts[t]), sf.subject, action.id_)
+                record_subject(actions, files[k].subject, res, slot, n_dim)
             t_end = time.perf_counter()
             per = (t_end - t_start) / len(group)
             for k, d in group:

@@ -14,6 +14,7 @@ generator like ``feature_dropout`` does).  Inference only: no autograd, BatchNor
 mode (the test context calls ``model.eval()``, common/trainloop/context.py:321).
 """
 import ctypes
+import itertools
 
 import torch
 import torch.nn as nn
@@ -61,6 +62,7 @@ class UNet(nn.Module):
     # rcu_unet_options (include/rcu.h): what the planner may choose.  The defaults are the shipped path; ``plan_options`` of an instance
     # overrides them for A/B measurements and for the parity tests that compare kernel families on the same input.
     PLAN_DEFAULTS = dict(conv_winograd=1, conv_winograd4=1, conv_first=1, act_layout=0)
+    _generations = itertools.count(1)      # every plan ever created gets the next number: a borrower's plan is valid for ONE generation of its donor's
 
     def __init__(self, nb_classes, in_channels, depth=DEFAULT_DEPTH, start_filters=DEFAULT_START_FILTERS,
                  dropout=DEFAULT_DROPOUT, dropout_center: int = None, residual=False, sigma_out=False,
@@ -116,6 +118,7 @@ class UNet(nn.Module):
         self.plan_options = {}   # overrides of PLAN_DEFAULTS; part of the plan's cache key
         self.fuse_head = True    # 1x1 classifier + softmax + statistics inside conv_cls.0's epilogue where the shapes allow
         self._donor = None       # share_workspace(): the model whose activation workspaces this one's plans borrow
+        self._last_generation = 0   # generation of the plan _handle returned last
         self.eval()
 
     # ------------------------------------------------------------------ weights
@@ -188,11 +191,15 @@ class UNet(nn.Module):
         slot = slot + (tuple(sorted(options.items())),)
         entry = self._handles.get(slot)
         donor_handle = None
+        donor_key = None
         if self._donor is not None:    # the donor's plan of this shape and lane first (it may have to grow): its workspace is ours
             donor_handle = self._donor._handle(h, w, n if entry is None else max(n, entry[1]), lane)
-        donor_key = None if donor_handle is None else donor_handle.value
+            # (the plan's generation, not the handle's address: a re-created plan often gets the freed one's address, and a borrower that
+            # kept its old plan would keep the OLD workspace alive and share nothing)
+            donor_key = self._donor._last_generation
         if entry is not None and entry[1] >= n and entry[2] == self._weights_version and entry[3] == donor_key:
             self._handles[slot] = self._handles.pop(slot)     # most recently used last
+            self._last_generation = entry[4]
             return entry[0]
         max_batch = n if entry is None else max(n, entry[1])
         if entry is not None:
@@ -218,7 +225,8 @@ class UNet(nn.Module):
         except Exception:
             lib.rcu_unet_destroy(handle)
             raise
-        self._handles[slot] = (handle, max_batch, self._weights_version, donor_key)
+        self._last_generation = next(UNet._generations)
+        self._handles[slot] = (handle, max_batch, self._weights_version, donor_key, self._last_generation)
         while len(self._handles) > self.MAX_HANDLES:    # images of many different sizes: drop the least recently used plan
             old = next(iter(self._handles))
             lib.rcu_unet_destroy(self._handles.pop(old)[0])
@@ -229,7 +237,8 @@ class UNet(nn.Module):
         """Largest batch of h x w images whose every activation tensor stays below the 2 GB that the Winograd kernels' 32-bit buffer offsets
         reach (csrc/rcu_api.hip pick_config: beyond it a layer falls back to the direct kernels -- correct, but slower).  The widest
         full-resolution tensor has ``start_filters`` channels (twice that for the classifier + sigma twin unit)."""
-        widest = max(8, self.start_filters * (2 if self.sigma_out else 1))
+        # (the planner pads every tensor's channels to a multiple of 32 -- pick_config's bound is on the PADDED tensor)
+        widest = max(8, (self.start_filters + 31) // 32 * 32 * (2 if self.sigma_out else 1))
         return max(1, ((1 << 31) - 1) // (int(h) * int(w) * 4 * widest))
 
     def reserve(self, h, w, n, lane=0):

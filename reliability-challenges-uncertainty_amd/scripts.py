@@ -89,6 +89,113 @@ class WriteHook(loops.TestLoopHook):
         nifti.join_all()
 
 
+class CollectOnDeviceStep(steps.BatchStep):
+    """Part of ``others.device_metrics`` (DeviceMetricsHook): right behind the predict steps, the batch's foreground probability and
+    arg-max prediction are copied -- device to device, on the compute stream -- into per-subject volumes that stay in HBM until the subject
+    has been evaluated there."""
+
+    def __init__(self, store):
+        self.store = store          # subject key -> {'p': [D, H, W] float32, 'prediction': [D, H, W] uint8} (2D subjects: [H, W])
+
+    def __call__(self, batch_context, task_context, context) -> None:
+        probabilities = batch_context.output.get('probabilities')
+        if probabilities is None or not probabilities.is_cuda:
+            return            # (a rank other than the root of a sharded run has nothing to evaluate)
+        pred, fg = steps.prediction_and_foreground(probabilities)            # what the writer derives on the host (brats_test_default.py:96-99)
+        batch = batch_context.input
+        if 'subject_index' in batch:                                        # slices of volumes
+            subjects = [int(v) for v in batch['subject_index']]
+            slices = [int(v) for v in batch['slice_index']]
+            b, n = 0, len(subjects)
+            while b < n:                                                    # runs of consecutive slices of one subject: one copy each
+                e = b + 1
+                while e < n and subjects[e] == subjects[b] and slices[e] == slices[e - 1] + 1:
+                    e += 1
+                vol = self.store.get(subjects[b])
+                if vol is None:
+                    depth = int(batch['shape'][b][0])
+                    vol = self.store[subjects[b]] = {'p': fg.new_empty((depth,) + tuple(fg.shape[1:])),
+                                                     'prediction': pred.new_empty((depth,) + tuple(pred.shape[1:]))}
+                vol['p'][slices[b]:slices[b] + (e - b)] = fg[b:e]
+                vol['prediction'][slices[b]:slices[b] + (e - b)] = pred[b:e]
+                b = e
+        else:                                                               # every sample is a subject (ISIC)
+            for b, id_ in enumerate(batch['ids']):
+                self.store[id_] = {'p': fg[b].clone(), 'prediction': pred[b].clone()}
+
+
+class DeviceMetricsHook(loops.TestLoopHook):
+    """OPT-IN (YAML ``others.device_metrics``, an rcu_amd extension): the calibration / uncertainty-error metrics of
+    bin-eval/eval_uncertainty.py computed on every subject while its maps are still in HBM -- no .nii.gz round trip
+    (bin-dl/brats_test_default.py:96-108 -> rechun/eval/analysis.py:75-107) -- and written as the CSV files the evaluation script would
+    write from the files of this run (same names, columns, rows: the float32 round trip through NIfTI is lossless).
+
+        others:
+          device_metrics:
+            actions: [minmax, ece_dice, calib, bnf_ue]     # default: all four
+            run_id: baseline_mc                            # the test_id column and the file names (default: the config's test_name)
+            gt_dir: /data/Brats18/Training                 # ground-truth tree (ISIC: the dataset prefix) the evaluation reads target and T2
+                                                           # mask from; without it: the dataset's labels, no mask
+            out_dir: null                                  # default: <test_dir>/eval
+
+    The reference's contract stays the file round trip; this hook is the fused path SURVEY.md 8(f)1 leaves optional."""
+
+    def __init__(self, dataset, spec, store):
+        spec = dict(spec or {}) if not isinstance(spec, (list, tuple)) else {'actions': list(spec)}
+        self.dataset = dataset
+        self.action_names = list(spec.get('actions') or ['minmax', 'ece_dice', 'calib', 'bnf_ue'])
+        self.run_id, self.gt_dir, self.out_dir = spec.get('run_id'), spec.get('gt_dir'), spec.get('out_dir')
+        self.store = store
+        self.actions, self.rows, self.gts = [], {}, None
+        self.batch = None
+
+    def on_test_start(self, task_context, context):
+        base = self.out_dir or os.path.join(context.test_dir, 'eval')
+        details = 'foreground' if (self.dataset == 'brats' and self.gt_dir) else ''      # eval_uncertainty.py:19-26
+        self.actions = evalrun.get_actions(self.action_names, os.path.join(base, evalrun.MINMAX_NAME), base, details)
+        entry = evalrun.EvalData(self.run_id or context.config.test_name, context.test_dir, 'probabilities')
+        for action in self.actions:
+            action.setup_eval(entry)
+        if not evalrun._fusable(entry, self.actions):
+            raise ValueError('others.device_metrics: unsupported actions {}'.format(self.action_names))
+        for action in self.actions:
+            action.start_eval()
+        self.want, self.thresholds, self.want_mask = evalrun.metrics_wanted(self.actions)
+        if self.gt_dir:
+            gts = (evalrun.collect_brats_ground_truth if self.dataset == 'brats' else evalrun.collect_isic_ground_truth)(self.gt_dir)
+            self.gts = {sf.subject: sf for sf in gts}
+
+    def on_test_subject_end(self, subject_context, task_context, context):
+        vol = self.store.pop(subject_context.subject_index, None)
+        if vol is None:
+            raise ValueError('others.device_metrics: subject {} was not collected on the device'.format(subject_context.subject_index))
+        name = str(loops._subject_name(subject_context))
+        mask = None
+        if self.gts is not None:             # the evaluation's own inputs (analysis.py:88-89, 118-125)
+            sf = self.gts[name]
+            target = (evalrun.read_label_image(sf.categories['labels']['gt']) > 0).astype(np.uint8)
+            if self.want_mask:
+                mask = nifti.read(sf.categories['images']['t2'])[0] > 0
+        else:
+            target = (np.asarray(subject_context.subject_data['labels']) > 0).astype(np.uint8)
+        n = vol['p'].numel()
+        target = np.squeeze(target) if target.size == n and target.shape != tuple(vol['p'].shape) else target
+        if self.batch is None or self.batch.n != n:
+            self.batch = ev.SubjectBatch(1, n, device=vol['p'].device, with_mask=self.want_mask)
+        self.batch.used = 0
+        self.batch.put(0, vol['p'], vol['prediction'], target, mask)
+        self.batch.upload()
+        self.rows[name] = (self.batch.metrics(thresholds=self.thresholds, want=self.want), target.ndim)
+
+    def on_test_end(self, task_context, context):
+        for name in sorted(self.rows):       # the evaluation script's subject order (rechun/eval/evaldata.py: sorted by subject)
+            res, n_dim = self.rows[name]
+            evalrun.record_subject(self.actions, name, res, 0, n_dim)
+        for action in self.actions:
+            action.finish_eval()
+        self.rows = {}
+
+
 class PrepareSubjectStep(steps.BatchStep):
     def __call__(self, batch_context, task_context, context) -> None:
         batch_context.output['labels'] = batch_context.input['labels'].unsqueeze(1)   # isic_test_default.py:62-66
@@ -126,8 +233,8 @@ def _default_steps(context, world):
     return [steps.SegmentationPredictStep(do_probs=True)]
 
 
-def _hooks(write_hook, context=None):
-    hooks = [loops.ConsoleTestLogHook(), loops.WriteTestMetricsCsvHook('metrics.csv'), write_hook]
+def _hooks(write_hook, extra=()):
+    hooks = [loops.ConsoleTestLogHook(), loops.WriteTestMetricsCsvHook('metrics.csv'), write_hook] + list(extra)
     return loops.ReducedComposeTestLoopHook(hooks)
 
 
@@ -177,6 +284,12 @@ def _run(context, dataset, test_steps, write_hook, entries, world=None):
             return context
     build = data_mod.BuildData(build_dataset=data_mod.BuildVolumeDataset() if dataset == 'brats' else data_mod.BuildIsicDataset())
     options = _loop_options(context)
+    extra_hooks = []
+    spec = _other(context, 'device_metrics')
+    if spec and world.is_root:      # opt-in: the evaluation's metrics on the maps while they are in HBM (DeviceMetricsHook)
+        store = {}
+        test_steps = test_steps + [CollectOnDeviceStep(store)]
+        extra_hooks.append(DeviceMetricsHook(dataset, spec, store))
     if dataset != 'brats':
         test_steps = test_steps + [PrepareSubjectStep()]
     if not world.is_root:
@@ -187,11 +300,11 @@ def _run(context, dataset, test_steps, write_hook, entries, world=None):
     elif dataset == 'brats':
         test = loops.Test(test_steps, [loops.ExtractSubjectInfoStep(), EvalSubjectStep()], loops.SubjectAssembler(),
                           entries=entries, **options)
-        hook = _hooks(write_hook, context)
+        hook = _hooks(write_hook, extra_hooks)
     else:
         test = loops.Test(test_steps, [EvalSubjectStep(squeeze_labels=True, keep_prediction=True)],
                           loops.Subject2dAssembler(), entries=entries, **options)
-        hook = _hooks(write_hook, context)
+        hook = _hooks(write_hook, extra_hooks)
     try:
         test(context, build, hook=hook)
     finally:

@@ -273,11 +273,37 @@ def test_isic_default_script_mc2(tmp_path):
     ctx = scripts.test_default('isic', cfg_path, None)
     rows = list(csv.DictReader(open(os.path.join(ctx.test_dir, 'metrics.csv'))))
     assert [r['subject'] for r in rows] == ids and all(0 <= float(r['dice']) <= 1 for r in rows)
-    for id_ in ids:
+    # the oracle's T = 2 passes under the masks the step drew: a function of (YAML seed 20, batch index, pass) -- rebuilt here from the step
+    from oracle import calib_oracle as co
+    from oracle import summary_oracle as so
+    from rcu_amd import data as data_mod
+    from rcu_amd import steps
+    from rcu_amd.model import UNet
+    dataset = data_mod.IsicDataset(str(prefix), data_mod.Compose([data_mod.IntensityRescale(0, 1, entries=('images', 'labels')),
+                                                                  data_mod.Permute((2, 0, 1), entries=('images', 'labels')), data_mod.Squeeze()]))
+    model = UNet(**params)
+    model.load_state_dict(st)
+    model = model.cuda()
+    step = steps.McPredictStep(2, seed=20)
+    sites = model.dropout_sites()
+    for k, id_ in enumerate(ids):
+        sample = dataset[k]
+        assert sample['ids'] == id_
+        x = torch.from_numpy(np.ascontiguousarray(sample['images']))[None]
+        steps.set_dropout_mode(model, True)
+        flat = [step._seeded_masks(model, x.cuda(), k, j) for j in (1, 2)]          # batch_size 1: batch k is image k
+        steps.set_dropout_mode(model, False)
+        mask_sets = [[m.view(1, -1).cpu() for m in torch.split(f, [c for _, c in sites])] for f in flat]
+        ws, multi = so.mc_probabilities(lambda xx, mk: uo.unet_forward(st, xx, mk, **params), x, mask_sets)
+        ref = so.multi_prediction_summary(multi)['probabilities'][0, 1].numpy()
         p = nifti.read(os.path.join(ctx.test_dir, id_ + '_probabilities.nii.gz'))[0]
         pred = nifti.read(os.path.join(ctx.test_dir, id_ + '_prediction.nii.gz'))[0]
         assert p.shape == (256, 256) and pred.shape == (256, 256) and p.dtype == np.float32
+        assert np.max(np.abs(p - ref)) < 1e-4                                        # north_star tolerance; measured ~1e-7
+        assert np.mean(pred == (ref > 0.5)) > 0.9999
         assert np.array_equal(pred, (p > 0.5).astype(np.uint8)) or np.mean(pred == (p > 0.5)) > 0.9999
+        tp, tn, fp, fn, n = co.confusion_counts(pred, (np.squeeze(sample['labels']) > 0.5).astype(np.uint8))
+        assert abs(float(rows[k]['dice']) - co.dice_from_counts(tp, fp, fn)) < 1e-12
         assert os.path.islink(os.path.join(ctx.test_dir, id_ + '.jpg'))
         assert os.path.islink(os.path.join(ctx.test_dir, id_ + '_segmentation.png'))
 
@@ -482,3 +508,46 @@ def test_isic_auxiliary_scripts(tmp_path):
         assert files, run
         assert all(0 <= float(r['ece']) <= 1 for f in files for r in csv.DictReader(open(f)))
     assert len(glob.glob(str(tmp_path / 'eval' / 'uncertainty' / 'eval_uncertainty_baseline_th*.csv'))) == 11
+
+
+def _gt_tree(root, vols):
+    from rcu_amd import nifti
+    for name, (images, labels, props) in vols.items():
+        (root / 'HGG' / name).mkdir(parents=True)
+        for mod, arr in (('flair', images[..., 0]), ('t1', images[..., 1]), ('t2', images[..., 2]), ('t1ce', images[..., 3]), ('seg', labels * 4)):
+            nifti.write(str(root / 'HGG' / name / '{}_{}.nii.gz'.format(name, mod)), arr, props)
+    return str(root)
+
+
+@pytest.mark.parametrize('with_gt', [True, False], ids=['gt-tree', 'dataset-labels'])
+def test_device_metrics_hook_writes_the_rows_of_the_evaluation_script(tmp_path, with_gt):
+    """``others.device_metrics`` (opt-in): ECE / calibration bins / uncertainty-error counts / min-max of every subject computed while its maps
+    are still in HBM must give, byte for byte, the CSV files bin-eval/eval_uncertainty.py writes from the .nii.gz files the SAME run wrote
+    (the float32 round trip through NIfTI is lossless).  With the ground-truth tree the hook reads target and T2 mask from where the
+    evaluation reads them; without it it takes the dataset's labels and no mask -- which is the evaluation with ece_details ''."""
+    from rcu_amd import scripts
+    cfg_path, vols, _, _ = _setup(tmp_path, mc=5)
+    gt = _gt_tree(tmp_path / 'gt', vols)
+    spec = dict(run_id='baseline_mc', gt_dir=gt) if with_gt else dict(run_id='baseline_mc')
+    ctx = scripts.test_default('brats', _with_others(cfg_path, 'dm', device_metrics=spec), None)
+
+    def all_csv(root):
+        return {os.path.relpath(f, root): open(f, 'rb').read() for f in sorted(glob.glob(os.path.join(root, '**', '*.csv'), recursive=True))}
+
+    on_device = all_csv(os.path.join(ctx.test_dir, 'eval'))
+    assert len(on_device) == 14
+    if with_gt:
+        scripts.eval_uncertainty('brats', {'baseline_mc': ctx.test_dir}, gt, str(tmp_path / 'eval'), expected_subjects=list(vols))
+        from_files = all_csv(str(tmp_path / 'eval'))
+    else:      # the evaluation driver without a mask (what the script does for ISIC): same loader, ece_details ''
+        from rcu_amd import evalrun
+        gts = evalrun.collect_brats_ground_truth(gt)
+        entry = evalrun.get_eval_data('baseline_mc', ctx.test_dir, gts, expected_subjects=list(vols))
+        evalrun.evaluate_runs([entry], ['minmax', 'ece_dice', 'calib', 'bnf_ue'], str(tmp_path / 'eval'), '')
+        from_files = all_csv(str(tmp_path / 'eval'))
+    assert sorted(on_device) == sorted(from_files)
+    for name in on_device:
+        assert on_device[name] == from_files[name], name
+    # a subset of the actions, given as a plain list
+    ctx2 = scripts.test_default('brats', _with_others(cfg_path, 'dm2', device_metrics=['bnf_ue']), None)
+    assert len(all_csv(os.path.join(ctx2.test_dir, 'eval'))) == 11
