@@ -183,6 +183,9 @@ static int pick_config(const ConvLayer& L, int n_slices, const rcu_unet_options&
             if (L.H % 16 == 0) return CONV_CFG_WINO4_S2T16x32_N32;
         }
         if (w4_ok && L.W == 16 && L.H % 8 == 0) return CONV_CFG_WINO4_S8T8x16_N32;
+        // the 12x8 level (bottom_convs): F(4x4,3x3) with a slice's 6 tiles in the 8 tile slots of the S8 block -- 3 multiplications per output
+        // pixel executed (2.25 x 4/3) against F(2x2,3x3)'s 4 (round 5; no pooled output in this geometry)
+        if (w4_ok && L.W == 8 && L.H % 12 == 0 && L.t_pool < 0) return CONV_CFG_WINO4_S8T12x8_N32;
         if (L.coutp == 32 && L.H % 16 == 0 && L.W % 32 == 0) return CONV_CFG_WINO_T16x32_N32;
         if (L.coutp > 32 && L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T16x16_N64;
         if (L.coutp > 32 && L.H % 8 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_S2T8x16_N64;
@@ -1124,6 +1127,7 @@ extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info*
         out->mfma_flops_per_slice = ci.WINO == 2 ? 2.0 * L.c1p * ncols * 9.0 * (px / 4.0)
                                     : ci.WINO == 3 ? 2.0 * (L.c1p + L.c2p) * ncols * 36.0 * (px / 16.0)
                                                    : 2.0 * (L.c1p + L.c2p) * ncols * (ci.WINO ? 4.0 : (double)ci.TAPS) * px;
+        if (L.cfg == CONV_CFG_WINO4_S8T12x8_N32) out->mfma_flops_per_slice *= 4.0 / 3.0;   // 8 tile slots per slice execute, 6 hold tiles
         if (L.cfg == CONV_CFG_FIRST_T8x32)   // K = 4 channels per tap unless more than four are real
             out->mfma_flops_per_slice = 2.0 * (L.cin1 > 4 ? 8 : 4) * ncols * 9.0 * px;
     }

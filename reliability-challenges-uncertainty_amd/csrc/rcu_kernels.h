@@ -92,6 +92,7 @@ enum ConvConfig {
     CONV_CFG_WINO4_T32x32_N32,                   // 32x32-pixel tile (64 Winograd tiles of 4x4)
     CONV_CFG_WINO4_S2T16x32_N32,                 // 16x32 pixels of two consecutive slices
     CONV_CFG_WINO4_S8T8x16_N32,                  // 8x16 pixels of eight consecutive slices, images 16 pixels wide
+    CONV_CFG_WINO4_S8T12x8_N32,                  // 12x8 pixels of eight consecutive slices (6 tiles per slice in the 8 tile slots of the S8 block), images 8 wide
     CONV_CFG_END
 };
 

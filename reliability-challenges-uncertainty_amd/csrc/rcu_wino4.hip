@@ -42,11 +42,16 @@ namespace rcu {
 // FULLW: the tile spans the image's width (checked by the launcher), so the halo columns are zero padding and are not staged at all:
 // the LDS image holds TW positions per row and the lanes of the first / last tile column zero their outer patch column themselves.
 // What it buys is LDS: eight slices of 8x16 pixels (the 24x16 level) fit the 160 KB only without the two halo columns.
-template <int SB_, int BR_, int BC_, int WS_, int WR_, bool FULLW_ = false>
+// FOLD: 12x8-pixel images (the BraTS bottom level).  A slice is 3 x 2 = 6 tiles of 4x4 pixels; they go into the 8 tile slots (2 block rows x 4
+// columns) a slice has in the S8 block geometry: slot k = 4 tr' + tc' holds tile (k / 2, k % 2) for k < 6, slots 6 and 7 are idle -- their MFMA rows
+// read tile 5's patch again and are never stored: 48 of a workgroup's 64 tile slots work (a lane's four tiles, slots 4g .. 4g+3 of one slice, are a
+// 2 x 2 block of tiles, the lower half of it idle for odd g), which still beats F(2x2,3x3)'s 4 multiplications per pixel with 2.25 x 4/3 = 3.
+template <int SB_, int BR_, int BC_, int WS_, int WR_, bool FULLW_ = false, bool FOLD_ = false>
 struct Wino4Tile {
     static constexpr int SB = SB_, BR = BR_, BC = BC_, WS = WS_, WR = WR_;
-    static constexpr bool FULLW = FULLW_;
-    static constexpr int TS = SB * WS, TH = 4 * BR * WR, TW = 4 * BC;
+    static constexpr bool FULLW = FULLW_, FOLD = FOLD_;
+    static constexpr int TS = SB * WS, TH = FOLD ? 12 : 4 * BR * WR, TW = FOLD ? 8 : 4 * BC;
+    static constexpr int TCOLS = FOLD ? 2 : BC;                              // tile columns of the workgroup tile
     static constexpr int BN = 32, KC = 8, THREADS = 256, WAVES = 4, NPOS = 36;
     static constexpr int XCOLS = FULLW ? TW : TW + 2;                        // staged pixel columns per row: x = -1 .. TW, or 0 .. TW - 1
     static constexpr int PITCH = (XCOLS + 3) / 4 * 4;                        // positions per halo row, a multiple of 4
@@ -61,6 +66,7 @@ struct Wino4Tile {
     static constexpr int BUF_DW = A_DW + W_DW;
     static constexpr int LDS_BYTES = 2 * BUF_DW * 4;
     static_assert(SB * BR * BC == 16 && WS * WR == WAVES && BC % 4 == 0, "block geometry");
+    static_assert(!FOLD || (SB == 2 && BR == 2 && BC == 4 && WS == 4 && WR == 1 && FULLW), "the folded 12x8 geometry rides on the S8 block");
     static_assert(W_DW % 256 == 0 && LDS_BYTES <= 160 * 1024, "LDS");
     // wave -> (first slice of its block inside the tile, top pixel row of its block inside the slice tile)
     static __device__ __forceinline__ void block_origin(int wave, int& s, int& y)
@@ -72,8 +78,14 @@ struct Wino4Tile {
     static __device__ __forceinline__ void tile_of(int m, int& sb, int& tr, int& tc)
     {
         sb = m / (BR * BC);
-        tr = (m / BC) % BR;
-        tc = m % BC;
+        if constexpr (FOLD) {
+            const int k = min(m % 8, 5);      // idle slots 6, 7 read tile 5's patch
+            tr = k >> 1;
+            tc = k & 1;
+        } else {
+            tr = (m / BC) % BR;
+            tc = m % BC;
+        }
     }
     static __device__ __forceinline__ int swizzle(int x, int s, int R) { return (((x >> 3) ^ s) & 1) | (((R >> 2) & 1) << 1); }
 };
@@ -247,6 +259,10 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
     const uint32_t vp = plan.pool + wino_out_offset(n0, Hp * Wp, CoutP, (uint32_t)((y0 >> 1) * Wp + (x0 >> 1)), ntile * T::BN, ppx_bytes, pchunk_bytes);
     wino_static_for<0, 4>([&](auto r_c) {
         constexpr int r = decltype(r_c)::value;
+        // where tile r of the lane's four sits relative to its first: the next tile column -- or, folded, a 2 x 2 block of tiles whose lower
+        // half (r = 2, 3) does not exist for the lanes that hold slots 4..7 of a slice (odd g): their stores go out of range
+        constexpr int tdx = T::FOLD ? 4 * (r & 1) : 4 * r, tdy = T::FOLD ? 4 * (r >> 1) : 0;
+        const uint32_t vo_r = (T::FOLD && r >= 2 && ((lane >> 4) & 1) != 0) ? WINO_OOB : vo;
         f32x2 y[4][4];   // [row][col], components = the two couts: packed operations throughout (one instruction costs the same
                          // matrix time whether it is packed or not, see the chunk pipeline)
         {
@@ -298,10 +314,10 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
                 recv.x = wino_swap_adjacent(send.x);
                 recv.y = wino_swap_adjacent(send.y);
                 const f32x4 o = odd ? f32x4{recv.x, recv.y, keep.x, keep.y} : f32x4{keep.x, keep.y, recv.x, recv.y};
-                store16(o, ro, vo, (uint32_t)(4 * r + 2 * h2) * px_bytes + (uint32_t)aa * row_bytes);
+                store16(o, ro, vo_r, (uint32_t)(tdx + 2 * h2) * px_bytes + (uint32_t)(tdy + aa) * row_bytes);
             }
         }
-        if (pool) {   // wave-uniform; 2x2 pooled pixels per tile: the even lane stores four couts of pooled column 0, the odd lane of column 1
+        if (!T::FOLD && pool) {   // wave-uniform; 2x2 pooled pixels per tile: the even lane stores four couts of pooled column 0, the odd lane of column 1 (the folded geometry -- the bottom level -- has no pooled output: launcher)
 #pragma unroll
             for (int a2 = 0; a2 < 2; ++a2) {
                 f32x2 mx[2];
@@ -409,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
             }
         if (T::FULLW) {
             zero_left = tc == 0;
-            zero_right = tc == T::BC - 1;
+            zero_right = tc == T::TCOLS - 1;
         }
     }
     const int b_addr = T::A_DW + (kq * T::BN + 2 * m16) * 2;
@@ -722,11 +738,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
 using W4Cfg0 = Wino4Tile<1, 2, 8, 1, 4>;   // 32x32 pixels of one slice
 using W4Cfg1 = Wino4Tile<1, 2, 8, 2, 2>;   // 16x32 pixels of two consecutive slices (heights not divisible by 32)
 using W4Cfg2 = Wino4Tile<2, 2, 4, 4, 1, true>;   // 8x16 pixels of eight consecutive slices, full image width (the 24x16 level)
+using W4Cfg3 = Wino4Tile<2, 2, 4, 4, 1, true, true>;   // 12x8 pixels of eight consecutive slices, folded into the same block geometry (the 12x8 level)
 
-static const ConvConfigInfo kWino4Info[3] = {
+static const ConvConfigInfo kWino4Info[4] = {
     {W4Cfg0::TS, W4Cfg0::TH, W4Cfg0::TW, W4Cfg0::BN, 8, 36, "conv3x3_winograd4<T32x32,N32,K8>", 8, 0, 3},
     {W4Cfg1::TS, W4Cfg1::TH, W4Cfg1::TW, W4Cfg1::BN, 8, 36, "conv3x3_winograd4<S2T16x32,N32,K8>", 8, 0, 3},
     {W4Cfg2::TS, W4Cfg2::TH, W4Cfg2::TW, W4Cfg2::BN, 8, 36, "conv3x3_winograd4<S8T8x16,N32,K8>", 8, 0, 3},
+    {W4Cfg3::TS, W4Cfg3::TH, W4Cfg3::TW, W4Cfg3::BN, 8, 36, "conv3x3_winograd4<S8T12x8,N32,K8>", 8, 0, 3},
 };
 
 const ConvConfigInfo& wino4_config_info(int cfg) { return kWino4Info[cfg - CONV_CFG_WINO4_T32x32_N32]; }
@@ -747,7 +765,7 @@ static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
 {
     const int nchunks = (a.C1 + a.C2) / T::KC;
     if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
-        (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 || (T::FULLW && a.W != T::TW) ||
+        (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 || (T::FULLW && a.W != T::TW) || (T::FOLD && a.pooled != nullptr) ||
         (size_t)a.N * a.H * a.W * a.CoutP * 4 >= ((size_t)1 << 31))
         return hipErrorInvalidValue;
 #ifdef RCU_WINO4_ABLATIONS   // timing experiments of tools/wino4_check.py (make EXTRA=-DRCU_WINO4_ABLATIONS); results are wrong
@@ -786,6 +804,7 @@ hipError_t launch_conv_wino4(int cfg, const ConvArgs& a, hipStream_t stream)
         case CONV_CFG_WINO4_T32x32_N32: return launch_wino4_cfg<W4Cfg0>(a, stream);
         case CONV_CFG_WINO4_S2T16x32_N32: return launch_wino4_cfg<W4Cfg1>(a, stream);
         case CONV_CFG_WINO4_S8T8x16_N32: return launch_wino4_cfg<W4Cfg2>(a, stream);
+        case CONV_CFG_WINO4_S8T12x8_N32: return launch_wino4_cfg<W4Cfg3>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -135,6 +135,7 @@ class SubjectBatch:
         self.target = torch.empty(shape, device=self.device, dtype=torch.uint8)
         self.mask = torch.empty(shape, device=self.device, dtype=torch.uint8) if with_mask else None
         self._pinned = None
+        self._staged = set()        # (entry, slot) pairs filled on the host since the last upload
         self.used = 0
 
     def _staging(self):
@@ -164,12 +165,22 @@ class SubjectBatch:
                     raise ValueError('subject of {} voxels in a batch of {}-voxel slots'.format(a.size, self.n))
                 dst = self._staging()[key][slot].numpy()
                 np.copyto(dst, a.reshape(-1), casting='unsafe')      # (bool / int64 label maps -> uint8, as torch's cast on the device would)
+                self._staged.add((key, slot))
         self.used = max(self.used, slot + 1)
 
     def upload(self):
-        if self._pinned is not None:
-            for key, host in self._pinned.items():
-                getattr(self, key)[:self.used].copy_(host[:self.used], non_blocking=True)
+        """Host-staged entries -> device (entries that were put as device tensors are there already and stay untouched)."""
+        for key in ('p', 'prediction', 'target', 'mask'):
+            slots = sorted(s_ for k_, s_ in self._staged if k_ == key)
+            if not slots:
+                continue
+            host, dev = self._pinned[key], getattr(self, key)
+            if slots == list(range(slots[0], slots[-1] + 1)):       # the usual case: a run of slots, one copy
+                dev[slots[0]:slots[-1] + 1].copy_(host[slots[0]:slots[-1] + 1], non_blocking=True)
+            else:
+                for s_ in slots:
+                    dev[s_].copy_(host[s_], non_blocking=True)
+        self._staged = set()
 
     def metrics(self, n_bins=10, thresholds=UE_THRESHOLDS, want=('minmax', 'ece', 'ue')):
         """-> dict of host arrays over the ``used`` subjects: ``min`` / ``max`` (float32), ``hist`` = (count, sum_conf, sum_pos) of the
