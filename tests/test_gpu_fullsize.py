@@ -429,7 +429,7 @@ def test_ensemble_members_share_one_activation_workspace(dev):
         assert torch.equal(out[key], ref[key]), key
     assert all(m._donor is shared[0] for m in shared[1:])
     for i, m in enumerate(shared[1:], start=1):
-        assert m.workspace_bytes(h, w, n, lane=i % 2) <= 120e6, i      # packed weights of the plan sized for 160 slices: 107 MB (Winograd tiles)
+        assert m.workspace_bytes(h, w, n, lane=i % 2) <= 150e6, i      # packed weights of the plan sized for 160 slices: 138 MB (Winograd tiles; 36 positions at the 12x8 level since round 5)
     assert shared[0].workspace_bytes(h, w, n) > 5e9
     # the workspace outlives its owner while a borrower still uses it: the borrower's plan of lane 1, called through the C ABI after
     # every plan of the owner has been destroyed

@@ -143,11 +143,14 @@ def _files(ctx):
     return {os.path.basename(f): open(f, 'rb').read() for f in sorted(glob.glob(os.path.join(ctx.test_dir, '*.nii.gz')))}
 
 
-def _with_others(cfg_path, suffix, **others):
-    """A copy of the YAML file with keys added to (None: removed from) ``config.others`` -- the rcu_amd loop options ride there."""
+def _with_others(cfg_path, suffix, test_dir=None, **others):
+    """A copy of the YAML file with keys added to (None: removed from) ``config.others`` -- the rcu_amd loop options ride there;
+    ``test_dir``: another output root (two runs within one second share the time-stamped directory name otherwise)."""
     import yaml
     with open(cfg_path) as f:
         doc = yaml.safe_load(f)
+    # (every variant gets an output root of its own: two runs within one second would share the time-stamped directory otherwise)
+    doc['config']['test_dir'] = test_dir if test_dir is not None else '{}_{}'.format(doc['config']['test_dir'], suffix)
     cur = dict(doc['config'].get('others') or {})
     for k, v in others.items():
         if v is None:
@@ -549,5 +552,5 @@ def test_device_metrics_hook_writes_the_rows_of_the_evaluation_script(tmp_path, 
     for name in on_device:
         assert on_device[name] == from_files[name], name
     # a subset of the actions, given as a plain list
-    ctx2 = scripts.test_default('brats', _with_others(cfg_path, 'dm2', device_metrics=['bnf_ue']), None)
+    ctx2 = scripts.test_default('brats', _with_others(cfg_path, 'dm2', test_dir=str(tmp_path / 'out2'), device_metrics=['bnf_ue']), None)
     assert len(all_csv(os.path.join(ctx2.test_dir, 'eval'))) == 11
