@@ -348,14 +348,14 @@ class ShardedMcRunner:
             return PendingSummary(self.step(x, step_index, mask_sets))
         if not hasattr(self, '_inflight'):
             self._inflight = collections.deque()
-            self._side = torch.cuda.Stream(device=x.device) if x.is_cuda else None
+        self._side_stream(x.device)
         while len(self._inflight) >= depth:
             self._inflight.popleft().retire()
         flat, stats, ws = self._run_jobs(x, step_index, mask_sets)
         works = self._exchange(flat, ws, step_index, async_op=True)
         pending = PendingSummary(None, works=works, keep=(flat, ws))
         if self.rank == self.root:
-            if self._side is not None:
+            if getattr(self, '_side', None) is not None:
                 with torch.cuda.stream(self._side):
                     for w in works:
                         w.wait()                       # the SIDE stream waits for RCCL's stream, compute does not
@@ -376,10 +376,10 @@ class ShardedMcRunner:
         return pending
 
     def reduce_async(self, x, step_index=0, mask_sets=None, depth=2):
-        """The step-seam form: this rank's jobs of the batch and the exchange, WITHOUT the finalize.  Root -> (merged statistics with
-        ``count`` = T, dict of the weight-scaling outputs or None): the calling stream waits for the collective, so
-        ``MultiPredictionSummary`` finalises them like the statistics of a one-process step.  Other ranks -> (None, None): the collective
-        stays in flight (at most ``depth`` per rank, their buffers kept alive) while the rank goes on to the next batch."""
+        """The step-seam form: this rank's jobs of the batch and the exchange, WITHOUT the finalize.  Root -> (``PendingStatistics``, None):
+        the merged statistics once the collective has completed -- ``MultiPredictionSummary`` finalises them on a side stream that waits for
+        the collective, so the root's compute stream goes straight on to the next batch's passes like every other rank's.  Other ranks ->
+        (None, None): the collective stays in flight (at most ``depth`` per rank, their buffers kept alive)."""
         if not hasattr(self, '_inflight'):
             self._inflight = collections.deque()
         while len(self._inflight) >= depth:
@@ -389,11 +389,19 @@ class ShardedMcRunner:
         if self.rank != self.root:
             self._inflight.append(PendingSummary(None, works=works, keep=(flat, ws)))
             return None, None
-        for w in works:
-            w.wait()            # RCCL: the current stream waits for the collective's stream; gloo: the host does
-        stats.count = self.mc_steps
-        stats.keep = flat       # the statistics are a view into the reduce buffer
-        return stats, (self._ws_outputs(ws) if ws is not None else None)
+        if not isinstance(stats, steps_mod.McStatistics):      # (an engine of the CPU tests: plain tensors, nothing to finalise later)
+            for w in works:
+                w.wait()
+            stats.count = self.mc_steps
+            return stats, (self._ws_outputs(ws) if ws is not None else None)
+        return PendingStatistics(self, stats, ws, works, flat), None
+
+    def _side_stream(self, device):
+        if device.type != 'cuda':
+            return None
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
 
     def drain(self):
         """Retire every reduce still in flight (call before destroying the process group)."""
@@ -441,6 +449,42 @@ class ShardedEnsembleRunner(ShardedMcRunner):
         else:
             self.engine.member_pass(self.members[job - 1], x, stats)
         self.forwards_run += 1
+
+
+class PendingStatistics:
+    """What a sharded predict step leaves under ``multi_probabilities`` on the root: the merged statistics of the batch, valid once the
+    collective has completed.  ``MultiPredictionSummary`` calls ``finalize_when_merged``: the finalize (and the hand-over of the
+    weight-scaling outputs out of the reduce buffer's tail) run on a side stream that waits for the collective; the compute stream does not."""
+
+    def __init__(self, runner, stats, ws, works, flat):
+        self.runner, self.stats, self.ws, self.works, self.flat = runner, stats, ws, list(works), flat
+
+    def finalize_when_merged(self, do_mi=False, do_var=False):
+        """-> (dict of the summary's outputs incl. the weight-scaling ones, event recorded behind them or None)."""
+        stats, runner = self.stats, self.runner
+        if (do_mi and not stats.do_mi) or (do_var and not stats.do_var):
+            raise ValueError('the sharded predict step did not track {}: construct it with the flags of the summary'.format(
+                'the entropy sum (do_mi)' if do_mi and not stats.do_mi else 'the squared sums (do_var)'))
+        side = runner._side_stream(stats.blob.device)
+
+        def finish():
+            for w in self.works:
+                w.wait()            # RCCL: the CURRENT (side) stream waits for the collective's stream; gloo: the host does
+            out = stats.finalize(do_mi, do_var, count=runner.mc_steps)
+            if self.ws is not None:
+                out.update(runner._ws_outputs(self.ws))
+            return out
+
+        if side is None:
+            return finish(), None
+        side.wait_stream(torch.cuda.current_stream(stats.blob.device))      # this rank's own passes wrote the buffer on the compute stream
+        with torch.cuda.stream(side):
+            out = finish()
+            event = torch.cuda.Event()
+            event.record(side)
+        self.flat.record_stream(side)
+        self.works = []
+        return out, event
 
 
 class PendingSummary:
@@ -549,7 +593,7 @@ class _ShardedStepBase(steps_mod.BatchStep):
         (MultiPredictionSummary then has nothing to do) and the reduce stays in flight behind the next batch's passes."""
         stats, ws = runner.reduce_async(x, step_index, mask_sets)
         self._batches += 1
-        batch_context.output['multi_probabilities'] = stats
+        batch_context.output['multi_probabilities'] = stats      # root: PendingStatistics (the summary finalises it on a side stream); else None
         if ws is not None:
             batch_context.output.update(ws)
         self._throttle(x.device)

@@ -549,13 +549,15 @@ class _Download:
 
     _buffers = {}
 
-    def __init__(self, tensors: dict, stream, slot):
+    def __init__(self, tensors: dict, stream, slot, outputs_ready=None):
         self.done = torch.cuda.Event()
         self.arrays = {}
         ready = torch.cuda.Event()
         ready.record()                                  # behind the batch's kernels on the compute stream
         with torch.cuda.stream(stream):
             stream.wait_event(ready)
+            if outputs_ready is not None:               # outputs a step finalised on a stream of its own (the root of a sharded predict step)
+                stream.wait_event(outputs_ready)
             for key, value in tensors.items():
                 value = steps_mod.channel_to_end(value)
                 if not value.is_cuda:                   # an entry a step left on the host (labels kept for the subject steps)
@@ -712,7 +714,7 @@ class Test:
         if side is None or self.subject_assembler is None:
             return None
         kept = self._kept(batch_context)
-        download = _Download(kept, side, slot)
+        download = _Download(kept, side, slot, batch_context.more.get('outputs_ready'))
         # up to max_inflight batches are enqueued before this one is finished: the entries nobody keeps must not stay on the GPU that long
         batch_context.output = {key: value for key, value in batch_context.output.items()
                                 if key in kept or not (isinstance(value, torch.Tensor) and value.is_cuda)}
@@ -724,6 +726,7 @@ class Test:
                 to_assemble = download.wait()
             else:
                 to_assemble = {}
+                steps_mod.wait_for_outputs(batch_context)
                 for key, value in self._kept(batch_context).items():
                     value = steps_mod.channel_to_end(value)
                     to_assemble[key] = self.convert_fn(value) if self.convert_fn else value

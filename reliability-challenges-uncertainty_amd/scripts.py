@@ -101,6 +101,7 @@ class CollectOnDeviceStep(steps.BatchStep):
         probabilities = batch_context.output.get('probabilities')
         if probabilities is None or not probabilities.is_cuda:
             return            # (a rank other than the root of a sharded run has nothing to evaluate)
+        steps.wait_for_outputs(batch_context)      # (the root of a sharded run: the summary's outputs come from a side stream)
         pred, fg = steps.prediction_and_foreground(probabilities)            # what the writer derives on the host (brats_test_default.py:96-99)
         batch = batch_context.input
         if 'subject_index' in batch:                                        # slices of volumes

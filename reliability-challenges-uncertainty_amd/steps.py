@@ -553,6 +553,14 @@ class MultiPredictionSummary(BatchStep):
             multi = batch_context.output['multi_probabilities']
         if multi is None:      # a rank other than the root of a sharded predict step (rcu_amd.distributed): the root alone has the merged statistics
             return
+        if hasattr(multi, 'finalize_when_merged'):
+            # the root of a sharded predict step: the statistics are merged by a collective that is still in flight.  The finalize runs on a
+            # side stream behind it; the outputs carry an event (wait_for_outputs) instead of holding the compute stream up
+            out, event = multi.finalize_when_merged(self.do_mi, self.do_var)
+            batch_context.output.update(out)
+            if event is not None:
+                batch_context.more['outputs_ready'] = event
+            return
         if isinstance(multi, McStatistics):
             stats = multi
             if (self.do_mi and not stats.do_mi) or (self.do_var and not stats.do_var):
@@ -665,6 +673,18 @@ class AleatoricMcPredictStep(BatchStep):
             batch_context.output['sigma'] = sigma_sum.div_(float(max(self.mc_steps, 1)))
         finally:
             set_dropout_mode(model, is_train=False)
+
+
+def wait_for_outputs(batch_context):
+    """Order the current stream behind outputs a step produced on a stream of its own (``batch_context.more['outputs_ready']``, set by
+    MultiPredictionSummary for the root of a sharded predict step).  Steps and hooks that read ``batch_context.output`` tensors on the
+    compute stream call this first; the test loop's download waits for the same event on its own stream."""
+    event = batch_context.more.get('outputs_ready')
+    if event is not None:
+        torch.cuda.current_stream().wait_event(event)
+        for value in batch_context.output.values():
+            if torch.is_tensor(value) and value.is_cuda:
+                value.record_stream(torch.cuda.current_stream())
 
 
 def prediction_and_foreground(probabilities):

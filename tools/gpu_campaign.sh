@@ -2,7 +2,7 @@
 # PMC passes (FETCH_SIZE / WRITE_SIZE / SQ counters, each in a run of its own with --kernel-trace only).  The raw CSVs
 # stay in /tmp on the box; only the condensed files land in gpurun_out/$TAG/ (merged back), to be copied into profiles/.
 #   gpurun --timeout 1500 -- 'bash tools/gpu_campaign.sh r01'
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 P=/tmp/prof_$TAG
@@ -42,6 +42,10 @@ timeout 300 bash tools/pmc_inst_mix.sh ${TAG}_mix > $OUT/inst_mix.txt 2>&1
 timeout 200 python tools/calib_bench.py 160 > $OUT/calib_bench.json 2>/dev/null
 timeout 200 python tools/agg_bench.py > $OUT/agg_bench.json 2>/dev/null
 timeout 600 bash tools/pmc_aggregation.sh ${TAG}_aggpmc > $OUT/aggregation_pmc.txt 2>&1
+# round 5: the compute side of 8 GPUs on one (rank 0's exact job list), and the evaluation script's hot loop end to end
+timeout 300 python tools/rank_share_of_world.py --out $OUT/rank_share_of_8.json > /dev/null 2> $OUT/rank_share.err
+timeout 600 python tools/eval_throughput.py --subjects 32 --out $OUT/eval_throughput.json > /dev/null 2> $OUT/eval_throughput.err
+timeout 300 python tools/layer_report.py 5 640 > $OUT/layer_report_640.txt 2>&1
 RCU_SCRIPT_PROFILE=0 timeout 200 python tools/script_throughput.py 16 20 32 > /dev/null 2>&1    # (a first run on a fresh box pages the interpreter, the NIfTI writers' zlib ... in: 0.12-0.16 s per subject; the recorded run is the second)
 RCU_SCRIPT_PROFILE=0 timeout 200 python tools/script_throughput.py 16 20 32 3932160 timing 2>&1 | grep -v "Holder\|conv2d_batch\|Conv2d\|Dropout2d\|BatchNorm2d\|^ *)\|^UNet\|^model" > $OUT/script_throughput.txt
 # the shipped batch_size: 32 as it is (no coalescing): the loop's run-ahead (rcu_amd.loops.Test.INFLIGHT_PIXELS) is what keeps the GPU busy there
