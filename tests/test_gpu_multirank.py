@@ -60,6 +60,31 @@ def test_bench_two_ranks_through_torch_distributed_run(extra):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
+def test_bench_takes_several_volumes_per_step_and_reports_its_devices():
+    """`--volumes-per-step 2` (the rule's choice at 8 ranks: a rank's passes of two consecutive volumes run as one launch, so the launches
+    keep the size they have on one GPU): `--steps 3` stays three VOLUMES -- one step of two and one of one --, the forward passes are counted
+    in volumes, the parity leg reads the first volume of the last chunk, and the line carries the all-gathered device identities."""
+    import json
+    env = dict(os.environ, RCU_BENCH_SINGLE_DEVICE='1', RCU_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+           str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--mc', '4', '--volumes-per-step', '2']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert d['steps'] == 3 and d['config']['volumes_per_step'] == 2 and d['config']['samples_per_launch'] == 640
+    assert sum(d['forwards_per_rank']) == 3 * 5                       # three volumes x (4 MC passes + the weight-scaling pass)
+    assert len(d['devices']) == 2 and {e['rank'] for e in d['devices']} == {0, 1} and all(e['name'] for e in d['devices'])
+    assert d['distinct_devices'] == 1                                 # both ranks on the one GPU of the test box
+    assert d['parity']['bin_ids_equal'] and d['parity']['ece_delta_same_maps'] < 1e-9 and d['parity']['ue_counts_equal']
+    assert d['all_outputs']['value'] > 0
+    # the rule itself: one volume per step up to 4 ranks, two at 8 (T + 1 = 21 jobs, groups of 4)
+    sys.path.insert(0, ROOT)
+    import bench
+    assert [bench.volumes_per_step(w, 21, 4) for w in (1, 2, 4, 8, 16)] == [1, 1, 1, 2, 4] and bench.volumes_per_step(8, 10, 1) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
 def test_bench_plain_command_line_starts_its_own_ranks():
     """`python bench.py --gpus 2` -- no launcher, the form the round driver uses for N = 1 -- must start the two ranks
     itself (a fresh child process, before any GPU call), print the one JSON line and exit 0.  Both ranks share the one GPU

@@ -16,9 +16,9 @@ python bench.py --aleatoric --mc 50 --steps 4 --no-cpu-baseline > $OUT/bench_ale
 # every output in the timed region (mutual information + variance: float64 statistics); the default line carries the same configuration as its `all_outputs` sub-record
 python bench.py --all-outputs --steps 20 --warmup 5 > $OUT/bench_all_outputs.json 2> $OUT/bench_all_outputs.err; cut -c1-200 $OUT/bench_all_outputs.json
 # the N > 1 exchange path over RCCL itself, as far as one GPU allows (a one-rank process group), and the bench line through it
-for m in lazy eager; do python tools/rccl_world1_rehearsal.py 160 20 8 $m 2> $OUT/rccl_world1.err | grep '^{"backend"' >> $OUT/rccl_world1.json; done; cut -c1-300 $OUT/rccl_world1.json
+for m in lazy; do python tools/rccl_world1_rehearsal.py 160 20 8 $m 2> $OUT/rccl_world1.err | grep '^{"backend"' >> $OUT/rccl_world1.json; done; cut -c1-300 $OUT/rccl_world1.json
 RCU_BENCH_FORCE_PG=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2> $OUT/bench_force_pg.err | grep '^{"metric"' > $OUT/bench_force_pg.json; cut -c1-200 $OUT/bench_force_pg.json
-RCU_BENCH_FORCE_PG=1 RCU_BENCH_PG_EAGER=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2> $OUT/bench_force_pg_eager.err | grep '^{"metric"' > $OUT/bench_force_pg_eager.json; cut -c1-200 $OUT/bench_force_pg_eager.json
+# (round 5: the eager-communicator leg, the RCCL kernel trace, the wait / instruction-mix / aggregation counter passes measure things that did not change: profiles/r04_*)
 # the N = 8 lines with all eight ranks on the one GPU over gloo (code-path runs, not throughputs): MC and -- now that members share a workspace -- the K = 10 ensemble
 RCU_BENCH_SINGLE_DEVICE=1 RCU_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 8 --warmup 2 --no-cpu-baseline 2> $OUT/bench_gpus8_one_device.err | grep '^{"metric"' > $OUT/bench_gpus8_one_device.json; cut -c1-200 $OUT/bench_gpus8_one_device.json
 RCU_BENCH_SINGLE_DEVICE=1 RCU_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --ensemble 10 --steps 8 --warmup 2 --no-cpu-baseline 2> $OUT/bench_ens10_gpus8_one_device.err | grep '^{"metric"' > $OUT/bench_ens10_gpus8_one_device.json; cut -c1-200 $OUT/bench_ens10_gpus8_one_device.json
@@ -29,19 +29,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats2 -o bench -- py
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --lanes 1 > $P/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --lanes 1 > $P/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/pmc_sq -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --lanes 1 > $P/pmc_sq.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $P/rccl -o rccl -- python3 $R/tools/rccl_world1_rehearsal.py 160 20 3 > $P/rccl.log 2>&1
 cd $R
-python tools/summarize_rocprof.py stats $(find $P/rccl -name "*kernel_stats.csv" | head -1) $OUT/rccl_world1_kernel_stats.csv
 python tools/summarize_rocprof.py stats $(find $P/stats -name "*kernel_stats.csv" | head -1) $OUT/bench_steps2_kernel_stats.csv
 python tools/summarize_rocprof.py stats $(find $P/stats2 -name "*kernel_stats.csv" | head -1) $OUT/bench_steps2_lanes2_kernel_stats.csv
 python bench.py --lanes 1 --no-cpu-baseline --steps 20 --warmup 5 > $OUT/bench_lanes1.json 2> $OUT/bench_lanes1.err; cut -c1-200 $OUT/bench_lanes1.json
 python tools/summarize_rocprof.py pmc $P/pmc_fetch $P/pmc_write $P/pmc_sq $OUT/bench_pmc.json --plan $OUT/bench_default.json
 head -12 $OUT/bench_steps2_kernel_stats.csv
-timeout 600 bash tools/pmc_wait_breakdown.sh ${TAG}_waits > $OUT/wait_breakdown.txt 2>&1
-timeout 300 bash tools/pmc_inst_mix.sh ${TAG}_mix > $OUT/inst_mix.txt 2>&1
 timeout 200 python tools/calib_bench.py 160 > $OUT/calib_bench.json 2>/dev/null
-timeout 200 python tools/agg_bench.py > $OUT/agg_bench.json 2>/dev/null
-timeout 600 bash tools/pmc_aggregation.sh ${TAG}_aggpmc > $OUT/aggregation_pmc.txt 2>&1
+python __graft_entry__.py smoke 2>&1 | tail -1 > $OUT/smoke.txt; cat $OUT/smoke.txt
 # round 5: the compute side of 8 GPUs on one (rank 0's exact job list), and the evaluation script's hot loop end to end
 timeout 300 python tools/rank_share_of_world.py --out $OUT/rank_share_of_8.json > /dev/null 2> $OUT/rank_share.err
 timeout 600 python tools/eval_throughput.py --subjects 32 --out $OUT/eval_throughput.json > /dev/null 2> $OUT/eval_throughput.err
