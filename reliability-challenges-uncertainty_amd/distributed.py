@@ -182,7 +182,7 @@ class ShardedMcRunner:
 
     def __init__(self, model, mc_steps, ws_pass=True, rank=0, world=1, engine=None, do_mi=False, do_var=False,
                  root=0, seed=0, pass_group=1, lanes=1, ws_transport=None, force_exchange=False, exact=True):
-        self.engine = engine if engine is not None else HipEngine(model, do_mi, do_var, exact)
+        self.engine = engine if engine is not None else HipEngine(model, do_mi, do_var, exact and mc_steps <= steps_mod._lib.RCU_MC_EXACT_MAX_PASSES)
         # force_exchange: run the exchange step (reduce / send-recv, asynchronous work handles, side-stream finalize) at world size 1 too --
         # the rehearsal of the RCCL path on a box with ONE GPU (tools/rccl_world1_rehearsal.py; needs an initialised process group).  A
         # sum-reduce over one rank leaves the buffer as it is, so the result carries the bits of the plain world-1 step.

@@ -360,7 +360,7 @@ class McPredictStep(BatchStep):
         self.group_pixels = self.GROUP_PIXELS if group_pixels is None else group_pixels
         self.lanes = self.LANES if lanes is None else max(1, int(lanes))
         self.seed = seed
-        self.exact = bool(exact)
+        self.exact = bool(exact) and mc_steps <= _lib.RCU_MC_EXACT_MAX_PASSES      # (beyond the exact form's 2,048 passes: plain float sums)
         self._generators = {}
 
     def _seeded_masks(self, model, images, batch_index, job):
@@ -523,10 +523,10 @@ class EnsemblePredictionStep(BatchStep):
             def run(mi, var, materialize=False):
                 if materialize:
                     return torch.stack([softmax(m(images)) for m in members])
-                st = McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var, exact=self.exact)
+                exact = self.exact and len(members) <= _lib.RCU_MC_EXACT_MAX_PASSES
+                st = McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var, exact=exact)
                 lanes = StreamLanes(images.device, min(self.lanes, len(members)))
-                lanes.begin(st, lambda: McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var, exact=self.exact),
-                            inputs=(images,))
+                lanes.begin(st, lambda: McStatistics(n, members[0].nb_classes, h, w, images.device, mi, var, exact=exact), inputs=(images,))
                 for m in members:      # (a member keeps to its lane from batch to batch: one workspace per member)
                     lanes.run(lambda s_, lane, m=m: m.forward_accumulate(images, s_, lane=lane))
                 lanes.end(merge_statistics)
@@ -628,7 +628,7 @@ class AleatoricMcPredictStep(BatchStep):
         self.masks = masks
         self.ws_pass = ws_pass
         self.lanes = McPredictStep.LANES if lanes is None else max(1, int(lanes))
-        self.exact = bool(exact)       # the probability statistics; the sigma sums stay float32 (unbounded addends)
+        self.exact = bool(exact) and mc_steps <= _lib.RCU_MC_EXACT_MAX_PASSES       # the probability statistics; the sigma sums stay float32 (unbounded addends)
 
     def __call__(self, batch_context, task_context, context) -> None:
         _check_context(context)

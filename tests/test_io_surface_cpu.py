@@ -145,3 +145,68 @@ def test_prediction_collection(tmp_path):
     os.remove(str(run / 'Brats18_Y_1_prediction.nii.gz'))
     with pytest.raises(AssertionError):
         evalrun.collect_predictions(str(run), ['prediction', 'probabilities'], ['labels', 'misc'])
+
+
+def test_fused_evaluation_fans_the_metrics_out_into_the_reference_rows(tmp_path):
+    """The fused subject loop of bin-eval/eval_uncertainty.py (evalrun._evaluate_fused, the device-metrics hook) computes every per-voxel scan
+    once per batch and `evalrun.record_subject` turns the raw numbers -- min / max, reliability histogram, 8 x 11 counts -- into the rows
+    the per-action strategies of the reference-ordered loop write.  Checked here without a GPU: the raw numbers come from the oracle, the
+    CSV files must hold the reference's columns in the reference's order and the oracle's values."""
+    import csv
+    from oracle import calib_oracle as co
+    rng = np.random.RandomState(12)
+    subjects = {}
+    for name in ('Brats18_B_1', 'Brats18_A_1'):
+        p = rng.rand(4, 10, 12).astype(np.float32)
+        p[0, 0, :3] = [0.0, 1.0, 0.5]
+        subjects[name] = (p, (p > 0.5).astype(np.uint8), (rng.rand(4, 10, 12) < 0.4).astype(np.uint8), rng.rand(4, 10, 12) > 0.3)
+    base = str(tmp_path / 'eval')
+    actions = evalrun.get_actions(['minmax', 'ece_dice', 'calib', 'bnf_ue'], os.path.join(base, evalrun.MINMAX_NAME), base, 'foreground')
+    entry = evalrun.EvalData('baseline_mc', str(tmp_path), 'probabilities')
+    for a in actions:
+        a.setup_eval(entry)
+    assert evalrun._fusable(entry, actions) and not evalrun._fusable(evalrun.EvalData('aleatoric', str(tmp_path), 'sigma'), actions)
+    want, thresholds, want_mask = evalrun.metrics_wanted(actions)
+    assert want == ['ece', 'minmax', 'ue'] and thresholds == co.UE_THRESHOLDS and want_mask
+    assert evalrun.metrics_wanted(actions[:1]) == (['minmax'], (0.5,), False)
+    for a in actions:
+        a.start_eval()
+    for name in sorted(subjects):
+        p, pred, tgt, mask = subjects[name]
+        hist = co.calibration_histogram(*co.select_foreground(np.stack([1 - p, p], -1), tgt, mask))
+        unc = co.normalised_entropy(co.add_background_probability(p))
+        counts = np.array([co.uncertainty_counts(pred.astype(bool), tgt.astype(bool), unc > t) for t in co.UE_THRESHOLDS], dtype=np.int64)
+        res = {'min': np.array([p.min()]), 'max': np.array([p.max()]), 'hist': tuple(np.asarray(h)[None] for h in hist), 'counts': counts[None]}
+        evalrun.record_subject(actions, name, res, 0, tgt.ndim)
+    for a in actions:
+        a.finish_eval()
+
+    def rows(*parts):
+        with open(os.path.join(base, *parts), newline='') as f:
+            return list(csv.reader(f))
+
+    ece = rows(evalrun.ECE_FOREGROUND_NAME, evalrun.ECE_PLACEHOLDER.format('baseline_mc'))
+    assert ece[0] == ['test_id', 'subject_name', 'ece', 'dice', 'tp', 'tn', 'fp', 'fn', 'n'] and [r[1] for r in ece[1:]] == sorted(subjects)
+    for r in ece[1:]:
+        p, pred, tgt, mask = subjects[r[1]]
+        assert abs(float(r[2]) - co.ece_binary(np.stack([1 - p, p], -1), tgt, mask=mask)) < 1e-15
+        tp, tn, fp, fn, n = co.confusion_counts(pred, tgt)
+        assert [int(v) for v in r[4:]] == [tp, tn, fp, fn, n] and abs(float(r[3]) - co.dice_from_counts(tp, fp, fn)) < 1e-15
+    cal = rows(evalrun.CALIB_NAME, evalrun.CALIBRATION_PLACEHOLDER.format('baseline_mc'))
+    assert cal[0][:2] == ['test_id', 'subject_name'] and cal[0][2] == 'bins_count_00' and cal[0][-2:] == ['ece', 'dice'] and len(cal[0]) == 2 + 4 * 10 + 2
+    mm = evalrun.read_min_max(os.path.join(base, evalrun.MINMAX_NAME, evalrun.MINMAX_PLACEHOLDER.format('baseline_mc')))
+    assert mm == (0.0, 1.0)
+    for t in co.UE_THRESHOLDS:
+        ue = rows(evalrun.UNCERTAINTY_NAME, evalrun.UNCERTAINTY_PLACEHOLDER.format('baseline_mc', '{:.2f}'.format(t).replace('.', '')))
+        assert ue[0][:10] == ['test_id', 'subject_name', 'tpu', 'tnu', 'fpu', 'fnu', 'tp', 'tn', 'fp', 'fn']
+        for r in ue[1:]:
+            p, pred, tgt, _ = subjects[r[1]]
+            unc = co.normalised_entropy(co.add_background_probability(p))
+            ref = co.correction_metrics(co.uncertainty_counts(pred.astype(bool), tgt.astype(bool), unc > t))
+            got = dict(zip(ue[0], r))
+            assert all(int(got[k]) == ref[k] for k in ('tpu', 'tnu', 'fpu', 'fnu', 'tp', 'tn', 'fp', 'fn'))
+            assert abs(float(got['corrected_dice']) - ref['corrected_dice']) < 1e-15 and got['dice_benefit'] == str(ref['dice_benefit'])
+    # a probability outside [0, 1] is rejected as the reference's preparation rejects it (rechun/eval/helper.py:31-47)
+    bad = dict(res, max=np.array([np.float32(1.5)]))
+    with pytest.raises(ValueError, match='larger than 1'):
+        evalrun.record_subject(actions, 'x', bad, 0, 3)

@@ -20,7 +20,8 @@ for m in lazy; do python tools/rccl_world1_rehearsal.py 160 20 8 $m 2> $OUT/rccl
 RCU_BENCH_FORCE_PG=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2> $OUT/bench_force_pg.err | grep '^{"metric"' > $OUT/bench_force_pg.json; cut -c1-200 $OUT/bench_force_pg.json
 # (round 5: the eager-communicator leg, the RCCL kernel trace, the wait / instruction-mix / aggregation counter passes measure things that did not change: profiles/r04_*)
 # the N = 8 lines with all eight ranks on the one GPU over gloo (code-path runs, not throughputs): MC and -- now that members share a workspace -- the K = 10 ensemble
-RCU_BENCH_SINGLE_DEVICE=1 RCU_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 8 --warmup 2 --no-cpu-baseline 2> $OUT/bench_gpus8_one_device.err | grep '^{"metric"' > $OUT/bench_gpus8_one_device.json; cut -c1-200 $OUT/bench_gpus8_one_device.json
+# (--lanes 1: since round 5 every rank sizes its plans for the canonical 640-sample launch on every lane -- 24.4 GB per lane; eight ranks with two lanes each do not fit ONE GPU's 288 GB, which only this rehearsal asks of them)
+RCU_BENCH_SINGLE_DEVICE=1 RCU_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --lanes 1 --steps 8 --warmup 2 --no-cpu-baseline 2> $OUT/bench_gpus8_one_device.err | grep '^{"metric"' > $OUT/bench_gpus8_one_device.json; cut -c1-200 $OUT/bench_gpus8_one_device.json
 RCU_BENCH_SINGLE_DEVICE=1 RCU_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 8 --ensemble 10 --steps 8 --warmup 2 --no-cpu-baseline 2> $OUT/bench_ens10_gpus8_one_device.err | grep '^{"metric"' > $OUT/bench_ens10_gpus8_one_device.json; cut -c1-200 $OUT/bench_ens10_gpus8_one_device.json
 cd /tmp && export TMPDIR=/tmp
 # kernel times: one lane (exclusive durations, what bench.py's roofline record is taken from); then the default two lanes, whose kernels overlap
