@@ -80,8 +80,9 @@ int64_t rcu_unet_workspace_bytes(const rcu_unet* h);
  * reads no environment variable on the product path). */
 typedef struct rcu_unet_options {
     int32_t conv_winograd;    /* 1 (default): Winograd kernels wherever their tiles fit; 0: the direct kernels everywhere */
-    int32_t conv_winograd4;   /* 1 (default): F(4x4,3x3) wherever its tiles fit; 0: F(2x2,3x3) only; 3: F(4x4,3x3) for the units with
-                                 >= 64 output channels only (the round-2 selection) */
+    int32_t conv_winograd4;   /* 1 (default): F(4x4,3x3) wherever its tiles fit -- at the 12x8 level where, for the batch the plan is sized for, its few long
+                                 work items fill the chip's rounds of workgroups (pick_config) --; 2: wherever its tiles fit, whatever the fill (parity
+                                 tests on small batches); 0: F(2x2,3x3) only; 3: F(4x4,3x3) for the units with >= 64 output channels only (the round-2 selection) */
     int32_t conv_first;       /* 1 (default): the unpadded first-unit kernel; 0: the tiled kernel + channels-last input copy */
     int32_t act_layout;       /* 0 (default): channel-blocked activations between Winograd kernels; 1: channels-last everywhere */
     int32_t fuse_head;        /* 1 (default): 1x1 classifier + softmax + statistics in conv_cls.0's epilogue where the shapes allow;

@@ -185,7 +185,16 @@ static int pick_config(const ConvLayer& L, int n_slices, const rcu_unet_options&
         if (w4_ok && L.W == 16 && L.H % 8 == 0) return CONV_CFG_WINO4_S8T8x16_N32;
         // the 12x8 level (bottom_convs): F(4x4,3x3) with a slice's 6 tiles in the 8 tile slots of the S8 block -- 3 multiplications per output
         // pixel executed (2.25 x 4/3) against F(2x2,3x3)'s 4 (round 5; no pooled output in this geometry)
-        if (w4_ok && L.W == 8 && L.H % 12 == 0 && L.t_pool < 0) return CONV_CFG_WINO4_S8T12x8_N32;
+        if (w4_ok && L.W == 8 && L.H % 12 == 0 && L.t_pool < 0) {
+            // ... where its few, long work items fill the chip's rounds: one item = 8 slices x 32 couts against F(2x2,3x3)'s 8 slices x a 4x8 strip x
+            // 64 couts.  Measured per round of 256 workgroups (bottom_convs, tools/layer_report.py): 0.282 against 0.210 ms, so the folded form wins
+            // when rounds_4 * 1.35 < rounds_2 -- 640 samples: 5 against 8 rounds (1.41 against 1.68 ms), 480: 4 against 6; but 160 samples
+            // (an ensemble member's launch): 2 against 2 (0.57 against 0.44 ms), 320: 3 against 4 (a tie) -- there F(2x2,3x3) stays
+            const long groups = (n_slices + 7) / 8;
+            const long rounds4 = (groups * (L.H / 12) * (L.coutp / 32) + 255) / 256;
+            const long rounds2 = (groups * (L.H / 4) * ((L.coutp + 63) / 64) + 255) / 256;
+            if (w4_mode == 2 || L.coutp <= 32 || (double)rounds4 * 1.35 < (double)rounds2) return CONV_CFG_WINO4_S8T12x8_N32;   // (2: whatever the fill -- parity tests on small batches)
+        }
         if (L.coutp == 32 && L.H % 16 == 0 && L.W % 32 == 0) return CONV_CFG_WINO_T16x32_N32;
         if (L.coutp > 32 && L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T16x16_N64;
         if (L.coutp > 32 && L.H % 8 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_S2T8x16_N64;
@@ -410,7 +419,7 @@ extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_op
     rcu_unet_default_options(&o);
     if (opts) {
         o = *opts;
-        if ((o.conv_winograd | 1) != 1 || (o.conv_winograd4 != 0 && o.conv_winograd4 != 1 && o.conv_winograd4 != 3) ||
+        if ((o.conv_winograd | 1) != 1 || (o.conv_winograd4 < 0 || o.conv_winograd4 > 3) ||
             (o.conv_first | 1) != 1 || (o.act_layout | 1) != 1 || (o.fuse_head | 1) != 1 || o.reserved[0] || o.reserved[1] || o.reserved[2])
             return fail(RCU_ERR_INVALID, "rcu_unet_create_with: bad rcu_unet_options value");
     }

@@ -196,3 +196,51 @@ def test_drop_in_script_under_torch_distributed_run_writes_the_one_process_files
     batches = shares[0][1]
     jobs = batches * (len(seeds) if len(seeds) > 1 else 6 + 1)         # K members, or T = 6 passes + the weight-scaling pass, per batch
     assert shares[1][1] == batches and shares[0][0] + shares[1][0] == jobs and abs(shares[0][0] - shares[1][0]) <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_isic_script_under_torch_distributed_run_writes_the_one_process_files(tmp_path):
+    """bin-dl/isic_test_default.py (every image a subject, labels prepared per batch, inputs linked next to the outputs) with `others.mc` under
+    the launcher, two ranks on the one GPU: the files of the plain run, byte for byte."""
+    from PIL import Image
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import test_gpu_scripts as tgs
+    from oracle import unet_oracle as uo
+    from rcu_amd import management as mgt
+    params = dict(nb_classes=2, in_channels=3, depth=4, start_filters=8, dropout=0.2)
+    prefix = tmp_path / 'isic' / 'ISIC-2017_Test_v2'
+    img_dir, lab_dir = str(prefix) + '_Data', str(prefix) + '_Part1_GroundTruth'
+    os.makedirs(img_dir)
+    os.makedirs(lab_dir)
+    rng = np.random.RandomState(8)
+    ids = ['ISIC_00002{:02d}'.format(i) for i in range(5)]
+    for i, id_ in enumerate(ids):
+        Image.fromarray(rng.randint(0, 255, (64, 64, 3)).astype(np.uint8)).save(os.path.join(img_dir, id_ + '.jpg'))
+        lab = np.zeros((64, 64), np.uint8)
+        lab[4 * i:4 * i + 20, 8:40] = 255
+        Image.fromarray(lab).save(os.path.join(lab_dir, id_ + '_segmentation.png'))
+    mf = mgt.ModelFiles(str(tmp_path / 'train'), 'isic')
+    mgt.save_model(mf, 'unet', params, uo.synthetic_state(27, **params))
+    cfgs = []
+    for tag in ('one', 'two'):
+        path = str(tmp_path / 'cfg_{}.yaml'.format(tag))
+        with open(path, 'w') as f:
+            f.write(tgs.ISIC_MC_YAML.format(test_dir=str(tmp_path / ('out_' + tag)), model_dir=mf.model_dir, dataset=str(prefix))
+                    .replace('mc: 2', 'mc: 5').replace('batch_size: 1', 'batch_size: 2'))
+        cfgs.append(path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    script = os.path.join(ROOT, 'bin-dl', 'isic_test_default.py')
+    r1 = subprocess.run([sys.executable, script, '-config_file', cfgs[0]], capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), script, '-config_file', cfgs[1]]
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    one, two = _written(str(tmp_path / 'out_one')), _written(str(tmp_path / 'out_two'))
+    assert sorted(one) == sorted(two) and len(one) == 2 * len(ids) + 1
+    for name in one:
+        assert one[name] == two[name], name
+    assert 'rank 1 of 2: ' in r2.stdout + r2.stderr

@@ -130,17 +130,19 @@ def test_winograd_kernels_vs_direct_and_oracle(dev):
     common = {'conv3x3_winograd<T16x32,N32,K8>',
               'upconv_winograd<T16x16,N64,K8>', 'upconv_winograd<T16x32,N32,K8>', 'upconv_winograd<S2T8x16,N64,K8>',
               'upconv_winograd<S8T4x8,N64,K8>'}
-    w4 = {'conv3x3_winograd4<T32x32,N32,K8>', 'conv3x3_winograd4<S2T16x32,N32,K8>', 'conv3x3_winograd4<S8T8x16,N32,K8>',
-          'conv3x3_winograd4<S8T12x8,N32,K8>'}          # (the last: the 12x8 bottom level, six tiles per slice in the eight slots of the S8 block; round 5)
-    w2 = {'conv3x3_winograd<T16x16,N64,K8>', 'conv3x3_winograd<S2T8x16,N64,K8>', 'conv3x3_winograd<S8T4x8,N64,K8>'}
+    w4 = {'conv3x3_winograd4<T32x32,N32,K8>', 'conv3x3_winograd4<S2T16x32,N32,K8>', 'conv3x3_winograd4<S8T8x16,N32,K8>'}
+    # the 12x8 bottom level: F(4x4,3x3) with six tiles per slice in the eight slots of the S8 block (round 5) where its long work items fill the
+    # chip's rounds -- 640-sample launches -- and always under conv_winograd4=2; F(2x2,3x3) for a plan of 8 slices under the default
+    fold, strip = {'conv3x3_winograd4<S8T12x8,N32,K8>'}, {'conv3x3_winograd<S8T4x8,N64,K8>'}
+    w2 = {'conv3x3_winograd<T16x16,N64,K8>', 'conv3x3_winograd<S2T8x16,N64,K8>'}
     outs = {}
-    for mode, expected in (('1', common | w4), ('3', common | w4), ('0', common | w2)):
+    for mode, expected in (('1', common | w4 | strip), ('2', common | w4 | fold), ('3', common | w4 | strip), ('0', common | w2 | strip)):
         m_w = _model(params, st, dev, conv_winograd4=int(mode))
         rows = m_w.layer_table(h, w, n)
         kernels = {row['kernel'] for row in rows}
         assert expected <= kernels, (mode, expected - kernels)
         n4 = sum('winograd4' in row['kernel'] for row in rows)
-        assert n4 == {'1': 17, '3': 14, '0': 0}[mode], (mode, n4)      # '3': the 96x64, 48x32, 24x16 and 12x8 levels; '1': + three 32-channel 192x128 units
+        assert n4 == {'1': 15, '2': 17, '3': 12, '0': 0}[mode], (mode, n4)      # '3': the 96x64, 48x32 and 24x16 levels; '1': + three 32-channel 192x128 units; '2': + the 12x8 level
         out_w = m_w(x.to(dev), masks).cpu().numpy()
         assert _maxdiff(out_w, ref) < LOGIT_TOL, mode
         assert _maxdiff(torch.softmax(torch.from_numpy(out_w), 1).numpy(), torch.softmax(torch.from_numpy(ref), 1).numpy()) < PROB_TOL
@@ -1295,10 +1297,10 @@ def test_unet_stress_golden_wide_activations_and_logits(golden, dev):
     _, sites = uo.unet_plan(**p)
     stride = int(g['stride'])
     mask_sets = [[g['mask{}_{}'.format(t, s)] for s in range(len(sites))] for t in range(3)]
-    m = _model(p, st, dev)
+    m = _model(p, st, dev, conv_winograd4=2)
     kernels = {row['kernel'] for row in m.layer_table(h, w, n)}
     assert {'conv3x3_winograd4<T32x32,N32,K8>', 'conv3x3_winograd4<S2T16x32,N32,K8>', 'conv3x3_winograd4<S8T8x16,N32,K8>',
-            'conv3x3_winograd4<S8T12x8,N32,K8>'} <= kernels
+            'conv3x3_winograd4<S8T12x8,N32,K8>'} <= kernels      # (conv_winograd4=2: the folded 12x8 form too, although two slices do not fill a round)
     xd = x.to(dev)
     refs = []
     for tag, mk in [('eval', None)] + [('mc{}'.format(t), mask_sets[t]) for t in range(3)]:
