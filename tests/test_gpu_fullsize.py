@@ -129,6 +129,10 @@ def test_pass_pair_of_the_full_volume_is_bit_identical_to_single_passes(dev):
     _, sites = uo.unet_plan(**PARAMS)
     mask_sets = [uo.sample_masks(sites, n, 0.3, g) for _ in range(8)]
     model = _model(PARAMS, st, dev)
+    # ONE plan for single passes, pairs and fours, as the predict steps make it (steps.reserve_canonical_plans): which kernel a layer gets depends
+    # on the batch its plan is sized for -- the 12x8 level runs F(4x4,3x3) in a 640-sample plan and F(2x2,3x3) in a 160-sample one -- and a
+    # pass's bits are a property of the plan
+    model.reserve(h, w, 4 * n)
     single = steps.McStatistics(n, 2, h, w, dev, do_mi=True)
     for ms in mask_sets:
         model.forward_accumulate(x, single, ms)
