@@ -360,6 +360,8 @@ class ShardedMcRunner:
                     for w in works:
                         w.wait()                       # the SIDE stream waits for RCCL's stream, compute does not
                     out = self.engine.finalize(stats, self.mc_steps)
+                    if ws is not None:      # (out of the reduce buffer's tail -- a float64 tail is converted here, BEHIND the collective)
+                        out.update(self._ws_outputs(ws))
                     pending.ready = torch.cuda.Event()
                     pending.ready.record(self._side)
                 flat.record_stream(self._side)
@@ -368,9 +370,9 @@ class ShardedMcRunner:
                 for w in works:
                     w.wait()
                 out = self.engine.finalize(stats, self.mc_steps)
+                if ws is not None:
+                    out.update(self._ws_outputs(ws))
                 pending.works = []
-            if ws is not None:
-                out.update(self._ws_outputs(ws))
             pending.value = out
         self._inflight.append(pending)
         return pending
