@@ -554,3 +554,40 @@ def test_device_metrics_hook_writes_the_rows_of_the_evaluation_script(tmp_path, 
     # a subset of the actions, given as a plain list
     ctx2 = scripts.test_default('brats', _with_others(cfg_path, 'dm2', test_dir=str(tmp_path / 'out2'), device_metrics=['bnf_ue']), None)
     assert len(all_csv(os.path.join(ctx2.test_dir, 'eval'))) == 11
+
+
+def test_device_metrics_hook_on_isic_subjects(tmp_path):
+    """``others.device_metrics`` where every image is a subject (ISIC: no evaluation mask, labels from the png files): the CSV files of
+    bin-eval/eval_uncertainty.py --ds isic on the files of the same run, byte for byte."""
+    from PIL import Image
+    from oracle import unet_oracle as uo
+    from rcu_amd import management as mgt
+    from rcu_amd import scripts
+    params = dict(nb_classes=2, in_channels=3, depth=4, start_filters=8, dropout=0.2)
+    prefix = tmp_path / 'isic' / 'ISIC-2017_Test_v2'
+    img_dir, lab_dir = str(prefix) + '_Data', str(prefix) + '_Part1_GroundTruth'
+    os.makedirs(img_dir)
+    os.makedirs(lab_dir)
+    rng = np.random.RandomState(9)
+    ids = ['ISIC_00003{:02d}'.format(i) for i in range(4)]
+    for i, id_ in enumerate(ids):
+        Image.fromarray(rng.randint(0, 255, (64, 48, 3)).astype(np.uint8)).save(os.path.join(img_dir, id_ + '.jpg'))
+        lab = np.zeros((64, 48), np.uint8)
+        lab[6 * i:6 * i + 24, 4:30] = 255
+        Image.fromarray(lab).save(os.path.join(lab_dir, id_ + '_segmentation.png'))
+    mf = mgt.ModelFiles(str(tmp_path / 'train'), 'isic')
+    mgt.save_model(mf, 'unet', params, uo.synthetic_state(28, **params))
+    cfg_path = str(tmp_path / 'test_isic_baseline_mc.yaml')
+    with open(cfg_path, 'w') as f:
+        f.write(ISIC_MC_YAML.format(test_dir=str(tmp_path / 'out'), model_dir=mf.model_dir, dataset=str(prefix)).replace('mc: 2', 'mc: 4'))
+    ctx = scripts.test_default('isic', _with_others(cfg_path, 'dm', device_metrics=dict(run_id='baseline_mc', gt_dir=str(prefix))), None)
+
+    def all_csv(root):
+        return {os.path.relpath(f, root): open(f, 'rb').read() for f in sorted(glob.glob(os.path.join(root, '**', '*.csv'), recursive=True))}
+
+    on_device = all_csv(os.path.join(ctx.test_dir, 'eval'))
+    scripts.eval_uncertainty('isic', {'baseline_mc': ctx.test_dir}, str(prefix), str(tmp_path / 'eval'), expected_subjects=ids)
+    from_files = all_csv(str(tmp_path / 'eval'))
+    assert sorted(on_device) == sorted(from_files) and len(on_device) == 14
+    for name in on_device:
+        assert on_device[name] == from_files[name], name
