@@ -104,7 +104,7 @@ class CollectOnDeviceStep(steps.BatchStep):
         steps.wait_for_outputs(batch_context)      # (the root of a sharded run: the summary's outputs come from a side stream)
         pred, fg = steps.prediction_and_foreground(probabilities)            # what the writer derives on the host (brats_test_default.py:96-99)
         batch = batch_context.input
-        if 'subject_index' in batch:                                        # slices of volumes
+        if 'slice_index' in batch:                                          # slices of volumes
             subjects = [int(v) for v in batch['subject_index']]
             slices = [int(v) for v in batch['slice_index']]
             b, n = 0, len(subjects)
