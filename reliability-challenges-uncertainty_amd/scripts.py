@@ -309,7 +309,7 @@ def _run(context, dataset, test_steps, write_hook, entries, world=None):
     try:
         test(context, build, hook=hook)
     finally:
-        if world.world > 1:
+        if world.world > 1 and sharded:      # (a run that is rank 0's alone has nobody to meet: the other ranks have left)
             import torch
             import torch.distributed as dist
             for s_ in sharded:
@@ -468,9 +468,18 @@ def _load_segmentation_model(context):
     return model.to(context.device).eval()
 
 
+def _single_rank_only(world):
+    """The auxiliary-network runs are one deterministic forward pass per batch: under a multi-process launch they are rank 0's alone."""
+    if world.world > 1 and not world.is_root:
+        logging.info('rank {}: this configuration has one forward pass per batch, nothing to shard; rank 0 runs it'.format(world.rank))
+        return False
+    return True
+
+
 def test_auxiliary_feat(dataset, config_file=None, device='cuda'):
-    context = loops.TorchTestContext(device)
-    context.load_from_config(config_file or os.path.join(CONFIG_DIR, 'test_{}_auxiliary_feat.yaml'.format(dataset)))
+    context, world = _context(device, config_file or os.path.join(CONFIG_DIR, 'test_{}_auxiliary_feat.yaml'.format(dataset)))
+    if not _single_rank_only(world):
+        return context
     test_model = _load_segmentation_model(context)
     if dataset == 'brats':
         build = data_mod.BuildData(build_dataset=data_mod.BuildVolumeDataset())
@@ -488,8 +497,9 @@ def test_auxiliary_feat(dataset, config_file=None, device='cuda'):
 
 
 def test_auxiliary_segm(dataset, config_file=None, device='cuda'):
-    context = loops.TorchTestContext(device)
-    context.load_from_config(config_file or os.path.join(CONFIG_DIR, 'test_{}_auxiliary_segm.yaml'.format(dataset)))
+    context, world = _context(device, config_file or os.path.join(CONFIG_DIR, 'test_{}_auxiliary_segm.yaml'.format(dataset)))
+    if not _single_rank_only(world):
+        return context
     if dataset == 'brats':
         build = data_mod.BuildData(build_dataset=data_mod.BuildVolumeDataset())
         test = loops.Test([AuxiliarySegmPredictStep()], [loops.ExtractSubjectInfoStep(), EvalAuxiliarySegmStep()],

@@ -244,3 +244,33 @@ def test_isic_script_under_torch_distributed_run_writes_the_one_process_files(tm
     for name in one:
         assert one[name] == two[name], name
     assert 'rank 1 of 2: ' in r2.stdout + r2.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_deterministic_script_under_the_launcher_is_rank_zeros_alone(tmp_path):
+    """A configuration with one deterministic forward pass per batch (no `others.mc`) has nothing to shard over samples: under
+    `torch.distributed.run` rank 0 runs it and writes the plain run's files, the other rank leaves at once -- and nobody waits for it."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import test_gpu_scripts as tgs
+    cfg, vols, _, _ = tgs._setup(tmp_path)            # mc=None: SegmentationPredictStep
+    with open(cfg) as f:
+        text = f.read()
+    cfgs = []
+    for tag in ('one', 'two'):
+        path = str(tmp_path / 'cfg_{}.yaml'.format(tag))
+        with open(path, 'w') as f:
+            f.write(text.replace(str(tmp_path / 'out'), str(tmp_path / 'out_{}'.format(tag))))
+        cfgs.append(path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    script = os.path.join(ROOT, 'bin-dl', 'brats_test_default.py')
+    r1 = subprocess.run([sys.executable, script, '-config_file', cfgs[0]], capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), script, '-config_file', cfgs[1]]
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    one, two = _written(str(tmp_path / 'out_one')), _written(str(tmp_path / 'out_two'))
+    assert sorted(one) == sorted(two) and len(one) == 2 * len(vols) + 1 and all(one[k] == two[k] for k in one)
+    assert 'rank 1: this configuration has one forward pass per batch' in r2.stdout + r2.stderr
