@@ -133,6 +133,26 @@ def test_rccl_world1_rehearsal_matches_the_plain_step_bit_for_bit():
     assert b['all_outputs']['value'] > 0
 
 
+def _launch_two_ranks(script, cfg, env, out_root=None, attempts=2):
+    """`python -m torch.distributed.run --nproc-per-node 2 <script> -config_file <cfg>`; gloo's loopback rendezvous has been seen to hang once with
+    three processes on one GPU, so a hung or failed attempt gets one retry (with the output root of the first attempt removed)."""
+    import shutil
+    last = None
+    for _ in range(attempts):
+        if out_root is not None:
+            shutil.rmtree(out_root, ignore_errors=True)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port()), script, '-config_file', cfg]
+        try:
+            last = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+        except subprocess.TimeoutExpired as exc:
+            last = subprocess.CompletedProcess(cmd, 124, stdout=str(exc.stdout or ''), stderr='timed out: ' + str(exc.stderr or ''))
+            continue
+        if last.returncode == 0:
+            break
+    return last
+
+
 def _script_setup(tmp_path, seeds=(20,), mc=6):
     """Two small BraTS-like subjects, model dir(s) + checkpoint(s), split and two YAML files that differ in their test_dir only."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -172,17 +192,7 @@ def test_drop_in_script_under_torch_distributed_run_writes_the_one_process_files
     path = os.path.join(ROOT, 'bin-dl', script)
     r1 = subprocess.run([sys.executable, path, '-config_file', cfg_one], capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
-    for attempt in range(2):          # (gloo's loopback rendezvous has been seen to hang once with three processes on one GPU: one retry)
-        import shutil
-        shutil.rmtree(str(tmp_path / 'out_two'), ignore_errors=True)
-        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-               '--master-port', str(_free_port()), path, '-config_file', cfg_two]
-        try:
-            r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
-        except subprocess.TimeoutExpired:
-            continue
-        if r2.returncode == 0:
-            break
+    r2 = _launch_two_ranks(path, cfg_two, env, str(tmp_path / 'out_two'))
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
     one, two = _written(str(tmp_path / 'out_one')), _written(str(tmp_path / 'out_two'))
     assert sorted(one) == sorted(two) and len(one) == 2 * len(vols) + 1
@@ -235,9 +245,7 @@ def test_isic_script_under_torch_distributed_run_writes_the_one_process_files(tm
     script = os.path.join(ROOT, 'bin-dl', 'isic_test_default.py')
     r1 = subprocess.run([sys.executable, script, '-config_file', cfgs[0]], capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), script, '-config_file', cfgs[1]]
-    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+    r2 = _launch_two_ranks(script, cfgs[1], env, str(tmp_path / 'out_two'))
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
     one, two = _written(str(tmp_path / 'out_one')), _written(str(tmp_path / 'out_two'))
     assert sorted(one) == sorted(two) and len(one) == 2 * len(ids) + 1
@@ -267,9 +275,7 @@ def test_deterministic_script_under_the_launcher_is_rank_zeros_alone(tmp_path):
     script = os.path.join(ROOT, 'bin-dl', 'brats_test_default.py')
     r1 = subprocess.run([sys.executable, script, '-config_file', cfgs[0]], capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), script, '-config_file', cfgs[1]]
-    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    r2 = _launch_two_ranks(script, cfgs[1], env, str(tmp_path / 'out_two'))
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
     one, two = _written(str(tmp_path / 'out_one')), _written(str(tmp_path / 'out_two'))
     assert sorted(one) == sorted(two) and len(one) == 2 * len(vols) + 1 and all(one[k] == two[k] for k in one)
