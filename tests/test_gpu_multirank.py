@@ -32,7 +32,7 @@ def test_two_ranks_one_gpu_pipelined_matches_single_rank():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [ln for ln in r.stdout.splitlines() if 'max |pipelined' in ln][-1]
     worst = float(line.rsplit('=', 1)[1])
-    assert worst < 1e-5      # float32 sums in a different order across ranks
+    assert worst == 0.0      # exact statistics (round 5): the ranks' partial sums merge to the one-rank bits, whatever the order
 
 
 @pytest.mark.gpu
