@@ -521,3 +521,44 @@ def test_the_test_loop_runs_ahead_by_a_pixel_budget():
     assert not loops._finish_oldest_now([one], True, budget, cap)
     assert loops._finish_oldest_now([one], False, budget, cap)
     assert loops._finish_oldest_now([volume, volume, volume], True, budget, cap)
+
+
+def test_round5_host_rules_seeds_worlds_and_loop_options(tmp_path, monkeypatch):
+    """Host-side rules that need no GPU: mask seeds are a function of (seed, batch, pass); the padded-channel cap of a pass group; the launcher
+    environment -> World; the rcu_amd keys of `others` -> Test options; steps fall back from exact sums beyond 2,048 passes."""
+    from rcu_amd import distributed as rdist
+    from rcu_amd import model as model_mod
+    from rcu_amd import scripts, steps
+    assert len({steps.job_seed(20, k, j) for k in range(40) for j in range(1, 41)}) == 1600
+    assert steps.job_seed(20, 3, 4) == rdist.job_seed(20, 3, 4) != steps.job_seed(21, 3, 4)
+    # ADVICE (round 4): the 2 GB cap of a pass group counts PADDED channels -- start_filters 16 pads to 32, with the sigma twin to 64
+    narrow = model_mod.UNet(2, 4, 4, 16, 0.05, sigma_out=True)
+    assert narrow.max_group_samples(192, 128) == ((1 << 31) - 1) // (192 * 128 * 4 * 64)
+    assert model_mod.UNet(2, 4, 4, 32, 0.05).max_group_samples(192, 128) == 682
+    # no launcher: a world of one, no process group
+    for key in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        monkeypatch.delenv(key, raising=False)
+    world = rdist.world_from_env('cuda')
+    assert (world.rank, world.world, world.is_root, world.device) == (0, 1, True, 'cuda')
+    # the YAML file's `others` -> loop options
+    context = loops.TorchTestContext('cpu')
+    context.config = cfg.TestConfiguration()
+    context.config.others = cfg.OtherParameters().from_dict(dict(mc=20, coalesce_pixels=7864320, pipelined=False, max_inflight=3, stream_lanes=1))
+    assert scripts._loop_options(context) == dict(coalesce=7864320, pipelined=False, max_inflight=3, loader_timing=False)
+    assert scripts._mask_seed(context, world) == context.config.seed == 20
+    built = scripts._default_steps(context, world)
+    assert type(built[0]) is steps.McPredictStep and (built[0].seed, built[0].lanes, built[0].exact, built[0].mc_steps) == (20, 1, True, 20)
+    context.config.others = cfg.OtherParameters().from_dict({})
+    assert scripts._loop_options(context) == dict(coalesce=None, pipelined=None, max_inflight=None, loader_timing=False)
+    assert type(scripts._default_steps(context, world)[0]) is steps.SegmentationPredictStep
+    test = loops.Test([], max_inflight=1, inflight_pixels=10, coalesce=5, pipelined=False, loader_timing=True)
+    assert (test.max_inflight, test.inflight_pixels, test.coalesce, test.pipelined, test.loader_timing) == (1, 10, 5, False, True)
+    assert loops.Test([]).max_inflight == loops.Test.MAX_INFLIGHT
+    # exact sums hold 2,048 passes; a step asked for more keeps plain float sums
+    assert steps.McPredictStep(20).exact and not steps.McPredictStep(4096).exact and not steps.McPredictStep(20, exact=False).exact
+    # the sharded steps need a seed (the masks of a pass must not depend on the rank that runs it)
+    with pytest.raises(ValueError):
+        rdist.ShardedMcPredictStep(20, rdist.World(1, 2), seed=None)
+    # bench.py's volumes-per-step rule
+    import bench
+    assert [bench.volumes_per_step(w, 21, 4) for w in (1, 2, 4, 8)] == [1, 1, 1, 2]
