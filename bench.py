@@ -495,6 +495,10 @@ def main():
     backend = os.environ.get('RCU_BENCH_BACKEND', 'nccl')
     if single_device:
         local_rank = 0
+        if world * args.lanes > 10:
+            # every rank sizes its plans for the canonical 640-sample launch on every lane (24.4 GB each): more than ten of them do not fit the ONE
+            # GPU this rehearsal puts all ranks on
+            args.lanes = 1
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     # Test-only switch: RCU_BENCH_FORCE_PG=1 at N = 1 initialises the RCCL process group with ONE rank and routes every step through the
