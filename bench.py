@@ -513,8 +513,7 @@ def main():
     # steps).  Measured at N = 1 through a one-rank group (round 4, profiles/r04_pg_h2d.txt): with `device_id=device` (eager creation at
     # init_process_group) every step that overlaps a prefetched host-to-device copy runs 4 ms longer -- 166.8-168.2 against 172.5-174.3
     # MC-sample-volumes/s, proportional to the step count, the same steps on a resident volume unaffected, GPU_MAX_HW_QUEUES and the
-    # order of the first copy irrelevant -- while the lazily created communicator costs 0.5 % (173.3-173.5).  RCU_BENCH_PG_EAGER=1: the eager form.
-    pg_kwargs = dict(device_id=device) if os.environ.get('RCU_BENCH_PG_EAGER') == '1' else {}
+    # order of the first copy irrelevant -- while the lazily created communicator costs 0.5 % (173.3-173.5; tools/pg_h2d_probe.py is the A/B).
     if force_pg:
         import socket
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -522,12 +521,12 @@ def main():
             with socket.socket() as sock:
                 sock.bind(('127.0.0.1', 0))
                 os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
-        dist.init_process_group(backend, rank=0, world_size=1, **(pg_kwargs if backend == 'nccl' else {}))
+        dist.init_process_group(backend, rank=0, world_size=1)
     collective = world > 1 or force_pg          # a process group exists: barriers and max-over-ranks as the contract prescribes
     barrier_kwargs = dict(device_ids=[local_rank]) if (collective and backend == 'nccl') else {}
     if world > 1:
         if backend == 'nccl':
-            dist.init_process_group('nccl', **pg_kwargs)   # "nccl" is RCCL on ROCm; the rank's device is the current device (set_device above)
+            dist.init_process_group('nccl')   # "nccl" is RCCL on ROCm; the rank's device is the current device (set_device above)
         else:
             dist.init_process_group(backend)
 
