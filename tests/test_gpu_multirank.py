@@ -280,3 +280,60 @@ def test_deterministic_script_under_the_launcher_is_rank_zeros_alone(tmp_path):
     one, two = _written(str(tmp_path / 'out_one')), _written(str(tmp_path / 'out_two'))
     assert sorted(one) == sorted(two) and len(one) == 2 * len(vols) + 1 and all(one[k] == two[k] for k in one)
     assert 'rank 1: this configuration has one forward pass per batch' in r2.stdout + r2.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_full_size_script_run_is_the_same_bytes_on_two_ranks(tmp_path):
+    """The headline configuration behind the drop-in script, at its own size: two BraTS-sized subjects (160 slices of 4 x 192 x 128), the shipped
+    `batch_size: 32`, `mc: 20`, once with loader batches as they are and once coalesced to one volume per step (640-sample pass groups, the
+    folded 12x8 kernel in the plan): `bin-dl/brats_test_default.py` under the launcher with two ranks (on the one GPU) writes the plain
+    run's files byte for byte -- canonical plans, exact statistics and seeded masks at full width."""
+    import json
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import bench
+    from rcu_amd import data as data_mod
+    from rcu_amd import management as mgt
+    from rcu_amd import nifti
+    from test_script_surface_cpu import BRATS_MC_YAML
+    x, _, target = bench.make_volume(20)
+    names = []
+    for i in range(2):
+        name = 'Brats18_FULL_{:03d}_1'.format(i)
+        props = nifti.ImageProperties((bench.WIDTH, bench.HEIGHT, bench.SLICES), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+        data_mod.write_volume(str(tmp_path / 'ds'), name, (x + 0.05 * i).permute(0, 2, 3, 1).numpy(), target.numpy(), props)
+        names.append(name)
+    torch.manual_seed(20)
+    from rcu_amd.model import UNet
+    model = UNet(**bench.MODEL_PARAMS)
+    mf = mgt.ModelFiles(str(tmp_path / 'train'), 'full')
+    mgt.save_model(mf, 'unet', bench.MODEL_PARAMS, {k: v.cpu() for k, v in model.state_dict().items()})
+    split = str(tmp_path / 'split.json')
+    with open(split, 'w') as f:
+        json.dump({'train': [], 'valid': [], 'test': names}, f)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    script = os.path.join(ROOT, 'bin-dl', 'brats_test_default.py')
+    for tag, extra in (('plain', ''), ('coalesced', '    coalesce_pixels: {}\n'.format(bench.SLICES * bench.HEIGHT * bench.WIDTH))):
+        cfgs = []
+        for world in ('one', 'two'):
+            out = tmp_path / 'out_{}_{}'.format(tag, world)
+            text = BRATS_MC_YAML.format(test_dir=str(out), model_dir=mf.model_dir, split=split, dataset=str(tmp_path / 'ds'))
+            text = text.replace('  others:\n', '  others:\n' + extra, 1)
+            path = str(tmp_path / 'cfg_{}_{}.yaml'.format(tag, world))
+            with open(path, 'w') as f:
+                f.write(text)
+            cfgs.append((path, str(out)))
+        r1 = subprocess.run([sys.executable, script, '-config_file', cfgs[0][0]], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+        r2 = _launch_two_ranks(script, cfgs[1][0], env, cfgs[1][1])
+        assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+        one, two = _written(cfgs[0][1]), _written(cfgs[1][1])
+        assert sorted(one) == sorted(two) and len(one) == 2 * len(names) + 1, tag
+        for name in one:
+            assert one[name] == two[name], (tag, name)
+        p = nifti.read(os.path.join([d for d in [os.path.join(cfgs[0][1], e) for e in os.listdir(cfgs[0][1])]][0], names[0] + '_probabilities.nii.gz'))[0]
+        assert p.shape == (bench.SLICES, bench.HEIGHT, bench.WIDTH) and 0 <= float(p.min()) and float(p.max()) <= 1 and float(p.std()) > 0
