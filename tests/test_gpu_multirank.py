@@ -133,7 +133,7 @@ def test_rccl_world1_rehearsal_matches_the_plain_step_bit_for_bit():
     assert b['all_outputs']['value'] > 0
 
 
-def _launch_two_ranks(script, cfg, env, out_root=None, attempts=2):
+def _launch_two_ranks(script, cfg, env, out_root=None, attempts=2, ranks=2):
     """`python -m torch.distributed.run --nproc-per-node 2 <script> -config_file <cfg>`; gloo's loopback rendezvous has been seen to hang once with
     three processes on one GPU, so a hung or failed attempt gets one retry (with the output root of the first attempt removed)."""
     import shutil
@@ -141,10 +141,10 @@ def _launch_two_ranks(script, cfg, env, out_root=None, attempts=2):
     for _ in range(attempts):
         if out_root is not None:
             shutil.rmtree(out_root, ignore_errors=True)
-        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr', '127.0.0.1',
                '--master-port', str(_free_port()), script, '-config_file', cfg]
         try:
-            last = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+            last = subprocess.run(cmd, capture_output=True, text=True, timeout=400 if ranks <= 2 else 700, cwd=ROOT, env=env)
         except subprocess.TimeoutExpired as exc:
             last = subprocess.CompletedProcess(cmd, 124, stdout=str(exc.stdout or ''), stderr='timed out: ' + str(exc.stderr or ''))
             continue
@@ -337,3 +337,26 @@ def test_full_size_script_run_is_the_same_bytes_on_two_ranks(tmp_path):
             assert one[name] == two[name], (tag, name)
         p = nifti.read(os.path.join([d for d in [os.path.join(cfgs[0][1], e) for e in os.listdir(cfgs[0][1])]][0], names[0] + '_probabilities.nii.gz'))[0]
         assert p.shape == (bench.SLICES, bench.HEIGHT, bench.WIDTH) and 0 <= float(p.min()) and float(p.max()) <= 1 and float(p.std()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_eight_ranks_write_the_one_process_files_too(tmp_path):
+    """World size 8 (all eight ranks on the one GPU, gloo): T + 1 = 7 jobs per batch leave most ranks one job and one rank none per batch, the
+    weight-scaling pass moves from rank to rank, eight partial sums meet in one reduce whose order is gloo's business -- and the files are
+    still the one-process run's, byte for byte: exact sums are associative."""
+    (cfg_one, cfg_two), vols = _script_setup(tmp_path, seeds=(20,))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    path = os.path.join(ROOT, 'bin-dl', 'brats_test_default.py')
+    r1 = subprocess.run([sys.executable, path, '-config_file', cfg_one], capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    r8 = _launch_two_ranks(path, cfg_two, env, str(tmp_path / 'out_two'), ranks=8)
+    assert r8.returncode == 0, r8.stdout[-2000:] + r8.stderr[-4000:]
+    one, eight = _written(str(tmp_path / 'out_one')), _written(str(tmp_path / 'out_two'))
+    assert sorted(one) == sorted(eight) and len(one) == 2 * len(vols) + 1
+    for name in one:
+        assert one[name] == eight[name], name
+    import re
+    shares = {int(m.group(1)): int(m.group(2)) for m in re.finditer(r'rank (\d) of 8: (\d+) forward passes in (\d+) batches', r8.stdout + r8.stderr)}
+    assert sorted(shares) == list(range(8)) and sum(shares.values()) == 4 * 7 and max(shares.values()) - min(shares.values()) <= 1
