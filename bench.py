@@ -720,8 +720,9 @@ def main():
     if args.lanes > 1:
         dom_ms, dom_layers = {}, {}
         for L, ms in zip(model.layer_table(height, width, n_slices * args.pass_group), slot_ms[1:]):
-            dom_ms[L['kernel']] = dom_ms.get(L['kernel'], 0.0) + ms
-            dom_layers[L['kernel']] = dom_layers.get(L['kernel'], 0) + 1
+            name = L['kernel'] + ('+head' if L['head_fusable'] and model.fuse_head else '')
+            dom_ms[name] = dom_ms.get(name, 0.0) + ms
+            dom_layers[name] = dom_layers.get(name, 0) + 1
         timed_region = dict(lanes=args.lanes, wall_ms_per_forward=elapsed * 1e3 / passes_run, profiled_forward_launches_lane0=launches,
                             kernel_ms_per_launch_lane0={k_: v / max(launches * dom_layers[k_], 1) for k_, v in dom_ms.items()},
                             note='start-to-end times of lane 0\'s kernels while the other lane(s) run: overlapped, not exclusive')
@@ -759,7 +760,9 @@ def main():
     layers = model.layer_table(height, width, n_slices * g)
     per_kernel = {}
     for L, ms in zip(layers, slot_ms[1:1 + len(layers)]):
-        e = per_kernel.setdefault(L['kernel'], dict(ms=0.0, flops=0.0, issued=0.0, launches=0))
+        # (conv_cls.0 runs with the classifier head in its epilogue: another kernel than the plain form of the same tile, under its own name)
+        name = L['kernel'] + ('+head' if L['head_fusable'] and model.fuse_head else '')
+        e = per_kernel.setdefault(name, dict(ms=0.0, flops=0.0, issued=0.0, launches=0))
         e['ms'] += ms
         e['flops'] += L['flops_per_slice'] * n_slices * passes_run
         e['issued'] += L['mfma_flops_per_slice'] * n_slices * passes_run

@@ -87,7 +87,9 @@ typedef struct rcu_unet_options {
     int32_t act_layout;       /* 0 (default): channel-blocked activations between Winograd kernels; 1: channels-last everywhere */
     int32_t fuse_head;        /* 1 (default): 1x1 classifier + softmax + statistics in conv_cls.0's epilogue where the shapes allow;
                                  0: the standalone head kernel (also settable per handle at run time: rcu_unet_set_fuse_head) */
-    int32_t reserved[3];      /* must be 0 */
+    int32_t head_winograd4;   /* 1 (default): conv_cls.0 -- with the classifier fused into its epilogue or not -- takes F(4x4,3x3) where the 32x32 tile
+                                 fits (and conv_winograd4 is 1 or 2); 0: it stays on F(2x2,3x3), the plan of rounds 1-4 (A/B measurements) */
+    int32_t reserved[2];      /* must be 0 */
 } rcu_unet_options;
 /* fills *opts with the defaults above */
 void rcu_unet_default_options(rcu_unet_options* opts);
@@ -162,6 +164,8 @@ typedef struct rcu_layer_info {
     char kernel[64];
     int32_t cin, cout, height, width;
     int32_t upsample, pooled, dual_source;
+    int32_t head_fusable;         /* 1: forwards that want logits or statistics (no sigma) run this unit with the classifier head in the kernel's epilogue
+                                     while rcu_unet_options.fuse_head is on -- profilers see that kernel as `kernel` + "+head"; rcu_unet_run_layer runs the plain one */
     double flops_per_slice;       /* algorithmic: 2*cin*cout*9*H*W of the layer as the reference computes it */
     double mfma_flops_per_slice;  /* what the kernel issues to the MFMA pipe (padded channels; 4 of 9 taps for the
                                      sub-pixel up-convolution; whole tiles) */

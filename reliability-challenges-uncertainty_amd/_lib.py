@@ -37,13 +37,13 @@ class UnetDesc(Structure):
 
 class UnetOptions(Structure):
     """rcu_unet_options (include/rcu.h): the planner's kernel-family / layout choices; defaults = the shipped path."""
-    _fields_ = [(n, c_int32) for n in ('conv_winograd', 'conv_winograd4', 'conv_first', 'act_layout', 'fuse_head')] + [('reserved', c_int32 * 3)]
+    _fields_ = [(n, c_int32) for n in ('conv_winograd', 'conv_winograd4', 'conv_first', 'act_layout', 'fuse_head', 'head_winograd4')] + [('reserved', c_int32 * 2)]
 
 
 class LayerInfo(Structure):
     _fields_ = [('name', c_char * 96), ('kernel', c_char * 64), ('cin', c_int32), ('cout', c_int32),
                 ('height', c_int32), ('width', c_int32), ('upsample', c_int32), ('pooled', c_int32),
-                ('dual_source', c_int32), ('flops_per_slice', c_double), ('mfma_flops_per_slice', c_double)]
+                ('dual_source', c_int32), ('head_fusable', c_int32), ('flops_per_slice', c_double), ('mfma_flops_per_slice', c_double)]
 
 
 class EceResult(Structure):

@@ -172,12 +172,15 @@ static int pick_config(const ConvLayer& L, int n_slices, const rcu_unet_options&
         // 256 -> 128 over F(2x2,3x3).  The 32-channel full-resolution layers -- four Cin chunks per tile, so a tile switch (cold fetch +
         // epilogue) per four chunks -- lost to F(2x2,3x3) while the activations were channels-last (0.39-0.69 against 0.36-0.64 ms); with
         // the channel-blocked layout, whose chunks are cold one at a time, they win too (round 3: 0.31 / 0.47 / 0.28 against
-        // 0.35 / 0.60 / 0.33 ms).  conv_cls.0 keeps its fused classifier head on F(2x2,3x3).  rcu_unet_options.conv_winograd4 = 0 keeps
-        // F(2x2,3x3) everywhere, 3 takes F(4x4,3x3) for the layers with >= 64 output channels only (the round-2 choice; A/B tests).
+        // 0.35 / 0.60 / 0.33 ms).  rcu_unet_options.conv_winograd4 = 0 keeps F(2x2,3x3) everywhere, 3 takes F(4x4,3x3) for the layers with
+        // >= 64 output channels only (the round-2 choice; A/B tests).
         const int w4_mode = opt.conv_winograd4;
-        // (the head unit stays on F(2x2,3x3) where its classifier can be fused into the epilogue -- one 32-cout tile, no sigma twin; the
-        // 64-cout cls + sigma twin unit has no fused form and takes F(4x4,3x3))
-        const bool w4_ok = w4_mode != 0 && (L.coutp >= 64 || w4_mode != 3) && !(is_head_unit(L) && L.name2.empty());
+        // The head unit (conv_cls.0 alone: one 32-cout tile, no sigma twin) has its classifier fused into the epilogue of either family
+        // (forward_impl); the F(4x4,3x3) form exists for the 32x32 tile only, elsewhere -- and under head_winograd4 = 0, the plan of
+        // rounds 1-4 -- it stays on F(2x2,3x3).  The 64-cout cls + sigma twin unit has no fused form and takes F(4x4,3x3) like any layer.
+        const bool lone_head = is_head_unit(L) && L.name2.empty();
+        const bool w4_ok = w4_mode != 0 && (L.coutp >= 64 || w4_mode != 3) &&
+                           !(lone_head && (opt.head_winograd4 == 0 || L.coutp != 32 || L.H % 32 != 0 || L.W % 32 != 0));
         if (w4_ok && L.W % 32 == 0) {
             if (L.H % 32 == 0) return CONV_CFG_WINO4_T32x32_N32;
             if (L.H % 16 == 0) return CONV_CFG_WINO4_S2T16x32_N32;
@@ -401,6 +404,7 @@ extern "C" void rcu_unet_default_options(rcu_unet_options* opts)
     opts->conv_first = 1;
     opts->act_layout = 0;
     opts->fuse_head = 1;
+    opts->head_winograd4 = 1;
 }
 
 extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_options* opts, rcu_unet* donor, rcu_unet** out)
@@ -420,7 +424,7 @@ extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_op
     if (opts) {
         o = *opts;
         if ((o.conv_winograd | 1) != 1 || (o.conv_winograd4 < 0 || o.conv_winograd4 > 3) ||
-            (o.conv_first | 1) != 1 || (o.act_layout | 1) != 1 || (o.fuse_head | 1) != 1 || o.reserved[0] || o.reserved[1] || o.reserved[2])
+            (o.conv_first | 1) != 1 || (o.act_layout | 1) != 1 || (o.fuse_head | 1) != 1 || (o.head_winograd4 | 1) != 1 || o.reserved[0] || o.reserved[1])
             return fail(RCU_ERR_INVALID, "rcu_unet_create_with: bad rcu_unet_options value");
     }
     rcu_unet* h = new rcu_unet();
@@ -752,6 +756,14 @@ extern "C" int rcu_unet_finalize_weights(rcu_unet* h)
 
 // `head`: when set (conv_cls.0 on the 32-cout Winograd tile, two classes), the 1x1 classifier + softmax + statistics run in
 // the layer's epilogue and its output tensor is not written (rcu_wino.hip, wino_epilogue_head).
+// the plan's last unit can take the classifier into its epilogue: two classes, no sigma twin, one 32-cout Winograd tile of either family
+static bool head_fusable(const rcu_unet* h)
+{
+    const ConvLayer& last = h->layers.back();
+    return (last.cfg == CONV_CFG_WINO_T16x32_N32 || last.cfg == CONV_CFG_WINO4_T32x32_N32) && h->d.nb_classes == 2 && last.name2.empty() &&
+           h->head_cph == 32;
+}
+
 struct FusedHead {
     float* logits;
     void* stats;
@@ -810,7 +822,7 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     a.wpack_bytes = (uint32_t)std::min<size_t>(L.wpack_floats * 4, 0xFFFFFFFFu);
     int cfg = L.cfg;
     if (head) {
-        cfg = CONV_CFG_WINO_T16x32_N32_HEAD;
+        cfg = L.cfg == CONV_CFG_WINO4_T32x32_N32 ? CONV_CFG_WINO4_T32x32_N32_HEAD : CONV_CFG_WINO_T16x32_N32_HEAD;
         a.head_w = h->w_cls; a.head_b = h->b_cls;
         a.head_logits = head->logits; a.head_stats = head->stats; a.head_flags = head->flags;
         a.head_passes = head->passes;
@@ -848,9 +860,7 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
     // rcu_unet_set_fuse_head keep them apart): two classes, no sigma twin, 32-cout Winograd tile; the passes of a pass group run back to back on the
     // workgroup that owns the tile, so their read-modify-writes of the statistics are ordered (pass 0 first, as head_kernel adds them)
     const ConvLayer& last = h->layers.back();
-    const bool fuse = last.cfg == CONV_CFG_WINO_T16x32_N32 && h->d.nb_classes == 2 && last.name2.empty() &&
-                      sigma == nullptr && (logits != nullptr || stats != nullptr) && h->head_cph == 32 &&
-                      h->opt.fuse_head != 0;
+    const bool fuse = head_fusable(h) && sigma == nullptr && (logits != nullptr || stats != nullptr) && h->opt.fuse_head != 0;
     for (const ConvLayer& L : h->layers) {
         const FusedHead fh{logits, stats, flags, passes};
         int rc = run_layer(h, L, n, masks, stream, (fuse && &L == &last) ? &fh : nullptr, direct_input ? x : nullptr, n_one);
@@ -1121,6 +1131,7 @@ extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info*
     out->cout = L.name2.empty() ? L.cout : 2 * L.cout;
     out->height = L.H; out->width = L.W;
     out->upsample = L.upsample; out->pooled = L.t_pool >= 0; out->dual_source = L.t_src2 >= 0;
+    out->head_fusable = (layer + 1 == (int)h->layers.size() && head_fusable(h)) ? 1 : 0;
     // an up-convolution works on the up-sampled grid, which a centre pad leaves smaller than the skip tensor it is padded to
     out->flops_per_slice = 2.0 * out->cin * out->cout * (L.is_1x1 ? 1.0 : 9.0) * (L.upsample ? 4.0 * (L.H / 2) * (L.W / 2) : (double)L.H * L.W);
     {

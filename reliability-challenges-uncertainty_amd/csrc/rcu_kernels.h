@@ -51,7 +51,7 @@ struct ConvArgs {
     uint32_t in_pix_bytes, in_chunk_bytes;
     uint32_t out_pix_bytes, out_chunk_bytes;
     uint32_t pool_pix_bytes, pool_chunk_bytes;
-    // fused 1x1 head of conv_cls.0 (rcu_wino.hip, two classes): when head_w is set the conv unit's output stays on chip
+    // fused 1x1 head of conv_cls.0 (rcu_wino.hip, rcu_wino4.hip; two classes): when head_w is set the conv unit's output stays on chip
     const float* head_w;   // [2][32] 1x1 weights, head_b[2] bias
     const float* head_b;
     float* head_logits;    // NCHW [N][2][H*W] or null
@@ -93,6 +93,7 @@ enum ConvConfig {
     CONV_CFG_WINO4_S2T16x32_N32,                 // 16x32 pixels of two consecutive slices
     CONV_CFG_WINO4_S8T8x16_N32,                  // 8x16 pixels of eight consecutive slices, images 16 pixels wide
     CONV_CFG_WINO4_S8T12x8_N32,                  // 12x8 pixels of eight consecutive slices (6 tiles per slice in the 8 tile slots of the S8 block), images 8 wide
+    CONV_CFG_WINO4_T32x32_N32_HEAD,              // T32x32_N32 with the 1x1 head + softmax + statistics in the epilogue (run-time choice of forward_impl, never a plan entry)
     CONV_CFG_END
 };
 

@@ -32,6 +32,7 @@
 //   * staging by LDS-DMA only, double-buffered chunk pipeline running across the tiles of a workgroup, buffer-resource zero
 //     padding: as rcu_wino.hip.
 #include "rcu_wino_common.h"
+#include "rcu_head_common.h"
 
 #include <cstdlib>
 
@@ -225,6 +226,49 @@ __device__ __forceinline__ Wino4StorePlan wino4_store_plan(const ConvArgs& a, in
     return p;
 }
 
+// Output transform A^T M A + conv-unit epilogue (scale, shift, ReLU) of tile R of the lane's four: y[row][col], components = the lane's two
+// couts -- packed operations throughout (one instruction costs the same matrix time whether it is packed or not, see the chunk pipeline).
+template <int R, int EV = 0>
+__device__ __forceinline__ void wino4_output_tile(const f32x4 (&accv)[8], const WinoEpi& ep, float relu_floor, f32x2 (&y)[4][4])
+{
+    constexpr int r = R;
+    const f32x2 scale = {ep.scale[0], ep.scale[1]}, shift = {ep.shift[0], ep.shift[1]}, floor2 = {relu_floor, relu_floor};
+    f32x2 nn[6][4];   // N[i][q] = sum_j M[i][j] A[j][q]
+    if constexpr ((EV & 4) != 0) {
+        wino_static_for<0, 16>([&](auto k_c) {
+            constexpr int k = decltype(k_c)::value;
+            y[k >> 2][k & 3] = f32x2{wino4_acc<0, k, r>(accv), wino4_acc<1, k, r>(accv)};
+        });
+    } else {
+        wino_static_for<0, 6>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            auto m = [&](auto j_c) {
+                constexpr int j = decltype(j_c)::value;
+                return f32x2{wino4_acc<0, 6 * i + j, r>(accv), wino4_acc<1, 6 * i + j, r>(accv)};
+            };
+            const f32x2 m0 = m(std::integral_constant<int, 0>{}), m1 = m(std::integral_constant<int, 1>{}), m2 = m(std::integral_constant<int, 2>{}),
+                        m3 = m(std::integral_constant<int, 3>{}), m4 = m(std::integral_constant<int, 4>{}), m5 = m(std::integral_constant<int, 5>{});
+            const f32x2 s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
+            nn[i][0] = (m0 + s1) + s3;
+            nn[i][1] = s2 + 2.f * s4;
+            nn[i][2] = s1 + 4.f * s3;
+            nn[i][3] = (s2 + 8.f * s4) + m5;
+        });
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x2 s1 = nn[1][q] + nn[2][q], s2 = nn[1][q] - nn[2][q], s3 = nn[3][q] + nn[4][q], s4 = nn[3][q] - nn[4][q];
+            const f32x2 v0 = (nn[0][q] + s1) + s3;
+            const f32x2 v1 = s2 + 2.f * s4;
+            const f32x2 v2 = s1 + 4.f * s3;
+            const f32x2 v3 = (s2 + 8.f * s4) + nn[5][q];
+            y[0][q] = __builtin_elementwise_max(v0 * scale + shift, floor2);
+            y[1][q] = __builtin_elementwise_max(v1 * scale + shift, floor2);
+            y[2][q] = __builtin_elementwise_max(v2 * scale + shift, floor2);
+            y[3][q] = __builtin_elementwise_max(v3 * scale + shift, floor2);
+        }
+    }
+}
+
 // Output transform + conv-unit epilogue of one finished tile.  acc[b][p][r]: MFMA block b (cout 2n+b), position p = 6 i + j,
 // tile r of the lane's four.
 template <class T, int EV = 0>   // EV (ablation build): 1 stores out of range, 2 no store instructions, 4 no output transform
@@ -263,45 +307,8 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
         // half (r = 2, 3) does not exist for the lanes that hold slots 4..7 of a slice (odd g): their stores go out of range
         constexpr int tdx = T::FOLD ? 4 * (r & 1) : 4 * r, tdy = T::FOLD ? 4 * (r >> 1) : 0;
         const uint32_t vo_r = (T::FOLD && r >= 2 && ((lane >> 4) & 1) != 0) ? WINO_OOB : vo;
-        f32x2 y[4][4];   // [row][col], components = the two couts: packed operations throughout (one instruction costs the same
-                         // matrix time whether it is packed or not, see the chunk pipeline)
-        {
-            const f32x2 scale = {ep.scale[0], ep.scale[1]}, shift = {ep.shift[0], ep.shift[1]}, floor2 = {relu_floor, relu_floor};
-            f32x2 nn[6][4];   // N[i][q] = sum_j M[i][j] A[j][q]
-            if constexpr ((EV & 4) != 0) {
-                wino_static_for<0, 16>([&](auto k_c) {
-                    constexpr int k = decltype(k_c)::value;
-                    y[k >> 2][k & 3] = f32x2{wino4_acc<0, k, r>(accv), wino4_acc<1, k, r>(accv)};
-                });
-            } else {
-            wino_static_for<0, 6>([&](auto i_c) {
-                constexpr int i = decltype(i_c)::value;
-                auto m = [&](auto j_c) {
-                    constexpr int j = decltype(j_c)::value;
-                    return f32x2{wino4_acc<0, 6 * i + j, r>(accv), wino4_acc<1, 6 * i + j, r>(accv)};
-                };
-                const f32x2 m0 = m(std::integral_constant<int, 0>{}), m1 = m(std::integral_constant<int, 1>{}), m2 = m(std::integral_constant<int, 2>{}),
-                            m3 = m(std::integral_constant<int, 3>{}), m4 = m(std::integral_constant<int, 4>{}), m5 = m(std::integral_constant<int, 5>{});
-                const f32x2 s1 = m1 + m2, s2 = m1 - m2, s3 = m3 + m4, s4 = m3 - m4;
-                nn[i][0] = (m0 + s1) + s3;
-                nn[i][1] = s2 + 2.f * s4;
-                nn[i][2] = s1 + 4.f * s3;
-                nn[i][3] = (s2 + 8.f * s4) + m5;
-            });
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x2 s1 = nn[1][q] + nn[2][q], s2 = nn[1][q] - nn[2][q], s3 = nn[3][q] + nn[4][q], s4 = nn[3][q] - nn[4][q];
-                const f32x2 v0 = (nn[0][q] + s1) + s3;
-                const f32x2 v1 = s2 + 2.f * s4;
-                const f32x2 v2 = s1 + 4.f * s3;
-                const f32x2 v3 = (s2 + 8.f * s4) + nn[5][q];
-                y[0][q] = __builtin_elementwise_max(v0 * scale + shift, floor2);
-                y[1][q] = __builtin_elementwise_max(v1 * scale + shift, floor2);
-                y[2][q] = __builtin_elementwise_max(v2 * scale + shift, floor2);
-                y[3][q] = __builtin_elementwise_max(v3 * scale + shift, floor2);
-            }
-            }
-        }
+        f32x2 y[4][4];   // [row][col], components = the two couts
+        wino4_output_tile<r, EV>(accv, ep, relu_floor, y);
         // Neighbouring lanes (couts 2n, 2n+1 | 2n+2, 2n+3 of the same pixels) trade pixel columns: the even lane ends up with four
         // couts of columns 0 and 2 of the tile, the odd lane with four couts of columns 1 and 3 -> 16-byte stores.
 #pragma unroll
@@ -333,6 +340,105 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
                 const f32x4 o = odd ? f32x4{recv.x, recv.y, keep.x, keep.y} : f32x4{keep.x, keep.y, recv.x, recv.y};
                 store16(o, rp, vp, (uint32_t)(2 * r) * ppx_bytes + (uint32_t)a2 * prow_bytes);
             }
+        }
+    });
+}
+
+// conv_cls.0 with the classifier behind it (common/model/unet.py:160-161, rechun/dl/customsteps.py:24,33), as rcu_wino.hip's wino_epilogue_head: the
+// finished tile's 32 channels never reach HBM; every lane ends up with whole pixels, computes the 1x1 conv to two logits and either stores them
+// (NCHW) or adds softmax / entropy into the MC statistics.  The dot product is summed exactly as head_kernel sums it (eight 4-channel fmaf
+// chains, pairwise tree), so a pass through this epilogue and a pass through this kernel's plain epilogue + head_kernel
+// (rcu_unet_set_fuse_head(h, 0)) give the same bits.
+//
+// Hand-over through LDS, WAVE-LOCAL (no workgroup barrier): for tile r of the lane's four, the 64 lanes of a wave hold 4 tiles (g) x 16 pixels
+// x 32 channels; lane (n, g) writes its two channels of the 16 pixels and then takes pixel n of tile g with all 32 channels.  A wave's 8 KB live
+// in ITS OWN 1 KB pieces of the weight region of LDS buffer 1 -- pieces wave, wave + 4, ... -- which nobody reads once the tile's last chunk is
+// past its barrier (the chunk's remaining weights are in registers by then) and which only this wave's own LDS-DMA writes again (the next
+// tile's second chunk, issued after this epilogue): the other waves may run ahead into the next tile meanwhile.
+//   byte address of (pixel k of tile g, channel pair j) = area + 1024 wave + 4096 (k >> 1) + 512 (k & 1) + 128 g + 8 (j ^ k)
+// -- the slab of a pixel index k is a compile-time offset of the writes, j ^ k spreads the 16 pixels a read instruction covers per tile over
+// 16 bank pairs: ds_write_b64 and ds_read_b64 (32 lanes per cycle over 64 banks) are both free of conflicts, one v_xor per access.
+// The statistics entries of the lane's voxel are requested before the output transform: their round trip runs beside it.  The classifier's
+// 64 weights + 2 biases are read from LDS (`wlds`: copied there once per kernel, WINO4_HEAD_LDS_BYTES behind the two chunk buffers; every lane
+// reads the same address: a broadcast) -- read through the kernel argument's pointer they became vector loads from global memory, four
+// dependent round trips per tile quarter on a wave that has nothing else to run meanwhile.
+constexpr int WINO4_HEAD_LDS_BYTES = 512;
+template <class T>
+__device__ __forceinline__ void wino4_epilogue_head(const ConvArgs& a, const f32x4 (&accv)[8], const WinoEpi& ep, int n0, int nstat, int y0, int x0,
+                                                    int wave, int lane, uint32_t area, uint32_t wlds)
+{
+    // the lane-constant parts of the addresses below are recomputed per tile: hoisted to the kernel's start they would be two more registers alive
+    // through the chunk pipeline, which has none to spare (the build spilled them to scratch)
+    asm volatile("" : "+v"(lane));
+    static_assert(T::TS == 1 && !T::FOLD && T::BC % 4 == 0 && T::BN == 32, "whole tiles of one slice, one 32-cout tile");
+    static_assert(7 * 4096 + 3 * 1024 + 1024 <= T::W_DW * 4, "the hand-over area lies inside the weight region");
+    asm volatile("s_nop 15\n\ts_nop 7");   // as wino4_epilogue: the MFMAs' results are read by v_accvgpr_read behind the compiler's back
+    const int n16 = lane & 15, g = lane >> 4;
+    // one batch of scalar loads
+    const int H = a.H, W = a.W, flags = a.head_flags;
+    float* const logits = a.head_logits;
+    void* const stats = a.head_stats;
+    const size_t V = a.head_V;
+    const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+    int bs, by, sb, tr, tc;
+    T::block_origin(wave, bs, by);
+    T::tile_of(4 * g, sb, tr, tc);
+    // the lane's pixel of tile (g, r): row n16 >> 2, column n16 & 3 of the tile, r tiles (4 r pixels) to the right of the lane's first
+    const size_t HW = (size_t)H * W;
+    const size_t hw0 = (size_t)(y0 + by + 4 * tr + (n16 >> 2)) * W + (size_t)(x0 + 4 * tc + (n16 & 3));
+    typedef volatile __attribute__((address_space(3))) f32x2 lds_f32x2;
+    const uint32_t mine = area + (uint32_t)wave * 1024u + (uint32_t)g * 128u;
+    const uint32_t wbase = mine + 8u * (uint32_t)n16;
+    const uint32_t rbase = mine + (uint32_t)(n16 >> 1) * 4096u + (uint32_t)(n16 & 1) * 512u + 8u * (uint32_t)n16;
+    wino_static_for<0, 4>([&](auto r_c) {
+        constexpr int r = decltype(r_c)::value;
+        const size_t hw = hw0 + 4 * r;
+        // (requesting the entries of all four quarters up front measured the same at 640 samples per launch and 4 % slower at 160: the round
+        // trip is not what the wave waits for)
+        VoxelStats<2> st;
+        if (stats != nullptr) st.load(stats, (size_t)nstat * HW + hw, V, flags);   // nstat: the image the sample is a pass of
+        {
+            f32x2 y[4][4];
+            wino4_output_tile<r>(accv, ep, relu_floor, y);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                *(lds_f32x2*)(uintptr_t)((wbase ^ (8u * k)) + (uint32_t)((k >> 1) * 4096 + (k & 1) * 512)) = y[k >> 2][k & 3];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float row[32];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const f32x2 v = *(lds_f32x2*)(uintptr_t)(rbase ^ (8u * j));
+            row[2 * j] = v.x;
+            row[2 * j + 1] = v.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // tile r + 1 overwrites the area: in order behind these reads (one wave, one LDS queue)
+        __builtin_amdgcn_wave_barrier();
+        float l[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float p[8];
+#pragma unroll
+            for (int sgm = 0; sgm < 8; ++sgm) {
+                const f32x4 w = *(const __attribute__((address_space(3))) f32x4*)(uintptr_t)(wlds + (uint32_t)(c * 32 + 4 * sgm) * 4u);
+                float t = fmaf(w.x, row[4 * sgm], 0.f);
+                t = fmaf(w.y, row[4 * sgm + 1], t);
+                t = fmaf(w.z, row[4 * sgm + 2], t);
+                p[sgm] = fmaf(w.w, row[4 * sgm + 3], t);
+            }
+            const float bias = *(const __attribute__((address_space(3))) float*)(uintptr_t)(wlds + (uint32_t)(64 + c) * 4u);
+            l[c] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) + bias;
+        }
+        if (logits != nullptr) {
+            logits[((size_t)n0 * 2 + 0) * HW + hw] = l[0];
+            logits[((size_t)n0 * 2 + 1) * HW + hw] = l[1];
+        }
+        if (stats != nullptr) {
+            softmax_inplace<2>(l);
+            st.add(flags, l);
+            st.store(stats, (size_t)nstat * HW + hw, V, flags);
         }
     });
 }
@@ -385,7 +491,10 @@ struct Wino4Trace<false> {
 #define WINO4_TRACE_FLUSH()
 #endif
 
-template <class T, int VAR = 0>
+// HEAD: the classifier head in the epilogue (wino4_epilogue_head).  total_items counts the tiles of ONE pass; the workgroup that owns a tile runs
+// the tile of every pass of the group back to back (sample n0 + pass * head_images), so the passes' read-modify-writes of a voxel's statistics
+// are ordered (pass 0 first, as head_kernel adds them) -- as rcu_wino.hip.
+template <class T, int VAR = 0, bool HEAD = false>
 __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, const int total_items)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -432,7 +541,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
     const uint32_t w_voff = (uint32_t)(lane * 16);
 
     int item = wino_xcd_virtual_block(a.NT < 4 ? 4 : a.NT);
-    bool has_next = item + (int)gridDim.x < total_items;
+    [[maybe_unused]] int pass = 0;
+    auto more_passes = [&]() {
+        if constexpr (HEAD) return pass + 1 < wino_cold_args().head_passes;
+        return false;
+    };
+    bool has_next = more_passes() || item + (int)gridDim.x < total_items;
     WinoTileId tile = wino_tile_id<T>(a, item), ntile = tile;
     // dp / dp_wtile: staging offsets and cout tile of the tile whose chunk the FRONT part of a chunk's LDS-DMA fetches (the chunk after the
     // current one), dpn / dpn_wtile: of the tile the BACK part fetches (the chunk after that).  They differ in a tile's last-but-one chunk.
@@ -491,6 +605,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
     {
         const DmaJob job = dma_job(dp_wtile, 0, 0, true);
         wino_static_for<0, T::NW + T::NA>([&](auto i_c) { dma_piece(job, dp, i_c); });
+    }
+    if constexpr (HEAD) {   // the classifier: [2][32] weights, [2] biases (wino4_epilogue_head)
+        if (tid < 66) smem[2 * T::BUF_DW + tid] = tid < 64 ? a.head_w[tid] : a.head_b[tid - 64];
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
@@ -591,7 +708,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         const bool more = kc + 1 < nchunks, more2 = kc + 2 < nchunks;
         if (kc == nchunks - 2 && has_next) {   // last-but-one chunk of the tile: from its barrier on the DMA works on the workgroup's next tile
             const WinoTileConsts ca = wino_tile_consts(wino_cold_args());   // one batch of scalar loads, one wait
-            ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
+            if (more_passes()) {
+                ntile = tile;
+                ntile.n0 = tile.n0 + wino_cold_args().head_images;
+            } else {
+                ntile = wino_tile_id<T>(ca, item + (int)gridDim.x);
+            }
             dpn_wtile = ntile.wtile;
             const WinoTileOffset nto = wino_tile_offset<T>(ca, ntile);
 #pragma unroll
@@ -719,7 +841,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         }
         }
         WINO4_TRACE_MARK(1);
-        if constexpr ((VAR & 2) == 0)
+        if constexpr (HEAD)
+            wino4_epilogue_head<T>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.n0, tile.n0 - pass * wino_cold_args().head_images, tile.y0, tile.x0,
+                                   wave, lane, lds_base + (uint32_t)(T::BUF_DW + T::A_DW) * 4u, lds_base + (uint32_t)(2 * T::BUF_DW) * 4u);
+        else if constexpr ((VAR & 2) == 0)
             wino4_epilogue<T, (VAR >> 8)>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, lane, store_plan);
         WINO4_TRACE_MARK(2);
         if (!has_next) break;
@@ -728,9 +853,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         load_first();
         WINO4_TRACE_MARK(5);
         WINO4_TRACE_FLUSH();
-        item += (int)gridDim.x;
+        if (more_passes()) {
+            ++pass;
+        } else {
+            pass = 0;
+            item += (int)gridDim.x;
+        }
         tile = ntile;
-        has_next = item + (int)gridDim.x < total_items;
+        has_next = more_passes() || item + (int)gridDim.x < total_items;
     }
 #endif
 }
@@ -740,36 +870,44 @@ using W4Cfg1 = Wino4Tile<1, 2, 8, 2, 2>;   // 16x32 pixels of two consecutive sl
 using W4Cfg2 = Wino4Tile<2, 2, 4, 4, 1, true>;   // 8x16 pixels of eight consecutive slices, full image width (the 24x16 level)
 using W4Cfg3 = Wino4Tile<2, 2, 4, 4, 1, true, true>;   // 12x8 pixels of eight consecutive slices, folded into the same block geometry (the 12x8 level)
 
-static const ConvConfigInfo kWino4Info[4] = {
+static const ConvConfigInfo kWino4Info[5] = {
     {W4Cfg0::TS, W4Cfg0::TH, W4Cfg0::TW, W4Cfg0::BN, 8, 36, "conv3x3_winograd4<T32x32,N32,K8>", 8, 0, 3},
     {W4Cfg1::TS, W4Cfg1::TH, W4Cfg1::TW, W4Cfg1::BN, 8, 36, "conv3x3_winograd4<S2T16x32,N32,K8>", 8, 0, 3},
     {W4Cfg2::TS, W4Cfg2::TH, W4Cfg2::TW, W4Cfg2::BN, 8, 36, "conv3x3_winograd4<S8T8x16,N32,K8>", 8, 0, 3},
     {W4Cfg3::TS, W4Cfg3::TH, W4Cfg3::TW, W4Cfg3::BN, 8, 36, "conv3x3_winograd4<S8T12x8,N32,K8>", 8, 0, 3},
+    {W4Cfg0::TS, W4Cfg0::TH, W4Cfg0::TW, W4Cfg0::BN, 8, 36, "conv3x3_winograd4<T32x32,N32,K8>+head", 8, 0, 3},
 };
 
 const ConvConfigInfo& wino4_config_info(int cfg) { return kWino4Info[cfg - CONV_CFG_WINO4_T32x32_N32]; }
 
-template <class T, int VAR>
+template <class T, int VAR, bool HEAD = false>
 static hipError_t launch_wino4_var(const ConvArgs& a, hipStream_t stream)
 {
-    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino4_stream<T, VAR>), T::LDS_BYTES);
+    constexpr int lds_bytes = T::LDS_BYTES + (HEAD ? WINO4_HEAD_LDS_BYTES : 0);
+    static_assert(lds_bytes <= 160 * 1024, "LDS");
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino4_stream<T, VAR, HEAD>), lds_bytes);
     if (e != hipSuccess) return e;
-    const unsigned items = (unsigned)a.NT * a.tiles_x * a.tiles_y * a.slice_groups;
+    // HEAD: the work items of one pass (TS == 1: a slice group is a sample); the kernel runs every pass of the group on each
+    const unsigned items = (unsigned)a.NT * a.tiles_x * a.tiles_y * (HEAD ? a.head_images : a.slice_groups);
     const unsigned grid = wino_persistent_grid(items);
-    hipLaunchKernelGGL((conv_wino4_stream<T, VAR>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);
+    hipLaunchKernelGGL((conv_wino4_stream<T, VAR, HEAD>), dim3(grid), dim3(T::THREADS), lds_bytes, stream, a, (int)items);
     return hipGetLastError();
 }
 
-template <class T>
+template <class T, bool HEAD = false>
 static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
 {
+    if (HEAD && (a.head_w == nullptr || a.head_b == nullptr || a.NT != 1 || a.pooled != nullptr || a.mask2 != nullptr || a.head_passes < 1 ||
+                 a.head_images * a.head_passes != a.N || (a.head_passes > 1 && a.head_logits != nullptr) ||
+                 (a.head_logits == nullptr && a.head_stats == nullptr)))
+        return hipErrorInvalidValue;
     const int nchunks = (a.C1 + a.C2) / T::KC;
     if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
         (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 || (T::FULLW && a.W != T::TW) || (T::FOLD && a.pooled != nullptr) ||
         (size_t)a.N * a.H * a.W * a.CoutP * 4 >= ((size_t)1 << 31))
         return hipErrorInvalidValue;
 #ifdef RCU_WINO4_ABLATIONS   // timing experiments of tools/wino4_check.py (make EXTRA=-DRCU_WINO4_ABLATIONS); results are wrong
-    const char* const v = getenv("RCU_W4_VARIANT");
+    const char* const v = HEAD ? nullptr : getenv("RCU_W4_VARIANT");
     switch (v ? atoi(v) : 0) {
         case 1: return launch_wino4_var<T, 1>(a, stream);
         case 2: return launch_wino4_var<T, 2>(a, stream);
@@ -795,7 +933,7 @@ static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
         default: break;
     }
 #endif
-    return launch_wino4_var<T, 0>(a, stream);
+    return launch_wino4_var<T, 0, HEAD>(a, stream);
 }
 
 hipError_t launch_conv_wino4(int cfg, const ConvArgs& a, hipStream_t stream)
@@ -805,6 +943,7 @@ hipError_t launch_conv_wino4(int cfg, const ConvArgs& a, hipStream_t stream)
         case CONV_CFG_WINO4_S2T16x32_N32: return launch_wino4_cfg<W4Cfg1>(a, stream);
         case CONV_CFG_WINO4_S8T8x16_N32: return launch_wino4_cfg<W4Cfg2>(a, stream);
         case CONV_CFG_WINO4_S8T12x8_N32: return launch_wino4_cfg<W4Cfg3>(a, stream);
+        case CONV_CFG_WINO4_T32x32_N32_HEAD: return launch_wino4_cfg<W4Cfg0, true>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }

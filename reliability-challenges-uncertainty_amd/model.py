@@ -61,7 +61,7 @@ class UNet(nn.Module):
     MAX_HANDLES = 6          # cached (height, width[, lane]) plans incl. their workspaces
     # rcu_unet_options (include/rcu.h): what the planner may choose.  The defaults are the shipped path; ``plan_options`` of an instance
     # overrides them for A/B measurements and for the parity tests that compare kernel families on the same input.
-    PLAN_DEFAULTS = dict(conv_winograd=1, conv_winograd4=1, conv_first=1, act_layout=0)
+    PLAN_DEFAULTS = dict(conv_winograd=1, conv_winograd4=1, conv_first=1, act_layout=0, head_winograd4=1)
     _generations = itertools.count(1)      # every plan ever created gets the next number: a borrower's plan is valid for ONE generation of its donor's
 
     def __init__(self, nb_classes, in_channels, depth=DEFAULT_DEPTH, start_filters=DEFAULT_START_FILTERS,
@@ -419,7 +419,7 @@ class UNet(nn.Module):
             _lib.check(lib.rcu_unet_layer_info(handle, i, ctypes.byref(info)))
             rows.append(dict(index=i, name=info.name.decode(), kernel=info.kernel.decode(), cin=info.cin,
                              cout=info.cout, height=info.height, width=info.width, upsample=bool(info.upsample),
-                             pooled=bool(info.pooled), dual_source=bool(info.dual_source),
+                             pooled=bool(info.pooled), dual_source=bool(info.dual_source), head_fusable=bool(info.head_fusable),
                              flops_per_slice=info.flops_per_slice,
                              mfma_flops_per_slice=info.mfma_flops_per_slice))
         return rows

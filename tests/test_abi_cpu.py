@@ -54,9 +54,9 @@ def test_argument_validation_without_gpu(lib):
     # values outside their sets are refused before anything touches the GPU
     opts = lib.UnetOptions()
     so.rcu_unet_default_options(ctypes.byref(opts))
-    assert (opts.conv_winograd, opts.conv_winograd4, opts.conv_first, opts.act_layout, opts.fuse_head) == (1, 1, 1, 0, 1)
+    assert (opts.conv_winograd, opts.conv_winograd4, opts.conv_first, opts.act_layout, opts.fuse_head, opts.head_winograd4) == (1, 1, 1, 0, 1, 1)
     desc.nb_classes = 2
-    for field, bad in (('conv_winograd4', 4), ('act_layout', 5), ('fuse_head', -1)):
+    for field, bad in (('conv_winograd4', 4), ('act_layout', 5), ('fuse_head', -1), ('head_winograd4', 2)):
         o = lib.UnetOptions()
         so.rcu_unet_default_options(ctypes.byref(o))
         setattr(o, field, bad)

@@ -116,8 +116,8 @@ def test_winograd_kernels_vs_direct_and_oracle(dev):
     csrc/rcu_wino_up.hip: F(2x2,2x2) sub-pixel up-convolutions) on the BraTS slice size with 8 slices -- enough for the work items
     that span 2 and 8 slices: against the oracle, against the direct kernels (plan option conv_winograd=0), and on ragged batches.  Three
     plans: the shipped selection (F(4x4,3x3) wherever it fits -- also the 32-channel full-resolution layers, the 2x2 max-pool in its
-    epilogue and the two-source K loop at that tile; conv_cls.0 keeps its fused head on F(2x2,3x3)), the round-2 selection
-    (conv_winograd4=3: only the layers with >= 64 output channels) and F(2x2,3x3) only (conv_winograd4=0)."""
+    epilogue and the two-source K loop at that tile, and conv_cls.0 with its fused head; head_winograd4=0 keeps that one on F(2x2,3x3)),
+    the round-2 selection (conv_winograd4=3: only the layers with >= 64 output channels) and F(2x2,3x3) only (conv_winograd4=0)."""
     from oracle import unet_oracle as uo
     params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
     st = uo.synthetic_state(21, **params)
@@ -127,8 +127,8 @@ def test_winograd_kernels_vs_direct_and_oracle(dev):
     _, sites = uo.unet_plan(**params)
     masks = uo.sample_masks(sites, n, 0.3, g)
     ref = uo.unet_forward(st, x, masks, **params).numpy()
-    common = {'conv3x3_winograd<T16x32,N32,K8>',
-              'upconv_winograd<T16x16,N64,K8>', 'upconv_winograd<T16x32,N32,K8>', 'upconv_winograd<S2T8x16,N64,K8>',
+    head2 = {'conv3x3_winograd<T16x32,N32,K8>'}      # conv_cls.0 on F(2x2,3x3)
+    common = {'upconv_winograd<T16x16,N64,K8>', 'upconv_winograd<T16x32,N32,K8>', 'upconv_winograd<S2T8x16,N64,K8>',
               'upconv_winograd<S8T4x8,N64,K8>'}
     w4 = {'conv3x3_winograd4<T32x32,N32,K8>', 'conv3x3_winograd4<S2T16x32,N32,K8>', 'conv3x3_winograd4<S8T8x16,N32,K8>'}
     # the 12x8 bottom level: F(4x4,3x3) with six tiles per slice in the eight slots of the S8 block (round 5) where its long work items fill the
@@ -136,13 +136,16 @@ def test_winograd_kernels_vs_direct_and_oracle(dev):
     fold, strip = {'conv3x3_winograd4<S8T12x8,N32,K8>'}, {'conv3x3_winograd<S8T4x8,N64,K8>'}
     w2 = {'conv3x3_winograd<T16x16,N64,K8>', 'conv3x3_winograd<S2T8x16,N64,K8>'}
     outs = {}
-    for mode, expected in (('1', common | w4 | strip), ('2', common | w4 | fold), ('3', common | w4 | strip), ('0', common | w2 | strip)):
-        m_w = _model(params, st, dev, conv_winograd4=int(mode))
+    for mode, expected in (('1', common | w4 | strip), ('1h', common | w4 | strip | head2), ('2', common | w4 | fold), ('3', common | w4 | strip | head2),
+                           ('0', common | w2 | strip | head2)):
+        m_w = _model(params, st, dev, conv_winograd4=int(mode[0]), head_winograd4=0 if mode.endswith('h') else 1)
         rows = m_w.layer_table(h, w, n)
         kernels = {row['kernel'] for row in rows}
         assert expected <= kernels, (mode, expected - kernels)
+        assert mode in ('1h', '3', '0') or not (head2 & kernels), mode
         n4 = sum('winograd4' in row['kernel'] for row in rows)
-        assert n4 == {'1': 15, '2': 17, '3': 12, '0': 0}[mode], (mode, n4)      # '3': the 96x64, 48x32 and 24x16 levels; '1': + three 32-channel 192x128 units; '2': + the 12x8 level
+        # '3': the 96x64, 48x32 and 24x16 levels; '1h': + three 32-channel 192x128 units; '1': + conv_cls.0; '2': + the 12x8 level
+        assert n4 == {'1': 16, '1h': 15, '2': 18, '3': 12, '0': 0}[mode], (mode, n4)
         out_w = m_w(x.to(dev), masks).cpu().numpy()
         assert _maxdiff(out_w, ref) < LOGIT_TOL, mode
         assert _maxdiff(torch.softmax(torch.from_numpy(out_w), 1).numpy(), torch.softmax(torch.from_numpy(ref), 1).numpy()) < PROB_TOL
@@ -332,16 +335,19 @@ def test_winograd_sigma_head_and_eval_mode(dev):
                 assert _maxdiff(out.cpu().numpy(), ref.numpy()) < LOGIT_TOL
 
 
-def test_fused_head_matches_head_kernel_bitwise(dev):
-    """conv_cls.0 with the 1x1 classifier + softmax + statistics in its epilogue (csrc/rcu_wino.hip, wino_epilogue_head)
-    against the separate head kernel (UNet.set_fuse_head(False) = rcu_unet_set_fuse_head): logits, MC statistics (incl. variance / mutual information) and
+@pytest.mark.parametrize('head_winograd4', [1, 0])
+def test_fused_head_matches_head_kernel_bitwise(dev, head_winograd4):
+    """conv_cls.0 with the 1x1 classifier + softmax + statistics in its epilogue (csrc/rcu_wino4.hip, wino4_epilogue_head: the shipped plan;
+    csrc/rcu_wino.hip, wino_epilogue_head: plan option head_winograd4=0) against the same conv kernel's plain epilogue + the separate head kernel (UNet.set_fuse_head(False) = rcu_unet_set_fuse_head): logits, MC statistics (incl. variance / mutual information) and
     pass groups (the fused epilogue runs the passes of a tile back to back on the workgroup that owns it, in pass order -- the
     order in which head_kernel adds them) must carry the same bits."""
     from oracle import unet_oracle as uo
     from rcu_amd import steps
     params = dict(nb_classes=2, in_channels=4, depth=3, start_filters=32, dropout=0.05)
     st = uo.synthetic_state(23, **params)
-    m = _model(params, st, dev)
+    m = _model(params, st, dev, head_winograd4=head_winograd4)
+    head_kernel = [row['kernel'] for row in m.layer_table(64, 64, 12) if row['name'].startswith('conv_cls.0')]
+    assert head_kernel == ['conv3x3_winograd4<T32x32,N32,K8>' if head_winograd4 else 'conv3x3_winograd<T16x32,N32,K8>']
     g = torch.Generator().manual_seed(8)
     x = torch.randn(3, 4, 64, 64, generator=g)
     _, sites = uo.unet_plan(**params)
@@ -356,20 +362,20 @@ def test_fused_head_matches_head_kernel_bitwise(dev):
         steps.MultiPredictionSummary(do_mi=True, do_var=True)(bc, None, ctx)
         return logits, {k: v.cpu().numpy() for k, v in bc.output.items()}
 
-    def run_single_passes(do_mi, do_var):   # one forward per pass: the fused epilogue updates the statistics itself
-        stats = steps.McStatistics(3, 2, 64, 64, dev, do_mi=do_mi, do_var=do_var)
+    def run_single_passes(do_mi, do_var, exact=False):   # one forward per pass: the fused epilogue updates the statistics itself
+        stats = steps.McStatistics(3, 2, 64, 64, dev, do_mi=do_mi, do_var=do_var, exact=exact)
         for ms in mask_sets:
             m.forward_accumulate(x.to(dev), stats, ms, passes=1)
         return stats.blob.cpu().numpy()
 
-    def run_groups(do_mi, do_var, passes):   # `passes` passes per launch: sample t * 3 + i is image i under mask rows [t * 3 + i]
-        stats = steps.McStatistics(3, 2, 64, 64, dev, do_mi=do_mi, do_var=do_var)
+    def run_groups(do_mi, do_var, exact, passes):   # `passes` passes per launch: sample t * 3 + i is image i under mask rows [t * 3 + i]
+        stats = steps.McStatistics(3, 2, 64, 64, dev, do_mi=do_mi, do_var=do_var, exact=exact)
         for t in range(0, T, passes):
             group = mask_sets[t:t + passes]
             m.forward_accumulate(x.to(dev), stats, group if len(group) > 1 else group[0], passes=len(group))
         return stats.blob.cpu().numpy()
 
-    flag_sets = ((False, False), (True, False), (True, True))
+    flag_sets = ((False, False, False), (True, False, False), (True, True, False), (True, False, True), (True, True, True))   # (mi, var, exact)
     m.set_fuse_head(True)
     lf, of = run()
     bf = [run_single_passes(*f) for f in flag_sets]

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Per-layer timing of the BraTS-shaped forward (HIP events between kernels): python tools/layer_report.py [forwards] [samples per launch, default 160]"""
+"""Per-layer timing of the BraTS-shaped forward (HIP events between kernels):
+    python tools/layer_report.py [forwards] [samples per launch, default 160] [stats] [option=value ...]
+`stats`: the product's launch -- the samples are pass groups of the 160-slice volume adding into exact MC statistics (MI on), as the MC step
+launches them -- instead of a logits forward; option=value: plan options (rcu_unet_options, e.g. head_winograd4=0)."""
 import os
 import sys
 
@@ -13,17 +16,28 @@ import bench  # noqa: E402
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     n = int(sys.argv[2]) if len(sys.argv) > 2 else bench.SLICES
+    rest = sys.argv[3:]
+    as_stats = 'stats' in rest
     dev = torch.device('cuda')
     model = bench.make_model(20, dev)
+    model.plan_options = {k: int(v) for k, v in (a.split('=') for a in rest if '=' in a)}
     x = bench.make_volume(20)[0]
-    x = x.repeat((n + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:n].to(dev)          # more samples than slices: the volume again (a pass group's batch)
     from rcu_amd import steps
     steps.set_dropout_mode(model, True)
+    if as_stats:
+        passes = max(n // x.shape[0], 1)
+        x = x.to(dev)
+        n = passes * x.shape[0]
+        stats = steps.McStatistics(x.shape[0], 2, bench.HEIGHT, bench.WIDTH, dev, do_mi=True, do_var=False, exact=True)
+        run = lambda: model.forward_accumulate(x, stats, passes=passes)  # noqa: E731
+    else:
+        x = x.repeat((n + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:n].to(dev)          # more samples than slices: the volume again (a pass group's batch)
+        run = lambda: model(x)  # noqa: E731
     for _ in range(2):
-        model(x)
+        run()
     model.profile_begin(bench.HEIGHT, bench.WIDTH, n, reps)
     for _ in range(reps):
-        model(x)
+        run()
     torch.cuda.synchronize()
     cnt, ms = model.profile_collect(bench.HEIGHT, bench.WIDTH, n)
     layers = model.layer_table(bench.HEIGHT, bench.WIDTH, n)
@@ -37,7 +51,7 @@ def main():
         issued = L['mfma_flops_per_slice'] * n
         tot_is += issued
         print('{:<52} {:>4}->{:<4} {:>3}x{:<3} {:<34} {:>8.3f} {:>7.1f} {:>6.1f} {:>6.1f}'.format(
-            L['name'][:52], L['cin'], L['cout'], L['height'], L['width'], L['kernel'], t, fl / t / 1e9, fl / t / 1e9 / 1.573,
+            L['name'][:52], L['cin'], L['cout'], L['height'], L['width'], L['kernel'] + ('+head' if L['head_fusable'] and model.fuse_head else ''), t, fl / t / 1e9, fl / t / 1e9 / 1.573,
             issued / t / 1e9 / 1.573))
     print('input re-layout {:.3f} ms, head {:.3f} ms'.format(ms[0] / cnt, ms[-1] / cnt))
     print('conv total {:.3f} ms  {:.1f} TF/s algorithmic ({:.1f}% of 157.3); MFMA pipe issue {:.1f}%'.format(

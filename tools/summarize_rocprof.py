@@ -32,13 +32,14 @@ def short(name):
         tile = ('S{}'.format(ts) if ts != '1' else '') + 'T{}x{}'.format(th, tw)
         return '{}<{},N{},K8>{}'.format('conv3x3_winograd' if kind == 'conv' else 'upconv_winograd', tile, bn,
                                         '+head' if ', true>' in name else '')
-    m = re.search(r'conv_wino4_stream<rcu::Wino4Tile<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\w+))?(?:, (\w+))?>', name)
-    if m:   # block = SB slices x BR x BC tiles of 4x4 pixels, workgroup = WS x WR blocks; the last flag: the folded 12x8 geometry
+    m = re.search(r'conv_wino4_stream<rcu::Wino4Tile<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\w+))?(?:, (\w+))?>(?:, \d+)?(?:, (\w+))?', name)
+    if m:   # block = SB slices x BR x BC tiles of 4x4 pixels, workgroup = WS x WR blocks; the tile's last flag: the folded 12x8 geometry;
+            # the kernel's last flag (behind the ablation variant): the classifier head in the epilogue
         sb, br, bc, ws, wr = (int(v) for v in m.groups()[:5])
         ts, th, tw = sb * ws, 4 * br * wr, 4 * bc
         if m.group(7) in ('true', '1'):
             th, tw = 12, 8
-        return 'conv3x3_winograd4<{}T{}x{},N32,K8>'.format('S{}'.format(ts) if ts != 1 else '', th, tw)
+        return 'conv3x3_winograd4<{}T{}x{},N32,K8>{}'.format('S{}'.format(ts) if ts != 1 else '', th, tw, '+head' if m.group(8) in ('true', '1') else '')
     if 'conv3x3_first_kernel' in name:   # anonymous namespace of rcu_first.hip; one tile shape
         return 'conv3x3_first<T8x32,K36>'
     m = re.search(r'rcu::(\w+)', name)
