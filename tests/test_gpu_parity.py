@@ -1167,7 +1167,10 @@ def test_unet_residual_full_width_vs_oracle(dev):
     for mk in (None, mask_sets[0]):
         ref = uo.unet_forward(st, x, mk, **params).numpy()
         scale = max(1.0, float(np.abs(ref).max()))                     # un-normalised sums: the logits can be of O(10)
-        assert _maxdiff(m(x.to(dev), mk).cpu().numpy(), ref) < LOGIT_TOL * scale
+        # 1.5 x: the residual sums feed conv_cls.0 activations well above the plain net's, and that unit runs in F(4x4,3x3) since round 5 --
+        # measured 2.3e-6 between the two float32 evaluations; with the unit on F(2x2,3x3) (the plan of rounds 1-4) the gate is the plain one
+        assert _maxdiff(m(x.to(dev), mk).cpu().numpy(), ref) < 1.5 * LOGIT_TOL * scale
+        assert _maxdiff(_model(params, st, dev, head_winograd4=0)(x.to(dev), mk).cpu().numpy(), ref) < LOGIT_TOL * scale
     bc = steps.BatchContext({'images': x}, 0)
     ctx = steps.TorchTestContext('cuda', m)
     steps.McPredictStep(2, masks=mask_sets)(bc, None, ctx)
