@@ -134,6 +134,34 @@ def test_host_side_metric_arithmetic_matches_oracle(golden):
             ev.ece_binary(np.zeros((2, 2), np.float32), np.zeros((2, 2), np.uint8))  # needs the GPU: fails loudly
 
 
+def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
+    """The Python host mirrors include/rcu.h's structs by hand (rcu_amd/_lib.py): compile the header with gcc -- as a C translation unit, the way a
+    reference-side binding would include it -- and compare size and every field offset with the ctypes classes."""
+    import ctypes
+    import subprocess
+    from rcu_amd import _lib
+    mirrors = {'rcu_unet_desc': _lib.UnetDesc, 'rcu_unet_options': _lib.UnetOptions, 'rcu_layer_info': _lib.LayerInfo, 'rcu_ece_result': _lib.EceResult}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rcu.h"', 'int main(void) {']
+    for cname, cls in mirrors.items():
+        lines.append('  printf("{0} size %zu\\n", sizeof({0}));'.format(cname))
+        for field in cls._fields_:
+            lines.append('  printf("{0} {1} %zu\\n", offsetof({0}, {1}));'.format(cname, field[0]))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines) + '\n')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    seen = {}
+    for line in subprocess.check_output([str(exe)]).decode().splitlines():
+        cname, field, value = line.split()
+        seen[(cname, field)] = int(value)
+    for cname, cls in mirrors.items():
+        assert seen[(cname, 'size')] == ctypes.sizeof(cls), cname
+        for field in cls._fields_:
+            assert seen[(cname, field[0])] == getattr(cls, field[0]).offset, (cname, field[0])
+    assert _lib.RCU_MAX_BINS * 8 * 3 == ctypes.sizeof(_lib.EceResult)
+
+
 @pytest.mark.timeout(600)
 def test_winograd4_kernel_owns_the_accumulator_file(tmp_path):
     """csrc/rcu_wino4.hip names its 256 accumulator registers literally in inline assembly (its header says why).  That is only
