@@ -144,6 +144,16 @@ def test_pass_pair_of_the_full_volume_is_bit_identical_to_single_passes(dev):
     model.forward_accumulate(x, fours, mask_sets[:4], passes=4)
     model.forward_accumulate(x, fours, mask_sets[4:], passes=4)
     assert torch.equal(single.blob, fours.blob)
+    # ... and exactly the statistics of the standalone head kernel behind conv_cls.0's plain epilogue: at this size every workgroup of the fused
+    # F(4x4,3x3) head kernel walks 60 tiles, its waves drifting apart between the chunk barriers -- the wave-local LDS hand-over of the head
+    # (csrc/rcu_wino4.hip, wino4_epilogue_head) must not depend on that
+    assert [r['kernel'] for r in model.layer_table(h, w, 4 * n) if r['head_fusable']] == ['conv3x3_winograd4<T32x32,N32,K8>']
+    model.set_fuse_head(False)
+    unfused = steps.McStatistics(n, 2, h, w, dev, do_mi=True)
+    model.forward_accumulate(x, unfused, mask_sets[:4], passes=4)
+    model.forward_accumulate(x, unfused, mask_sets[4:], passes=4)
+    model.set_fuse_head(True)
+    assert torch.equal(fours.blob, unfused.blob)
     # no layer of the 640-sample plan has left the Winograd kernels (an up-convolution reads the LOW-resolution grid: 1.0 GB, not 3 GB)
     assert not [r['kernel'] for r in model.layer_table(h, w, 4 * n) if 'igemm' in r['kernel']]
     assert steps.pass_group_size(model, n, h, w, steps.McPredictStep.GROUP_PIXELS) == 4

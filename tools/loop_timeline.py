@@ -9,7 +9,6 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 os.environ['RCU_SCRIPT_PROFILE'] = '0'
-import torch
 from rcu_amd import loops
 log = []
 T0 = time.perf_counter()
