@@ -438,36 +438,51 @@ def get_actions(action_names, min_max_dir, base_dir, ece_details):
 # ------------------------------------------------------------------------ the fused subject loop
 class _ReadAhead:
     """The files of the coming subjects, read by a few threads while the current ones are evaluated (zlib releases the GIL: the .nii.gz
-    streams really inflate side by side).  ``get(i)`` -> the ``to_eval`` dict of subject i (blocks until its files are in)."""
+    streams really inflate side by side).  One task per FILE -- a subject's two to four files inflate side by side too, and the float32
+    maps do not queue behind a neighbour's label images.  ``get(i)`` -> the ``to_eval`` dict of subject i (blocks until its files are in)."""
 
-    def __init__(self, subject_files, params, depth, threads=4):
+    def __init__(self, subject_files, params, depth, threads=None):
         import concurrent.futures
+        if threads is None:       # gunzip is what the fused loop waits for (tools/eval_throughput.py): as many streams as the host can spare, at most 8
+            threads = min(8, max(2, (os.cpu_count() or 4) // 2))
         self.subject_files, self.params, self.depth = subject_files, params, max(1, int(depth))
         self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=threads, thread_name_prefix='rcu-eval-read')
         self.futures = {}
         self.next = 0
 
-    def _read(self, sf):
+    @staticmethod
+    def _timed(fn, *args):
         t0 = time.perf_counter()
+        return fn(*args), time.perf_counter() - t0
+
+    def _tasks(self, sf):
         cats, p = sf.categories, self.params
-        out = {p.misc_entry: nifti.read(cats['misc'][p.misc_entry])[0]}
+        tasks = {p.misc_entry: (lambda path: nifti.read(path)[0], cats['misc'][p.misc_entry])}
         if p.need_target:
-            out['target'] = (read_label_image(cats['labels']['gt']) > 0).astype(np.uint8)       # analysis.py:88-89
+            tasks['target'] = (lambda path: (read_label_image(path) > 0).astype(np.uint8), cats['labels']['gt'])       # analysis.py:88-89
         if p.need_prediction:
-            out['prediction'] = nifti.read(cats['labels']['prediction'], np.uint8)[0]
+            tasks['prediction'] = (lambda path: nifti.read(path, np.uint8)[0], cats['labels']['prediction'])
         if p.need_t2_mask:
-            out['mask'] = nifti.read(cats['images']['t2'])[0] > 0
-        out['_read_s'] = time.perf_counter() - t0
-        return out
+            tasks['mask'] = (lambda path: nifti.read(path)[0] > 0, cats['images']['t2'])
+        return tasks
 
     def _fill(self, upto):
         while self.next < min(upto, len(self.subject_files)):
-            self.futures[self.next] = self.pool.submit(self._read, self.subject_files[self.next])
+            self.futures[self.next] = {key: self.pool.submit(self._timed, fn, path)
+                                       for key, (fn, path) in self._tasks(self.subject_files[self.next]).items()}
             self.next += 1
 
     def get(self, i):
         self._fill(i + 1 + self.depth)
-        return self.futures.pop(i).result()
+        entry = self.futures.pop(i)
+        if isinstance(entry, _Done):
+            return entry.result()
+        out, read_s = {}, 0.0
+        for key, future in entry.items():
+            out[key], seconds = future.result()
+            read_s += seconds
+        out['_read_s'] = read_s
+        return out
 
     def close(self):
         self.pool.shutdown(wait=False, cancel_futures=True)

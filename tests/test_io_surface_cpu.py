@@ -79,6 +79,56 @@ def test_nifti_qform_only_header_and_zero_slope(tmp_path):
     assert np.allclose(nifti.read(path)[0], a * 2.0 + 1.0)
 
 
+def test_gzip_streams_inflate_in_one_call_like_the_gzip_module(tmp_path):
+    """nifti.read inflates a .gz file member by member in single zlib calls (the evaluation loop's reader threads then run without the GIL):
+    the bytes of gzip.open(...).read() for one member, several members and zero padding behind the last; a truncated stream and a wrong
+    checksum raise as the gzip module raises; the reader threads of the fused loop deliver the subjects' arrays in order."""
+    import gzip
+    import zlib
+    from rcu_amd import evalrun, nifti
+    rng = np.random.default_rng(5)
+    payload = rng.integers(0, 4, 300000, dtype=np.uint8).tobytes()
+    one = tmp_path / 'one.bin.gz'
+    one.write_bytes(gzip.compress(payload, mtime=0))
+    many = tmp_path / 'many.bin.gz'
+    many.write_bytes(gzip.compress(payload[:1000], mtime=0) + gzip.compress(b'', mtime=0) + gzip.compress(payload[1000:], mtime=0) + b'\0' * 7)
+    for path in (one, many):
+        assert nifti._file_bytes(str(path)) == gzip.open(str(path), 'rb').read() == payload
+    plain = tmp_path / 'plain.bin'
+    plain.write_bytes(payload[:99])
+    assert nifti._file_bytes(str(plain)) == payload[:99]
+    cut = tmp_path / 'cut.bin.gz'
+    cut.write_bytes(one.read_bytes()[:-12])
+    with pytest.raises(EOFError):
+        nifti._file_bytes(str(cut))
+    bad = bytearray(one.read_bytes())
+    bad[-6] ^= 0x55                                        # inside the CRC-32 of the trailer
+    (tmp_path / 'bad.bin.gz').write_bytes(bytes(bad))
+    with pytest.raises(zlib.error):
+        nifti._file_bytes(str(tmp_path / 'bad.bin.gz'))
+    # the reader: one task per file, results in subject order whatever order the threads finish in
+    vols = {}
+    files = []
+    for i in range(5):
+        p = rng.random((3, 8, 6)).astype(np.float32)
+        pred = (p > 0.5).astype(np.uint8)
+        vols[i] = (p, pred)
+        nifti.write(str(tmp_path / 'p{}.nii.gz'.format(i)), p)
+        nifti.write(str(tmp_path / 'l{}.nii.gz'.format(i)), pred)
+        files.append(type('SF', (), {'categories': {'misc': {'probabilities': str(tmp_path / 'p{}.nii.gz'.format(i))},
+                                                    'labels': {'prediction': str(tmp_path / 'l{}.nii.gz'.format(i)),
+                                                               'gt': str(tmp_path / 'l{}.nii.gz'.format(i))}}})())
+    params = evalrun.Loader.Params('probabilities', need_target=True, need_prediction=True, need_t2_mask=False)
+    reader = evalrun._ReadAhead(files, params, depth=3, threads=3)
+    try:
+        for i in range(5):
+            got = reader.get(i)
+            assert np.array_equal(got['probabilities'], vols[i][0]) and np.array_equal(got['prediction'], vols[i][1])
+            assert np.array_equal(got['target'], vols[i][1]) and got['target'].dtype == np.uint8 and got['_read_s'] >= 0.0
+    finally:
+        reader.close()
+
+
 def test_write_subject_files(tmp_path):
     rng = np.random.RandomState(1)
     p = rng.rand(4, 8, 8, 2).astype(np.float32)
