@@ -30,6 +30,10 @@ def _device():
 
 
 def _to_dev(a, dtype):
+    # (Measured and NOT done: staging through pinned buffers + asynchronous copies.  Next to a test loop that has run ahead -- every CU held by a
+    # persistent conv kernel -- a small operation of the metric seam waits tens of milliseconds whichever way its bytes travel, and the pinned
+    # form was the slower one on the same box: tools/host_costs_probe.py, 0.175-0.25 against 0.139 s per subject.  The drop-in scripts
+    # therefore take their per-subject Dice counts at batch time, on the compute stream: scripts.ConfusionOnDeviceStep.)
     if isinstance(a, torch.Tensor):
         return a.to(device=_device(), dtype=dtype).contiguous()
     a = np.ascontiguousarray(a)
@@ -219,9 +223,8 @@ class SubjectBatch:
 
 
 # ---------------------------------------------------------------------- uncertainty-error counts
-def uncertainty_counts(prediction, target, uncertainty, thresholds=UE_THRESHOLDS, mask=None, n_volumes=1):
-    """int64 ``[n_volumes, len(thresholds), 8]`` = tp, tn, fp, fn, tpu, tnu, fpu, fnu with
-    uncertain := uncertainty > threshold (numpyfunctions.py:86-107), all thresholds in one GPU pass."""
+def _uncertainty_counts_device(prediction, target, uncertainty, thresholds, mask, n_volumes):
+    """-> device int64 ``[n_volumes, len(thresholds), 8]`` (see ``uncertainty_counts``); asynchronous on the current stream."""
     is64 = uncertainty.dtype == (torch.float64 if isinstance(uncertainty, torch.Tensor) else np.float64)
     u = _to_dev(uncertainty, torch.float64 if is64 else torch.float32).reshape(n_volumes, -1)
     pr = _to_dev(prediction, torch.uint8).reshape(n_volumes, -1)
@@ -234,7 +237,13 @@ def uncertainty_counts(prediction, target, uncertainty, thresholds=UE_THRESHOLDS
     ws = torch.empty(max(lib.rcu_unc_workspace_bytes(n, n_volumes), 8), device=u.device, dtype=torch.uint8)
     _lib.check(lib.rcu_unc_counts(_lib.ptr(u), int(is64), _lib.ptr(pr), _lib.ptr(tg), _lib.ptr(m), n, n_volumes, thr,
                                   len(thresholds), _lib.ptr(out), _lib.ptr(ws), _lib.current_stream()))
-    return out.cpu().numpy()
+    return out
+
+
+def uncertainty_counts(prediction, target, uncertainty, thresholds=UE_THRESHOLDS, mask=None, n_volumes=1):
+    """int64 ``[n_volumes, len(thresholds), 8]`` = tp, tn, fp, fn, tpu, tnu, fpu, fnu with
+    uncertain := uncertainty > threshold (numpyfunctions.py:86-107), all thresholds in one GPU pass."""
+    return _uncertainty_counts_device(prediction, target, uncertainty, thresholds, mask, n_volumes).cpu().numpy()
 
 
 def from_p_supported(thresholds):
@@ -343,9 +352,33 @@ def confusion_matrx(prediction, target):
     return tp, tn, fp, fn, tp + tn + fp + fn
 
 
+_zero_maps = {}
+
+
 def _zeros_like_map(a):
+    """An all-zero uncertainty map of a's size (nothing is "uncertain": the first four of the eight counts are the confusion matrix).  Kept
+    per size -- read-only to every kernel -- so that a subject's Dice does not start with an allocation and a memset kernel."""
     n = a.numel() if isinstance(a, torch.Tensor) else int(np.prod(np.shape(a)))
-    return torch.zeros(n, device=_device(), dtype=torch.float32)
+    z = _zero_maps.get(n)
+    if z is None:
+        if len(_zero_maps) >= 4:
+            _zero_maps.clear()
+        z = _zero_maps[n] = torch.zeros(n, device=_device(), dtype=torch.float32)
+    return z
+
+
+def confusion_counts_on_device(prediction, target):
+    """Device tensors ``[N, ...]`` uint8 (N slices / images) -> device int64 ``[N, 4]`` = tp, tn, fp, fn per slice, asynchronous on the current
+    stream: ``confusion_matrx``'s counts taken where the prediction is made (scripts.ConfusionOnDeviceStep).  Counts are integers: the
+    rows of a subject's slices add up to the counts of the assembled subject."""
+    n = prediction.shape[0]
+    counts = _uncertainty_counts_device(prediction, target, _zeros_like_map(prediction), (0.5,), None, n)
+    return counts[:, 0, :4].contiguous()
+
+
+def dice_from_counts(tp, fp, fn):
+    """Dice from ``confusion_matrx``'s integers (0 / 0 = 1: pymia's convention, see above)."""
+    return _dice(int(tp), int(fp), int(fn))
 
 
 def _dice(tp, fp, fn):

@@ -164,6 +164,49 @@ def _with_others(cfg_path, suffix, test_dir=None, **others):
     return out
 
 
+def test_dice_counts_taken_at_batch_time_are_the_subject_level_ones(tmp_path, monkeypatch):
+    """scripts.ConfusionOnDeviceStep: the subjects' Dice counts are taken slice by slice on the compute stream behind the predict steps and
+    travel with the batches (the default for the BraTS scripts) -- metrics.csv and the files must be those of the subject-level evaluation
+    (``others.device_confusion: false``: EvalSubjectStep's own arg-max + evaluation.confusion_matrx, the reference's order), on batches that
+    straddle subjects (6 and 7 slices in batches of 4), coalesced into one step, and in the reference-ordered serial loop; and the default
+    run must not call the subject-level GPU path at all (its three synchronous GPU operations are what the step exists to avoid)."""
+    from rcu_amd import evaluation as ev
+    from rcu_amd import loops, scripts
+    cfg, vols, _, _ = _setup(tmp_path, mc=3)
+
+    def run(suffix, **others):
+        ctx = scripts.test_default('brats', _with_others(cfg, suffix, **others), None)
+        return _files(ctx), open(os.path.join(ctx.test_dir, 'metrics.csv'), 'rb').read()
+
+    calls = []
+    inner = ev.confusion_matrx
+    monkeypatch.setattr(ev, 'confusion_matrx', lambda *a, **k: (calls.append(1), inner(*a, **k))[1])
+    files_dev, csv_dev = run('dev')
+    assert not calls
+    files_sub, csv_sub = run('sub', device_confusion=False)
+    assert len(calls) == len(vols)
+    assert csv_dev == csv_sub and b'dice' in csv_dev.splitlines()[0] and len(csv_dev.splitlines()) == 1 + len(vols)
+    assert sorted(files_dev) == sorted(files_sub) and all(files_dev[k] == files_sub[k] for k in files_dev)
+    del calls[:]
+    _, csv_serial = run('serial', pipelined=False)
+    assert csv_serial == csv_dev and not calls
+    # coalescing renumbers the batches (other masks: another sample), so it is compared with its own subject-level run
+    _, csv_merged = run('merged', coalesce_pixels=loops.Test.COALESCE_PIXELS)
+    _, csv_merged_sub = run('merged_sub', coalesce_pixels=loops.Test.COALESCE_PIXELS, device_confusion=False)
+    assert csv_merged == csv_merged_sub
+    # the Dice values themselves: from the written prediction files against the dataset's labels
+    from rcu_amd import nifti
+    rows = {line.split(b',')[0].decode(): line.split(b',') for line in csv_dev.splitlines()[1:]}
+    col = csv_dev.splitlines()[0].split(b',').index(b'dice')
+    ctx = scripts.test_default('brats', _with_others(cfg, 'again'), None)
+    for name, (_, labels, _) in vols.items():
+        pred = nifti.read(os.path.join(ctx.test_dir, name + '_prediction.nii.gz'))[0].astype(bool)
+        tgt = labels.astype(bool)
+        den = pred.sum() + tgt.sum()
+        want = 2.0 * (pred & tgt).sum() / den if den else 1.0
+        assert abs(float(rows[name][col]) - want) < 1e-12, name
+
+
 def test_pipelined_coalesced_loop_writes_the_files_of_the_serial_loop(tmp_path, monkeypatch):
     """The test loop's pipeline (loader thread, batches coalesced up to a volume, outputs downloaded on a side stream, NIfTI files
     written by a pool of threads) must not change a byte of what the reference-ordered serial loop writes: deterministic config --
