@@ -313,6 +313,20 @@ class VolumeDataset(torch_data.Dataset):
 
         def collated(k):
             shape = (n,) + tuple(blocks[k][0].shape[1:])
+            if len(shape) == 4 and all(blk.ndim == 4 and blk.transpose(0, 2, 3, 1).flags['C_CONTIGUOUS'] and not blk.flags['C_CONTIGUOUS']
+                                       for blk in blocks[k]):
+                # The blocks are channel-first VIEWS of the file's channel-last slices (Permute).  The batch keeps the file's memory order -- a
+                # plain memcpy per block, straight out of the file mapping -- and is handed over as the channel-first view of it (torch's
+                # channels_last memory format: same shape, same values as the stacked per-slice samples); the re-ordering happens on the GPU,
+                # behind the upload (steps._images_to_device).  The transposing copy on this thread -- numpy: 12 ms per 32 BraTS slices; torch's
+                # OpenMP copy: 3 ms alone, 25 ms beside a busy test loop -- was what the loop waited for with the shipped batch_size 32
+                # (tools/loop_timeline.py, round 5).
+                base = np.empty((n,) + tuple(blocks[k][0].shape[2:]) + (shape[1],), dtype=blocks[k][0].dtype)
+                at = 0
+                for blk in blocks[k]:
+                    np.copyto(base[at:at + blk.shape[0]], blk.transpose(0, 2, 3, 1))
+                    at += blk.shape[0]
+                return torch.from_numpy(base).permute(0, 3, 1, 2)
             dst = torch.from_numpy(np.empty(shape, dtype=blocks[k][0].dtype))
             at = 0
             for blk in blocks[k]:       # one (transposing) copy per block, straight out of the file mapping

@@ -74,6 +74,15 @@ class HipEngine:
         else:                                                     # float64 statistics: the tail is float64 too
             ws_out.copy_(steps_mod.softmax(self.model(x)))
 
+    def sample_group_masks(self, x, generator, seeds):
+        """The masks of the pass group whose passes are seeded with ``seeds`` (UNet.sample_group_masks: the draws of ``sample_masks`` pass by
+        pass, in the group launch's layout)."""
+        steps_mod.set_dropout_mode(self.model, True)
+        try:
+            return self.model.sample_group_masks(x.shape[0], x.device, seeds, generator)
+        finally:
+            steps_mod.set_dropout_mode(self.model, False)
+
     def sample_masks(self, x, generator, passes=1):
         """Dropout factors of ``passes`` stochastic passes over x (rows [site][passes * N][C_site]) from ``generator``."""
         steps_mod.set_dropout_mode(self.model, True)
@@ -269,8 +278,14 @@ class ShardedMcRunner:
             if len(group) > 1:     # consecutive MC passes of this rank as one batch of N * g samples
                 def run_group(st, lane, group=group):
                     if mask_sets is None:
-                        ms = [self.masks_of(x, step_index, j) for j in group]
-                        ms = None if any(m is None for m in ms) else ms
+                        grouped = getattr(self.engine, 'sample_group_masks', None)
+                        if self.seed is not None and grouped is not None:
+                            if self._generator is None:
+                                self._generator = torch.Generator(device=x.device)
+                            ms = grouped(x, self._generator, [job_seed(self.seed, step_index, j) for j in group])
+                        else:
+                            ms = [self.masks_of(x, step_index, j) for j in group]
+                            ms = None if any(m is None for m in ms) else ms
                     else:
                         ms = [mask_sets[j - 1] for j in group]
                     if lane:

@@ -369,8 +369,9 @@ class _Staged:
     loop gives it back (``release``) with a CUDA event recorded behind the step's host-to-device copy, and the worker waits for
     that event before it writes the buffer again."""
 
-    def __init__(self, shape, dtype):
-        self.tensor = torch.empty(shape, dtype=dtype, pin_memory=True)
+    def __init__(self, shape, dtype, channels_last=False):
+        self.tensor = torch.empty(shape, dtype=dtype, pin_memory=True,
+                                  memory_format=torch.channels_last if channels_last else torch.contiguous_format)
         self.event = None
         self.busy = False
         self.released = 0        # order of the releases (the worker waits for the oldest one when none has completed)
@@ -396,7 +397,9 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',), timing=False
     def staged(key, v):
         pieces = v if isinstance(v, list) else [v]          # a list: the pieces of a batch group, merged by the copy itself
         shape = (sum(int(t.shape[0]) for t in pieces),) + tuple(pieces[0].shape[1:])
-        ring_key = (key, shape, pieces[0].dtype)
+        # a batch in the file's channel-last order (data.VolumeDataset): staged as it is -- memcpy -- and re-ordered on the GPU
+        channels_last = all(t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last) for t in pieces)
+        ring_key = (key, shape, pieces[0].dtype, channels_last)
         if ring_key not in ring and len(ring) >= 4:        # batches of many shapes: drop the oldest shape's buffers (those still
             ring.pop(next(iter(ring)))                     # in flight stay alive through the batches that hold them)
         bufs = ring.setdefault(ring_key, [])
@@ -420,7 +423,7 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',), timing=False
             if free:
                 buf = free[0]
             else:
-                buf = _Staged(shape, pieces[0].dtype)
+                buf = _Staged(shape, pieces[0].dtype, channels_last)
                 bufs.append(buf)
             buf.busy = True
         t_b = time.perf_counter()
@@ -430,7 +433,10 @@ def prefetch(iterable, depth=2, pin=False, pin_entries=('images',), timing=False
         t_c = time.perf_counter()
         at = 0
         for t in pieces:
-            buf.tensor[at:at + t.shape[0]].copy_(t)
+            if channels_last:      # (numpy's memcpy on the underlying [n, H, W, C] arrays: a torch CPU copy starts an OpenMP team on this thread)
+                np.copyto(buf.tensor[at:at + t.shape[0]].permute(0, 2, 3, 1).numpy(), t.permute(0, 2, 3, 1).numpy())
+            else:
+                buf.tensor[at:at + t.shape[0]].copy_(t)
             at += t.shape[0]
         spent['ring'] += t_b - t_a
         spent['sync'] += t_c - t_b

@@ -308,8 +308,13 @@ class BatchStep(abc.ABC):
 
 def _images_to_device(batch_context, context):
     # non_blocking: a no-op for pageable host memory, asynchronous when the loader pinned the batch (rcu_amd.loops.prefetch)
-    batch_context.input['images'] = batch_context.input['images'].float().to(context.device, non_blocking=True)
-    return batch_context.input['images']
+    images = batch_context.input['images'].float().to(context.device, non_blocking=True)
+    if not images.is_contiguous():
+        # the volume loader hands the file's channel-last order over (data.VolumeDataset.__getitems__; the copy keeps the strides): the
+        # re-ordering to [N, C, H, W] is a kernel behind the upload, not a strided copy on the loader thread
+        images = images.contiguous()
+    batch_context.input['images'] = images
+    return images
 
 
 class SegmentationPredictStep(BatchStep):
@@ -379,8 +384,14 @@ class McPredictStep(BatchStep):
             return self.masks[first] if count == 1 else self.masks[first:first + count]
         if self.seed is None:
             return None
-        sets = [self._seeded_masks(model, images, batch_index, j + 1) for j in range(first, first + count)]
-        return sets[0] if count == 1 else sets
+        if count == 1:
+            return self._seeded_masks(model, images, batch_index, first + 1)
+        dev = images.device
+        gen = self._generators.get(dev)
+        if gen is None:
+            gen = self._generators[dev] = torch.Generator(device=dev)
+        # the group's masks in one buffer: the same draws as pass by pass (UNet.sample_group_masks), already in the launch's layout
+        return model.sample_group_masks(images.shape[0], dev, [job_seed(self.seed, batch_index, j + 1) for j in range(first, first + count)], gen)
 
     def __call__(self, batch_context, task_context, context) -> None:
         _check_context(context)

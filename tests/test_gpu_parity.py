@@ -164,6 +164,30 @@ def test_winograd_kernels_vs_direct_and_oracle(dev):
         assert _maxdiff(outs[mode], out_d) < 2e-5, mode
 
 
+def test_group_masks_drawn_into_one_buffer_are_the_per_pass_draws(dev):
+    """UNet.sample_group_masks (every pass's Bernoulli draw into its row of one buffer, one division, one gather) against the path it
+    replaces on the predict steps' launches -- ``sample_masks`` pass by pass under the same seeds + ``group_masks`` -- bit for bit, for
+    several group sizes and batch sizes, with dropout at every site and with ``dropout_center`` (sites of mixed state: the general path)."""
+    from oracle import unet_oracle as uo
+    from rcu_amd import steps
+    for extra in ({}, {'dropout_center': 2}):
+        params = dict(nb_classes=2, in_channels=4, depth=2, start_filters=8, dropout=0.3, **extra)
+        m = _model(params, uo.synthetic_state(3, **params), dev)
+        steps.set_dropout_mode(m, True)
+        gen = torch.Generator(device=dev)
+        for n, seeds in ((1, [5, 6]), (3, [11, 12, 13, 14]), (32, list(range(100, 110))), (2, [7])):
+            sets = []
+            for seed in seeds:
+                gen.manual_seed(seed)
+                sets.append(m.sample_masks(n, dev, generator=gen))
+            want = m.group_masks(sets, n, dev) if len(seeds) > 1 else sets[0]
+            got = m.sample_group_masks(n, dev, seeds, gen)
+            assert got.shape == want.shape and torch.equal(got, want), (extra, n, len(seeds))
+            got_again = m.sample_group_masks(n, dev, seeds, gen)          # (the cached gather index)
+            assert torch.equal(got_again, want)
+        steps.set_dropout_mode(m, False)
+
+
 @pytest.mark.parametrize('in_channels,start_filters', [(3, 32), (4, 32), (6, 32), (4, 64), (1, 16)])
 def test_first_layer_kernel_vs_tiled_kernel_and_oracle(dev, in_channels, start_filters):
     """csrc/rcu_first.hip (unpadded K = 9 taps x 4 or 8 channels, NCHW input read in place, 32 or 64 output channels) against
