@@ -250,6 +250,17 @@ int rcu_aleatoric(const float* logits_dev, const float* sigma_raw_dev, size_t n,
 int rcu_prediction_and_foreground(const float* probs_dev, size_t n, size_t hw, int nb_classes,
                                   uint8_t* prediction_dev, float* p_foreground_dev, void* stream);
 
+/* Dropout2d factors of the MC passes of a launch, drawn on the device in one kernel: the `masks_dev` argument of
+ * rcu_unet_forward_accumulate_passes (passes == 1: of rcu_unet_forward / rcu_unet_forward_accumulate) for seeded passes.
+ * seeds_host[t]: the seed of pass t (the predict steps use job_seed(YAML seed, batch index, pass)); site_channels_host / site_keep_host:
+ * channels and 1 - p of the n_sites Dropout2d sites in execution order (site_keep < 0: the site is not active -- factor 1; 0: p = 1 -- factor 0).
+ * out_dev: float32 [site][passes * n + i][C_site], sample t * n + i = image i in pass t.  Element r of pass t's own mask
+ * ([site][n][C_site] flattened) is 1 / keep where the 24-bit uniform from word r & 3 of Philox4x32-10(key = seeds[t], counter = r >> 2)
+ * is below keep, else 0: Bernoulli(1 - p) / (1 - p), the law of torch's Dropout2d (common/model/unet.py:16), and a function of
+ * (seed, r) alone -- a pass's mask does not depend on the group, lane or rank it is launched in. */
+int rcu_dropout_masks(const uint64_t* seeds_host, int passes, int n, const int32_t* site_channels_host, const float* site_keep_host,
+                      int n_sites, float* out_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Metric seam: calibration histograms (numpyfunctions.py:6-107)
  * ------------------------------------------------------------------------------------------ */

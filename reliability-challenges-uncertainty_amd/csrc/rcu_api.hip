@@ -1241,6 +1241,33 @@ extern "C" int rcu_prediction_and_foreground(const float* probs, size_t n, size_
     return RCU_OK;
 }
 
+extern "C" int rcu_dropout_masks(const uint64_t* seeds, int passes, int n, const int32_t* site_channels, const float* site_keep,
+                                 int n_sites, float* out, void* stream)
+{
+    if (!seeds || !site_channels || !site_keep || !out) return fail(RCU_ERR_INVALID, "rcu_dropout_masks: null argument");
+    if (passes < 1 || n < 1 || n_sites < 1 || n_sites > MASK_MAX_SITES)
+        return fail(RCU_ERR_INVALID, "rcu_dropout_masks: passes, n >= 1 and 1 <= n_sites <= 40");
+    MaskArgs a{};
+    long end = 0;
+    for (int s = 0; s < n_sites; ++s) {
+        if (site_channels[s] < 1 || !(site_keep[s] <= 1.f)) return fail(RCU_ERR_INVALID, "rcu_dropout_masks: site_channels >= 1, site_keep <= 1");
+        end += (long)n * site_channels[s];
+        if (end * (long)passes >= (1l << 31)) return fail(RCU_ERR_INVALID, "rcu_dropout_masks: more than 2^31 factors");
+        a.site_end[s] = (int)end;
+        a.site_keep[s] = site_keep[s];
+    }
+    a.sites = n_sites;
+    a.per_pass = (int)end;
+    a.passes = passes;
+    // MASK_MAX_PASSES seeds travel as kernel arguments: a longer group takes several launches, each writing its passes' rows of `out`
+    for (a.first = 0; a.first < passes; a.first += MASK_MAX_PASSES) {
+        a.count = std::min(MASK_MAX_PASSES, passes - a.first);
+        for (int t = 0; t < a.count; ++t) a.seed[t] = seeds[a.first + t];
+        RCU_HIP(launch_dropout_masks(a, out, static_cast<hipStream_t>(stream)));
+    }
+    return RCU_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // metric seam
 // ------------------------------------------------------------------------------------------------

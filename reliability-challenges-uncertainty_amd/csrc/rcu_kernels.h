@@ -200,6 +200,18 @@ hipError_t launch_aleatoric(const float* logits, const float* sigma_raw, int C, 
                             hipStream_t stream);
 hipError_t launch_argmax_fg(const float* probs_nchw, int C, size_t N, size_t HW, uint8_t* prediction, float* p_fg,
                             hipStream_t stream);
+// Dropout2d factors of the passes of a pass group, drawn in one launch (include/rcu.h: rcu_dropout_masks)
+constexpr int MASK_MAX_PASSES = 32;      // seeds per launch (kernel arguments)
+constexpr int MASK_MAX_SITES = 40;       // 2 * (2 * 8 + 1) + the head units: depth <= 8
+struct MaskArgs {
+    unsigned long long seed[MASK_MAX_PASSES];
+    int site_end[MASK_MAX_SITES];        // exclusive prefix sums of n * C_site: site s covers [site_end[s - 1], site_end[s]) of a pass's own mask
+    float site_keep[MASK_MAX_SITES];     // 1 - p of the site; < 0: the site is not active (factor 1); 0: p = 1 (factor 0)
+    int passes;                          // passes of the whole group: rows per site of the output layout
+    int first, count;                    // this launch draws passes first .. first + count - 1 (seed[0 .. count - 1])
+    int sites, per_pass;
+};
+hipError_t launch_dropout_masks(const MaskArgs& a, float* out, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // calibration kernels (rcu_calib.hip)

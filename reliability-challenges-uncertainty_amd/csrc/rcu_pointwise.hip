@@ -641,4 +641,56 @@ hipError_t launch_argmax_fg(const float* probs, int C, size_t N, size_t HW, uint
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dropout2d factors of the MC passes of a launch, all in ONE kernel (rcu_dropout_masks).  Drawn with torch -- one bernoulli_ per
+// pass, a division, a gather into the group layout -- a 62k-element draw is a 5 us kernel that takes 160 us to get its turn beside the
+// persistent conv kernels (profiles/r05_script_trace.txt): 20 of them per volume sit in front of the lanes' conv launches.
+// Element r of pass t's own mask ([site][n][C_site], r = 0 .. per_pass - 1) is word r & 3 of Philox4x32-10 under key seeds[t], counter
+// (r >> 2, 0, 0, 0): a function of (seed, r) alone -- the same value whatever the group the pass is launched in.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t (&out)[4])
+{
+    uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__global__ __launch_bounds__(PW_THREADS) void dropout_masks_kernel(const MaskArgs a, float* __restrict__ out)
+{
+    const int quads = (a.per_pass + 3) >> 2;
+    const int q = blockIdx.x * PW_THREADS + threadIdx.x;
+    const int t = blockIdx.y;
+    if (q >= quads) return;
+    uint32_t w[4];
+    philox4x32_10((uint32_t)a.seed[t], (uint32_t)(a.seed[t] >> 32), (uint32_t)q, 0u, w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = 4 * q + k;
+        if (r >= a.per_pass) break;
+        int s = 0;
+        while (r >= a.site_end[s]) ++s;                  // <= 40 sites, ascending: the site of element r
+        const int begin = s ? a.site_end[s - 1] : 0, len = a.site_end[s] - begin;
+        const float keep = a.site_keep[s];
+        const float u = (float)(w[k] >> 8) * (1.0f / 16777216.0f);        // uniform in [0, 1), 24 bits
+        const float factor = keep < 0.f ? 1.f : (keep > 0.f && u < keep) ? 1.f / keep : 0.f;
+        // group layout: [site][pass][n * C_site]
+        out[(size_t)a.passes * begin + (size_t)(a.first + t) * len + (r - begin)] = factor;
+    }
+}
+
+hipError_t launch_dropout_masks(const MaskArgs& a, float* out, hipStream_t stream)
+{
+    const int quads = (a.per_pass + 3) >> 2;
+    hipLaunchKernelGGL(dropout_masks_kernel, dim3((quads + PW_THREADS - 1) / PW_THREADS, a.count), dim3(PW_THREADS), 0, stream, a, out);
+    return hipGetLastError();
+}
+
 }  // namespace rcu

@@ -74,12 +74,12 @@ class HipEngine:
         else:                                                     # float64 statistics: the tail is float64 too
             ws_out.copy_(steps_mod.softmax(self.model(x)))
 
-    def sample_group_masks(self, x, generator, seeds):
-        """The masks of the pass group whose passes are seeded with ``seeds`` (UNet.sample_group_masks: the draws of ``sample_masks`` pass by
-        pass, in the group launch's layout)."""
+    def seeded_masks(self, x, seeds):
+        """The masks of the passes seeded with ``seeds`` over x, in the layout of their group launch (UNet.seeded_masks: one kernel, pass t
+        a function of seeds[t] alone)."""
         steps_mod.set_dropout_mode(self.model, True)
         try:
-            return self.model.sample_group_masks(x.shape[0], x.device, seeds, generator)
+            return self.model.seeded_masks(x.shape[0], x.device, seeds)
         finally:
             steps_mod.set_dropout_mode(self.model, False)
 
@@ -222,6 +222,9 @@ class ShardedMcRunner:
     def masks_of(self, x, step_index, job):
         """The device mask tensor MC pass ``job`` (1..T) of volume ``step_index`` runs under (None without a seed / an engine
         that samples on its own)."""
+        seeded = getattr(self.engine, 'seeded_masks', None)
+        if self.seed is not None and seeded is not None:
+            return seeded(x, [job_seed(self.seed, step_index, job)])
         sample = getattr(self.engine, 'sample_masks', None)
         if self.seed is None or sample is None:
             return None
@@ -278,11 +281,9 @@ class ShardedMcRunner:
             if len(group) > 1:     # consecutive MC passes of this rank as one batch of N * g samples
                 def run_group(st, lane, group=group):
                     if mask_sets is None:
-                        grouped = getattr(self.engine, 'sample_group_masks', None)
-                        if self.seed is not None and grouped is not None:
-                            if self._generator is None:
-                                self._generator = torch.Generator(device=x.device)
-                            ms = grouped(x, self._generator, [job_seed(self.seed, step_index, j) for j in group])
+                        seeded = getattr(self.engine, 'seeded_masks', None)
+                        if self.seed is not None and seeded is not None:
+                            ms = seeded(x, [job_seed(self.seed, step_index, j) for j in group])
                         else:
                             ms = [self.masks_of(x, step_index, j) for j in group]
                             ms = None if any(m is None for m in ms) else ms

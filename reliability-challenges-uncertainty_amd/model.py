@@ -119,7 +119,6 @@ class UNet(nn.Module):
         self.fuse_head = True    # 1x1 classifier + softmax + statistics inside conv_cls.0's epilogue where the shapes allow
         self._donor = None       # share_workspace(): the model whose activation workspaces this one's plans borrow
         self._last_generation = 0   # generation of the plan _handle returned last
-        self._group_index = {}      # (passes, n, device) -> gather index of sample_group_masks
         self.eval()
 
     # ------------------------------------------------------------------ weights
@@ -285,43 +284,21 @@ class UNet(nn.Module):
             return None
         return chunks[0] if len(chunks) == 1 else torch.cat(chunks)
 
-    def sample_group_masks(self, n, device, seeds, generator):
-        """The masks of a pass GROUP -- pass j drawn from ``generator`` re-seeded with ``seeds[j]``, exactly the values
-        ``sample_masks(n, device, generator)`` gives pass by pass -- in the ``[site][passes * n][C_site]`` layout of
-        ``forward_accumulate(..., passes=g)``, made with 2 g + 2 small kernels instead of the 5 g + 20 of g ``sample_masks`` calls +
-        ``group_masks`` (per-site splits and concatenations): every pass's Bernoulli draw goes straight into its row of one ``[g, total]``
-        buffer, one division scales them all, one gather (index cached per (g, n)) re-orders rows to sites.  With the shipped
-        ``batch_size: 32`` the mask bookkeeping was 47 ms of the test loop's main thread per BraTS subject (tools/host_costs_probe.py).
-        Falls back to the general path unless every site is active with one p (the shipped configurations)."""
+    def seeded_masks(self, n, device, seeds):
+        """The Dropout2d factors of ``len(seeds)`` MC passes over n images, drawn on the device by ONE kernel (include/rcu.h,
+        rcu_dropout_masks) on the current stream: pass t from ``seeds[t]`` alone -- the same values whatever group, lane or rank the pass is
+        launched in -- in the ``[site][passes * n][C_site]`` layout ``forward_accumulate(..., passes=len(seeds))`` reads (one pass: the layout
+        of ``sample_masks``).  Sites whose Dropout2d is in eval mode get ones, p = 1 zeros, as ``sample_masks`` gives them."""
         sites = self.dropout_sites()
-        states = {float(m.p) if (m.training and m.p > 0) else None for m in self._site_modules}
-        g = len(seeds)
-        if not sites or len(states) != 1 or None in states or next(iter(states)) >= 1 or g < 2:
-            sets = []
-            for seed in seeds:
-                generator.manual_seed(int(seed))
-                sets.append(self.sample_masks(n, device, generator=generator))
-            return self.group_masks(sets, n, device) if g > 1 else sets[0]
-        keep = 1.0 - next(iter(states))
-        total = n * sum(c for _, c in sites)
-        buf = torch.empty((g, total), device=device)
-        for j, seed in enumerate(seeds):
-            generator.manual_seed(int(seed))
-            buf[j].bernoulli_(keep, generator=generator)
-        buf.div_(keep)
-        key = (g, n, str(device))
-        index = self._group_index.get(key)
-        if index is None:
-            # output position (site s, pass j, r) <- buffer position j * total + offset_s + r
-            parts, offset = [], 0
-            for _, c in sites:
-                length = n * c
-                parts.append((torch.arange(g).view(g, 1) * total + offset + torch.arange(length).view(1, length)).reshape(-1))
-                offset += length
-            if len(self._group_index) >= 8:
-                self._group_index.clear()
-            index = self._group_index[key] = torch.cat(parts).to(device)
-        return buf.view(-1).index_select(0, index)
+        if not sites:
+            return None
+        g, count = len(seeds), len(sites)
+        keeps = [(max(0.0, 1.0 - float(m.p)) if (m.training and m.p > 0) else -1.0) for m in self._site_modules]
+        out = torch.empty(g * n * sum(c for _, c in sites), device=device, dtype=torch.float32)
+        _lib.check(_lib.load().rcu_dropout_masks((ctypes.c_uint64 * g)(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds]), g, n,
+                                                 (ctypes.c_int32 * count)(*[c for _, c in sites]), (ctypes.c_float * count)(*keeps), count,
+                                                 _lib.ptr(out), _lib.current_stream()))
+        return out
 
     def pack_masks(self, masks, n, device):
         """List of per-site ``[n, C_site]`` arrays/tensors -> the concatenated device layout."""

@@ -366,16 +366,10 @@ class McPredictStep(BatchStep):
         self.lanes = self.LANES if lanes is None else max(1, int(lanes))
         self.seed = seed
         self.exact = bool(exact) and mc_steps <= _lib.RCU_MC_EXACT_MAX_PASSES      # (beyond the exact form's 2,048 passes: plain float sums)
-        self._generators = {}
 
     def _seeded_masks(self, model, images, batch_index, job):
         """The mask tensor of MC pass ``job`` (1..T) of batch ``batch_index`` under ``self.seed`` (dropout mode is on)."""
-        dev = images.device
-        gen = self._generators.get(dev)
-        if gen is None:
-            gen = self._generators[dev] = torch.Generator(device=dev)
-        gen.manual_seed(job_seed(self.seed, batch_index, job))
-        return model.sample_masks(images.shape[0], dev, generator=gen)
+        return model.seeded_masks(images.shape[0], images.device, [job_seed(self.seed, batch_index, job)])
 
     def _launch_masks(self, model, images, batch_index, first, count):
         """``masks`` argument of the launch that runs the passes first .. first + count - 1 (0-based): injected sets, seeded draws, or
@@ -384,14 +378,8 @@ class McPredictStep(BatchStep):
             return self.masks[first] if count == 1 else self.masks[first:first + count]
         if self.seed is None:
             return None
-        if count == 1:
-            return self._seeded_masks(model, images, batch_index, first + 1)
-        dev = images.device
-        gen = self._generators.get(dev)
-        if gen is None:
-            gen = self._generators[dev] = torch.Generator(device=dev)
-        # the group's masks in one buffer: the same draws as pass by pass (UNet.sample_group_masks), already in the launch's layout
-        return model.sample_group_masks(images.shape[0], dev, [job_seed(self.seed, batch_index, j + 1) for j in range(first, first + count)], gen)
+        # one kernel for the launch's passes, on the stream that reads them, already in the launch's layout (UNet.seeded_masks)
+        return model.seeded_masks(images.shape[0], images.device, [job_seed(self.seed, batch_index, j + 1) for j in range(first, first + count)])
 
     def __call__(self, batch_context, task_context, context) -> None:
         _check_context(context)

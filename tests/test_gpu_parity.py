@@ -164,28 +164,49 @@ def test_winograd_kernels_vs_direct_and_oracle(dev):
         assert _maxdiff(outs[mode], out_d) < 2e-5, mode
 
 
-def test_group_masks_drawn_into_one_buffer_are_the_per_pass_draws(dev):
-    """UNet.sample_group_masks (every pass's Bernoulli draw into its row of one buffer, one division, one gather) against the path it
-    replaces on the predict steps' launches -- ``sample_masks`` pass by pass under the same seeds + ``group_masks`` -- bit for bit, for
-    several group sizes and batch sizes, with dropout at every site and with ``dropout_center`` (sites of mixed state: the general path)."""
+def test_seeded_masks_are_a_function_of_the_seed_alone(dev):
+    """UNet.seeded_masks (rcu_dropout_masks: the Dropout2d factors of a launch's passes in one kernel).  A pass's mask must not depend on the
+    group it is drawn in (any split of the seeds gives the rows the single-pass calls give, in the group layout -- ``group_masks`` of the
+    single draws), nor on the call (same seed, same bits); groups beyond the 32 seeds one launch carries; values in {0, 1 / keep} with the
+    Bernoulli(1 - p) law per element and no visible correlation between passes; sites in eval mode get ones, p = 1 zeros
+    (sites of mixed state), as ``sample_masks`` gives them."""
     from oracle import unet_oracle as uo
     from rcu_amd import steps
-    for extra in ({}, {'dropout_center': 2}):
-        params = dict(nb_classes=2, in_channels=4, depth=2, start_filters=8, dropout=0.3, **extra)
-        m = _model(params, uo.synthetic_state(3, **params), dev)
-        steps.set_dropout_mode(m, True)
-        gen = torch.Generator(device=dev)
-        for n, seeds in ((1, [5, 6]), (3, [11, 12, 13, 14]), (32, list(range(100, 110))), (2, [7])):
-            sets = []
-            for seed in seeds:
-                gen.manual_seed(seed)
-                sets.append(m.sample_masks(n, dev, generator=gen))
-            want = m.group_masks(sets, n, dev) if len(seeds) > 1 else sets[0]
-            got = m.sample_group_masks(n, dev, seeds, gen)
-            assert got.shape == want.shape and torch.equal(got, want), (extra, n, len(seeds))
-            got_again = m.sample_group_masks(n, dev, seeds, gen)          # (the cached gather index)
-            assert torch.equal(got_again, want)
-        steps.set_dropout_mode(m, False)
+    params = dict(nb_classes=2, in_channels=4, depth=2, start_filters=8, dropout=0.3)
+    m = _model(params, uo.synthetic_state(3, **params), dev)
+    steps.set_dropout_mode(m, True)
+    for n, seeds in ((1, [5, 6]), (3, [11, 12, 13, 14]), (32, list(range(100, 110))), (2, [7]), (2, list(range(1, 72)))):
+        singles = [m.seeded_masks(n, dev, [seed]) for seed in seeds]
+        want = m.group_masks(singles, n, dev) if len(seeds) > 1 else singles[0]
+        got = m.seeded_masks(n, dev, seeds)
+        assert got.shape == want.shape and torch.equal(got, want), (n, len(seeds))
+        assert torch.equal(m.seeded_masks(n, dev, seeds), got)
+        half = len(seeds) // 2
+        if half:            # a prefix of the group drawn on its own: the same rows
+            assert torch.equal(m.seeded_masks(n, dev, seeds[:half]), m.group_masks(singles[:half], n, dev) if half > 1 else singles[0])
+    big = m.seeded_masks(64, dev, list(range(1000, 1040)))                 # 40 passes x 64 images x 72 channels
+    values = torch.unique(big)
+    keep = 1.0 - 0.3
+    assert values.numel() == 2 and float(values[0]) == 0.0 and abs(float(values[1]) - 1.0 / keep) < 1e-6
+    frac = float((big > 0).double().mean())
+    assert abs(frac - keep) < 4 * (keep * (1 - keep) / big.numel()) ** 0.5 + 1e-4, frac
+    a, b = m.seeded_masks(64, dev, [1000]) > 0, m.seeded_masks(64, dev, [1001]) > 0
+    agree = float((a == b).double().mean())                                 # independent draws agree with probability keep^2 + (1 - keep)^2
+    assert abs(agree - (keep * keep + (1 - keep) ** 2)) < 0.03, agree
+    assert not torch.equal(m.seeded_masks(4, dev, [2 ** 40 + 9]), m.seeded_masks(4, dev, [9]))          # the high word of the seed counts
+    steps.set_dropout_mode(m, False)
+    assert float(m.seeded_masks(2, dev, [3]).min()) == 1.0 and float(m.seeded_masks(2, dev, [3]).max()) == 1.0
+    # sites of mixed state (two Dropout2d modules put back into eval mode by hand): the layout and the ones of the inactive sites
+    steps.set_dropout_mode(m, True)
+    m._site_modules[1].eval()
+    m._site_modules[4].eval()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    torch_way = m.sample_masks(3, dev, generator=g)                         # (other values: torch's generator; the same sites are constant)
+    ours = m.seeded_masks(3, dev, [1])
+    assert ours.shape == torch_way.shape and torch.equal(ours == 1.0, torch_way == 1.0)
+    assert 0 < int((ours == 1.0).sum()) < ours.numel()
+    steps.set_dropout_mode(m, False)
 
 
 @pytest.mark.parametrize('in_channels,start_filters', [(3, 32), (4, 32), (6, 32), (4, 64), (1, 16)])
