@@ -113,7 +113,7 @@ class ConfusionOnDeviceStep(steps.BatchStep):
     RING = 4
 
     def __init__(self):
-        self._pinned = []          # [(pinned uint8 tensor, event of the copy that read it last)]
+        self._pinned = [None] * self.RING      # (pinned uint8 tensor, event of the copy that read it last)
         self._next = 0
         self._volumes = {}         # subject index -> device uint8 [D, H, W]
 
@@ -121,8 +121,6 @@ class ConfusionOnDeviceStep(steps.BatchStep):
         vol = self._volumes.get(subject)
         if vol is None:
             labels = np.ascontiguousarray(dataset.direct_extract(subject, ('labels',))['labels'], dtype=np.uint8)
-            if len(self._pinned) < self.RING:
-                self._pinned.append(None)
             slot = self._next % self.RING
             self._next += 1
             entry = self._pinned[slot]

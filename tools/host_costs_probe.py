@@ -72,52 +72,6 @@ for cls_name in ('SubjectAssembler', 'Subject2dAssembler'):
         wrap(getattr(loops, cls_name), 'add_batch', cls_name + '.add_batch')
         wrap(getattr(loops, cls_name), 'get_assembled_subject', cls_name + '.get_assembled_subject')
 
-if 'detail' in sys.argv:      # the phases of ConfusionOnDeviceStep._labels_of, re-stated with a timer behind each
-    sys.argv.remove('detail')
-    import numpy as np
-    import torch
-
-    def detailed_labels_of(self, subject, dataset, device):
-        vol = self._volumes.get(subject)
-        if vol is not None:
-            return vol
-
-        def lap(label, t):
-            e = acc['_labels_of: ' + label]
-            e[0] += 1
-            e[1] += time.perf_counter() - t
-            return time.perf_counter()
-        t = time.perf_counter()
-        labels = np.ascontiguousarray(dataset.direct_extract(subject, ('labels',))['labels'], dtype=np.uint8)
-        t = lap('direct_extract', t)
-        if len(self._pinned) < self.RING:
-            self._pinned.append(None)
-        slot = self._next % self.RING
-        self._next += 1
-        entry = self._pinned[slot]
-        if entry is None or entry[0].numel() < labels.size:
-            entry = (torch.empty(labels.size, dtype=torch.uint8, pin_memory=True), torch.cuda.Event())
-            t = lap('pinned allocation', t)
-        else:
-            entry[1].synchronize()
-            t = lap('wait for the buffer', t)
-        self._pinned[slot] = entry
-        host = entry[0][:labels.size]
-        np.copyto(host.numpy(), labels.reshape(-1))
-        t = lap('copy into pinned memory', t)
-        vol = torch.empty(labels.size, dtype=torch.uint8, device=device)
-        t = lap('device allocation', t)
-        vol.copy_(host, non_blocking=True)
-        t = lap('enqueue the copy', t)
-        entry[1].record()
-        shape = labels.shape[:-1] if (labels.ndim == 4 and labels.shape[-1] == 1) else labels.shape
-        vol = self._volumes[subject] = vol.view(shape)
-        for other in [k for k in self._volumes if k != subject][:-1]:
-            del self._volumes[other]
-        lap('rest', t)
-        return vol
-    scripts.ConfusionOnDeviceStep._labels_of = detailed_labels_of
-
 for arg in list(sys.argv):
     if arg == 'confusion=0':          # others.device_confusion: false -- the subjects' Dice counts at subject level (three synchronous GPU operations)
         inner_other = scripts._other
