@@ -48,12 +48,24 @@ class EvalSubjectStep(loops.SubjectStep):
     def __call__(self, subject_context, task_context, context) -> None:
         probabilities = subject_context.subject_data['probabilities']
         per_slice = subject_context.subject_data.pop('confusion', None)
-        if per_slice is not None and not self.keep_prediction:
+        if per_slice is not None:
             # the counts were taken slice by slice on the GPU, behind the predict step (ConfusionOnDeviceStep), and came to the host with the
-            # batches: integers, so their sum IS the confusion matrix of the assembled subject.  Nothing here touches the GPU -- and the
-            # arg-max for the *_prediction file stays with the writer thread
+            # batches: integers, so their sum IS the confusion matrix of the assembled subject.  Nothing here touches the GPU -- and a
+            # volume's arg-max for the *_prediction file stays with the writer thread
             tp, _, fp, fn = (int(v) for v in np.asarray(per_slice).reshape(-1, 4).sum(axis=0))
             subject_context.metrics.update({'dice': ev.dice_from_counts(tp, fp, fn)})
+            made = subject_context.subject_data.get('prediction')       # 2-D subjects: the arg-max map came with the batch too
+            if made is not None:
+                made = np.asarray(made, dtype=np.uint8)
+                made = made[..., 0] if (made.ndim == np.ndim(probabilities) and made.shape[-1] == 1) else made
+                subject_context.more['prediction'] = (made, probabilities)
+            if self.keep_prediction:
+                if made is None:
+                    made = nifti.argmax_last(probabilities, np.uint8)
+                    subject_context.more['prediction'] = (made, probabilities)
+                subject_context.subject_data['prediction'] = made.astype(np.int64)
+            elif made is not None:
+                del subject_context.subject_data['prediction']
             return
         prediction = nifti.argmax_last(probabilities, np.uint8)      # (class indices: uint8 holds them; np.argmax's int64 where it is kept)
         if self.keep_prediction:
@@ -99,67 +111,84 @@ class WriteHook(loops.TestLoopHook):
 
 
 class ConfusionOnDeviceStep(steps.BatchStep):
-    """The Dice counts of the subjects' evaluation (EvalSubjectStep: brats_test_default.py:63-77) taken at BATCH time, on the compute stream,
-    right behind the predict steps: tp / tn / fp / fn of every slice of the batch against the dataset's labels -> ``output['confusion']``
-    ``[N, 4]`` int64, which travels to the host with the batch's other kept entries and is assembled like them (``[D, 4]`` per subject).
+    """The Dice counts of the subjects' evaluation (EvalSubjectStep: brats_test_default.py:63-77, isic_test_default.py:70-86) taken at BATCH
+    time, on the compute stream, right behind the predict steps: tp / tn / fp / fn of every slice (image) of the batch against its labels ->
+    ``output['confusion']`` ``[N, 4]`` int64, which travels to the host with the batch's other kept entries and is assembled like them
+    (``[D, 4]`` per volume, ``[4]`` per 2-D subject).  2-D subjects also get ``output['prediction']`` -- the arg-max map (uint8) their
+    evaluation and their writer want.
     Why: at subject level the same counts cost the test loop's MAIN thread three small synchronous GPU operations, and next to a loop that
-    has run ahead -- every CU held by a persistent conv kernel -- each of them waits 20-30 ms: 72-94 ms per BraTS subject
-    (tools/host_costs_probe.py), more than the host could spare with the shipped ``batch_size: 32``.  Here they are stream-ordered work
-    like any kernel of the batch and nobody waits for them.
-    A subject's label volume is uploaded once, through pinned memory (a ring of buffers: a copy may still be queued behind the batches
-    the loop has run ahead with), and sliced on the device.  Volume datasets only (``slice_index`` in the batch, labels by subject from the
-    dataset): 2-D subjects carry their labels in the batch and are small."""
+    has run ahead -- every CU held by a persistent conv kernel -- each of them waits its turn: 72-94 ms per BraTS subject, 6.8 ms per ISIC
+    image (218 ms per batch of 32, whose GPU work takes 61: tools/host_costs_probe.py, tools/isic_script_throughput.py).  Here they are
+    stream-ordered work like any kernel of the batch and nobody waits for them.
+    Labels reach the device through a ring of pinned buffers (a copy may still be queued behind the batches the loop has run ahead with):
+    a volume's labels once per subject -- from the dataset, sliced on the device --, a 2-D batch's own ``labels`` entry once per batch."""
 
-    RING = 4
+    RING = 16          # > loops.Test.MAX_INFLIGHT: the copy that used a buffer last has long run when its turn comes again
 
     def __init__(self):
         self._pinned = [None] * self.RING      # (pinned uint8 tensor, event of the copy that read it last)
         self._next = 0
         self._volumes = {}         # subject index -> device uint8 [D, H, W]
 
+    def _upload(self, labels, device):
+        """host uint8 array -> device tensor of its shape, asynchronously on the current stream."""
+        slot = self._next % self.RING
+        self._next += 1
+        entry = self._pinned[slot]
+        if entry is None or entry[0].numel() < labels.size:
+            entry = (torch.empty(labels.size, dtype=torch.uint8, pin_memory=True), torch.cuda.Event())
+        else:
+            entry[1].synchronize()       # the copy that used this buffer RING uploads ago has run
+        self._pinned[slot] = entry
+        host = entry[0][:labels.size]
+        # (numpy's copy, not torch's: a torch CPU copy of this size starts an OpenMP team on the calling thread -- beside the loader thread's
+        # own team the 4 MB took 35 ms, tools/host_costs_probe.py)
+        np.copyto(host.numpy(), labels.reshape(-1))
+        dev = torch.empty(labels.size, dtype=torch.uint8, device=device)
+        dev.copy_(host, non_blocking=True)
+        entry[1].record()
+        return dev.view(labels.shape)
+
     def _labels_of(self, subject, dataset, device):
         vol = self._volumes.get(subject)
         if vol is None:
             labels = np.ascontiguousarray(dataset.direct_extract(subject, ('labels',))['labels'], dtype=np.uint8)
-            slot = self._next % self.RING
-            self._next += 1
-            entry = self._pinned[slot]
-            if entry is None or entry[0].numel() < labels.size:
-                entry = (torch.empty(labels.size, dtype=torch.uint8, pin_memory=True), torch.cuda.Event())
-            else:
-                entry[1].synchronize()       # the copy that used this buffer RING subjects ago has run
-            self._pinned[slot] = entry
-            host = entry[0][:labels.size]
-            # (numpy's copy, not torch's: a torch CPU copy of this size starts an OpenMP team on the calling thread -- beside the loader thread's
-            # own team the 4 MB took 35 ms, tools/host_costs_probe.py)
-            np.copyto(host.numpy(), labels.reshape(-1))
-            vol = torch.empty(labels.size, dtype=torch.uint8, device=device)
-            vol.copy_(host, non_blocking=True)
-            entry[1].record()
-            shape = labels.shape[:-1] if (labels.ndim == 4 and labels.shape[-1] == 1) else labels.shape
-            vol = self._volumes[subject] = vol.view(shape)
+            if labels.ndim == 4 and labels.shape[-1] == 1:
+                labels = labels[..., 0]
+            vol = self._volumes[subject] = self._upload(labels, device)
             for other in [k for k in self._volumes if k != subject][:-1]:      # this subject and the one before it (a batch may span two)
                 del self._volumes[other]
         return vol
 
     def __call__(self, batch_context, task_context, context) -> None:
         probabilities = batch_context.output.get('probabilities')
+        if probabilities is None or not probabilities.is_cuda:
+            return            # (a rank other than the root of a sharded run has nothing to evaluate)
         batch = batch_context.input
         dataset = getattr(getattr(task_context, 'data', None), 'dataset', None)
-        if (probabilities is None or not probabilities.is_cuda or 'slice_index' not in batch or not hasattr(dataset, 'direct_extract')):
-            return            # (a rank other than the root of a sharded run has nothing to evaluate; 2-D subjects: EvalSubjectStep's own path)
+        volumes = 'slice_index' in batch and hasattr(dataset, 'direct_extract')
+        labels = None if volumes else batch.get('labels')
+        if not volumes and not (torch.is_tensor(labels) and labels.numel() == probabilities.shape[0] * probabilities.shape[2] * probabilities.shape[3]):
+            return            # (no labels of the batch's shape at hand: EvalSubjectStep evaluates the assembled subject itself)
         steps.wait_for_outputs(batch_context)      # (the root of a sharded run: the summary's outputs come from a side stream)
         prediction, _ = steps.prediction_and_foreground(probabilities)
-        subjects = [int(v) for v in batch['subject_index']]
-        slices = [int(v) for v in batch['slice_index']]
-        pieces, b, n = [], 0, len(subjects)
-        while b < n:                                                        # runs of consecutive slices of one subject
-            e = b + 1
-            while e < n and subjects[e] == subjects[b] and slices[e] == slices[e - 1] + 1:
-                e += 1
-            pieces.append(self._labels_of(subjects[b], dataset, prediction.device)[slices[b]:slices[b] + (e - b)])
-            b = e
-        target = pieces[0] if len(pieces) == 1 else torch.cat(pieces)
+        if volumes:
+            subjects = [int(v) for v in batch['subject_index']]
+            slices = [int(v) for v in batch['slice_index']]
+            pieces, b, n = [], 0, len(subjects)
+            while b < n:                                                        # runs of consecutive slices of one subject
+                e = b + 1
+                while e < n and subjects[e] == subjects[b] and slices[e] == slices[e - 1] + 1:
+                    e += 1
+                pieces.append(self._labels_of(subjects[b], dataset, prediction.device)[slices[b]:slices[b] + (e - b)])
+                b = e
+            target = pieces[0] if len(pieces) == 1 else torch.cat(pieces)
+        else:
+            # the cast evaluation._to_dev makes of the assembled subject's labels (the shipped ISIC configs rescale them to float 0 / 1)
+            host = labels.detach().cpu().numpy()
+            host = host if host.dtype == np.uint8 else host.astype(np.uint8)
+            target = self._upload(np.ascontiguousarray(host).reshape(prediction.shape), prediction.device)
+            batch_context.output['prediction'] = prediction.unsqueeze(1)      # (outputs carry the channel dim at 1: the loop moves it to the end)
         batch_context.output['confusion'] = ev.confusion_counts_on_device(prediction, target)
 
 
@@ -365,12 +394,12 @@ def _run(context, dataset, test_steps, write_hook, entries, world=None):
         store = {}
         test_steps = test_steps + [CollectOnDeviceStep(store)]
         extra_hooks.append(DeviceMetricsHook(dataset, spec, store))
-    if dataset != 'brats':
-        test_steps = test_steps + [PrepareSubjectStep()]
-    elif world.is_root and bool(_other(context, 'device_confusion', True)):
+    if world.is_root and bool(_other(context, 'device_confusion', True)):
         # the subjects' Dice counts ride with the batches (ConfusionOnDeviceStep; ``others.device_confusion: false`` keeps them at subject level)
         test_steps = test_steps + [ConfusionOnDeviceStep()]
         entries = None if entries is None else tuple(entries) + ('confusion',)
+    if dataset != 'brats':
+        test_steps = test_steps + [PrepareSubjectStep()]
     if not world.is_root:
         # a rank other than the root of a sharded run: the same loader and the same batch steps, nothing assembled, evaluated or written
         # (the same coalescing: every rank must see the root's batches -- batch indices seed the masks, shapes size the collective)

@@ -398,6 +398,19 @@ def test_isic_many_batches_keep_their_own_labels(tmp_path, monkeypatch, coalesce
         dices.append(co.dice_from_counts(tp, fp, fn))
         assert abs(float(rows[id_]['dice']) - dices[-1]) < 1e-12, id_
     assert len(set(round(d, 9) for d in dices)) > 5          # the subjects are told apart by their labels
+    # The Dice counts (and the arg-max maps) above came with the batches (scripts.ConfusionOnDeviceStep, the default): the subject-level
+    # evaluation -- three synchronous GPU operations per image on the loop's main thread -- gives the same metrics.csv and the same files
+    from rcu_amd import evaluation as ev
+    calls = []
+    inner = ev.confusion_matrx
+    monkeypatch.setattr(ev, 'confusion_matrx', lambda *a, **k: (calls.append(1), inner(*a, **k))[1])
+    again = scripts.test_default('isic', _with_others(cfg_path, 'again'), None)
+    assert not calls
+    subject_level = scripts.test_default('isic', _with_others(cfg_path, 'subject_level', device_confusion=False), None)
+    assert len(calls) == len(ids)
+    for run in (again, subject_level):
+        assert open(os.path.join(run.test_dir, 'metrics.csv'), 'rb').read() == open(os.path.join(ctx.test_dir, 'metrics.csv'), 'rb').read()
+        assert _files(run) == _files(ctx)
 
 
 def _confidence(ctx, name):
