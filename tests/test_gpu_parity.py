@@ -184,6 +184,12 @@ def test_seeded_masks_are_a_function_of_the_seed_alone(dev):
         half = len(seeds) // 2
         if half:            # a prefix of the group drawn on its own: the same rows
             assert torch.equal(m.seeded_masks(n, dev, seeds[:half]), m.group_masks(singles[:half], n, dev) if half > 1 else singles[0])
+    # ... and they are the oracle's (oracle/mask_oracle.py: Philox4x32-10 pinned by the published known-answer vectors), bit for bit
+    from oracle import mask_oracle as mo
+    sites = m.dropout_sites()
+    for n, seeds in ((3, [11, 12, 13, 14]), (1, [2 ** 63 + 5]), (5, list(range(40, 75)))):
+        want = mo.group_masks(seeds, n, [c for _, c in sites], [0.7] * len(sites))
+        assert np.array_equal(m.seeded_masks(n, dev, seeds).cpu().numpy(), want), (n, len(seeds))
     big = m.seeded_masks(64, dev, list(range(1000, 1040)))                 # 40 passes x 64 images x 72 channels
     values = torch.unique(big)
     keep = 1.0 - 0.3

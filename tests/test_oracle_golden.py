@@ -357,3 +357,33 @@ def test_confusion_dice_accuracy_against_sklearn_g19(golden):
         else:
             assert dice == 1.0 and float(g[name + '::f1_zero_division_0']) == 0.0          # the convention case
         assert abs(co.accuracy_from_counts(tp, tn, n) - float(g[name + '::accuracy'])) < 1e-15, name
+
+
+def test_mask_oracle_against_the_published_philox_vectors():
+    """oracle/mask_oracle.py restates the generator behind rcu_dropout_masks: Philox4x32-10 (Salmon et al., SC'11) pinned by the three
+    known-answer vectors of the Random123 distribution (kat_vectors: `philox4x32 10`), then the mask definition's own properties -- values in
+    {0, 1 / keep}, the Bernoulli(keep) share, inactive / p = 1 sites, the group layout as the row-wise interleave of the passes' own masks."""
+    from oracle import mask_oracle as mo
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for counter, key, want in kats:
+        got = mo.philox4x32_10(np.array(counter, dtype=np.uint32), key)
+        assert tuple(int(v) for v in got) == want
+    channels, keep = [8, 8, 16, 5], [0.7, -1.0, 0.7, 0.0]
+    one = mo.pass_mask(12345, 3, channels, keep)
+    assert one.dtype == np.float32 and one.size == 3 * sum(channels)
+    assert set(np.unique(one[:24])) <= {np.float32(0.0), np.float32(1.0) / np.float32(0.7)}
+    assert np.all(one[24:48] == 1.0) and np.all(one[96:] == 0.0)
+    big = mo.pass_mask(7, 64, [256], [0.95])
+    assert abs(float((big > 0).mean()) - 0.95) < 4 * (0.95 * 0.05 / big.size) ** 0.5
+    assert not np.array_equal(mo.pass_mask(7, 4, [32], [0.5]), mo.pass_mask(7 + 2 ** 32, 4, [32], [0.5]))      # both key words count
+    seeds = [3, 4, 5]
+    grouped = mo.group_masks(seeds, 3, channels, keep)
+    singles = [mo.pass_mask(s, 3, channels, keep) for s in seeds]
+    at, out = 0, 0
+    for c in channels:
+        for m in singles:
+            assert np.array_equal(grouped[out:out + 3 * c], m[at:at + 3 * c])
+            out += 3 * c
+        at += 3 * c
