@@ -668,8 +668,9 @@ class Test:
         # batch the order of the callbacks is the reference's (batch start, steps, subject start / steps / end, batch end); only
         # "batch k + 1 start" now comes before "subjects of batch k".  A custom convert_fn or a CPU device keeps the plain order.
         pipelined = True if self.pipelined is None else self.pipelined
-        pipelined = bool(pipelined) and (self.convert_fn is tensor_to_numpy and self.subject_assembler is not None and
-                                         getattr(context.device, 'type', 'cpu') == 'cuda')
+        # (a loop without an assembler -- a rank other than the root of a sharded run: same loader, same steps, nothing to finish -- is pipelined
+        # too: its batches come through the loader thread's pinned staging instead of a synchronous copy from pageable memory per batch)
+        pipelined = bool(pipelined) and (self.convert_fn is tensor_to_numpy and getattr(context.device, 'type', 'cpu') == 'cuda')
         side = torch.cuda.Stream(device=context.device) if pipelined else None
         self._subject_stream = torch.cuda.Stream(device=context.device) if pipelined else None
         loader = task_context.data.loader

@@ -403,7 +403,8 @@ def _run(context, dataset, test_steps, write_hook, entries, world=None):
     if not world.is_root:
         # a rank other than the root of a sharded run: the same loader and the same batch steps, nothing assembled, evaluated or written
         # (the same coalescing: every rank must see the root's batches -- batch indices seed the masks, shapes size the collective)
-        test = loops.Test(test_steps, [], None, entries=(), coalesce=options['coalesce'], pipelined=False)
+        test = loops.Test(test_steps, [], None, entries=(), coalesce=options['coalesce'], pipelined=options['pipelined'],
+                          max_inflight=options['max_inflight'])
         hook = loops.TestLoopHook()
     elif dataset == 'brats':
         test = loops.Test(test_steps, [loops.ExtractSubjectInfoStep(), EvalSubjectStep()], loops.SubjectAssembler(),
