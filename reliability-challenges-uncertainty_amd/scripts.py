@@ -152,7 +152,10 @@ class ConfusionOnDeviceStep(steps.BatchStep):
     def _labels_of(self, subject, dataset, device):
         vol = self._volumes.get(subject)
         if vol is None:
-            labels = np.ascontiguousarray(dataset.direct_extract(subject, ('labels',))['labels'], dtype=np.uint8)
+            labels = dataset.direct_extract(subject, ('labels',)).get('labels')
+            if labels is None:           # a dataset without labels: nothing to count (EvalSubjectStep will say so, as in the reference)
+                return None
+            labels = np.ascontiguousarray(labels, dtype=np.uint8)
             if labels.ndim == 4 and labels.shape[-1] == 1:
                 labels = labels[..., 0]
             vol = self._volumes[subject] = self._upload(labels, device)
@@ -180,7 +183,10 @@ class ConfusionOnDeviceStep(steps.BatchStep):
                 e = b + 1
                 while e < n and subjects[e] == subjects[b] and slices[e] == slices[e - 1] + 1:
                     e += 1
-                pieces.append(self._labels_of(subjects[b], dataset, prediction.device)[slices[b]:slices[b] + (e - b)])
+                volume = self._labels_of(subjects[b], dataset, prediction.device)
+                if volume is None:
+                    return
+                pieces.append(volume[slices[b]:slices[b] + (e - b)])
                 b = e
             target = pieces[0] if len(pieces) == 1 else torch.cat(pieces)
         else:
