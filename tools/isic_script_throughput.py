@@ -70,7 +70,10 @@ def main():
                                (scripts.EvalSubjectStep, '__call__', 'EvalSubjectStep.__call__'), (evaluation, 'confusion_matrx', None),
                                (nifti, 'argmax_last', None), (scripts.WriteHook, 'on_test_subject_end', 'WriteHook.on_test_subject_end'),
                                (loops.Subject2dAssembler, 'add_batch', 'Subject2dAssembler.add_batch'),
-                               (steps.McPredictStep, '__call__', 'McPredictStep.__call__')):
+                               (steps.McPredictStep, '__call__', 'McPredictStep.__call__'), (nifti, 'do_work', None), (nifti, 'write_subject', None),
+                               (os, 'symlink', 'os.symlink'), (scripts.ConfusionOnDeviceStep, '__call__', 'ConfusionOnDeviceStep.__call__'),
+                               (loops._Download, '__init__', '_Download.__init__'), (steps.MultiPredictionSummary, '__call__', 'MultiPredictionSummary.__call__'),
+                               (loops.ConsoleTestLogHook, 'on_test_subject_end', 'ConsoleTestLogHook.on_test_subject_end')):
         wrap(owner, name, label)
     stamps = []
     inner = scripts.WriteHook.on_test_subject_end
