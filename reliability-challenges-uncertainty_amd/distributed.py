@@ -177,8 +177,9 @@ job_seed = steps_mod.job_seed      # seed of the dropout masks of MC pass ``job`
 
 
 class ShardedMcRunner:
-    """``seed``: base seed of the dropout masks.  The masks of MC pass j of volume k are drawn from a generator seeded with
-    ``job_seed(seed, k, j)``, so they do not depend on the rank that runs the pass nor on the world size: every world size
+    """``seed``: base seed of the dropout masks.  The masks of MC pass j of volume k are drawn from the seed ``job_seed(seed, k, j)``
+    (an engine with ``seeded_masks``: the library's own counter-based draw, include/rcu.h rcu_dropout_masks; else a torch generator seeded
+    with it), so they do not depend on the rank that runs the pass nor on the world size: every world size
     aggregates the same T samples (ranks that are all seeded alike, as the reference's ``do_seed`` does with
     ``config.seed``, would otherwise draw the same mask sequence on every rank and the T passes would hold only about T / world
     distinct samples).  ``seed=None`` draws from the device's default generator after seeding it per rank once.

@@ -338,8 +338,8 @@ class SegmentationPredictStep(BatchStep):
 class McPredictStep(BatchStep):
     """T stochastic passes (plus the deterministic 'weight scaling' pass the reference always runs
     first, customsteps.py:22-25).
-    ``seed``: the Dropout2d masks of pass j of batch k are drawn from a generator seeded with ``job_seed(seed, k, j)`` (k =
-    ``batch_context.batch_index``) instead of the device's default generator: the T samples of a batch are then a function of (seed,
+    ``seed``: the Dropout2d masks of pass j of batch k are drawn from the seed ``job_seed(seed, k, j)`` (k = ``batch_context.batch_index``;
+    UNet.seeded_masks: one kernel per launch, include/rcu.h rcu_dropout_masks) instead of the device's default generator: the T samples of a batch are then a function of (seed,
     batch, pass) alone -- the same whatever the pass groups and stream lanes, and the same when the passes are sharded over several GPUs
     (rcu_amd.distributed.ShardedMcPredictStep).  The drop-in scripts pass the YAML file's ``seed``.
     ``exact`` (default): the statistics are exact sums (McStatistics), so that ``MultiPredictionSummary``'s outputs do not depend on
