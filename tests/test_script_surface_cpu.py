@@ -418,6 +418,12 @@ def test_block_loader_equals_the_per_slice_loader(tmp_path, monkeypatch):
                     assert a[key].dtype == b[key].dtype and torch.equal(a[key], b[key]), key
                 else:
                     assert list(a[key]) == list(b[key]), key
+    # the image batch keeps the FILE's channel-last memory order and is handed over as the channel-first view of it (torch's channels_last
+    # format): a memcpy per block on the loader thread, the re-ordering on the GPU behind the upload (steps._images_to_device)
+    ds = data_mod.VolumeDataset(root, transform(), slice_categories=('images',))
+    first = next(iter(torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=data_mod.CollateDict())))['images']
+    assert tuple(first.shape) == (4, 4, 12, 10) and not first.is_contiguous() and first.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(first.contiguous(), torch.from_numpy(np.stack([ds[i]['images'] for i in range(4)])))
     # a transform without a batched form keeps the per-slice path
     class Odd:
         def __call__(self, sample):
@@ -562,3 +568,36 @@ def test_round5_host_rules_seeds_worlds_and_loop_options(tmp_path, monkeypatch):
     # bench.py's volumes-per-step rule
     import bench
     assert [bench.volumes_per_step(w, 21, 4) for w in (1, 2, 4, 8)] == [1, 1, 1, 2]
+
+
+def test_eval_subject_step_sums_the_counts_that_came_with_the_batches():
+    """scripts.EvalSubjectStep with ``subject_data['confusion']`` (scripts.ConfusionOnDeviceStep: tp / tn / fp / fn per slice, taken on the GPU at
+    batch time) -- pure host arithmetic: the rows' sum is the subject's confusion matrix, Dice as evaluation.dice computes it (0 / 0 = 1), the
+    entry is consumed; a 2-D subject's arg-max map that came along is handed to the writer (and kept as int64 where the script keeps it);
+    without the entry the step evaluates the assembled subject itself (needs the GPU: fails loudly here)."""
+    import torch
+    from rcu_amd import loops, scripts
+    rng = np.random.RandomState(1)
+    probabilities = rng.rand(5, 6, 4, 2).astype(np.float32)
+    counts = np.array([[3, 10, 2, 1], [0, 24, 0, 0], [5, 1, 9, 9], [0, 0, 0, 24], [7, 7, 5, 5]], dtype=np.int64)
+    sc = loops.SubjectContext(0, {'probabilities': probabilities, 'confusion': counts.copy(), 'labels': np.zeros((5, 6, 4), np.uint8)})
+    scripts.EvalSubjectStep()(sc, None, None)
+    tp, fp, fn = counts[:, 0].sum(), counts[:, 2].sum(), counts[:, 3].sum()
+    assert sc.metrics == {'dice': 2 * tp / (2 * tp + fp + fn)} and 'confusion' not in sc.subject_data and 'prediction' not in sc.more
+    empty = loops.SubjectContext(1, {'probabilities': probabilities, 'confusion': np.array([[0, 24, 0, 0]]), 'labels': None})
+    scripts.EvalSubjectStep()(empty, None, None)
+    assert empty.metrics == {'dice': 1.0}
+    made = (probabilities[0, ..., 1] > probabilities[0, ..., 0]).astype(np.uint8)[..., None]          # [H, W, 1], as the loop delivers it
+    two_d = loops.SubjectContext('ISIC_1', {'probabilities': probabilities[0], 'confusion': counts[0], 'prediction': made.copy(), 'labels': None})
+    scripts.EvalSubjectStep(squeeze_labels=True, keep_prediction=True)(two_d, None, None)
+    assert two_d.metrics == {'dice': 2 * 3 / (2 * 3 + 2 + 1)}
+    assert two_d.subject_data['prediction'].dtype == np.int64 and np.array_equal(two_d.subject_data['prediction'], made[..., 0])
+    cached, source = two_d.more['prediction']
+    assert cached.dtype == np.uint8 and np.array_equal(cached, made[..., 0]) and source is two_d.subject_data['probabilities']
+    dropped = loops.SubjectContext('ISIC_2', {'probabilities': probabilities[0], 'confusion': counts[0], 'prediction': made.copy(), 'labels': None})
+    scripts.EvalSubjectStep()(dropped, None, None)
+    assert 'prediction' not in dropped.subject_data and np.array_equal(dropped.more['prediction'][0], made[..., 0])
+    if not torch.cuda.is_available():
+        plain = loops.SubjectContext(2, {'probabilities': probabilities, 'labels': np.zeros((5, 6, 4), np.uint8)})
+        with pytest.raises(RuntimeError):
+            scripts.EvalSubjectStep()(plain, None, None)
