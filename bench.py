@@ -977,7 +977,7 @@ def main():
         'devices': devices_seen,
         'distinct_devices': len({(d_['uuid'], d_['pci'], d_['device_index']) for d_ in devices_seen}),
         'forwards_per_rank': forwards_per_rank,
-        'device_allocs_in_timed_region': device_allocs_in_timed_region,   # hipMalloc calls (implicit device syncs) the timed steps caused: 0 in the steady state
+        'device_allocs_in_timed_region': device_allocs_in_timed_region,   # hipMalloc calls of torch's allocator inside the timed steps: ~2.6 per step -- the summaries of all K volumes are held until the region ends (dropping them early: 16 instead of 103 calls in 40 steps, the same rate: 176.0-176.5 either way, round 5)
         'resident': dict(value=units * args.steps / elapsed_resident, ms_per_step=elapsed_resident / args.steps * 1e3, steps=args.steps,
                          note='the same steps with the volume already in HBM when the clock starts (no host-to-device copy): the '
                               'secondary figure; `value` has the prefetched copy inside'),
