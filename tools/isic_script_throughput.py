@@ -17,6 +17,7 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 from rcu_amd import evaluation, loops, nifti, scripts, steps  # noqa: E402
+from rcu_amd import model as model_mod  # noqa: E402
 from rcu_amd import management as mgt  # noqa: E402
 from test_gpu_scripts import ISIC_MC_YAML  # noqa: E402  (the reference's YAML layout)
 
@@ -73,8 +74,14 @@ def main():
                                (steps.McPredictStep, '__call__', 'McPredictStep.__call__'), (nifti, 'do_work', None), (nifti, 'write_subject', None),
                                (os, 'symlink', 'os.symlink'), (scripts.ConfusionOnDeviceStep, '__call__', 'ConfusionOnDeviceStep.__call__'),
                                (loops._Download, '__init__', '_Download.__init__'), (steps.MultiPredictionSummary, '__call__', 'MultiPredictionSummary.__call__'),
-                               (loops.ConsoleTestLogHook, 'on_test_subject_end', 'ConsoleTestLogHook.on_test_subject_end')):
+                               (loops.ConsoleTestLogHook, 'on_test_subject_end', 'ConsoleTestLogHook.on_test_subject_end'),
+                               (steps, 'reserve_canonical_plans', None), (steps, '_images_to_device', None), (steps, 'set_dropout_mode', None),
+                               (steps, 'softmax', None), (steps, 'merge_statistics', None), (steps.McStatistics, '__init__', 'McStatistics.__init__'),
+                               (steps.StreamLanes, 'begin', 'StreamLanes.begin'), (steps.StreamLanes, 'run', 'StreamLanes.run'),
+                               (steps.StreamLanes, 'end', 'StreamLanes.end'), (scripts.PrepareSubjectStep, '__call__', 'PrepareSubjectStep.__call__')):
         wrap(owner, name, label)
+    for name in ('forward', 'forward_accumulate', 'seeded_masks', '_handle'):
+        wrap(model_mod.UNet, name, 'UNet.' + name)
     stamps = []
     inner = scripts.WriteHook.on_test_subject_end
 
