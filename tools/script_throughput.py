@@ -53,6 +53,16 @@ def main():
         assert 'coalesce_pixels' in text
     if len(sys.argv) > 5 and sys.argv[5] == 'timing':
         text = text.replace('  others:\n', '  others:\n    loader_timing: true\n', 1)
+    # RCU_SCRIPT_ENSEMBLE=K: bin-dl/brats_test_ensemble.py's surface instead -- K members (the first is the config's model_dir), no MC passes
+    members = int(os.environ.get('RCU_SCRIPT_ENSEMBLE', '0'))
+    if members > 1:
+        extra = []
+        for k in range(1, members):
+            mk = mgt.ModelFiles(os.path.join(tmp, 'train_{}'.format(k)), 'syn{}'.format(k))
+            mgt.save_model(mk, 'unet', bench.MODEL_PARAMS, {key: v.cpu() for key, v in bench.make_model(20 + k, torch.device('cuda')).state_dict().items()})
+            extra.append(mk.model_dir)
+        text = text.replace('    mc: {}\n'.format(mc), '    model_dir:\n' + ''.join('    - {}\n'.format(d) for d in extra) + '    test_at: best\n')
+        assert '    model_dir:\n    - ' in text
     cfg = os.path.join(tmp, 'test_brats_baseline_mc.yaml')
     with open(cfg, 'w') as f:
         f.write(text)
@@ -69,7 +79,10 @@ def main():
     t0 = time.perf_counter()
     if profile:
         prof.enable()
-    scripts.test_default('brats', cfg, None)
+    if members > 1:
+        scripts.test_ensemble('brats', cfg)
+    else:
+        scripts.test_default('brats', cfg, None)
     if profile:
         prof.disable()
     dt = time.perf_counter() - t0
