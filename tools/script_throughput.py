@@ -36,9 +36,11 @@ def main():
         props = nifti.ImageProperties((bench.WIDTH, bench.HEIGHT, bench.SLICES), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
         data_mod.write_volume(os.path.join(tmp, 'ds'), name, images, target.numpy(), props)
         names.append(name)
-    model = bench.make_model(20, torch.device('cuda'))
+    aleatoric = os.environ.get('RCU_SCRIPT_ALEATORIC') == '1'      # bin-dl/brats_test_aleatoric.py's surface: sigma head, one deterministic pass per batch
+    model = bench.make_model(20, torch.device('cuda'), sigma_out=aleatoric)
     mf = mgt.ModelFiles(os.path.join(tmp, 'train'), 'syn')
-    mgt.save_model(mf, 'unet', bench.MODEL_PARAMS, {k: v.cpu() for k, v in model.state_dict().items()})
+    mgt.save_model(mf, 'unet', dict(bench.MODEL_PARAMS, sigma_out=True) if aleatoric else bench.MODEL_PARAMS,
+                   {k: v.cpu() for k, v in model.state_dict().items()})
     split = os.path.join(tmp, 'split.json')
     with open(split, 'w') as f:
         json.dump({'train': [], 'valid': [], 'test': names}, f)
@@ -81,6 +83,8 @@ def main():
         prof.enable()
     if members > 1:
         scripts.test_ensemble('brats', cfg)
+    elif aleatoric:
+        scripts.test_aleatoric('brats', cfg)
     else:
         scripts.test_default('brats', cfg, None)
     if profile:
