@@ -488,6 +488,33 @@ class _ReadAhead:
         self.pool.shutdown(wait=False, cancel_futures=True)
 
 
+class _LoaderAhead:
+    """``Loader`` objects for the coming subjects of the reference-ordered loop, their caches filled by the reader threads: the union of what
+    the run's actions will ask ``Loader.get_data`` for (one task per file, as ``_ReadAhead``)."""
+
+    def __init__(self, subject_files, params_list, depth):
+        # (the actions of a run share its confidence entry; an action that wants another one reads it itself: a cache miss in Loader)
+        union = Loader.Params(params_list[0].misc_entry, need_target=False, need_prediction=False, need_t2_mask=False)
+        for p in params_list:
+            union.need_target |= bool(p.need_target)
+            union.need_prediction |= bool(p.need_prediction)
+            union.need_t2_mask |= bool(p.need_t2_mask)
+        self.reader = _ReadAhead(subject_files, union, depth)
+        self.subject_files = subject_files
+
+    def get(self, i):
+        sf = self.subject_files[i]
+        loader = Loader()
+        loader.cached_subject = sf.subject
+        data = self.reader.get(i)
+        data.pop('_read_s', None)
+        loader.cached.update(data)
+        return loader
+
+    def close(self):
+        self.reader.close()
+
+
 def _fusable(entry, actions):
     """The fused loop covers the runs whose confidence entry IS the probability map (baseline, baseline_mc, center, center_mc, ensemble:
     evaldata.py:21-47) -- no rescaling, no uncertainty-to-probability conversion -- and the four actions of the script."""
@@ -622,12 +649,20 @@ def evaluate_runs(eval_data_list, action_names, base_dir, ece_details='', fused=
             for action in actions:
                 action.finish_eval()
             continue
-        for i, sf in enumerate(entry.subject_files):
-            print('[{}/{}] {}'.format(i + 1, len(entry.subject_files), sf.subject), end=' ', flush=True)
-            loader = Loader()
-            start = time.time()
-            for action in actions:
-                action.eval_subject(sf, loader)
-            print('({}s)'.format(time.time() - start))
+        # the reference's subject-by-subject, action-by-action order (eval_uncertainty.py:36-46); the files of the coming subjects are read by
+        # the threads of _ReadAhead meanwhile, into the caches of the subjects' Loaders (what an action asks for first is there already)
+        wanted = [a.load_params for a in actions if a.load_params is not None]
+        ahead = _LoaderAhead(entry.subject_files, wanted, depth=4) if (wanted and len(entry.subject_files) > 1) else None
+        try:
+            for i, sf in enumerate(entry.subject_files):
+                print('[{}/{}] {}'.format(i + 1, len(entry.subject_files), sf.subject), end=' ', flush=True)
+                loader = ahead.get(i) if ahead is not None else Loader()
+                start = time.time()
+                for action in actions:
+                    action.eval_subject(sf, loader)
+                print('({}s)'.format(time.time() - start))
+        finally:
+            if ahead is not None:
+                ahead.close()
         for action in actions:
             action.finish_eval()
