@@ -89,7 +89,11 @@ typedef struct rcu_unet_options {
                                  0: the standalone head kernel (also settable per handle at run time: rcu_unet_set_fuse_head) */
     int32_t head_winograd4;   /* 1 (default): conv_cls.0 -- with the classifier fused into its epilogue or not -- takes F(4x4,3x3) where the 32x32 tile
                                  fits (and conv_winograd4 is 1 or 2); 0: it stays on F(2x2,3x3), the plan of rounds 1-4 (A/B measurements) */
-    int32_t reserved[2];      /* must be 0 */
+    int32_t pad_levels;       /* 1 (default): a level whose real extent (height >> l) x (width >> l) is not a whole number of Winograd tiles is ALLOCATED with
+                                 a padded extent -- the padding holds zeros no kernel writes, which is the conv's own zero padding -- and runs on the Winograd
+                                 kernels (the reference's BraTS slices are 240 x 240: levels 240, 120, 60, 30, 15; ISIC's 192 x 256 ends in a 12 x 16 level);
+                                 0: real extents only, such levels take the direct kernels (the plans of rounds 1-5; A/B measurements) */
+    int32_t reserved[1];      /* must be 0 */
 } rcu_unet_options;
 /* fills *opts with the defaults above */
 void rcu_unet_default_options(rcu_unet_options* opts);
@@ -99,6 +103,10 @@ void rcu_unet_default_options(rcu_unet_options* opts);
  * 6 GB of activations.  Handles that share a workspace must not run concurrently (launch them on ONE stream); the workspace is
  * freed when its last user is destroyed, in any order. */
 int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_options* opts, rcu_unet* workspace_donor, rcu_unet** out);
+/* The plan alone -- which kernel runs which layer on which grid (rcu_unet_num_layers / rcu_unet_layer_info) -- without any device memory: a handle
+ * that can be inspected and destroyed, nothing else (weights and forwards fail with RCU_ERR_STATE / RCU_ERR_HIP).  What a caller sizes its launches
+ * by, and what the planner's tests read without a GPU. */
+int rcu_unet_plan(const rcu_unet_desc* desc, const rcu_unet_options* opts, rcu_unet** out);
 /* Run-time form of rcu_unet_options.fuse_head (benchmarks time the standalone head kernel on the plan of the timed run). */
 int rcu_unet_set_fuse_head(rcu_unet* h, int on);
 
@@ -163,6 +171,8 @@ typedef struct rcu_layer_info {
     char name[96];
     char kernel[64];
     int32_t cin, cout, height, width;
+    int32_t grid_height, grid_width; /* the grid the kernel's tiles walk: the ALLOCATED extent of the layer's level (an up-convolution's low-resolution
+                                        level), larger than the real one on a padded level (rcu_unet_options.pad_levels) */
     int32_t upsample, pooled, dual_source;
     int32_t head_fusable;         /* 1: forwards that want logits or statistics (no sigma) run this unit with the classifier head in the kernel's epilogue
                                      while rcu_unet_options.fuse_head is on -- profilers see that kernel as `kernel` + "+head"; rcu_unet_run_layer runs the plain one */

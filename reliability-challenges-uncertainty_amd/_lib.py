@@ -37,12 +37,12 @@ class UnetDesc(Structure):
 
 class UnetOptions(Structure):
     """rcu_unet_options (include/rcu.h): the planner's kernel-family / layout choices; defaults = the shipped path."""
-    _fields_ = [(n, c_int32) for n in ('conv_winograd', 'conv_winograd4', 'conv_first', 'act_layout', 'fuse_head', 'head_winograd4')] + [('reserved', c_int32 * 2)]
+    _fields_ = [(n, c_int32) for n in ('conv_winograd', 'conv_winograd4', 'conv_first', 'act_layout', 'fuse_head', 'head_winograd4', 'pad_levels')] + [('reserved', c_int32 * 1)]
 
 
 class LayerInfo(Structure):
     _fields_ = [('name', c_char * 96), ('kernel', c_char * 64), ('cin', c_int32), ('cout', c_int32),
-                ('height', c_int32), ('width', c_int32), ('upsample', c_int32), ('pooled', c_int32),
+                ('height', c_int32), ('width', c_int32), ('grid_height', c_int32), ('grid_width', c_int32), ('upsample', c_int32), ('pooled', c_int32),
                 ('dual_source', c_int32), ('head_fusable', c_int32), ('flops_per_slice', c_double), ('mfma_flops_per_slice', c_double)]
 
 
@@ -58,6 +58,7 @@ SIGNATURES = {
     'rcu_unet_create': (c_int, [POINTER(UnetDesc), POINTER(c_void_p)]),
     'rcu_unet_destroy': (c_int, [c_void_p]),
     'rcu_unet_default_options': (None, [POINTER(UnetOptions)]),
+    'rcu_unet_plan': (c_int, [POINTER(UnetDesc), POINTER(UnetOptions), POINTER(c_void_p)]),
     'rcu_unet_create_with': (c_int, [POINTER(UnetDesc), POINTER(UnetOptions), c_void_p, POINTER(c_void_p)]),
     'rcu_unet_set_fuse_head': (c_int, [c_void_p, c_int]),
     'rcu_unet_workspace_bytes': (c_int64, [c_void_p]),

@@ -46,7 +46,9 @@ struct ConvLayer {
     int cout = 0;            // real output channels (per twin)
     int coutp = 0;           // padded output channels (both twins)
     int csplit = 0;          // first channel of the twin
-    int H = 0, W = 0;
+    int H = 0, W = 0;        // REAL extent of the unit's output grid (an up-convolution: of the up-sampled grid before the centre pad)
+    int level = 0;           // level of the tile grid: the unit's own level, an up-convolution's LOW-resolution level
+    int gh = 0, gw = 0;      // ALLOCATED extent of that level = the grid the tiles walk (== its real extent unless the level is padded)
     int upsample = 0, relu = 0;
     int is_1x1 = 0;          // ConvResidualBlock's residual conv: a 1x1 kernel, run as a 3x3 unit whose centre tap alone is non-zero
     int accumulate = 0;      // the unit's result is added to what its output tensor holds (the residual conv's output)
@@ -61,7 +63,9 @@ struct Tensor {
     size_t floats_per_slice = 0;
     float* dev = nullptr;
     bool zero_fill = false;   // centre-padded up-conv output: the border is never written and must read as zero
-    int H = 0, W = 0, cp = 0;
+    int H = 0, W = 0, cp = 0; // ALLOCATED extent (floats_per_slice = H W cp)
+    int Hr = 0, Wr = 0;       // real extent; smaller on a padded level (choose_level_extents): the pixels beyond it hold zeros nobody writes
+    bool padded() const { return H != Hr || W != Wr; }
     bool blocked = false;     // [N][C/8][H][W][8] instead of NHWC (rcu_kernels.h, ConvArgs): decided per tensor by assign_layouts
 };
 
@@ -85,6 +89,7 @@ struct rcu_unet {
     bool ws_borrowed = false;
     std::vector<ConvLayer> layers;
     std::vector<Tensor> tensors;
+    std::vector<std::pair<int, int>> level_ext;       // allocated (H, W) of the activation tensors of level 0 .. depth (choose_level_extents)
     std::vector<std::pair<std::string, int>> sites;   // (name, channels)
     std::vector<int> site_offset;                     // prefix sums of channels
     int mask_floats = 0;
@@ -93,6 +98,7 @@ struct rcu_unet {
     std::map<std::string, std::vector<float>> host_weights;
     float *w_cls = nullptr, *b_cls = nullptr, *w_sig = nullptr, *b_sig = nullptr;
     bool finalized = false;
+    bool plan_only = false;   // rcu_unet_plan: no workspace -- the handle can be inspected, never run
     int64_t workspace_bytes = 0;
     std::vector<void*> allocs;
     // optional per-layer timing with HIP events on the caller's stream (rcu_unet_profile_*)
@@ -102,11 +108,14 @@ struct rcu_unet {
 
 static int prof_slots(const rcu_unet* h) { return (int)h->layers.size() + 3; }
 
-static int new_tensor(rcu_unet* h, int H, int W, int cp)
+// a tensor of level `level` (allocated with the level's extent), or -- level < 0 -- one that is exactly Hr x Wr
+static int new_tensor(rcu_unet* h, int level, int Hr, int Wr, int cp)
 {
     Tensor t;
-    t.H = H; t.W = W; t.cp = cp;
-    t.floats_per_slice = (size_t)H * W * cp;
+    t.Hr = Hr; t.Wr = Wr; t.cp = cp;
+    t.H = level >= 0 ? h->level_ext[level].first : Hr;
+    t.W = level >= 0 ? h->level_ext[level].second : Wr;
+    t.floats_per_slice = (size_t)t.H * t.W * cp;
     h->tensors.push_back(t);
     return (int)h->tensors.size() - 1;
 }
@@ -131,7 +140,9 @@ static size_t conv_tile_floats(const ConvConfigInfo& ci)
 
 static bool is_head_unit(const ConvLayer& L) { return L.name.rfind("conv_cls.0", 0) == 0; }
 
-static int pick_config(const ConvLayer& L, int n_slices, const rcu_unet_options& opt)
+// Which kernel runs a layer.  (gh, gw) = L.gh x L.gw is the grid the tiles walk: the ALLOCATED extent of the layer's level (an up-convolution's
+// low-resolution level), which is the real extent unless the level is padded (choose_level_extents); oh x ow the allocated extent of its output tensor.
+static int pick_config(const ConvLayer& L, int n_slices, const rcu_unet_options& opt, int oh, int ow)
 {
     // Winograd kernels (rcu_wino.hip, rcu_wino_up.hip): 16/36 (conv units) and 9/36 (up-convolutions) of the
     // multiplications.  They address activations through 32-bit byte offsets of a buffer resource (tensors < 2 GB)
@@ -141,27 +152,28 @@ static int pick_config(const ConvLayer& L, int n_slices, const rcu_unet_options&
     // rcu_unet_options.conv_winograd = 0 keeps every layer on the direct kernels of rcu_conv.hip (A/B tests)
     // a unit that adds to its output tensor (ConvResidualBlock's second unit) runs on the direct kernels, whose epilogue can
     const bool wino_on = opt.conv_winograd != 0 && !L.accumulate;
+    const int gh = L.gh, gw = L.gw;
     // (an up-convolution reads the LOW-resolution grid: L.H x L.W is its output grid)
-    const size_t in_px = L.upsample ? (size_t)(L.H / 2) * (L.W / 2) : (size_t)L.H * L.W;
-    const size_t max_bytes = (size_t)n_slices * std::max(in_px * (size_t)std::max(L.c1p, L.c2p), (size_t)L.H * L.W * (size_t)L.coutp) * 4;
+    const size_t in_px = (size_t)gh * gw;
+    const size_t max_bytes = (size_t)n_slices * std::max(in_px * (size_t)std::max(L.c1p, L.c2p), (size_t)oh * ow * (size_t)L.coutp) * 4;
     const bool center_pad = L.upsample && (2 * (L.H / 2) != L.H || 2 * (L.W / 2) != L.W);   // unet.py:110-116: direct kernel only
     if (L.upsample && !center_pad && wino_on && L.c1p % 32 == 0 && L.c2p == 0 && max_bytes < ((size_t)1 << 31)) {
-        const int lh = L.H / 2, lw = L.W / 2;
+        const int lh = gh, lw = gw;
         if (L.coutp == 32 && lh % 16 == 0 && lw % 32 == 0) return CONV_CFG_UPW_T16x32_N32;
         if (L.coutp > 32 && lh % 16 == 0 && lw % 16 == 0) return CONV_CFG_UPW_T16x16_N64;
         if (L.coutp > 32 && lh % 8 == 0 && lw % 16 == 0) return CONV_CFG_UPW_S2T8x16_N64;
         if (L.coutp > 32 && lh % 4 == 0 && lw == 8) return CONV_CFG_UPW_S8T4x8_N64;
     }
-    if (L.upsample) {   // sub-pixel form; L.H x L.W is the OUTPUT grid, tiles run over the low-res input grid
-        if (L.coutp <= 32) return ((L.H / 2) % 16 == 0 && (L.W / 2) % 16 == 0) ? CONV_CFG_UP_T16x16_N32 : CONV_CFG_UP_T8x16_N32;
-        if (L.H == 24 && L.W == 16) return CONV_CFG_UP_S2T12x8_N64;
+    if (L.upsample) {   // sub-pixel form; tiles run over the low-res input grid
+        if (L.coutp <= 32) return (gh % 16 == 0 && gw % 16 == 0) ? CONV_CFG_UP_T16x16_N32 : CONV_CFG_UP_T8x16_N32;
+        if (gh == 12 && gw == 8) return CONV_CFG_UP_S2T12x8_N64;
         return CONV_CFG_UP_T8x16_N64;
     }
     if (L.c1p + L.c2p == 8) {
         // the network's first conv unit: unpadded K = 9 x 4 (8) on whole 8x32 tiles (rcu_first.hip); rcu_unet_options.conv_first = 0
         // keeps the tiled kernel (A/B tests)
         const bool first_on = opt.conv_first != 0;
-        if (first_on && L.c2p == 0 && L.H % 8 == 0 && L.W % 32 == 0 && (L.coutp == 32 || L.coutp == 64) && L.t_pool < 0 &&
+        if (first_on && L.c2p == 0 && gh % 8 == 0 && gw % 32 == 0 && (L.coutp == 32 || L.coutp == 64) && L.t_pool < 0 &&
             L.name2.empty() && !L.accumulate)
             return CONV_CFG_FIRST_T8x32;
         return CONV_CFG_T8x16_N32_FIRST;
@@ -180,48 +192,48 @@ static int pick_config(const ConvLayer& L, int n_slices, const rcu_unet_options&
         // rounds 1-4 -- it stays on F(2x2,3x3).  The 64-cout cls + sigma twin unit has no fused form and takes F(4x4,3x3) like any layer.
         const bool lone_head = is_head_unit(L) && L.name2.empty();
         const bool w4_ok = w4_mode != 0 && (L.coutp >= 64 || w4_mode != 3) &&
-                           !(lone_head && (opt.head_winograd4 == 0 || L.coutp != 32 || L.H % 32 != 0 || L.W % 32 != 0));
-        if (w4_ok && L.W % 32 == 0) {
-            if (L.H % 32 == 0) return CONV_CFG_WINO4_T32x32_N32;
-            if (L.H % 16 == 0) return CONV_CFG_WINO4_S2T16x32_N32;
+                           !(lone_head && (opt.head_winograd4 == 0 || L.coutp != 32 || gh % 32 != 0 || gw % 32 != 0));
+        if (w4_ok && gw % 32 == 0) {
+            if (gh % 32 == 0) return CONV_CFG_WINO4_T32x32_N32;
+            if (gh % 16 == 0) return CONV_CFG_WINO4_S2T16x32_N32;
         }
-        if (w4_ok && L.W == 16 && L.H % 8 == 0) return CONV_CFG_WINO4_S8T8x16_N32;
+        if (w4_ok && gw == 16 && gh % 8 == 0) return CONV_CFG_WINO4_S8T8x16_N32;
         // the 12x8 level (bottom_convs): F(4x4,3x3) with a slice's 6 tiles in the 8 tile slots of the S8 block -- 3 multiplications per output
         // pixel executed (2.25 x 4/3) against F(2x2,3x3)'s 4 (round 5; no pooled output in this geometry)
-        if (w4_ok && L.W == 8 && L.H % 12 == 0 && L.t_pool < 0) {
+        if (w4_ok && gw == 8 && gh % 12 == 0 && L.t_pool < 0) {
             // ... where its few, long work items fill the chip's rounds: one item = 8 slices x 32 couts against F(2x2,3x3)'s 8 slices x a 4x8 strip x
             // 64 couts.  Measured per round of 256 workgroups (bottom_convs, tools/layer_report.py): 0.282 against 0.210 ms, so the folded form wins
             // when rounds_4 * 1.35 < rounds_2 -- 640 samples: 5 against 8 rounds (1.41 against 1.68 ms), 480: 4 against 6; but 160 samples
             // (an ensemble member's launch): 2 against 2 (0.57 against 0.44 ms), 320: 3 against 4 (a tie) -- there F(2x2,3x3) stays
             const long groups = (n_slices + 7) / 8;
-            const long rounds4 = (groups * (L.H / 12) * (L.coutp / 32) + 255) / 256;
-            const long rounds2 = (groups * (L.H / 4) * ((L.coutp + 63) / 64) + 255) / 256;
+            const long rounds4 = (groups * (gh / 12) * (L.coutp / 32) + 255) / 256;
+            const long rounds2 = (groups * (gh / 4) * ((L.coutp + 63) / 64) + 255) / 256;
             if (w4_mode == 2 || L.coutp <= 32 || (double)rounds4 * 1.35 < (double)rounds2) return CONV_CFG_WINO4_S8T12x8_N32;   // (2: whatever the fill -- parity tests on small batches)
         }
-        if (L.coutp == 32 && L.H % 16 == 0 && L.W % 32 == 0) return CONV_CFG_WINO_T16x32_N32;
-        if (L.coutp > 32 && L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_T16x16_N64;
-        if (L.coutp > 32 && L.H % 8 == 0 && L.W % 16 == 0) return CONV_CFG_WINO_S2T8x16_N64;
-        if (L.coutp > 32 && L.H % 4 == 0 && L.W == 8) return CONV_CFG_WINO_S8T4x8_N64;
+        if (L.coutp == 32 && gh % 16 == 0 && gw % 32 == 0) return CONV_CFG_WINO_T16x32_N32;
+        if (L.coutp > 32 && gh % 16 == 0 && gw % 16 == 0) return CONV_CFG_WINO_T16x16_N64;
+        if (L.coutp > 32 && gh % 8 == 0 && gw % 16 == 0) return CONV_CFG_WINO_S2T8x16_N64;
+        if (L.coutp > 32 && gh % 4 == 0 && gw == 8) return CONV_CFG_WINO_S8T4x8_N64;
     }
     if (L.coutp > 32) {
-        if (L.H == 12 && L.W == 8) return CONV_CFG_S2T12x8_N64;
+        if (gh == 12 && gw == 8) return CONV_CFG_S2T12x8_N64;
         // 128-pixel tiles run 3 workgroups per CU (768 slots), 256-pixel tiles 2 (512 slots) with half the staging,
         // barriers and fragment reads per MFMA.  Measured on the BraTS levels (tools/layer_report.py): the big tile
         // wins where every work item stages its own input tile (one channel tile) and where the small tile's last
         // round of work items is badly filled (24x16: 2.5 rounds); it loses 3 % at 48x32 (5 full rounds).
         const int nt = (L.coutp + 63) / 64;
-        const long items = (long)((L.H + 7) / 8) * ((L.W + 15) / 16) * n_slices * nt;
+        const long items = (long)((gh + 7) / 8) * ((gw + 15) / 16) * n_slices * nt;
         const double fill = (double)items / (double)((items + 767) / 768 * 768);
         if (nt == 1 || fill < 0.9) {
-            if (L.H % 16 == 0 && L.W % 16 == 0) return CONV_CFG_T16x16_N64;
-            if (L.H % 8 == 0 && L.W % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_S2T8x16_N64;
+            if (gh % 16 == 0 && gw % 16 == 0) return CONV_CFG_T16x16_N64;
+            if (gh % 8 == 0 && gw % 16 == 0 && n_slices % 2 == 0) return CONV_CFG_S2T8x16_N64;
         }
         return CONV_CFG_T8x16_N64;
     }
-    return (L.H % 16 == 0 && L.W % 16 == 0) ? CONV_CFG_T16x16_N32 : CONV_CFG_T8x16_N32;
+    return (gh % 16 == 0 && gw % 16 == 0) ? CONV_CFG_T16x16_N32 : CONV_CFG_T8x16_N32;
 }
 
-static void add_unit(rcu_unet* h, const std::string& prefix, int cin1, int c1p, int cin2, int c2p, int cout, int H, int W,
+static void add_unit(rcu_unet* h, const std::string& prefix, int cin1, int c1p, int cin2, int c2p, int cout, int level, int H, int W,
                      bool dropout, int t_src1, int t_src2, int t_out, int t_pool, bool residual_tail = false)
 {
     ConvLayer L;
@@ -230,6 +242,7 @@ static void add_unit(rcu_unet* h, const std::string& prefix, int cin1, int c1p, 
     L.cin1 = cin1; L.c1p = c1p; L.cin2 = cin2; L.c2p = c2p;
     L.cout = cout; L.coutp = round_up(cout, 32); L.csplit = L.coutp;
     L.H = H; L.W = W; L.relu = residual_tail ? 0 : 1;
+    L.level = level; L.gh = h->level_ext[level].first; L.gw = h->level_ext[level].second;
     L.accumulate = residual_tail ? 1 : 0;
     if (dropout) {
         L.site = (int)h->sites.size();
@@ -241,7 +254,7 @@ static void add_unit(rcu_unet* h, const std::string& prefix, int cin1, int c1p, 
 
 // ConvResidualBlock (common/model/unet.py:42-60): conv1x1(block input) + bias into the block's output tensor; the block's second
 // unit (no ReLU) then adds its result to it.  `prefix`: the block's module path ("down_convs.0.block", "bottom_convs", ...).
-static void add_residual_conv(rcu_unet* h, const std::string& prefix, int cin1, int c1p, int cin2, int c2p, int cout, int H, int W,
+static void add_residual_conv(rcu_unet* h, const std::string& prefix, int cin1, int c1p, int cin2, int c2p, int cout, int level, int H, int W,
                               int t_src1, int t_src2, int t_out)
 {
     ConvLayer L;
@@ -250,45 +263,58 @@ static void add_residual_conv(rcu_unet* h, const std::string& prefix, int cin1, 
     L.cin1 = cin1; L.c1p = c1p; L.cin2 = cin2; L.c2p = c2p;
     L.cout = cout; L.coutp = round_up(cout, 32); L.csplit = L.coutp;
     L.H = H; L.W = W; L.relu = 0;
+    L.level = level; L.gh = h->level_ext[level].first; L.gw = h->level_ext[level].second;
     L.t_src1 = t_src1; L.t_src2 = t_src2; L.t_out = t_out;
     h->layers.push_back(L);
 }
 
 static void assign_layouts(rcu_unet* h);
 
-static int build_plan(rcu_unet* h)
+// the kernels whose store side honours ConvArgs::part (a padded level): the Winograd families and rcu_first.hip
+static bool cfg_handles_padding(int cfg)
+{
+    return cfg == CONV_CFG_FIRST_T8x32 || (cfg >= CONV_CFG_WINO_T16x16_N64 && cfg <= CONV_CFG_UPW_S8T4x8_N64) ||
+           (cfg >= CONV_CFG_WINO4_T32x32_N32 && cfg < CONV_CFG_END);
+}
+
+// Builds layers and tensors for the level extents in h->level_ext (build_plan: the real extents; choose_level_extents tries padded ones).
+// *valid = false when a layer that touches a padded tensor got a kernel that cannot: such a plan must not run.
+static int build_plan_for(rcu_unet* h, bool* valid)
 {
     const rcu_unet_desc& d = h->d;
     const int depth = d.depth;
+    h->layers.clear();
+    h->tensors.clear();
+    h->sites.clear();
     h->in_cp = round_up(d.in_channels, 8);
-    h->t_input = new_tensor(h, d.height, d.width, h->in_cp);
+    h->t_input = new_tensor(h, 0, d.height, d.width, h->in_cp);
     std::vector<int> skip(depth), skip_c(depth);
     int cur = h->t_input, cur_c = d.in_channels, cur_cp = h->in_cp;
     int c = d.start_filters;
     char buf[128];
     for (int l = 0; l < depth; ++l) {
         const int H = d.height >> l, W = d.width >> l, cp = round_up(c, 32);
-        const int t_tmp = new_tensor(h, H, W, cp), t_skip = new_tensor(h, H, W, cp);
-        const int t_pool = new_tensor(h, H / 2, W / 2, cp);
+        const int t_tmp = new_tensor(h, l, H, W, cp), t_skip = new_tensor(h, l, H, W, cp);
+        const int t_pool = new_tensor(h, l + 1, H / 2, W / 2, cp);
         snprintf(buf, sizeof buf, "down_convs.%d.block.block.0", l);
-        add_unit(h, buf, cur_c, cur_cp, 0, 0, c, H, W, unit_has_dropout(d, l, true, 0), cur, -1, t_tmp, -1);
+        add_unit(h, buf, cur_c, cur_cp, 0, 0, c, l, H, W, unit_has_dropout(d, l, true, 0), cur, -1, t_tmp, -1);
         if (d.residual) {
             snprintf(buf, sizeof buf, "down_convs.%d.block", l);
-            add_residual_conv(h, buf, cur_c, cur_cp, 0, 0, c, H, W, cur, -1, t_skip);
+            add_residual_conv(h, buf, cur_c, cur_cp, 0, 0, c, l, H, W, cur, -1, t_skip);
         }
         snprintf(buf, sizeof buf, "down_convs.%d.block.block.1", l);
-        add_unit(h, buf, c, cp, 0, 0, c, H, W, unit_has_dropout(d, l, true, 1), t_tmp, -1, t_skip, t_pool, d.residual != 0);
+        add_unit(h, buf, c, cp, 0, 0, c, l, H, W, unit_has_dropout(d, l, true, 1), t_tmp, -1, t_skip, t_pool, d.residual != 0);
         skip[l] = t_skip; skip_c[l] = c;
         cur = t_pool; cur_c = c; cur_cp = cp;
         c *= 2;
     }
     {
         const int H = d.height >> depth, W = d.width >> depth, cp = round_up(c, 32);
-        const int t_tmp = new_tensor(h, H, W, cp), t_out = new_tensor(h, H, W, cp);
-        add_unit(h, "bottom_convs.block.0", cur_c, cur_cp, 0, 0, c, H, W, unit_has_dropout(d, depth, true, 0), cur, -1,
+        const int t_tmp = new_tensor(h, depth, H, W, cp), t_out = new_tensor(h, depth, H, W, cp);
+        add_unit(h, "bottom_convs.block.0", cur_c, cur_cp, 0, 0, c, depth, H, W, unit_has_dropout(d, depth, true, 0), cur, -1,
                  t_tmp, -1);
-        if (d.residual) add_residual_conv(h, "bottom_convs", cur_c, cur_cp, 0, 0, c, H, W, cur, -1, t_out);
-        add_unit(h, "bottom_convs.block.1", c, cp, 0, 0, c, H, W, unit_has_dropout(d, depth, true, 1), t_tmp, -1, t_out,
+        if (d.residual) add_residual_conv(h, "bottom_convs", cur_c, cur_cp, 0, 0, c, depth, H, W, cur, -1, t_out);
+        add_unit(h, "bottom_convs.block.1", c, cp, 0, 0, c, depth, H, W, unit_has_dropout(d, depth, true, 1), t_tmp, -1, t_out,
                  -1, d.residual != 0);
         cur = t_out; cur_c = c; cur_cp = cp;
     }
@@ -296,33 +322,35 @@ static int build_plan(rcu_unet* h)
         const int l = depth - 1 - j;
         const int H = d.height >> l, W = d.width >> l;
         const int co = cur_c / 2, cop = round_up(co, 32);
-        const int t_up = new_tensor(h, H, W, cop), t_tmp = new_tensor(h, H, W, cop), t_out = new_tensor(h, H, W, cop);
+        const int t_up = new_tensor(h, l, H, W, cop), t_tmp = new_tensor(h, l, H, W, cop), t_out = new_tensor(h, l, H, W, cop);
         ConvLayer U;   // nearest x2 + conv3x3 + bias, no BN / ReLU / dropout (unet.py:105)
         snprintf(buf, sizeof buf, "up_convs.%d.upconv.1", j);
         U.name = buf;
         U.cin1 = cur_c; U.c1p = cur_cp; U.cout = co; U.coutp = cop; U.csplit = cop;
         U.H = H; U.W = W; U.upsample = 1; U.relu = 0;
+        U.level = l + 1; U.gh = h->level_ext[l + 1].first; U.gw = h->level_ext[l + 1].second;   // its tiles walk the low-resolution level
         U.t_src1 = cur; U.t_out = t_up;
         if (2 * (H / 2) != H || 2 * (W / 2) != W) h->tensors[t_up].zero_fill = true;   // centre pad (unet.py:110-116)
         h->layers.push_back(U);
         // cat((up, skip), 1) -> block: K split over the two tensors (unet.py:118-119)
         snprintf(buf, sizeof buf, "up_convs.%d.block.block.0", j);
-        add_unit(h, buf, co, cop, skip_c[l], round_up(skip_c[l], 32), co, H, W, unit_has_dropout(d, l, false, 0), t_up,
+        add_unit(h, buf, co, cop, skip_c[l], round_up(skip_c[l], 32), co, l, H, W, unit_has_dropout(d, l, false, 0), t_up,
                  skip[l], t_tmp, -1);
         if (d.residual) {
             snprintf(buf, sizeof buf, "up_convs.%d.block", j);
-            add_residual_conv(h, buf, co, cop, skip_c[l], round_up(skip_c[l], 32), co, H, W, t_up, skip[l], t_out);
+            add_residual_conv(h, buf, co, cop, skip_c[l], round_up(skip_c[l], 32), co, l, H, W, t_up, skip[l], t_out);
         }
         snprintf(buf, sizeof buf, "up_convs.%d.block.block.1", j);
-        add_unit(h, buf, co, cop, 0, 0, co, H, W, unit_has_dropout(d, l, false, 1), t_tmp, -1, t_out, -1, d.residual != 0);
+        add_unit(h, buf, co, cop, 0, 0, co, l, H, W, unit_has_dropout(d, l, false, 1), t_tmp, -1, t_out, -1, d.residual != 0);
         cur = t_out; cur_c = co; cur_cp = cop;
     }
     {   // head unit(s): conv_cls.0 [+ conv_sigma.0 stacked on the output channels] (unet.py:161-164)
         const int cp = round_up(cur_c, 32);
         h->head_cph = cp;
         h->head_cp = d.sigma_out ? 2 * cp : cp;
-        h->t_head = new_tensor(h, d.height, d.width, h->head_cp);
-        add_unit(h, "conv_cls.0", cur_c, cur_cp, 0, 0, cur_c, d.height, d.width, d.has_dropout != 0, cur, -1, h->t_head,
+        // the head unit's output is read by head_kernel as [voxel][channel]: exactly the real image, whatever level 0 is allocated with
+        h->t_head = new_tensor(h, -1, d.height, d.width, h->head_cp);
+        add_unit(h, "conv_cls.0", cur_c, cur_cp, 0, 0, cur_c, 0, d.height, d.width, d.has_dropout != 0, cur, -1, h->t_head,
                  -1);
         ConvLayer& L = h->layers.back();
         if (d.sigma_out) {
@@ -339,16 +367,91 @@ static int build_plan(rcu_unet* h)
     h->site_offset.assign(h->sites.size() + 1, 0);
     for (size_t s = 0; s < h->sites.size(); ++s) h->site_offset[s + 1] = h->site_offset[s] + h->sites[s].second;
     h->mask_floats = h->site_offset.back();
+    if (valid) *valid = true;
     for (ConvLayer& L : h->layers) {
-        L.cfg = pick_config(L, h->d.max_batch, h->opt);
+        const Tensor& to = h->tensors[L.t_out];
+        L.cfg = pick_config(L, h->d.max_batch, h->opt, to.H, to.W);
         const ConvConfigInfo& ci = conv_config_info(L.cfg);
         if ((L.c1p % ci.KC) != 0 || (L.c2p % ci.KC) != 0)
             return fail(RCU_ERR_INVALID, "internal: channel chunking does not divide for layer " + L.name);
         L.NT = (L.coutp + ci.BN - 1) / ci.BN;
+        // a padded tensor may only be touched by a kernel that keeps its zeros: read as a tile grid and written by the Winograd families /
+        // rcu_first.hip -- or written by a direct up-convolution, which places its image in a larger tensor anyway (the centre pad)
+        const bool src_padded = h->tensors[L.t_src1].padded() && L.t_src1 != h->t_input;
+        const bool first_reads_caller = L.t_src1 == h->t_input && h->tensors[L.t_src1].padded();
+        const bool pool_padded = L.t_pool >= 0 && h->tensors[L.t_pool].padded();
+        const bool out_padded = to.padded() && !(L.upsample && !cfg_handles_padding(L.cfg) && !h->tensors[L.t_src1].padded());
+        if ((src_padded || first_reads_caller || pool_padded || out_padded) && !cfg_handles_padding(L.cfg) && valid) *valid = false;
     }
     assign_layouts(h);
     return RCU_OK;
 }
+
+// Rough time of a plan's conv stack per slice, arbitrary units: multiplications the layer's kernel executes on whole tiles of the grid it walks
+// / the executed fraction of the matrix peak the kernel family has measured at (the direct kernels: profiles/r06_*).  It
+// only has to rank "pad the level to whole Winograd tiles" against "keep the real extent on the direct kernels" and one padding against another.
+static double plan_cost(const rcu_unet* h)
+{
+    double total = 0.0;
+    for (const ConvLayer& L : h->layers) {
+        const ConvConfigInfo& ci = conv_config_info(L.cfg);
+        const double tiles = (double)((L.gh + ci.TH - 1) / ci.TH) * ((L.gw + ci.TW - 1) / ci.TW);
+        const double px = tiles * ci.TH * ci.TW;           // pixels of the grid the tiles walk (an up-convolution: the low-resolution grid)
+        const double kn = (double)(L.c1p + L.c2p) * (double)(L.NT * ci.BN);
+        double mults, eff;
+        if (L.cfg == CONV_CFG_FIRST_T8x32) { mults = 9.0; eff = 0.25; }                 // a write stream, not a matrix kernel
+        else if (ci.WINO == 3) { mults = L.cfg == CONV_CFG_WINO4_S8T12x8_N32 ? 3.0 : 2.25; eff = (L.c1p + L.c2p) <= 32 ? 0.45 : 0.58; }
+        else if (ci.WINO == 2) { mults = 9.0; eff = 0.72; }                              // four classes x 9 / 4 per low-resolution pixel
+        else if (ci.WINO == 1) { mults = 4.0; eff = 0.62; }
+        else if (L.upsample) { mults = 16.0; eff = 0.55; }                               // four classes x 2x2 taps per low-resolution pixel
+        else { mults = 9.0; eff = 0.55; }
+        total += px * kn * mults / eff;
+    }
+    return total;
+}
+
+// Allocated extent of every level.  A Winograd kernel takes whole tiles; where the real extent of a level (H >> l) x (W >> l) is not a
+// whole number of them -- the reference's BraTS slices are 240 x 240 (levels 240, 120, 60, 30, 15: scripts/create_brats18_dataset.py:53-72 never
+// crops), ISIC's 192 x 256 ends in a 12 x 16 level (scripts/prepare_isic_data.py:29-30) -- the level's tensors are ALLOCATED with a padded extent,
+// the padding holds zeros that no kernel writes (ConvArgs::part), and the level runs on the Winograd kernels instead of the direct ones: 2.25 x
+// (1 + padding) instead of 9 multiplications per pixel.  Every level chooses for itself: a pooled output and an up-convolution carry the extents
+// of the tensors on both sides.  The choice minimises plan_cost over a small set of roundings per axis; a level keeps its real extent where
+// nothing is gained (whole tiles fit: the benchmark's 192 x 128) or where a layer of the level has no kernel that keeps the zeros (residual
+// blocks' adding units, feature taps).
+static int choose_level_extents(rcu_unet* h)
+{
+    const rcu_unet_desc& d = h->d;
+    h->level_ext.resize(d.depth + 1);
+    for (int l = 0; l <= d.depth; ++l) h->level_ext[l] = {d.height >> l, d.width >> l};
+    bool valid = true;
+    int rc = build_plan_for(h, &valid);
+    if (rc != RCU_OK || h->opt.pad_levels == 0 || h->opt.conv_winograd == 0) return rc;
+    double best = plan_cost(h);
+    static const int kRound[] = {4, 8, 12, 16, 32};
+    for (int sweep = 0; sweep < 2; ++sweep)
+        for (int l = 0; l <= d.depth; ++l) {
+            if (l == 0 && d.provide_features) continue;   // rcu_unet_features hands the level-0 tensor out as [voxel][channel]
+            const int Hl = d.height >> l, Wl = d.width >> l;
+            std::pair<int, int> keep = h->level_ext[l];
+            for (int rh : kRound)
+                for (int rw : kRound) {
+                    const std::pair<int, int> cand = {round_up(Hl, rh), round_up(Wl, rw)};
+                    if (cand == keep || (rw == 12)) continue;
+                    h->level_ext[l] = cand;
+                    rc = build_plan_for(h, &valid);
+                    if (rc != RCU_OK) return rc;
+                    const double cost = plan_cost(h);
+                    if (valid && cost < best * 0.999) {
+                        best = cost;
+                        keep = cand;
+                    }
+                }
+            h->level_ext[l] = keep;
+        }
+    return build_plan_for(h, &valid);
+}
+
+static int build_plan(rcu_unet* h) { return choose_level_extents(h); }
 
 // Which activation tensors take the channel-blocked layout [N][C/8][H][W][8] (rcu_kernels.h, ConvArgs): every tensor all of whose
 // producers and consumers are Winograd kernels (rcu_first.hip as a producer), except the network input, the head unit's output
@@ -405,9 +508,11 @@ extern "C" void rcu_unet_default_options(rcu_unet_options* opts)
     opts->act_layout = 0;
     opts->fuse_head = 1;
     opts->head_winograd4 = 1;
+    opts->pad_levels = 1;
 }
 
-extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_options* opts, rcu_unet* donor, rcu_unet** out)
+// desc / options checks + the plan (layers, tensors, level extents); no device memory
+static int make_plan(const rcu_unet_desc* desc, const rcu_unet_options* opts, const rcu_unet* donor, rcu_unet** out)
 {
     if (!desc || !out) return fail(RCU_ERR_INVALID, "rcu_unet_create: null argument");
     const rcu_unet_desc& d = *desc;
@@ -424,7 +529,7 @@ extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_op
     if (opts) {
         o = *opts;
         if ((o.conv_winograd | 1) != 1 || (o.conv_winograd4 < 0 || o.conv_winograd4 > 3) ||
-            (o.conv_first | 1) != 1 || (o.act_layout | 1) != 1 || (o.fuse_head | 1) != 1 || (o.head_winograd4 | 1) != 1 || o.reserved[0] || o.reserved[1])
+            (o.conv_first | 1) != 1 || (o.act_layout | 1) != 1 || (o.fuse_head | 1) != 1 || (o.head_winograd4 | 1) != 1 || (o.pad_levels | 1) != 1 || o.reserved[0])
             return fail(RCU_ERR_INVALID, "rcu_unet_create_with: bad rcu_unet_options value");
     }
     rcu_unet* h = new rcu_unet();
@@ -438,6 +543,23 @@ extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_op
         delete h;
         return rc;
     }
+    *out = h;
+    return RCU_OK;
+}
+
+extern "C" int rcu_unet_plan(const rcu_unet_desc* desc, const rcu_unet_options* opts, rcu_unet** out)
+{
+    int rc = make_plan(desc, opts, nullptr, out);
+    if (rc == RCU_OK) (*out)->plan_only = true;
+    return rc;
+}
+
+extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_options* opts, rcu_unet* donor, rcu_unet** out)
+{
+    rcu_unet* h = nullptr;
+    int rc = make_plan(desc, opts, donor, &h);
+    if (rc != RCU_OK) return rc;
+    const rcu_unet_desc& d = *desc;
     // 32-bit element offsets inside the conv kernel
     for (const Tensor& t : h->tensors)
         if (t.floats_per_slice * (size_t)h->d.max_batch >= (size_t)1 << 31) {
@@ -449,8 +571,8 @@ extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_op
         bool same = donor->ws && donor->tensors.size() == h->tensors.size() && donor->ws->max_batch >= d.max_batch;
         for (size_t i = 0; same && i < h->tensors.size(); ++i) {
             const Tensor &a = h->tensors[i], &b = donor->tensors[i];
-            same = a.floats_per_slice == b.floats_per_slice && a.H == b.H && a.W == b.W && a.cp == b.cp && a.blocked == b.blocked &&
-                   a.zero_fill == b.zero_fill;
+            same = a.floats_per_slice == b.floats_per_slice && a.H == b.H && a.W == b.W && a.Hr == b.Hr && a.Wr == b.Wr && a.cp == b.cp &&
+                   a.blocked == b.blocked && a.zero_fill == b.zero_fill;
         }
         if (!same) {
             delete h;
@@ -474,11 +596,11 @@ extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_op
         h->ws->dev.push_back(t.dev);
         h->ws->bytes.push_back(bytes);
         h->workspace_bytes += (int64_t)bytes;
-        if (t.zero_fill) {
+        if (t.zero_fill || t.padded()) {   // pixels no kernel ever writes and every reader takes for the conv's zero padding
             e = hipMemset(t.dev, 0, bytes);
             if (e != hipSuccess) {
                 rcu_unet_destroy(h);
-                return hip_fail(e, "hipMemset(centre-pad border)");
+                return hip_fail(e, "hipMemset(centre-pad border / level padding)");
             }
         }
     }
@@ -714,6 +836,7 @@ static int fold_conv(rcu_unet* h, const ConvLayer& L, const std::string& conv, c
 extern "C" int rcu_unet_finalize_weights(rcu_unet* h)
 {
     if (!h) return fail(RCU_ERR_INVALID, "null handle");
+    if (h->plan_only) return fail(RCU_ERR_STATE, "rcu_unet_finalize_weights: the handle is a plan without a workspace (rcu_unet_plan)");
     if (h->finalized) return RCU_OK;
     for (ConvLayer& L : h->layers) {
         const ConvConfigInfo& ci = conv_config_info(L.cfg);
@@ -783,10 +906,26 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     a.mask2 = (masks && L.site2 >= 0) ? masks + (size_t)n * h->site_offset[L.site2] : nullptr;
     a.out = h->tensors[L.t_out].dev;
     a.pooled = L.t_pool >= 0 ? h->tensors[L.t_pool].dev : nullptr;
-    const int gh = L.upsample ? L.H / 2 : L.H, gw = L.upsample ? L.W / 2 : L.W;   // tile grid = input grid
+    const int gh = L.gh, gw = L.gw;   // tile grid = the (allocated) input grid
     a.N = n; a.H = gh; a.W = gw;
-    if (L.upsample && (2 * gh != L.H || 2 * gw != L.W)) {   // centre pad: F.pad(up, (dw // 2, dw - dw // 2, dh // 2, dh - dh // 2))
-        a.out_H = L.H; a.out_W = L.W;
+    const Tensor& tsrc = h->tensors[L.t_src1];
+    const Tensor& tout = h->tensors[L.t_out];
+    const int os = L.upsample ? 2 : 1;
+    if (cfg_handles_padding(L.cfg)) {
+        // padded level on either side (ConvArgs::part): the tiles walk the allocated grid, the stores keep to the real image, the output and
+        // pooled tensors have the extents of their own levels (the head unit's output: exactly the real image)
+        const bool pool_differs = L.t_pool >= 0 && (h->tensors[L.t_pool].H != gh / 2 || h->tensors[L.t_pool].W != gw / 2);
+        if (tsrc.padded() || tout.H != os * gh || tout.W != os * gw || pool_differs) {
+            a.part = 1;
+            a.Hr = L.upsample ? 2 * (L.H / 2) : L.H;
+            a.Wr = L.upsample ? 2 * (L.W / 2) : L.W;
+            a.out_H = tout.H; a.out_W = tout.W;
+            if (L.t_pool >= 0) { a.pool_H = h->tensors[L.t_pool].H; a.pool_W = h->tensors[L.t_pool].W; }
+        }
+    } else if (L.upsample && (2 * gh != tout.H || 2 * gw != tout.W)) {
+        // the direct up-convolution places its 2 gh x 2 gw image in a larger tensor: the reference's centre pad
+        // F.pad(up, (dw // 2, dw - dw // 2, dh // 2, dh - dh // 2)) (unet.py:110-116), and / or a padded level around it
+        a.out_H = tout.H; a.out_W = tout.W;
         a.out_y0 = (L.H - 2 * gh) / 2; a.out_x0 = (L.W - 2 * gw) / 2;
     }
     a.C1 = L.c1p; a.C2 = L.c2p; a.CoutP = L.coutp;
@@ -854,7 +993,7 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
     const bool direct_input = h->layers.front().cfg == CONV_CFG_FIRST_T8x32;
     if (!direct_input)
         RCU_HIP(launch_pack_input(x, h->tensors[h->t_input].dev, n_one, h->d.in_channels, h->in_cp, h->d.height, h->d.width,
-                                  passes, stream));
+                                  h->tensors[h->t_input].H, h->tensors[h->t_input].W, passes, stream));
     if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
     // conv_cls.0 and the classifier as one kernel where the shapes allow (the shipped configurations; rcu_unet_options.fuse_head = 0 /
     // rcu_unet_set_fuse_head keep them apart): two classes, no sigma twin, 32-cout Winograd tile; the passes of a pass group run back to back on the
@@ -1130,6 +1269,7 @@ extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info*
     out->cin = L.cin1 + L.cin2;
     out->cout = L.name2.empty() ? L.cout : 2 * L.cout;
     out->height = L.H; out->width = L.W;
+    out->grid_height = L.gh; out->grid_width = L.gw;
     out->upsample = L.upsample; out->pooled = L.t_pool >= 0; out->dual_source = L.t_src2 >= 0;
     out->head_fusable = (layer + 1 == (int)h->layers.size() && head_fusable(h)) ? 1 : 0;
     // an up-convolution works on the up-sampled grid, which a centre pad leaves smaller than the skip tensor it is padded to
@@ -1137,7 +1277,7 @@ extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info*
     {
         // executed on the matrix pipe: padded K and N, full tiles, 4 taps per output pixel for the sub-pixel form
         const ConvConfigInfo ci = conv_config_info(L.cfg);
-        const int lh = L.upsample ? L.H / 2 : L.H, lw = L.upsample ? L.W / 2 : L.W;   // grid the tiles walk
+        const int lh = L.gh, lw = L.gw;   // grid the tiles walk: the allocated extent of the level (rcu_layer_info.grid_height / grid_width)
         const double tiles = (double)((lh + ci.TH - 1) / ci.TH) * ((lw + ci.TW - 1) / ci.TW);
         const double px = tiles * ci.TH * ci.TW * (L.upsample ? 4.0 : 1.0);
         const double ncols = (double)L.NT * ci.BN;

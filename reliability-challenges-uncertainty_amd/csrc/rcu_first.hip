@@ -55,6 +55,8 @@ __global__ __launch_bounds__(FIRST_THREADS) void conv3x3_first_kernel(const Conv
     }
     const int tiles_x = a.W / FIRST_TW, tiles_y = a.H / FIRST_TH;
     const float floor_v = a.relu ? 0.f : -__builtin_inff();
+    // padded level (ConvArgs::part): H x W is the allocated extent of the output (and of src1), the caller's planes and the stored pixels are Hr x Wr
+    const int Hr = a.part ? a.Hr : a.H, Wr = a.part ? a.Wr : a.W;
 
     // Pass groups (x_nchw set, N = passes * n_images: sample p * n_images + i is image i under the masks of pass p): the convolution
     // of an image tile is the same in every pass -- only the Dropout2d factors behind it differ --, so a tile is staged and multiplied
@@ -70,10 +72,10 @@ __global__ __launch_bounds__(FIRST_THREADS) void conv3x3_first_kernel(const Conv
             const int r = rem / FIRST_HC, c = rem % FIRST_HC;
             const int gy = y0 + r - 1, gx = x0 + c - 1;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            if (gy >= 0 && gy < Hr && gx >= 0 && gx < Wr) {
                 if (a.x_nchw != nullptr) {   // the caller's NCHW planes: consecutive threads read consecutive columns of a plane
-                    const size_t HW = (size_t)a.H * a.W;
-                    const float* const px = a.x_nchw + (size_t)(n % a.n_images) * a.cin_real * HW + (size_t)gy * a.W + gx;
+                    const size_t HW = (size_t)Hr * Wr;
+                    const float* const px = a.x_nchw + (size_t)(n % a.n_images) * a.cin_real * HW + (size_t)gy * Wr + gx;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (ks * 4 + k < a.cin_real) v[k] = px[(size_t)(ks * 4 + k) * HW];
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(FIRST_THREADS) void conv3x3_first_kernel(const Conv
 #pragma unroll
             for (int seg = 0; seg < 4; ++seg) {
                 const int r = 2 * wave + (seg >> 1), c0 = 16 * (seg & 1);
+                if (y0 + r >= Hr || x0 + c0 + n16 >= Wr) continue;   // beyond the real image (padded level): the zeros there are never written
                 // (sample, pixel, channel b * 16 + 4 g): NHWC or blocked [C/8][H][W][8], see ConvArgs
                 char* const op = reinterpret_cast<char*>(a.out) + (size_t)ns * a.H * a.W * a.CoutP * 4 +
                                  (size_t)((y0 + r) * a.W + x0 + c0 + n16) * a.out_pix_bytes + (size_t)(g >> 1) * a.out_chunk_bytes + (g & 1) * 16;

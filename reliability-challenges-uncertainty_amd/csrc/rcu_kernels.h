@@ -31,6 +31,13 @@ struct ConvArgs {
     int out_H, out_W;    // sub-pixel up-conv (direct kernels): extent of the output tensor when it is larger than 2H x 2W -- the
     int out_y0, out_x0;  //   reference's centre pad (common/model/unet.py:110-116) -- and where the 2H x 2W image sits in it; 0: 2H x 2W
     int N, H, W;         // input grid = pixel-tile grid
+    // Padded levels (`part` = 1; Winograd kernels + rcu_first.hip; rcu_api.hip, choose_level_extents): the tensors of a level are allocated with
+    // extents rounded up to whole tiles, H x W above are those ALLOCATED extents of the source level, and the pixels beyond the real image hold
+    // zeros that no kernel ever writes -- so a tile that hangs over the real border reads exactly the zero padding the reference's conv applies
+    // (common/model/unet.py:13: padding=1) and the load side of the kernels is the whole-tile one.  What changes is the store side:
+    int part;            //   1: the fields below are set and the kernel's store side honours them
+    int Hr, Wr;          //   real extent of the OUTPUT grid (up-convolutions: of the up-sampled grid): pixels at or beyond it are not stored
+    int pool_H, pool_W;  //   allocated extent of `pooled` (out_H, out_W above: of `out`) -- a level's padding is its own, not half its parent's
     int C1, C2;          // padded channel counts of the two sources
     int cin_real;        // first-layer kernel (rcu_first.hip): input channels that are not padding
     const float* x_nchw; // first-layer kernel: when set, the caller's [n_images][cin_real][H][W] input is read in place of src1
@@ -159,7 +166,8 @@ hipError_t set_max_dynamic_lds(const void* kernel, int bytes);
 // ---------------------------------------------------------------------------------------------
 // layout / head / aggregation kernels (rcu_pointwise.hip)
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_pack_input(const float* x_nchw, float* out_nhwc, int N, int C, int CP, int H, int W, int replicas,
+// out_nhwc is allocated PH x PW >= H x W per image (a padded level 0): only the H x W real pixels are written
+hipError_t launch_pack_input(const float* x_nchw, float* out_nhwc, int N, int C, int CP, int H, int W, int PH, int PW, int replicas,
                              hipStream_t stream);
 
 // MC statistics blob: planes over the voxel index v = n*HW + hw.

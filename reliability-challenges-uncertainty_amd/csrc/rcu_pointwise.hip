@@ -23,26 +23,28 @@ static inline unsigned grid_for(size_t n) { return (unsigned)((n + PW_THREADS - 
 
 // ------------------------------------------------------------------------------- NCHW -> padded NHWC
 // `replicas` > 1: the N input images are written `replicas` times one after the other (pass groups).
+// The output image is allocated PH x PW >= H x W (a padded level 0, rcu_api.hip): only the real pixels are written.
 __global__ __launch_bounds__(PW_THREADS) void pack_input_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                                 int C, int CP, size_t HW, size_t V, size_t N)
+                                                                 int C, int CP, size_t HW, size_t V, size_t N, int W, int PH, int PW)
 {
     const size_t v = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;
     if (v >= V) return;
-    const size_t n = (v / HW) % N, hw = v % HW;
+    const size_t s = v / HW, n = s % N, hw = v % HW;
+    const size_t vo = (s * PH + hw / W) * PW + hw % W;
     for (int c = 0; c < CP; c += 4) {
         float4 q;
         q.x = (c + 0 < C) ? x[(n * C + c + 0) * HW + hw] : 0.f;
         q.y = (c + 1 < C) ? x[(n * C + c + 1) * HW + hw] : 0.f;
         q.z = (c + 2 < C) ? x[(n * C + c + 2) * HW + hw] : 0.f;
         q.w = (c + 3 < C) ? x[(n * C + c + 3) * HW + hw] : 0.f;
-        *reinterpret_cast<float4*>(out + v * CP + c) = q;
+        *reinterpret_cast<float4*>(out + vo * CP + c) = q;
     }
 }
 
-hipError_t launch_pack_input(const float* x, float* out, int N, int C, int CP, int H, int W, int replicas, hipStream_t stream)
+hipError_t launch_pack_input(const float* x, float* out, int N, int C, int CP, int H, int W, int PH, int PW, int replicas, hipStream_t stream)
 {
     const size_t HW = (size_t)H * W, V = HW * N * (size_t)replicas;
-    hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(V)), dim3(PW_THREADS), 0, stream, x, out, C, CP, HW, V, (size_t)N);
+    hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(V)), dim3(PW_THREADS), 0, stream, x, out, C, CP, HW, V, (size_t)N, W, PH, PW);
     return hipGetLastError();
 }
 

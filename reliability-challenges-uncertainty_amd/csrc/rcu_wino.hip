@@ -43,7 +43,9 @@ namespace rcu {
 
 // Output transform + conv-unit epilogue of one finished tile.  acc[b][p][r]: MFMA block b (cout 2n+b), position p,
 // tile r of the lane's four.
-template <class T>
+// PART: the level is padded (ConvArgs::part) -- the tile may hang over the real image: pixels at or beyond (Hr, Wr) go out of range, where the
+// buffer resource drops the write, and the output / pooled tensors have extents of their own.
+template <class T, bool PART = false>
 __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&acc)[2][16], const WinoEpi& ep, int ntile, int n0, int y0,
                                               int x0, int wm, int wn, int lane)
 {
@@ -63,10 +65,13 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
     const int odd = n16 & 1;
     // Whole tiles only (checked by the launcher) and tensors below 2 GB: stores through a buffer resource, one per-lane byte offset
     // per tile, the steps between a lane's pixels in SGPRs -- no 64-bit address arithmetic, no per-store predicates.
-    const uint32_t row_bytes = (uint32_t)a.W * a.out_pix_bytes;
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (uint32_t)(a.N * a.H * a.W) * (uint32_t)a.CoutP * 4u, 0x00020000);
-    const uint32_t vo = wino_out_offset(n, a.H * a.W, a.CoutP, (uint32_t)(yb * a.W + xb + odd), co - 2 * odd, a.out_pix_bytes, a.out_chunk_bytes);
+    const int oH = PART ? a.out_H : a.H, oW = PART ? a.out_W : a.W;
+    const uint32_t row_bytes = (uint32_t)oW * a.out_pix_bytes;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (uint32_t)(a.N * oH * oW) * (uint32_t)a.CoutP * 4u, 0x00020000);
+    const uint32_t vo = wino_out_offset(n, oH * oW, a.CoutP, (uint32_t)(yb * oW + xb + odd), co - 2 * odd, a.out_pix_bytes, a.out_chunk_bytes);
     const uint32_t px_step = 2u * a.out_pix_bytes;   // two pixels to the right
+    // PART: the lane stores pixels (yb + aa, xb + odd + 2 r): real iff aa < ylim && 2 r < xlim
+    [[maybe_unused]] const int ylim = PART ? a.Hr - yb : 0, xlim = PART ? a.Wr - (xb + odd) : 0;
     f32x2 mx[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -102,8 +107,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
             recv.y = wino_swap_adjacent(send.y);
             o[aa] = odd ? f32x4{recv.x, recv.y, y[aa][1].x, y[aa][1].y} : f32x4{y[aa][0].x, y[aa][0].y, recv.x, recv.y};
         }
-        wino_store16(o[0], ro, vo, r * px_step);
-        wino_store16(o[1], ro, vo, r * px_step + row_bytes);
+        wino_store16(o[0], ro, (PART && !(0 < ylim && 2 * r < xlim)) ? WINO_OOB : vo, r * px_step);
+        wino_store16(o[1], ro, (PART && !(1 < ylim && 2 * r < xlim)) ? WINO_OOB : vo, r * px_step + row_bytes);
         if (a.pooled != nullptr) {
             mx[r].x = fmaxf(fmaxf(y[0][0].x, y[0][1].x), fmaxf(y[1][0].x, y[1][1].x));
             mx[r].y = fmaxf(fmaxf(y[0][0].y, y[0][1].y), fmaxf(y[1][0].y, y[1][1].y));
@@ -111,7 +116,10 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
     }
     if (a.pooled != nullptr) {
         // same trade for the pooled pixels (one per tile): the even lane stores four couts of tile r, the odd lane of tile r + 1
-        const int Hp = a.H >> 1, Wp = a.W >> 1;
+        const int Hp = PART ? a.pool_H : a.H >> 1, Wp = PART ? a.pool_W : a.W >> 1;
+        // PART: pooled pixel ((yb >> 1), (xb >> 1) + odd + r) for r = 0, 2 of the pooled image of (Hr >> 1) x (Wr >> 1) real pixels
+        [[maybe_unused]] const bool prow_in = PART ? (yb >> 1) < (a.Hr >> 1) : true;
+        [[maybe_unused]] const int pxlim = PART ? (a.Wr >> 1) - ((xb >> 1) + odd) : 0;
         const __amdgpu_buffer_rsrc_t rp =
             __builtin_amdgcn_make_buffer_rsrc(a.pooled, 0, (uint32_t)(a.N * Hp * Wp * a.CoutP) * 4u, 0x00020000);
         const uint32_t vp = wino_out_offset(n, Hp * Wp, a.CoutP, (uint32_t)((yb >> 1) * Wp + (xb >> 1) + odd), co - 2 * odd, a.pool_pix_bytes,
@@ -124,7 +132,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
             recv.x = wino_swap_adjacent(send.x);
             recv.y = wino_swap_adjacent(send.y);
             const f32x4 o = odd ? f32x4{recv.x, recv.y, mx[r + 1].x, mx[r + 1].y} : f32x4{mx[r].x, mx[r].y, recv.x, recv.y};
-            wino_store16(o, rp, vp, (r >> 1) * pp_step);
+            wino_store16(o, rp, (PART && !(prow_in && r < pxlim)) ? WINO_OOB : vp, (r >> 1) * pp_step);
         }
     }
 }
@@ -135,7 +143,8 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, const f32x4 (&a
 // The dot product is summed exactly as head_kernel sums it (eight 4-channel fmaf chains, pairwise tree), so a pass
 // through this epilogue and a pass through head_kernel (rcu_unet_set_fuse_head(h, 0); sigma / feature outputs) give the same bits.
 constexpr int WINO_HEAD_PITCH = 34;
-template <class T>
+// PART: the level is padded (ConvArgs::part) -- logits and statistics are the caller's arrays over the REAL Hr x Wr image.
+template <class T, bool PART = false>
 __device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x4 (&acc)[2][16], const WinoEpi& ep, int n0, int nstat, int y0,
                                                    int x0, int wm, int wn, int lane, int tid, float* hl)
 {
@@ -144,8 +153,9 @@ __device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x
     // the dot products instead of behind the softmax -- one plane's load / add / store behind the other's, as accumulate_voxel does it, kept the
     // whole workgroup (both waves of every SIMD are in this phase together) waiting for two memory round trips per tile.  Same operations, same bits.
     const int gy = y0 + tid / T::TW, gx = x0 + tid % T::TW;
-    const bool inside = n0 < a.N && gy < a.H && gx < a.W;
-    const size_t hw = (size_t)gy * a.W + gx, HW = (size_t)a.H * a.W;
+    const int Hi = PART ? a.Hr : a.H, Wi = PART ? a.Wr : a.W;   // the image the logits / statistics are arrays over
+    const bool inside = n0 < a.N && gy < Hi && gx < Wi;
+    const size_t hw = (size_t)gy * Wi + gx, HW = (size_t)Hi * Wi;
     VoxelStats<2> st;
     if (inside && a.head_stats != nullptr) st.load(a.head_stats, (size_t)nstat * HW + hw, a.head_V, a.head_flags);   // nstat: the image the sample is a pass of
     {
@@ -213,7 +223,7 @@ __device__ __forceinline__ void wino_epilogue_head(const ConvArgs& a, const f32x
     }
 }
 
-template <class T, bool HEAD = false>
+template <class T, bool HEAD = false, bool PART = false>
 __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, const int total_items)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource types and LDS-DMA builtins exist in the device pass only
@@ -428,10 +438,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino_stream(const ConvArgs a, con
             chunk(std::integral_constant<int, 1>{}, std::false_type{}, kc + 1);
         }
         if constexpr (HEAD)
-            wino_epilogue_head<T>(wino_cold_args(), acc, wino_epilogue_fold(epr), tile.n0, tile.n0 - pass * wino_cold_args().head_images, tile.y0, tile.x0, wm,
-                                  wn, lane, tid, smem + 2 * T::BUF_DW);
+            wino_epilogue_head<T, PART>(wino_cold_args(), acc, wino_epilogue_fold(epr), tile.n0, tile.n0 - pass * wino_cold_args().head_images, tile.y0, tile.x0, wm,
+                                        wn, lane, tid, smem + 2 * T::BUF_DW);
         else
-            wino_epilogue<T>(wino_cold_args(), acc, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wm, wn, lane);
+            wino_epilogue<T, PART>(wino_cold_args(), acc, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wm, wn, lane);
         if (!has_next) break;
         if (more_passes()) {
             ++pass;
@@ -473,13 +483,22 @@ static hipError_t launch_wino_cfg(const ConvArgs& a, hipStream_t stream)
         (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 ||
         (size_t)a.N * a.H * a.W * a.CoutP * 4 >= ((size_t)1 << 31))
         return hipErrorInvalidValue;
-    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_stream<T, HEAD>), lds_bytes);
-    if (e != hipSuccess) return e;
+    // padded level: the real image lies inside the tile grid, the output / pooled tensors hold it
+    if (a.part && (a.Hr < 1 || a.Wr < 1 || a.Hr > a.H || a.Wr > a.W || a.out_H < a.Hr || a.out_W < a.Wr ||
+                   (size_t)a.N * a.out_H * a.out_W * a.CoutP * 4 >= ((size_t)1 << 31) ||
+                   (a.pooled != nullptr && (a.pool_H < (a.Hr >> 1) || a.pool_W < (a.Wr >> 1)))))
+        return hipErrorInvalidValue;
     // HEAD: the work items of one pass (TS == 1: a slice group is a sample); the kernel runs every pass of the group on each
     const unsigned items = (unsigned)a.NT * a.tiles_x * a.tiles_y * (HEAD ? a.head_images : a.slice_groups);
     const unsigned grid = wino_persistent_grid(items);
-    hipLaunchKernelGGL((conv_wino_stream<T, HEAD>), dim3(grid), dim3(T::THREADS), lds_bytes, stream, a, (int)items);
-    return hipGetLastError();
+    auto launch = [&](auto part_c) {
+        constexpr bool PART = decltype(part_c)::value;
+        hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_stream<T, HEAD, PART>), lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((conv_wino_stream<T, HEAD, PART>), dim3(grid), dim3(T::THREADS), lds_bytes, stream, a, (int)items);
+        return hipGetLastError();
+    };
+    return a.part ? launch(std::true_type{}) : launch(std::false_type{});
 }
 
 hipError_t launch_conv_wino(int cfg, const ConvArgs& a, hipStream_t stream)

@@ -212,16 +212,18 @@ __device__ __forceinline__ float wino4_acc(const f32x4 (&accv)[8])
 struct Wino4StorePlan {
     uint32_t out, pool;
 };
-template <class T>
+template <class T, bool PART>
 __device__ __forceinline__ Wino4StorePlan wino4_store_plan(const ConvArgs& a, int wave, int lane)
 {
     int bs, by, sb, tr, tc;
     T::block_origin(wave, bs, by);
     T::tile_of(4 * (lane >> 4), sb, tr, tc);
     const int n16 = lane & 15, odd = n16 & 1, c = 2 * n16 - 2 * odd;   // the even lane stores four couts of one pixel column, the odd lane of the next
-    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    // PART (padded levels, ConvArgs::part): `out` and `pooled` have extents of their own
+    const int oH = PART ? a.out_H : a.H, oW = PART ? a.out_W : a.W;
+    const int Hp = PART ? a.pool_H : a.H >> 1, Wp = PART ? a.pool_W : a.W >> 1;
     Wino4StorePlan p;
-    p.out = wino_out_offset(bs + sb, a.H * a.W, a.CoutP, (uint32_t)((by + 4 * tr) * a.W + 4 * tc + odd), c, a.out_pix_bytes, a.out_chunk_bytes);
+    p.out = wino_out_offset(bs + sb, oH * oW, a.CoutP, (uint32_t)((by + 4 * tr) * oW + 4 * tc + odd), c, a.out_pix_bytes, a.out_chunk_bytes);
     p.pool = wino_out_offset(bs + sb, Hp * Wp, a.CoutP, (uint32_t)(((by + 4 * tr) >> 1) * Wp + 2 * tc + odd), c, a.pool_pix_bytes, a.pool_chunk_bytes);
     return p;
 }
@@ -271,9 +273,11 @@ __device__ __forceinline__ void wino4_output_tile(const f32x4 (&accv)[8], const 
 
 // Output transform + conv-unit epilogue of one finished tile.  acc[b][p][r]: MFMA block b (cout 2n+b), position p = 6 i + j,
 // tile r of the lane's four.
-template <class T, int EV = 0>   // EV (ablation build): 1 stores out of range, 2 no store instructions, 4 no output transform
+// PART: the level is padded (ConvArgs::part) -- the tile may hang over the real image: pixels at or beyond (Hr, Wr) go out of range like the
+// slices beyond the batch, and the output / pooled tensors have extents of their own.
+template <class T, int EV = 0, bool PART = false>   // EV (ablation build): 1 stores out of range, 2 no store instructions, 4 no output transform
 __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&accv)[8], const WinoEpi& ep, int ntile, int n0, int y0, int x0,
-                                               int lane, const Wino4StorePlan& plan)
+                                               int wave, int lane, const Wino4StorePlan& plan)
 {
     auto store16 = [&](const f32x4& o, const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, uint32_t soff) {
         if constexpr ((EV & 2) != 0)
@@ -293,14 +297,28 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
     float* const pooled = a.pooled;
     const float relu_floor = a.relu ? 0.f : -__builtin_inff();
     const bool pool = pooled != nullptr;
-    const int Hp = H >> 1, Wp = W >> 1;
-    const uint32_t row_bytes = (uint32_t)W * px_bytes, prow_bytes = (uint32_t)Wp * ppx_bytes;
+    const int oH = PART ? a.out_H : H, oW = PART ? a.out_W : W;
+    const int Hp = PART ? a.pool_H : H >> 1, Wp = PART ? a.pool_W : W >> 1;
+    const uint32_t row_bytes = (uint32_t)oW * px_bytes, prow_bytes = (uint32_t)Wp * ppx_bytes;
     // store offsets = the lane's plan (made once per kernel: everything but the tile's origin and cout tile) + the tile's scalars.  Lanes of
     // slices beyond the batch need no flag: their offsets lie behind the tensor, where the buffer resource drops the write.
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, (uint32_t)(N * H * W) * (uint32_t)CoutP * 4u, 0x00020000);
-    const uint32_t vo = plan.out + wino_out_offset(n0, H * W, CoutP, (uint32_t)(y0 * W + x0), ntile * T::BN, px_bytes, chunk_bytes);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, (uint32_t)(N * oH * oW) * (uint32_t)CoutP * 4u, 0x00020000);
+    const uint32_t vo = plan.out + wino_out_offset(n0, oH * oW, CoutP, (uint32_t)(y0 * oW + x0), ntile * T::BN, px_bytes, chunk_bytes);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(pool ? pooled : out, 0, pool ? (uint32_t)(N * Hp * Wp * CoutP) * 4u : 0u, 0x00020000);
     const uint32_t vp = plan.pool + wino_out_offset(n0, Hp * Wp, CoutP, (uint32_t)((y0 >> 1) * Wp + (x0 >> 1)), ntile * T::BN, ppx_bytes, pchunk_bytes);
+    // PART: rows / columns of the real image left from the lane's first pixel (row by + 4 tr, column 4 tc + odd of the workgroup tile), and the same
+    // for its first pooled pixel: a pixel `dy` rows down and `dx` columns right of the first is real iff dy < ylim && dx < xlim
+    [[maybe_unused]] int ylim = 0, xlim = 0, pylim = 0, pxlim = 0;
+    if constexpr (PART) {
+        int bs, by, sb, tr, tc;
+        T::block_origin(wave, bs, by);
+        T::tile_of(4 * (lane >> 4), sb, tr, tc);
+        const int Hr = a.Hr, Wr = a.Wr;
+        ylim = Hr - (y0 + by + 4 * tr);
+        xlim = Wr - (x0 + 4 * tc + odd);
+        pylim = (Hr >> 1) - ((y0 + by + 4 * tr) >> 1);
+        pxlim = (Wr >> 1) - (((x0 + 4 * tc) >> 1) + odd);
+    }
     wino_static_for<0, 4>([&](auto r_c) {
         constexpr int r = decltype(r_c)::value;
         // where tile r of the lane's four sits relative to its first: the next tile column -- or, folded, a 2 x 2 block of tiles whose lower
@@ -321,7 +339,8 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
                 recv.x = wino_swap_adjacent(send.x);
                 recv.y = wino_swap_adjacent(send.y);
                 const f32x4 o = odd ? f32x4{recv.x, recv.y, keep.x, keep.y} : f32x4{keep.x, keep.y, recv.x, recv.y};
-                store16(o, ro, vo_r, (uint32_t)(tdx + 2 * h2) * px_bytes + (uint32_t)(tdy + aa) * row_bytes);
+                const uint32_t vo_s = (PART && !(tdy + aa < ylim && tdx + 2 * h2 < xlim)) ? WINO_OOB : vo_r;
+                store16(o, ro, vo_s, (uint32_t)(tdx + 2 * h2) * px_bytes + (uint32_t)(tdy + aa) * row_bytes);
             }
         }
         if (!T::FOLD && pool) {   // wave-uniform; 2x2 pooled pixels per tile: the even lane stores four couts of pooled column 0, the odd lane of column 1 (the folded geometry -- the bottom level -- has no pooled output: launcher)
@@ -338,7 +357,8 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
                 recv.x = wino_swap_adjacent(send.x);
                 recv.y = wino_swap_adjacent(send.y);
                 const f32x4 o = odd ? f32x4{recv.x, recv.y, keep.x, keep.y} : f32x4{keep.x, keep.y, recv.x, recv.y};
-                store16(o, rp, vp, (uint32_t)(2 * r) * ppx_bytes + (uint32_t)a2 * prow_bytes);
+                const uint32_t vp_s = (PART && !(a2 < pylim && 2 * r < pxlim)) ? WINO_OOB : vp;
+                store16(o, rp, vp_s, (uint32_t)(2 * r) * ppx_bytes + (uint32_t)a2 * prow_bytes);
             }
         }
     });
@@ -363,7 +383,9 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
 // reads the same address: a broadcast) -- read through the kernel argument's pointer they became vector loads from global memory, four
 // dependent round trips per tile quarter on a wave that has nothing else to run meanwhile.
 constexpr int WINO4_HEAD_LDS_BYTES = 512;
-template <class T>
+// PART: the level is padded (ConvArgs::part) -- logits and statistics are the caller's arrays over the REAL Hr x Wr image; the lanes whose pixel lies
+// beyond it take part in the hand-over and touch no memory.
+template <class T, bool PART = false>
 __device__ __forceinline__ void wino4_epilogue_head(const ConvArgs& a, const f32x4 (&accv)[8], const WinoEpi& ep, int n0, int nstat, int y0, int x0,
                                                     int wave, int lane, uint32_t area, uint32_t wlds)
 {
@@ -375,7 +397,7 @@ __device__ __forceinline__ void wino4_epilogue_head(const ConvArgs& a, const f32
     asm volatile("s_nop 15\n\ts_nop 7");   // as wino4_epilogue: the MFMAs' results are read by v_accvgpr_read behind the compiler's back
     const int n16 = lane & 15, g = lane >> 4;
     // one batch of scalar loads
-    const int H = a.H, W = a.W, flags = a.head_flags;
+    const int H = PART ? a.Hr : a.H, W = PART ? a.Wr : a.W, flags = a.head_flags;
     float* const logits = a.head_logits;
     void* const stats = a.head_stats;
     const size_t V = a.head_V;
@@ -386,6 +408,8 @@ __device__ __forceinline__ void wino4_epilogue_head(const ConvArgs& a, const f32
     // the lane's pixel of tile (g, r): row n16 >> 2, column n16 & 3 of the tile, r tiles (4 r pixels) to the right of the lane's first
     const size_t HW = (size_t)H * W;
     const size_t hw0 = (size_t)(y0 + by + 4 * tr + (n16 >> 2)) * W + (size_t)(x0 + 4 * tc + (n16 & 3));
+    [[maybe_unused]] const bool row_in = y0 + by + 4 * tr + (n16 >> 2) < H;
+    [[maybe_unused]] const int xlim = W - (x0 + 4 * tc + (n16 & 3));
     typedef volatile __attribute__((address_space(3))) f32x2 lds_f32x2;
     const uint32_t mine = area + (uint32_t)wave * 1024u + (uint32_t)g * 128u;
     const uint32_t wbase = mine + 8u * (uint32_t)n16;
@@ -395,8 +419,9 @@ __device__ __forceinline__ void wino4_epilogue_head(const ConvArgs& a, const f32
         const size_t hw = hw0 + 4 * r;
         // (requesting the entries of all four quarters up front measured the same at 640 samples per launch and 4 % slower at 160: the round
         // trip is not what the wave waits for)
+        const bool inside = !PART || (row_in && 4 * r < xlim);
         VoxelStats<2> st;
-        if (stats != nullptr) st.load(stats, (size_t)nstat * HW + hw, V, flags);   // nstat: the image the sample is a pass of
+        if (stats != nullptr && inside) st.load(stats, (size_t)nstat * HW + hw, V, flags);   // nstat: the image the sample is a pass of
         {
             f32x2 y[4][4];
             wino4_output_tile<r>(accv, ep, relu_floor, y);
@@ -431,11 +456,11 @@ __device__ __forceinline__ void wino4_epilogue_head(const ConvArgs& a, const f32
             const float bias = *(const __attribute__((address_space(3))) float*)(uintptr_t)(wlds + (uint32_t)(64 + c) * 4u);
             l[c] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) + bias;
         }
-        if (logits != nullptr) {
+        if (logits != nullptr && inside) {
             logits[((size_t)n0 * 2 + 0) * HW + hw] = l[0];
             logits[((size_t)n0 * 2 + 1) * HW + hw] = l[1];
         }
-        if (stats != nullptr) {
+        if (stats != nullptr && inside) {
             softmax_inplace<2>(l);
             st.add(flags, l);
             st.store(stats, (size_t)nstat * HW + hw, V, flags);
@@ -494,7 +519,7 @@ struct Wino4Trace<false> {
 // HEAD: the classifier head in the epilogue (wino4_epilogue_head).  total_items counts the tiles of ONE pass; the workgroup that owns a tile runs
 // the tile of every pass of the group back to back (sample n0 + pass * head_images), so the passes' read-modify-writes of a voxel's statistics
 // are ordered (pass 0 first, as head_kernel adds them) -- as rcu_wino.hip.
-template <class T, int VAR = 0, bool HEAD = false>
+template <class T, int VAR = 0, bool HEAD = false, bool PART = false>
 __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, const int total_items)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -559,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         dp[j] = dpn[j] = wino_slot_offset(geo[j], wino_tile_offset<T>(a, tile));
     }
 
-    Wino4StorePlan store_plan = wino4_store_plan<T>(a, wave, lane);
+    Wino4StorePlan store_plan = wino4_store_plan<T, PART>(a, wave, lane);
     asm volatile("" : "+v"(store_plan.out), "+v"(store_plan.pool));   // two registers through the loop, not their ingredients
 
     // LDS-DMA of Cin chunk kc of a tile into LDS buffer `buf`: the wave's NW weight pieces and NA input pieces of 1 KB.  No branch
@@ -842,10 +867,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         }
         WINO4_TRACE_MARK(1);
         if constexpr (HEAD)
-            wino4_epilogue_head<T>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.n0, tile.n0 - pass * wino_cold_args().head_images, tile.y0, tile.x0,
-                                   wave, lane, lds_base + (uint32_t)(T::BUF_DW + T::A_DW) * 4u, lds_base + (uint32_t)(2 * T::BUF_DW) * 4u);
+            wino4_epilogue_head<T, PART>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.n0, tile.n0 - pass * wino_cold_args().head_images, tile.y0, tile.x0,
+                                         wave, lane, lds_base + (uint32_t)(T::BUF_DW + T::A_DW) * 4u, lds_base + (uint32_t)(2 * T::BUF_DW) * 4u);
         else if constexpr ((VAR & 2) == 0)
-            wino4_epilogue<T, (VAR >> 8)>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, lane, store_plan);
+            wino4_epilogue<T, (VAR >> 8), PART>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wave, lane, store_plan);
         WINO4_TRACE_MARK(2);
         if (!has_next) break;
         WINO4_TRACE_MARK(3);   // (no wait and no barrier here any more: the tile's last chunk waited for the next tile's first chunk at its barrier)
@@ -880,17 +905,17 @@ static const ConvConfigInfo kWino4Info[5] = {
 
 const ConvConfigInfo& wino4_config_info(int cfg) { return kWino4Info[cfg - CONV_CFG_WINO4_T32x32_N32]; }
 
-template <class T, int VAR, bool HEAD = false>
+template <class T, int VAR, bool HEAD = false, bool PART = false>
 static hipError_t launch_wino4_var(const ConvArgs& a, hipStream_t stream)
 {
     constexpr int lds_bytes = T::LDS_BYTES + (HEAD ? WINO4_HEAD_LDS_BYTES : 0);
     static_assert(lds_bytes <= 160 * 1024, "LDS");
-    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino4_stream<T, VAR, HEAD>), lds_bytes);
+    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino4_stream<T, VAR, HEAD, PART>), lds_bytes);
     if (e != hipSuccess) return e;
     // HEAD: the work items of one pass (TS == 1: a slice group is a sample); the kernel runs every pass of the group on each
     const unsigned items = (unsigned)a.NT * a.tiles_x * a.tiles_y * (HEAD ? a.head_images : a.slice_groups);
     const unsigned grid = wino_persistent_grid(items);
-    hipLaunchKernelGGL((conv_wino4_stream<T, VAR, HEAD>), dim3(grid), dim3(T::THREADS), lds_bytes, stream, a, (int)items);
+    hipLaunchKernelGGL((conv_wino4_stream<T, VAR, HEAD, PART>), dim3(grid), dim3(T::THREADS), lds_bytes, stream, a, (int)items);
     return hipGetLastError();
 }
 
@@ -905,6 +930,11 @@ static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
     if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
         (a.C2 != 0 && a.C2 != a.C1) || a.H % T::TH != 0 || a.W % T::TW != 0 || (T::FULLW && a.W != T::TW) || (T::FOLD && a.pooled != nullptr) ||
         (size_t)a.N * a.H * a.W * a.CoutP * 4 >= ((size_t)1 << 31))
+        return hipErrorInvalidValue;
+    // padded level: the real image lies inside the tile grid, the output / pooled tensors hold it
+    if (a.part && (a.Hr < 1 || a.Wr < 1 || a.Hr > a.H || a.Wr > a.W || a.out_H < a.Hr || a.out_W < a.Wr ||
+                   (size_t)a.N * a.out_H * a.out_W * a.CoutP * 4 >= ((size_t)1 << 31) ||
+                   (a.pooled != nullptr && (a.pool_H < (a.Hr >> 1) || a.pool_W < (a.Wr >> 1)))))
         return hipErrorInvalidValue;
 #ifdef RCU_WINO4_ABLATIONS   // timing experiments of tools/wino4_check.py (make EXTRA=-DRCU_WINO4_ABLATIONS); results are wrong
     const char* const v = HEAD ? nullptr : getenv("RCU_W4_VARIANT");
@@ -933,6 +963,7 @@ static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
         default: break;
     }
 #endif
+    if (a.part) return launch_wino4_var<T, 0, HEAD, true>(a, stream);
     return launch_wino4_var<T, 0, HEAD>(a, stream);
 }
 

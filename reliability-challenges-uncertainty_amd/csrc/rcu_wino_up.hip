@@ -24,7 +24,9 @@ namespace rcu {
 
 // Output transform + epilogue.  acc[blk][p][r]; the lane's tile r of class (pa, b) yields the output pixels
 // (2 (ly + u) + pa, 2 (lx + v) + b), u, v in {0, 1}, of the up-sampled grid.
-template <class T>
+// PART: a padded level on either side (ConvArgs::part) -- the tiles walk the ALLOCATED low-resolution grid, output pixels at or beyond the real
+// up-sampled image (Hr, Wr) go out of range, where the buffer resource drops the write, and the output tensor has extents of its own.
+template <class T, bool PART = false>
 __device__ __forceinline__ void wino_up_epilogue(const ConvArgs& a, const f32x4 (&acc)[2][18], const WinoEpi& ep, int ntile, int pa,
                                                  int n0, int y0, int x0, int wm, int wn, int lane)
 {
@@ -37,8 +39,10 @@ __device__ __forceinline__ void wino_up_epilogue(const ConvArgs& a, const f32x4 
     if (n >= a.N) return;
     const int lyb = y0 + by + 2 * (g >> 1);                       // low-res row of the lane's tiles
     const int lxb = x0 + bx + (T::SW == 2 ? 0 : 8 * (g & 1));     // low-res column of the lane's first tile
-    const int OH = 2 * a.H, OW = 2 * a.W;
+    const int OH = PART ? a.out_H : 2 * a.H, OW = PART ? a.out_W : 2 * a.W;
     const int odd = n16 & 1;
+    // PART: the lane stores output pixels (2 lyb + pa + 2 u, 2 (lxb + odd) + 4 r + b): real iff 2 u < ylim && 4 r + b < xlim
+    [[maybe_unused]] const int ylim = PART ? a.Hr - (2 * lyb + pa) : 0, xlim = PART ? a.Wr - 2 * (lxb + odd) : 0;
     const float relu_floor = a.relu ? 0.f : -__builtin_inff();
     // whole tiles only (checked by the launcher), output below 2 GB: buffer stores, one per-lane byte offset per tile, scalar steps
     const uint32_t px_bytes = a.out_pix_bytes, row_bytes = (uint32_t)OW * px_bytes;
@@ -76,13 +80,13 @@ __device__ __forceinline__ void wino_up_epilogue(const ConvArgs& a, const f32x4 
                 recv.x = wino_swap_adjacent(send.x);
                 recv.y = wino_swap_adjacent(send.y);
                 const f32x4 o = odd ? f32x4{recv.x, recv.y, y[u][1].x, y[u][1].y} : f32x4{y[u][0].x, y[u][0].y, recv.x, recv.y};
-                wino_store16(o, ro, vo, (4 * r + b) * px_bytes + u * 2 * row_bytes);
+                wino_store16(o, ro, (PART && !(2 * u < ylim && 4 * r + b < xlim)) ? WINO_OOB : vo, (4 * r + b) * px_bytes + u * 2 * row_bytes);
             }
         }
     }
 }
 
-template <class T>
+template <class T, bool PART = false>
 __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, const int total_items)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource types and LDS-DMA builtins exist in the device pass only
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(512, 1) void upconv_wino_stream(const ConvArgs a, c
         }
         {
             const ConvArgs& ca = wino_cold_args();
-            wino_up_epilogue<T>(ca, acc, wino_epilogue_fold(wino_epilogue_load<T>(ca, tile.wtile % a.NT, tile.n0, wm, wn, lane)), tile.wtile % a.NT,
+            wino_up_epilogue<T, PART>(ca, acc, wino_epilogue_fold(wino_epilogue_load<T>(ca, tile.wtile % a.NT, tile.n0, wm, wn, lane)), tile.wtile % a.NT,
                                 tile.wtile / a.NT, tile.n0, tile.y0, tile.x0, wm, wn, lane);
         }
         if (!has_next) break;
@@ -309,14 +313,23 @@ static hipError_t launch_wino_up_cfg(const ConvArgs& a, hipStream_t stream)
 {
     const int nchunks = a.C1 / T::KC;
     if (nchunks < 4 || (nchunks & 1) != 0 || a.C2 != 0 || a.NTW_total != 2 * a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
-        a.H % T::TH != 0 || a.W % T::TW != 0 || (size_t)a.N * a.H * a.W * a.CoutP * 16 >= ((size_t)1 << 31))
+        a.H % T::TH != 0 || a.W % T::TW != 0 ||
+        (!a.part && (size_t)a.N * a.H * a.W * a.CoutP * 16 >= ((size_t)1 << 31)))
         return hipErrorInvalidValue;
-    hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&upconv_wino_stream<T>), T::LDS_BYTES);
-    if (e != hipSuccess) return e;
+    // padded level on either side: the real up-sampled image lies inside twice the tile grid, the output tensor holds it
+    if (a.part && (a.Hr < 1 || a.Wr < 1 || a.Hr > 2 * a.H || a.Wr > 2 * a.W || a.out_H < a.Hr || a.out_W < a.Wr ||
+                   (size_t)a.N * a.out_H * a.out_W * a.CoutP * 4 >= ((size_t)1 << 31)))
+        return hipErrorInvalidValue;
     const unsigned items = (unsigned)a.NTW_total * a.tiles_x * a.tiles_y * a.slice_groups;
     const unsigned grid = wino_persistent_grid(items);
-    hipLaunchKernelGGL(upconv_wino_stream<T>, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);
-    return hipGetLastError();
+    auto launch = [&](auto part_c) {
+        constexpr bool PART = decltype(part_c)::value;
+        hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&upconv_wino_stream<T, PART>), T::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((upconv_wino_stream<T, PART>), dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, a, (int)items);
+        return hipGetLastError();
+    };
+    return a.part ? launch(std::true_type{}) : launch(std::false_type{});
 }
 
 hipError_t launch_upconv_wino(int cfg, const ConvArgs& a, hipStream_t stream)

@@ -61,7 +61,7 @@ class UNet(nn.Module):
     MAX_HANDLES = 6          # cached (height, width[, lane]) plans incl. their workspaces
     # rcu_unet_options (include/rcu.h): what the planner may choose.  The defaults are the shipped path; ``plan_options`` of an instance
     # overrides them for A/B measurements and for the parity tests that compare kernel families on the same input.
-    PLAN_DEFAULTS = dict(conv_winograd=1, conv_winograd4=1, conv_first=1, act_layout=0, head_winograd4=1)
+    PLAN_DEFAULTS = dict(conv_winograd=1, conv_winograd4=1, conv_first=1, act_layout=0, head_winograd4=1, pad_levels=1)
     _generations = itertools.count(1)      # every plan ever created gets the next number: a borrower's plan is valid for ONE generation of its donor's
 
     def __init__(self, nb_classes, in_channels, depth=DEFAULT_DEPTH, start_filters=DEFAULT_START_FILTERS,
@@ -239,7 +239,12 @@ class UNet(nn.Module):
         full-resolution tensor has ``start_filters`` channels (twice that for the classifier + sigma twin unit)."""
         # (the planner pads every tensor's channels to a multiple of 32 -- pick_config's bound is on the PADDED tensor)
         widest = max(8, (self.start_filters + 31) // 32 * 32 * (2 if self.sigma_out else 1))
-        return max(1, ((1 << 31) - 1) // (int(h) * int(w) * 4 * widest))
+        # ... and, where the image is not a whole number of 32 x 32 tiles, level 0 may be ALLOCATED with an extent rounded up to them
+        # (rcu_unet_options.pad_levels; the reference's 240 x 240 BraTS slices: 256 x 256 at most) -- the bound is on that tensor
+        h, w = int(h), int(w)
+        if self._options().get('pad_levels', 1) and (h % 32 or w % 32):
+            h, w = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+        return max(1, ((1 << 31) - 1) // (h * w * 4 * widest))
 
     def reserve(self, h, w, n, lane=0):
         """Make the plan and the activation workspace for batches of up to ``n`` images of h x w now (a step that knows it will run pass
@@ -434,7 +439,8 @@ class UNet(nn.Module):
             info = _lib.LayerInfo()
             _lib.check(lib.rcu_unet_layer_info(handle, i, ctypes.byref(info)))
             rows.append(dict(index=i, name=info.name.decode(), kernel=info.kernel.decode(), cin=info.cin,
-                             cout=info.cout, height=info.height, width=info.width, upsample=bool(info.upsample),
+                             cout=info.cout, height=info.height, width=info.width, grid_height=info.grid_height, grid_width=info.grid_width,
+                             upsample=bool(info.upsample),
                              pooled=bool(info.pooled), dual_source=bool(info.dual_source), head_fusable=bool(info.head_fusable),
                              flops_per_slice=info.flops_per_slice,
                              mfma_flops_per_slice=info.mfma_flops_per_slice))
