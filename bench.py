@@ -12,7 +12,10 @@ reported next to it (`resident`).  N > 1 shards the T+1 forward passes of every 
     python bench.py --gpus N ...                  (starts its N ranks itself, as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 `--workload isic` is BASELINE.json's configs[1] (ISIC baseline_mc: 32 images of 3 x 256 x 256, T = 20) with the same
-JSON schema.
+JSON schema.  `--workload brats-native` / `isic-native` are the shapes the reference's real data has -- 155 slices of 4 x 240 x 240 (the
+reference never crops BraTS: scripts/create_brats18_dataset.py:53-72) and 32 images of 3 x 192 x 256 (scripts/prepare_isic_data.py:29-30) --,
+whose levels are not whole Winograd tiles and run on padded levels (rcu_unet_options.pad_levels); the default run carries the first as the
+sub-record `native_shapes` (a child process of rank 0, behind the headline's timed region; never in the headline's place).
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (HIP events recorded on the
 launch stream between the kernels, see rcu_unet_profile_begin in include/rcu.h -- inside the timed region with
@@ -62,12 +65,18 @@ def make_model(seed, device, sigma_out=False, params=None):
     return model.to(device)
 
 
-def make_volume(seed, n=SLICES):
+# the reference's real data (not BASELINE's benchmark shapes): a BraTS volume is 155 slices of 240 x 240 (never cropped:
+# scripts/create_brats18_dataset.py:53-72; config/test_brats_baseline_mc.yaml:30-31 slices it), an ISIC image 192 x 256 (scripts/prepare_isic_data.py:29-30)
+NATIVE_SLICES, NATIVE_HEIGHT, NATIVE_WIDTH = 155, 240, 240
+ISIC_NATIVE_HEIGHT, ISIC_NATIVE_WIDTH = 192, 256
+
+
+def make_volume(seed, n=SLICES, height=HEIGHT, width=WIDTH, slices=SLICES):
     """x ~ N(0,1) zeroed outside a centred ellipsoid (= the ECE brain mask); target = smaller ellipsoid."""
     gen = torch.Generator().manual_seed(seed)
-    x = torch.randn(n, CHANNELS, HEIGHT, WIDTH, generator=gen)
-    zz, yy, xx = torch.meshgrid(torch.linspace(-1, 1, SLICES)[:n] if n <= SLICES else torch.linspace(-1, 1, n),
-                                torch.linspace(-1, 1, HEIGHT), torch.linspace(-1, 1, WIDTH), indexing='ij')
+    x = torch.randn(n, CHANNELS, height, width, generator=gen)
+    zz, yy, xx = torch.meshgrid(torch.linspace(-1, 1, slices)[:n] if n <= slices else torch.linspace(-1, 1, n),
+                                torch.linspace(-1, 1, height), torch.linspace(-1, 1, width), indexing='ij')
     r2 = (zz / 0.9) ** 2 + (yy / 0.85) ** 2 + (xx / 0.8) ** 2
     mask = r2 < 1.0
     target = ((zz / 0.35) ** 2 + ((yy - 0.1) / 0.3) ** 2 + ((xx + 0.1) / 0.3) ** 2 < 1.0).to(torch.uint8)
@@ -75,12 +84,12 @@ def make_volume(seed, n=SLICES):
     return x, mask, target
 
 
-def make_isic_batch(seed, n=ISIC_IMAGES):
+def make_isic_batch(seed, n=ISIC_IMAGES, height=ISIC_HEIGHT, width=ISIC_WIDTH):
     """x ~ U(0,1) [n, 3, 256, 256] (images rescaled to 0..1); target = a centred ellipse per image (a lesion),
     no evaluation mask (the ISIC evaluation has none)."""
     gen = torch.Generator().manual_seed(seed)
-    x = torch.rand(n, ISIC_CHANNELS, ISIC_HEIGHT, ISIC_WIDTH, generator=gen)
-    yy, xx = torch.meshgrid(torch.linspace(-1, 1, ISIC_HEIGHT), torch.linspace(-1, 1, ISIC_WIDTH), indexing='ij')
+    x = torch.rand(n, ISIC_CHANNELS, height, width, generator=gen)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, height), torch.linspace(-1, 1, width), indexing='ij')
     radius = 0.3 + 0.4 * torch.rand(n, generator=gen)
     target = (((yy / 0.9) ** 2 + xx ** 2)[None] < (radius ** 2)[:, None, None]).to(torch.uint8)
     return x, torch.ones_like(target, dtype=torch.bool), target
@@ -423,8 +432,29 @@ def plan_fingerprint(layers, samples_per_launch):
     """Short hash of what determines a kernel's HBM traffic per launch: the layer table (kernel instantiation and shape of every layer)
     and the samples a launch covers."""
     import hashlib
-    text = ';'.join('{name}|{kernel}|{cin}|{cout}|{height}x{width}'.format(**L) for L in layers) + ';n={}'.format(samples_per_launch)
+    text = ';'.join('{name}|{kernel}|{cin}|{cout}|{height}x{width}|{grid_height}x{grid_width}'.format(**L) for L in layers) + ';n={}'.format(samples_per_launch)
     return hashlib.sha256(text.encode()).hexdigest()[:12]
+
+
+def native_sub_record(T, lanes, steps=4, warmup=1):
+    """`python bench.py --workload brats-native --brief` as a child process (started fresh: no exec from this GPU-touched process), condensed."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'brats-native', '--brief', '--steps', str(steps), '--warmup', str(warmup),
+           '--mc', str(T), '--lanes', str(lanes), '--cpu-budget', '8']
+    try:
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=dict(os.environ, RCU_BENCH_NATIVE='0'))
+        line = [ln for ln in proc.stdout.decode().splitlines() if ln.startswith('{"metric"')][-1]
+        r = json.loads(line)
+    except Exception as exc:  # noqa: BLE001 - the headline must not depend on the sub-record
+        return dict(error='{}: {}'.format(type(exc).__name__, exc))
+    roof = r['roofline']
+    keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'achieved_canonical', 'canonical_frac', 'traffic', 'launches', 'avg_launch_ms',
+            'flops_per_launch', 'executed_flops_per_launch', 'all_conv_kernels', 'per_kernel', 'plan_fingerprint', 'measured_in')
+    return {'brats_155x240x240': dict(metric=r['metric'], value=r['value'], unit=r['unit'], steps=r['steps'], warmup=r['warmup'],
+                                      ms_per_step=r['ms_per_step'], config=r['config'], resident=r['resident'],
+                                      roofline={k: roof.get(k) for k in keep}, parity=r['parity'],
+                                      cpu_baseline={k: r['cpu_baseline'].get(k) for k in ('value', 'unit', 'cores', 'kind', 'sample')} if r.get('cpu_baseline') else None,
+                                      command=' '.join(cmd[1:]))}
 
 
 def split_masks(model, flat, n, rows):
@@ -442,8 +472,13 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mc', type=int, default=20, help='T: stochastic passes per volume')
-    ap.add_argument('--workload', choices=('brats', 'isic'), default='brats',
-                    help='brats: 160 slices of 4x192x128 (the headline, BASELINE configs[2]); isic: 32 images of 3x256x256 (configs[1])')
+    ap.add_argument('--workload', choices=('brats', 'isic', 'brats-native', 'isic-native'), default='brats',
+                    help='brats: 160 slices of 4x192x128 (the headline, BASELINE configs[2]); isic: 32 images of 3x256x256 (configs[1]); '
+                         'brats-native / isic-native: the shapes of the reference\'s real data, 155 slices of 4x240x240 / 32 images of 3x192x256 '
+                         '(padded levels)')
+    ap.add_argument('--brief', action='store_true',
+                    help='the timed region, roofline and parity only: no all-outputs leg, no standalone aggregation / calibration kernel probes, '
+                         'no native-shape sub-record (what the default run\'s `native_shapes` child runs with)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=24.0, help='seconds of CPU work the oracle leg may take (bounded sample)')
     ap.add_argument('--ws-transport', choices=('reduce', 'p2p'), default=None,
@@ -506,8 +541,14 @@ def main():
     # N > 1 code on a box with one GPU (tools/rccl_world1_rehearsal.py; profiles/r04_rccl_world1.txt).
     force_pg = world == 1 and os.environ.get('RCU_BENCH_FORCE_PG') == '1'
     seed = 20                                   # config seed (config/test_brats_baseline_mc.yaml:6)
-    isic = args.workload == 'isic'
-    x_cpu, mask_cpu, target_cpu = make_isic_batch(seed) if isic else make_volume(seed)
+    isic = args.workload in ('isic', 'isic-native')
+    native = args.workload.endswith('-native')
+    if isic:
+        n_slices, height, width = (ISIC_IMAGES, ISIC_NATIVE_HEIGHT, ISIC_NATIVE_WIDTH) if native else (ISIC_IMAGES, ISIC_HEIGHT, ISIC_WIDTH)
+        x_cpu, mask_cpu, target_cpu = make_isic_batch(seed, n_slices, height, width)
+    else:
+        n_slices, height, width = (NATIVE_SLICES, NATIVE_HEIGHT, NATIVE_WIDTH) if native else (SLICES, HEIGHT, WIDTH)
+        x_cpu, mask_cpu, target_cpu = make_volume(seed, n_slices, height, width, n_slices)
     feeder = VolumePrefetcher(x_cpu, device)
     # The RCCL process group is initialised WITHOUT `device_id=` (the communicator is then created at the first collective, in the warm-up
     # steps).  Measured at N = 1 through a one-rank group (round 4, profiles/r04_pg_h2d.txt): with `device_id=device` (eager creation at
@@ -536,7 +577,6 @@ def main():
 
     T = args.mc
     params = ISIC_PARAMS if isic else MODEL_PARAMS
-    n_slices, height, width = (ISIC_IMAGES, ISIC_HEIGHT, ISIC_WIDTH) if isic else (SLICES, HEIGHT, WIDTH)
     unit_name = 'image' if isic else 'volume'
     model = make_model(seed, device, sigma_out=args.aleatoric, params=params)
     if args.ensemble:
@@ -680,7 +720,7 @@ def main():
     # step), over the SAME step indices as the headline's timed region: the runner's masks are a function of (seed, step, pass), so its last
     # volume runs under the masks of the headline's last volume and the CPU leg below is the reference of both.
     all_out, out_ao = None, None
-    if not (args.all_outputs or args.ensemble or args.aleatoric):
+    if not (args.all_outputs or args.ensemble or args.aleatoric or args.brief):
         ao_volumes = sum(timed_sizes[-min(len(timed_sizes), 5):])
         runner_ao = rdist.ShardedMcRunner(model, T, ws_pass=not args.no_ws, rank=rank, world=world, seed=seed, pass_group=args.pass_group,
                                           lanes=args.lanes, ws_transport=args.ws_transport, do_mi=True, do_var=True, force_exchange=force_pg)
@@ -805,64 +845,65 @@ def main():
     # csrc/rcu_wino.hip, wino_epilogue_head; pass groups too) and have no launch of their own; the standalone head kernel
     # -- the path of the sigma / feature outputs and of more than two classes, same arithmetic, same bits -- is timed here, outside
     # the timed region, on the same volume (UNet.set_fuse_head = rcu_unet_set_fuse_head, include/rcu.h).
-    fused_head_ms = slot_ms[-1] / passes_run
-    model.set_fuse_head(False)
-    try:
-        probe = steps.McStatistics(n_slices, 2, height, width, device)
-        model.forward_accumulate(x, probe)
-        model.profile_begin(height, width, n_slices, 3)
-        for _ in range(3):
+    if not args.brief:
+        fused_head_ms = slot_ms[-1] / passes_run
+        model.set_fuse_head(False)
+        try:
+            probe = steps.McStatistics(n_slices, 2, height, width, device)
             model.forward_accumulate(x, probe)
-        torch.cuda.synchronize()
-        cnt_h, ms_h = model.profile_collect(height, width, n_slices)
-        head_ms = ms_h[-1] / max(cnt_h, 1)
-        del probe
-        # the same kernel with every output tracked (mutual information + variance: float64 statistics, S = 5 planes)
-        probe = steps.McStatistics(n_slices, 2, height, width, device, True, True)
-        model.forward_accumulate(x, probe)
-        model.profile_begin(height, width, n_slices, 3)
-        for _ in range(3):
+            model.profile_begin(height, width, n_slices, 3)
+            for _ in range(3):
+                model.forward_accumulate(x, probe)
+            torch.cuda.synchronize()
+            cnt_h, ms_h = model.profile_collect(height, width, n_slices)
+            head_ms = ms_h[-1] / max(cnt_h, 1)
+            del probe
+            # the same kernel with every output tracked (mutual information + variance: float64 statistics, S = 5 planes)
+            probe = steps.McStatistics(n_slices, 2, height, width, device, True, True)
             model.forward_accumulate(x, probe)
-        torch.cuda.synchronize()
-        cnt_h, ms_h = model.profile_collect(height, width, n_slices)
-        head_all_ms = ms_h[-1] / max(cnt_h, 1)
-        del probe
-    finally:
-        model.set_fuse_head(True)
-    roofline['other_ms_per_forward']['head_fused_into'] = 'conv_cls.0 epilogue' if fused_head_ms < 0.5 * head_ms else None
-    # the first conv kernel (csrc/rcu_first.hip) reads the NCHW input itself: no re-layout kernel in the timed region then
-    roofline['other_ms_per_forward']['input_read_by'] = layers[0]['kernel'] if layers[0]['kernel'].startswith('conv3x3_first') else 'pack_input_kernel'
-    roofline['aggregation'] = dict(bound='hbm', kernel='head_stream_kernel', achieved=head_bytes / head_ms / 1e6, peak=PEAK_HBM_GBS,
-                                   unit='GB/s', frac=head_bytes / head_ms / 1e6 / PEAK_HBM_GBS, bytes_per_launch=head_bytes,
-                                   avg_launch_ms=head_ms, measured='standalone launches outside the timed region')
-    roofline['aggregation'].update(aggregation_kernels(device, n_slices, height, width))
-    # the aggregation with every output tracked (188.7 MB per sample-volume = V*C*4 of logits + 2*S*4*V of statistics,
-    # S = 5).  The head kernel never sees logits -- it reads the 32-channel feature map (4*V*32) -- and its planes are float64 (2*S*8*V):
-    # `achieved` prices the ALGORITHMIC bytes against its time, `moved_*` the bytes it really moves.
-    ao_alg = vox * (2 * 4 + 2 * 5 * 4.0)
-    ao_moved = 4.0 * vox * 32 + 2 * 5 * 8.0 * vox
-    agg_all = dict(bound='hbm', kernel='head_kernel (MI + variance statistics)', avg_launch_ms=head_all_ms,
-                   bytes_per_launch=ao_alg, achieved=ao_alg / head_all_ms / 1e6, peak=PEAK_HBM_GBS, unit='GB/s',
-                   frac=ao_alg / head_all_ms / 1e6 / PEAK_HBM_GBS, moved_bytes_per_launch=ao_moved,
-                   moved_gbs=ao_moved / head_all_ms / 1e6, moved_frac=ao_moved / head_all_ms / 1e6 / PEAK_HBM_GBS,
-                   measured='standalone launches outside the timed region; in the timed steps the update runs inside conv_cls.0')
-    agg_all.update(aggregation_kernels(device, n_slices, height, width, all_outputs=True))
-    roofline['aggregation_all_outputs'] = agg_all
+            model.profile_begin(height, width, n_slices, 3)
+            for _ in range(3):
+                model.forward_accumulate(x, probe)
+            torch.cuda.synchronize()
+            cnt_h, ms_h = model.profile_collect(height, width, n_slices)
+            head_all_ms = ms_h[-1] / max(cnt_h, 1)
+            del probe
+        finally:
+            model.set_fuse_head(True)
+        roofline['other_ms_per_forward']['head_fused_into'] = 'conv_cls.0 epilogue' if fused_head_ms < 0.5 * head_ms else None
+        # the first conv kernel (csrc/rcu_first.hip) reads the NCHW input itself: no re-layout kernel in the timed region then
+        roofline['other_ms_per_forward']['input_read_by'] = layers[0]['kernel'] if layers[0]['kernel'].startswith('conv3x3_first') else 'pack_input_kernel'
+        roofline['aggregation'] = dict(bound='hbm', kernel='head_stream_kernel', achieved=head_bytes / head_ms / 1e6, peak=PEAK_HBM_GBS,
+                                       unit='GB/s', frac=head_bytes / head_ms / 1e6 / PEAK_HBM_GBS, bytes_per_launch=head_bytes,
+                                       avg_launch_ms=head_ms, measured='standalone launches outside the timed region')
+        roofline['aggregation'].update(aggregation_kernels(device, n_slices, height, width))
+        # the aggregation with every output tracked (188.7 MB per sample-volume = V*C*4 of logits + 2*S*4*V of statistics,
+        # S = 5).  The head kernel never sees logits -- it reads the 32-channel feature map (4*V*32) -- and its planes are float64 (2*S*8*V):
+        # `achieved` prices the ALGORITHMIC bytes against its time, `moved_*` the bytes it really moves.
+        ao_alg = vox * (2 * 4 + 2 * 5 * 4.0)
+        ao_moved = 4.0 * vox * 32 + 2 * 5 * 8.0 * vox
+        agg_all = dict(bound='hbm', kernel='head_kernel (MI + variance statistics)', avg_launch_ms=head_all_ms,
+                       bytes_per_launch=ao_alg, achieved=ao_alg / head_all_ms / 1e6, peak=PEAK_HBM_GBS, unit='GB/s',
+                       frac=ao_alg / head_all_ms / 1e6 / PEAK_HBM_GBS, moved_bytes_per_launch=ao_moved,
+                       moved_gbs=ao_moved / head_all_ms / 1e6, moved_frac=ao_moved / head_all_ms / 1e6 / PEAK_HBM_GBS,
+                       measured='standalone launches outside the timed region; in the timed steps the update runs inside conv_cls.0')
+        agg_all.update(aggregation_kernels(device, n_slices, height, width, all_outputs=True))
+        roofline['aggregation_all_outputs'] = agg_all
     # HBM traffic of the dominant kernel: a builder-run PMC figure (profiles/pmc_traffic.json), reported only while the plan it was
     # measured on is the plan of this run (kernel per layer, shapes, samples per launch) -- a changed tile shape must not inherit it
     plan_hash = plan_fingerprint(layers, n_slices * g)
     roofline['plan_fingerprint'] = plan_hash
-    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(pmc_path) and not isic:
+    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json' if args.workload == 'brats' else 'pmc_traffic_{}.json'.format(args.workload))
+    if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
         meta = pmc.get('_meta', {})
         if dominant in pmc and meta.get('plan_fingerprint') == plan_hash:
             roofline['traffic'] = pmc[dominant]
-            roofline['traffic_source'] = ('profiles/pmc_traffic.json: HBM bytes per launch from a builder-run rocprofv3 --pmc pass on the '
+            roofline['traffic_source'] = (os.path.relpath(pmc_path, ROOT) + ': HBM bytes per launch from a builder-run rocprofv3 --pmc pass on the '
                                           'same plan (fingerprint {}; separate run, not measured in this process)'.format(plan_hash))
         elif dominant in pmc:
-            roofline['traffic_source'] = ('none: profiles/pmc_traffic.json was measured on another plan (fingerprint {} there, {} here)'
+            roofline['traffic_source'] = ('none: ' + os.path.relpath(pmc_path, ROOT) + ' was measured on another plan (fingerprint {} there, {} here)'
                                           .format(meta.get('plan_fingerprint'), plan_hash))
 
     # ---- parity, outside the timed region, of the TIMED output (last step): ECE on the GPU maps vs the oracle on the same maps,
@@ -939,7 +980,7 @@ def main():
             rec['slices_compared'] = [int(v) for v in sel]
 
     units = T * (n_slices if isic else 1)
-    shape = '{}x{}x{}'.format(ISIC_CHANNELS, height, width) if isic else '4x160x192x128'
+    shape = '{}x{}x{}'.format(ISIC_CHANNELS, height, width) if isic else '4x{}x{}x{}'.format(n_slices, height, width)
     result = {
         'metric': ('ensemble-member-{}s/sec ({}, K={})'.format(unit_name, shape, T) if args.ensemble
                    else 'MC-sample-{}s/sec ({}, T={}{}{})'.format(unit_name, shape, T, ', sigma head' if args.aleatoric else '',
@@ -953,16 +994,17 @@ def main():
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': ('ISIC {}: 2D U-Net(2,3,depth 4,start_filters 32,dropout 0.05) over a batch of {} images of 3x256x256, '
+        'config': {'workload': ('ISIC {}: 2D U-Net(2,3,depth 4,start_filters 32,dropout 0.05) over a batch of {} images of 3x{}x{}, '
                                 '{} + mean/entropy aggregation per step'
-                                .format('ensemble' if args.ensemble else 'baseline_mc', n_slices,
+                                .format('ensemble' if args.ensemble else 'baseline_mc', n_slices, height, width,
                                         '{} members'.format(T) if args.ensemble else
                                         'T={} MC-dropout passes{}'.format(T, '' if args.no_ws else ' + weight-scaling pass'))) if isic else
-                               ('BraTS ensemble: {} U-Net(2,4,depth 4,start_filters 32) members over 160 slices of 4x192x128 '
-                                '+ mean/entropy aggregation per step'.format(T)) if args.ensemble else
-                               ('BraTS {}: 2D U-Net(2,4,depth 4,start_filters 32,dropout 0.05{}) over 160 slices '
-                                'of 4x192x128, T={} MC-dropout passes{} + mean/entropy aggregation per step'
+                               ('BraTS ensemble: {} U-Net(2,4,depth 4,start_filters 32) members over {} slices of 4x{}x{} '
+                                '+ mean/entropy aggregation per step'.format(T, n_slices, height, width)) if args.ensemble else
+                               ('BraTS {}: 2D U-Net(2,4,depth 4,start_filters 32,dropout 0.05{}) over {} slices '
+                                'of 4x{}x{}{}, T={} MC-dropout passes{} + mean/entropy aggregation per step'
                                 .format('aleatoric + MC' if args.aleatoric else 'baseline_mc', ', sigma_out' if args.aleatoric else '',
+                                        n_slices, height, width, ' (the reference\'s uncropped BraTS slices: padded levels)' if native else '',
                                         T, '' if args.no_ws else ' + weight-scaling pass')),
                    'T': T, 'ws_pass': not (args.no_ws or args.ensemble), 'slices': n_slices, 'height': height, 'width': width,
                    'pass_group': g, 'lanes': args.lanes, 'volumes_per_step': v_step, 'samples_per_launch': samples_per_launch,
@@ -982,11 +1024,16 @@ def main():
                          note='the same steps with the volume already in HBM when the clock starts (no host-to-device copy): the '
                               'secondary figure; `value` has the prefetched copy inside'),
         'roofline': roofline,
-        'calibration_kernels': calibration_kernels(device) if (world == 1 and not isic) else None,
+        'calibration_kernels': calibration_kernels(device) if (world == 1 and not isic and not args.brief) else None,
         'cpu_baseline': cpu,
         'parity': parity,
         'all_outputs': all_out,
     }
+    # ---- the reference's real BraTS shape as a sub-record of the default run (a child process: this process keeps its plans; the child has the
+    # GPU to itself while rank 0 waits), with its own roofline and parity -- never in the headline's place
+    if (args.workload == 'brats' and world == 1 and not (args.brief or args.ensemble or args.aleatoric or args.all_outputs or args.no_cpu_baseline)
+            and os.environ.get('RCU_BENCH_NATIVE', '1') != '0'):
+        result['native_shapes'] = native_sub_record(T, args.lanes)
     if force_pg:
         result['rccl_rehearsal'] = dict(backend=dist.get_backend(), world=dist.get_world_size(), ws_transport=runner.ws_transport,
                                         p2p_messages=runner.p2p_messages,

@@ -376,20 +376,21 @@ static int build_plan_for(rcu_unet* h, bool* valid)
             return fail(RCU_ERR_INVALID, "internal: channel chunking does not divide for layer " + L.name);
         L.NT = (L.coutp + ci.BN - 1) / ci.BN;
         // a padded tensor may only be touched by a kernel that keeps its zeros: read as a tile grid and written by the Winograd families /
-        // rcu_first.hip -- or written by a direct up-convolution, which places its image in a larger tensor anyway (the centre pad)
+        // rcu_first.hip -- or written by a direct up-convolution, which places its image in a larger tensor anyway (the centre pad), or as
+        // the pooled output of a direct conv unit (it writes the real pooled pixels at the tensor's own pitch)
         const bool src_padded = h->tensors[L.t_src1].padded() && L.t_src1 != h->t_input;
         const bool first_reads_caller = L.t_src1 == h->t_input && h->tensors[L.t_src1].padded();
-        const bool pool_padded = L.t_pool >= 0 && h->tensors[L.t_pool].padded();
         const bool out_padded = to.padded() && !(L.upsample && !cfg_handles_padding(L.cfg) && !h->tensors[L.t_src1].padded());
-        if ((src_padded || first_reads_caller || pool_padded || out_padded) && !cfg_handles_padding(L.cfg) && valid) *valid = false;
+        if ((src_padded || first_reads_caller || out_padded) && !cfg_handles_padding(L.cfg) && valid) *valid = false;
     }
     assign_layouts(h);
     return RCU_OK;
 }
 
 // Rough time of a plan's conv stack per slice, arbitrary units: multiplications the layer's kernel executes on whole tiles of the grid it walks
-// / the executed fraction of the matrix peak the kernel family has measured at (the direct kernels: profiles/r06_*).  It
-// only has to rank "pad the level to whole Winograd tiles" against "keep the real extent on the direct kernels" and one padding against another.
+// / the executed fraction of the matrix peak the kernel family has measured at (the direct kernels on the native BraTS
+// volume: profiles/r06_layer_report_native_155_nopad.txt, 0.73-0.80).  It only has to rank "pad the level to whole Winograd tiles" against
+// "keep the real extent on the direct kernels" and one padding against another.
 static double plan_cost(const rcu_unet* h)
 {
     double total = 0.0;
@@ -403,8 +404,8 @@ static double plan_cost(const rcu_unet* h)
         else if (ci.WINO == 3) { mults = L.cfg == CONV_CFG_WINO4_S8T12x8_N32 ? 3.0 : 2.25; eff = (L.c1p + L.c2p) <= 32 ? 0.45 : 0.58; }
         else if (ci.WINO == 2) { mults = 9.0; eff = 0.72; }                              // four classes x 9 / 4 per low-resolution pixel
         else if (ci.WINO == 1) { mults = 4.0; eff = 0.62; }
-        else if (L.upsample) { mults = 16.0; eff = 0.55; }                               // four classes x 2x2 taps per low-resolution pixel
-        else { mults = 9.0; eff = 0.55; }
+        else if (L.upsample) { mults = 16.0; eff = 0.72; }                               // four classes x 2x2 taps per low-resolution pixel
+        else { mults = 9.0; eff = 0.75; }
         total += px * kn * mults / eff;
     }
     return total;
@@ -922,6 +923,8 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
             a.out_H = tout.H; a.out_W = tout.W;
             if (L.t_pool >= 0) { a.pool_H = h->tensors[L.t_pool].H; a.pool_W = h->tensors[L.t_pool].W; }
         }
+    } else if (L.t_pool >= 0 && h->tensors[L.t_pool].padded()) {
+        a.pool_H = h->tensors[L.t_pool].H; a.pool_W = h->tensors[L.t_pool].W;   // a direct unit pooling into a padded level
     } else if (L.upsample && (2 * gh != tout.H || 2 * gw != tout.W)) {
         // the direct up-convolution places its 2 gh x 2 gw image in a larger tensor: the reference's centre pad
         // F.pad(up, (dw // 2, dw - dw // 2, dh // 2, dh - dh // 2)) (unet.py:110-116), and / or a padded level around it

@@ -131,6 +131,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&
     const bool full_tile = (y0 + T::TH <= a.H) && (x0 + T::TW <= a.W) && (n0 + T::TS <= a.N);
     const size_t row_stride = (size_t)OW * a.CoutP * OS, col_stride = (size_t)a.CoutP * OS;
     const int Hp = a.H >> 1, Wp = a.W >> 1;
+    // the pooled tensor may belong to a padded level (ConvArgs::pool_H / pool_W, rcu_api.hip choose_level_extents): its own extents, our pixels
+    const int PHs = a.pool_H > 0 ? a.pool_H : Hp, PWs = a.pool_W > 0 ? a.pool_W : Wp;
 #pragma unroll
     for (int ni = 0; ni < NTW; ++ni) {
         const int co = ntile * T::BN + (wn * NTW + ni) * 32 + m;
@@ -174,7 +176,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&
                         const int i0 = (2 * pr) * 4 + 2 * pc;
                         const float mx = fmaxf(fmaxf(v[i0], v[i0 + 1]), fmaxf(v[i0 + 4], v[i0 + 5]));
                         const int py = (yb >> 1) + pr, px = (xb >> 1) + pc;
-                        if (py < Hp && px < Wp) a.pooled[((size_t)(n * Hp + py) * Wp + px) * a.CoutP + co] = mx;
+                        if (py < Hp && px < Wp) a.pooled[((size_t)(n * PHs + py) * PWs + px) * a.CoutP + co] = mx;
                     }
             }
         }

@@ -232,3 +232,63 @@ def test_uncertain_voxel_table_matches_fixture_g20():
         text = f.read()
     for k in range(11):
         assert '0x{:08x}u, {}u, 0x{:08x}u, {}u'.format(int(g['lo_first'][k]), int(g['lo_width'][k]), int(g['hi_first_false'][k]), int(g['hi_width'][k])) in text
+
+
+def _plan_rows(h, w, n, cin=4, **options):
+    """The planner alone (rcu_unet_plan: no device memory): [(name, kernel, height, width, grid_height, grid_width)] of the shipped BraTS / ISIC architecture."""
+    import ctypes
+    from rcu_amd import _lib
+    lib = _lib.load()
+    desc = _lib.UnetDesc(nb_classes=2, in_channels=cin, depth=4, start_filters=32, has_dropout=1, dropout_center=-1, sigma_out=options.pop('sigma_out', 0),
+                         bn=1, height=h, width=w, max_batch=n, residual=options.pop('residual', 0), provide_features=options.pop('provide_features', 0))
+    opts = _lib.UnetOptions()
+    lib.rcu_unet_default_options(ctypes.byref(opts))
+    for key, value in options.items():
+        setattr(opts, key, value)
+    handle = ctypes.c_void_p()
+    _lib.check(lib.rcu_unet_plan(ctypes.byref(desc), ctypes.byref(opts), ctypes.byref(handle)))
+    try:
+        assert lib.rcu_unet_finalize_weights(handle) == -4      # RCU_ERR_STATE: a plan is inspected, never run
+        rows = []
+        for i in range(lib.rcu_unet_num_layers(handle)):
+            info = _lib.LayerInfo()
+            _lib.check(lib.rcu_unet_layer_info(handle, i, ctypes.byref(info)))
+            rows.append((info.name.decode(), info.kernel.decode(), info.height, info.width, info.grid_height, info.grid_width))
+        return rows
+    finally:
+        lib.rcu_unet_destroy(handle)
+
+
+def test_planner_pads_the_levels_of_the_references_real_shapes():
+    """csrc/rcu_api.hip choose_level_extents (round 6).  The reference's BraTS slices are 240 x 240 (scripts/create_brats18_dataset.py:53-72 never
+    crops; levels 240 / 120 / 60 / 30 / 15), ISIC's 192 x 256 ends in a 12 x 16 level (scripts/prepare_isic_data.py:29-30): their levels are
+    ALLOCATED with whole-tile extents and every layer runs a Winograd kernel (rounds 1-5: >= 16 of 23 layers of a 240 x 240 slice on the direct
+    kernels).  Whole-tile shapes -- the benchmark's 192 x 128 and 256 x 256 -- keep their plans; pad_levels = 0, residual blocks' adding units
+    and the feature tap keep real extents where they must."""
+    native = _plan_rows(240, 240, 155)
+    assert len(native) == 23 and native[0][1].startswith('conv3x3_first')
+    assert sum('winograd' in r[1] for r in native) == 22 and not any('igemm' in r[1] for r in native)
+    grids = {(r[2], r[3]): (r[4], r[5]) for r in native if 'upconv' not in r[0]}
+    assert grids[(120, 120)] == (128, 128) and grids[(60, 60)] == (64, 64) and grids[(30, 30)] == (32, 32) and grids[(15, 15)] == (16, 16)
+    assert grids[(240, 240)][0] in (240, 256) and grids[(240, 240)][1] == 256
+    up = {(r[2], r[3]): (r[4], r[5]) for r in native if 'upconv' in r[0]}          # an up-convolution's tiles walk the low-resolution level
+    assert up[(30, 30)] == (16, 16) and up[(240, 240)] == (128, 128)
+    isic = _plan_rows(192, 256, 32, cin=3)
+    assert sum('winograd' in r[1] for r in isic) == 22
+    assert {(r[2], r[3]): (r[4], r[5]) for r in isic if 'upconv' not in r[0]}[(12, 16)] == (16, 16)
+    assert all((r[2], r[3]) == (r[4], r[5]) for r in isic if r[2] >= 48 and 'upconv' not in r[0])       # the levels with whole tiles are left alone
+    # the benchmark shapes: nothing is padded, the round-5 kernels
+    bench = _plan_rows(192, 128, 640)
+    assert all((r[4], r[5]) == ((r[2] // 2, r[3] // 2) if 'upconv' in r[0] else (r[2], r[3])) for r in bench)
+    assert [r[1] for r in bench][1] == 'conv3x3_winograd4<T32x32,N32,K8>' and bench[9][1] == 'conv3x3_winograd4<S8T12x8,N32,K8>'
+    assert all((r[2], r[3]) == (r[4], r[5]) for r in _plan_rows(256, 256, 32, cin=3) if 'upconv' not in r[0])
+    # A/B switch, and the layers that have no kernel that keeps the padding's zeros
+    direct = _plan_rows(240, 240, 155, pad_levels=0)
+    assert sum('igemm' in r[1] for r in direct) >= 16 and all((r[4], r[5]) == (r[2], r[3]) for r in direct if 'upconv' not in r[0])
+    residual = _plan_rows(240, 240, 8, residual=1)
+    assert all((r[4], r[5]) == (r[2], r[3]) for r in residual if 'upconv' not in r[0])      # the adding units run the direct kernels: real extents
+    feat = [r for r in _plan_rows(240, 240, 8, provide_features=1) if 'upconv' not in r[0]]
+    assert all((r[4], r[5]) == (240, 240) for r in feat if r[2] == 240) and any((r[4], r[5]) != (r[2], r[3]) for r in feat if r[2] < 240)
+    # a batch whose padded level 0 would pass 2 GB keeps to what fits: 640 samples of 240 x 240 x 32 channels are 4.7 GB -- the plan is refused
+    # at creation either way (rcu_unet_create: 2^31 elements), the planner itself must not crash
+    assert len(_plan_rows(240, 240, 640)) == 23

@@ -4,9 +4,9 @@
   reciprocal multiplication, 256-workgroup grids streaming over thousands of tiles).  The first / middle / last slices of the
   160-slice launch are compared bit for bit with an 8-slice launch of the same slices (slices are independent and every
   kernel sums in a fixed order) and with the oracle; the fused forward + softmax + accumulate path likewise with injected masks.
-* Native BraTS 240 x 240 slices (levels 240/120/60/30/15: odd sizes -> the direct igemm kernels next to the Winograd ones), the
-  reference's real ISIC size 192 x 256 (scripts/prepare_isic_data.py:29-30) and 3 x 256 x 256, full width, against the
-  oracle, asserting which kernel every layer got.
+* Native BraTS 240 x 240 slices (levels 240/120/60/30/15: no whole Winograd tile below the first level -> padded levels, round 6:
+  csrc/rcu_api.hip choose_level_extents), the reference's real ISIC size 192 x 256 (scripts/prepare_isic_data.py:29-30) and
+  3 x 256 x 256, full width, against the oracle, asserting which kernel every layer got.
 """
 import numpy as np
 import pytest
@@ -99,14 +99,18 @@ def test_real_data_shapes_full_width_vs_oracle(dev, cin, n, h, w):
     assert len(rows) == 23                                       # 19 conv units (conv_cls.0 last) + 4 up-convolutions
     # kernel selection (csrc/rcu_api.hip, pick_config): which family every layer got at this shape
     kernels = [r['kernel'] for r in rows]
+    # the first unit on its own kernel (whole 8x32 tiles), every other layer on a Winograd kernel -- at 240x240 (levels 240 / 120 / 60 / 30 / 15) and
+    # at 192x256's 12x16 bottom level through levels ALLOCATED with whole-tile extents (rcu_unet_options.pad_levels; rounds 1-5: >= 16 of the 23
+    # layers of a 240x240 slice ran the direct kernels)
+    assert kernels[0].startswith('conv3x3_first'), kernels
+    assert sum('winograd' in k for k in kernels[1:]) == 22, kernels
+    grids = {(r['height'], r['width'], r['grid_height'], r['grid_width']) for r in rows if not r['upsample']}
     if (h, w) == (240, 240):
-        # levels 240 / 120 / 60 / 30 / 15: no whole Winograd tile fits below the first level -> the direct igemm kernels carry it
-        assert sum('igemm' in k for k in kernels) >= 16, kernels
+        assert {(120, 120, 128, 128), (60, 60, 64, 64), (30, 30, 32, 32), (15, 15, 16, 16)} <= grids, grids
+    elif (h, w) == (192, 256):
+        assert (12, 16, 16, 16) in grids and (192, 256, 192, 256) in grids, grids
     else:
-        # 192x256 and 256x256: the first unit on its own kernel (whole 8x32 tiles), every other layer on a Winograd kernel
-        assert kernels[0].startswith('conv3x3_first'), kernels
-        # (the 12x16 bottom level of 192x256 has no whole Winograd tile: two units + the up-convolution out of it stay direct)
-        assert sum('winograd' in k for k in kernels[1:]) >= (22 if h == 256 else 19), kernels
+        assert all(g[:2] == g[2:] for g in grids), grids
     for mk in (None, masks):
         ref = uo.unet_forward(st, x, mk, **params).numpy()
         out = m(x.to(dev), mk).cpu().numpy()

@@ -173,3 +173,25 @@ def test_padding_stays_zero_whatever_ran_before(dev):
     fresh = _model(WIDE, st, dev)
     fresh.reserve(h, w, 9)
     assert torch.equal(used(x.to(dev), masks), fresh(x.to(dev), masks))
+
+
+@pytest.mark.timeout(900)
+def test_feature_tap_keeps_level_0_real_and_pools_into_a_padded_level(dev):
+    """provide_features (common/model/unet.py:135-136, 178-179): the feature tensor is handed out as [voxel][channel], so level 0 keeps its real
+    extent and the direct kernels -- whose pooled output then lands in the PADDED level 1, and whose input is the up-convolution out of it."""
+    from oracle import unet_oracle as uo
+    params = dict(WIDE, provide_features=True)
+    st = uo.synthetic_state(47, **WIDE)
+    g = torch.Generator().manual_seed(81)
+    n, h, w = 2, 240, 240
+    x = torch.randn(n, 4, h, w, generator=g)
+    _, sites = uo.unet_plan(**WIDE)
+    masks = uo.sample_masks(sites, n, 0.3, g)
+    m = _model(params, st, dev)
+    rows = m.layer_table(h, w, n)
+    assert all((r['grid_height'], r['grid_width']) == (240, 240) for r in rows if r['height'] == 240 and not r['upsample'])
+    assert any((r['grid_height'], r['grid_width']) == (128, 128) for r in rows)
+    ref_logits, ref_feat = uo.unet_forward(st, x, masks, return_features=True, **WIDE)
+    out = m(x.to(dev), masks)
+    assert _maxdiff(out.cpu().numpy(), ref_logits.numpy()) < LOGIT_TOL
+    assert _maxdiff(m.features.cpu().numpy(), ref_feat.numpy()) < 2e-5 * float(ref_feat.abs().max())
