@@ -457,6 +457,22 @@ def native_sub_record(T, lanes, steps=4, warmup=1):
                                       command=' '.join(cmd[1:]))}
 
 
+def sharding_record(runner, world, args, n_slices, height, width, v_step):
+    """What crosses xGMI per volume: one sum-reduce of the per-voxel statistics (exact float64 sums: two planes for mean + entropy) and the
+    weight-scaling probabilities -- point to point from their owner by default on RCCL (round 6), or in the reduce buffer's tail."""
+    vox = n_slices * height * width
+    planes = 2 + (3 if args.all_outputs else 0)
+    stats_bytes = planes * 8 * vox
+    ws_bytes = 0 if (args.no_ws or args.ensemble) else 2 * 8 * vox
+    transport = getattr(runner, 'ws_transport', None) or ('p2p' if dist.get_backend() == 'nccl' else 'reduce')
+    return dict(what='MC passes / members over ranks (job i of step k on rank (i + k * jobs) mod world), one RCCL sum-reduce of the statistics per step',
+                ws_transport=transport if ws_bytes else None,
+                reduce_bytes_per_volume=stats_bytes + (ws_bytes if transport == 'reduce' else 0),
+                p2p_bytes_per_volume=ws_bytes if transport == 'p2p' else 0,
+                p2p_note='only on the volumes whose weight-scaling pass the root does not run itself' if (ws_bytes and transport == 'p2p') else None,
+                statistics='exact float64 sums ({} planes of {} voxels)'.format(planes, vox), volumes_per_step=v_step)
+
+
 def split_masks(model, flat, n, rows):
     """Concatenated device mask tensor [site][n][C_site] -> list of per-site [len(rows), C_site] CPU tensors."""
     out, off = [], 0
@@ -1013,7 +1029,7 @@ def main():
                    'h2d': 'prefetched, inside timed region ({} MB per {} from pinned host memory on a copy stream, one event wait per '
                           '{}; rechun/dl/customsteps.py:20)'.format(feeder.bytes // 1000000, unit_name if not isic else 'batch',
                                                                     unit_name if not isic else 'batch'),
-                   'sharding': 'passes over ranks, one RCCL sum-reduce of the statistics per step' if world > 1 else 'none',
+                   'sharding': sharding_record(runner, world, args, n_slices, height, width, v_step) if world > 1 else 'none',
                    'gflop_per_sample_{}'.format(unit_name): conv_flops / passes_run / 1e9 / (n_slices if isic else 1)},
         'n_ranks_seen': n_ranks_seen,
         'devices': devices_seen,

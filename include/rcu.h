@@ -262,14 +262,17 @@ int rcu_prediction_and_foreground(const float* probs_dev, size_t n, size_t hw, i
 
 /* Dropout2d factors of the MC passes of a launch, drawn on the device in one kernel: the `masks_dev` argument of
  * rcu_unet_forward_accumulate_passes (passes == 1: of rcu_unet_forward / rcu_unet_forward_accumulate) for seeded passes.
- * seeds_host[t]: the seed of pass t (the predict steps use job_seed(YAML seed, batch index, pass)); site_channels_host / site_keep_host:
+ * seeds_host[t]: the seed of pass t (the predict steps use job_seed(YAML seed, pass)); first_sample: the GLOBAL index of the batch's sample 0 --
+ * its position in the run's stream of slices / images, whatever batches the loader cuts that stream into; site_channels_host / site_keep_host:
  * channels and 1 - p of the n_sites Dropout2d sites in execution order (site_keep < 0: the site is not active -- factor 1; 0: p = 1 -- factor 0).
- * out_dev: float32 [site][passes * n + i][C_site], sample t * n + i = image i in pass t.  Element r of pass t's own mask
- * ([site][n][C_site] flattened) is 1 / keep where the 24-bit uniform from word r & 3 of Philox4x32-10(key = seeds[t], counter = r >> 2)
- * is below keep, else 0: Bernoulli(1 - p) / (1 - p), the law of torch's Dropout2d (common/model/unet.py:16), and a function of
- * (seed, r) alone -- a pass's mask does not depend on the group, lane or rank it is launched in. */
-int rcu_dropout_masks(const uint64_t* seeds_host, int passes, int n, const int32_t* site_channels_host, const float* site_keep_host,
-                      int n_sites, float* out_dev, void* stream);
+ * out_dev: float32 [site][passes * n + i][C_site], sample t * n + i = image i in pass t.  The factor of (pass t, image i, site s, channel c) is
+ * 1 / keep where the 24-bit uniform from word e & 3 of Philox4x32-10(key = seeds[t], counter = e >> 2) is below keep, else 0, with
+ * e = (first_sample + i) * sum_s C_s + (C_0 + ... + C_{s-1}) + c: Bernoulli(1 - p) / (1 - p), the law of torch's Dropout2d
+ * (common/model/unet.py:16), and a function of (seed, global sample index, site, channel) alone -- a slice's MC sample does not depend on the
+ * batch_size it is loaded with (round 6; rounds 1-5 keyed the draw by the batch and the position in it), nor on the group, lane or rank the
+ * pass is launched in. */
+int rcu_dropout_masks(const uint64_t* seeds_host, int passes, int n, uint64_t first_sample, const int32_t* site_channels_host,
+                      const float* site_keep_host, int n_sites, float* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Metric seam: calibration histograms (numpyfunctions.py:6-107)

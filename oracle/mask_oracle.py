@@ -27,34 +27,39 @@ def philox4x32_10(counter, key):
     return c
 
 
-def pass_mask(seed, n, site_channels, site_keep):
-    """The mask of ONE pass in its own layout [site][n][C_site], flattened: element r is 1 / keep where the 24-bit uniform from word r & 3 of
-    Philox4x32-10(key = (seed low, seed high), counter = (r >> 2, 0, 0, 0)) is below keep, else 0; keep < 0: the site is inactive (ones)."""
-    lengths = [n * int(c) for c in site_channels]
-    total = sum(lengths)
-    quads = (total + 3) // 4
-    counter = np.zeros((quads, 4), dtype=np.uint32)
-    counter[:, 0] = np.arange(quads, dtype=np.uint32)
+def pass_mask(seed, n, site_channels, site_keep, first_sample=0):
+    """The mask of ONE pass in its own layout [site][n][C_site], flattened.  The factor of (image i, site s, channel c) is 1 / keep where the 24-bit
+    uniform from word e & 3 of Philox4x32-10(key = (seed low, seed high), counter = (e >> 2 low, e >> 2 high, 0, 0)) is below keep, else 0, with
+    e = (first_sample + i) * sum(site_channels) + sum(site_channels[:s]) + c -- a function of the image's global index, not of its batch;
+    keep < 0: the site is inactive (ones)."""
+    channels = [int(c) for c in site_channels]
+    per_sample = sum(channels)
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    words = philox4x32_10(counter, (seed & 0xFFFFFFFF, seed >> 32)).reshape(-1)[:total]
-    u = (words >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-    out = np.empty(total, dtype=np.float32)
-    at = 0
-    for length, keep in zip(lengths, site_keep):
+    chunks, off = [], 0
+    for ch, keep in zip(channels, site_keep):
+        g = np.uint64(first_sample) + np.arange(n, dtype=np.uint64)
+        e = (g[:, None] * np.uint64(per_sample) + np.uint64(off) + np.arange(ch, dtype=np.uint64)[None, :]).reshape(-1)
+        q = e >> np.uint64(2)
+        counter = np.zeros((e.size, 4), dtype=np.uint32)
+        counter[:, 0] = (q & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        counter[:, 1] = (q >> np.uint64(32)).astype(np.uint32)
+        words = philox4x32_10(counter, (seed & 0xFFFFFFFF, seed >> 32))
+        word = words[np.arange(e.size), (e & np.uint64(3)).astype(np.int64)]
+        u = (word >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
         keep = np.float32(keep)
         if keep < 0:
-            out[at:at + length] = 1.0
+            chunks.append(np.ones(e.size, dtype=np.float32))
         elif keep == 0:
-            out[at:at + length] = 0.0
+            chunks.append(np.zeros(e.size, dtype=np.float32))
         else:
-            out[at:at + length] = np.where(u[at:at + length] < keep, np.float32(1.0) / keep, np.float32(0.0))
-        at += length
-    return out
+            chunks.append(np.where(u < keep, np.float32(1.0) / keep, np.float32(0.0)).astype(np.float32))
+        off += ch
+    return np.concatenate(chunks)
 
 
-def group_masks(seeds, n, site_channels, site_keep):
+def group_masks(seeds, n, site_channels, site_keep, first_sample=0):
     """The passes of a launch in its layout [site][pass * n + i][C_site], flattened (what rcu_dropout_masks writes)."""
-    per_pass = [pass_mask(s, n, site_channels, site_keep) for s in seeds]
+    per_pass = [pass_mask(s, n, site_channels, site_keep, first_sample) for s in seeds]
     chunks, at = [], 0
     for c in site_channels:
         length = n * int(c)

@@ -93,7 +93,7 @@ SIGNATURES = {
     'rcu_aleatoric': (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     'rcu_prediction_and_foreground': (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
-    'rcu_dropout_masks': (c_int, [POINTER(c_uint64), c_int, c_int, POINTER(c_int32), POINTER(c_float), c_int, c_void_p, c_void_p]),
+    'rcu_dropout_masks': (c_int, [POINTER(c_uint64), c_int, c_int, c_uint64, POINTER(c_int32), POINTER(c_float), c_int, c_void_p, c_void_p]),
     'rcu_ece_thresholds': (c_int, [c_int, POINTER(c_float)]),
     'rcu_ece_workspace_bytes': (c_size_t, [c_size_t, c_int]),
     'rcu_ece_hist': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_float), c_int, c_void_p,

@@ -1384,8 +1384,8 @@ extern "C" int rcu_prediction_and_foreground(const float* probs, size_t n, size_
     return RCU_OK;
 }
 
-extern "C" int rcu_dropout_masks(const uint64_t* seeds, int passes, int n, const int32_t* site_channels, const float* site_keep,
-                                 int n_sites, float* out, void* stream)
+extern "C" int rcu_dropout_masks(const uint64_t* seeds, int passes, int n, uint64_t first_sample, const int32_t* site_channels,
+                                 const float* site_keep, int n_sites, float* out, void* stream)
 {
     if (!seeds || !site_channels || !site_keep || !out) return fail(RCU_ERR_INVALID, "rcu_dropout_masks: null argument");
     if (passes < 1 || n < 1 || n_sites < 1 || n_sites > MASK_MAX_SITES)
@@ -1398,7 +1398,11 @@ extern "C" int rcu_dropout_masks(const uint64_t* seeds, int passes, int n, const
         if (end * (long)passes >= (1l << 31)) return fail(RCU_ERR_INVALID, "rcu_dropout_masks: more than 2^31 factors");
         a.site_end[s] = (int)end;
         a.site_keep[s] = site_keep[s];
+        a.site_ch[s] = site_channels[s];
+        a.site_off[s] = a.per_sample;
+        a.per_sample += site_channels[s];
     }
+    a.first_sample = first_sample;
     a.sites = n_sites;
     a.per_pass = (int)end;
     a.passes = passes;

@@ -218,6 +218,10 @@ struct MaskArgs {
     int passes;                          // passes of the whole group: rows per site of the output layout
     int first, count;                    // this launch draws passes first .. first + count - 1 (seed[0 .. count - 1])
     int sites, per_pass;
+    int site_ch[MASK_MAX_SITES];         // channels of the site
+    int site_off[MASK_MAX_SITES];        // offset of the site in ONE sample's factors (prefix sums of site_ch); per_sample = their total
+    int per_sample;
+    unsigned long long first_sample;     // global index of the batch's sample 0 (include/rcu.h, rcu_dropout_masks)
 };
 hipError_t launch_dropout_masks(const MaskArgs& a, float* out, hipStream_t stream);
 

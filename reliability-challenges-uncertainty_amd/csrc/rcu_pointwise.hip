@@ -647,8 +647,9 @@ hipError_t launch_argmax_fg(const float* probs, int C, size_t N, size_t HW, uint
 // Dropout2d factors of the MC passes of a launch, all in ONE kernel (rcu_dropout_masks).  Drawn with torch -- one bernoulli_ per
 // pass, a division, a gather into the group layout -- a 62k-element draw is a 5 us kernel that takes 160 us to get its turn beside the
 // persistent conv kernels (profiles/r05_script_trace.txt): 20 of them per volume sit in front of the lanes' conv launches.
-// Element r of pass t's own mask ([site][n][C_site], r = 0 .. per_pass - 1) is word r & 3 of Philox4x32-10 under key seeds[t], counter
-// (r >> 2, 0, 0, 0): a function of (seed, r) alone -- the same value whatever the group the pass is launched in.
+// The factor of (pass t, sample i, site s, channel c) is word e & 3 of Philox4x32-10 under key seeds[t], counter (e >> 2 as two words, 0, 0) with
+// e = (first_sample + i) * per_sample + site_off[s] + c: a function of (seed, GLOBAL sample index, site, channel) alone -- the same value whatever
+// the batch the sample arrives in, the group the pass is launched in, the lane and the rank.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t (&out)[4])
 {
@@ -667,31 +668,27 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
 
 __global__ __launch_bounds__(PW_THREADS) void dropout_masks_kernel(const MaskArgs a, float* __restrict__ out)
 {
-    const int quads = (a.per_pass + 3) >> 2;
-    const int q = blockIdx.x * PW_THREADS + threadIdx.x;
+    const int r = blockIdx.x * PW_THREADS + threadIdx.x;      // element of the pass's own mask [site][n][C_site]
     const int t = blockIdx.y;
-    if (q >= quads) return;
+    if (r >= a.per_pass) return;
+    int s = 0;
+    while (r >= a.site_end[s]) ++s;                  // <= 40 sites, ascending: the site of element r
+    const int begin = s ? a.site_end[s - 1] : 0, len = a.site_end[s] - begin;
+    const int ch = a.site_ch[s], i = (r - begin) / ch, c = (r - begin) - i * ch;
+    const unsigned long long e = (a.first_sample + (unsigned long long)i) * (unsigned long long)a.per_sample + (unsigned long long)(a.site_off[s] + c);
     uint32_t w[4];
-    philox4x32_10((uint32_t)a.seed[t], (uint32_t)(a.seed[t] >> 32), (uint32_t)q, 0u, w);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = 4 * q + k;
-        if (r >= a.per_pass) break;
-        int s = 0;
-        while (r >= a.site_end[s]) ++s;                  // <= 40 sites, ascending: the site of element r
-        const int begin = s ? a.site_end[s - 1] : 0, len = a.site_end[s] - begin;
-        const float keep = a.site_keep[s];
-        const float u = (float)(w[k] >> 8) * (1.0f / 16777216.0f);        // uniform in [0, 1), 24 bits
-        const float factor = keep < 0.f ? 1.f : (keep > 0.f && u < keep) ? 1.f / keep : 0.f;
-        // group layout: [site][pass][n * C_site]
-        out[(size_t)a.passes * begin + (size_t)(a.first + t) * len + (r - begin)] = factor;
-    }
+    philox4x32_10((uint32_t)a.seed[t], (uint32_t)(a.seed[t] >> 32), (uint32_t)(e >> 2), (uint32_t)(e >> 34), w);
+    const uint32_t word = (e & 3) == 0 ? w[0] : (e & 3) == 1 ? w[1] : (e & 3) == 2 ? w[2] : w[3];
+    const float keep = a.site_keep[s];
+    const float u = (float)(word >> 8) * (1.0f / 16777216.0f);        // uniform in [0, 1), 24 bits
+    const float factor = keep < 0.f ? 1.f : (keep > 0.f && u < keep) ? 1.f / keep : 0.f;
+    // group layout: [site][pass][n * C_site]
+    out[(size_t)a.passes * begin + (size_t)(a.first + t) * len + (r - begin)] = factor;
 }
 
 hipError_t launch_dropout_masks(const MaskArgs& a, float* out, hipStream_t stream)
 {
-    const int quads = (a.per_pass + 3) >> 2;
-    hipLaunchKernelGGL(dropout_masks_kernel, dim3((quads + PW_THREADS - 1) / PW_THREADS, a.count), dim3(PW_THREADS), 0, stream, a, out);
+    hipLaunchKernelGGL(dropout_masks_kernel, dim3((a.per_pass + PW_THREADS - 1) / PW_THREADS, a.count), dim3(PW_THREADS), 0, stream, a, out);
     return hipGetLastError();
 }
 

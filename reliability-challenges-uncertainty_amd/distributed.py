@@ -74,12 +74,12 @@ class HipEngine:
         else:                                                     # float64 statistics: the tail is float64 too
             ws_out.copy_(steps_mod.softmax(self.model(x)))
 
-    def seeded_masks(self, x, seeds):
-        """The masks of the passes seeded with ``seeds`` over x, in the layout of their group launch (UNet.seeded_masks: one kernel, pass t
-        a function of seeds[t] alone)."""
+    def seeded_masks(self, x, seeds, first_sample=0):
+        """The masks of the passes seeded with ``seeds`` over x, in the layout of their group launch (UNet.seeded_masks: one kernel, the factors
+        of sample i in pass t a function of seeds[t] and the sample's global index ``first_sample + i`` alone)."""
         steps_mod.set_dropout_mode(self.model, True)
         try:
-            return self.model.seeded_masks(x.shape[0], x.device, seeds)
+            return self.model.seeded_masks(x.shape[0], x.device, seeds, first_sample)
         finally:
             steps_mod.set_dropout_mode(self.model, False)
 
@@ -173,13 +173,15 @@ class AleatoricHipEngine(HipEngine):
         return {'ws_probabilities': ws[0], 'ws_sigma': ws[1]}
 
 
-job_seed = steps_mod.job_seed      # seed of the dropout masks of MC pass ``job`` of volume ``step_index``: a function of (seed, volume, pass) only
+job_seed = steps_mod.job_seed      # seed of a torch generator for the masks of MC pass ``job`` of volume ``step_index`` (engines without the library's draw)
+pass_seed = steps_mod.pass_seed    # key of the library's counter-based draw for MC pass ``job``: the counter carries the sample's global index
 
 
 class ShardedMcRunner:
-    """``seed``: base seed of the dropout masks.  The masks of MC pass j of volume k are drawn from the seed ``job_seed(seed, k, j)``
-    (an engine with ``seeded_masks``: the library's own counter-based draw, include/rcu.h rcu_dropout_masks; else a torch generator seeded
-    with it), so they do not depend on the rank that runs the pass nor on the world size: every world size
+    """``seed``: base seed of the dropout masks.  The masks of MC pass j over the samples of volume / batch k are drawn under the key
+    ``pass_seed(seed, j)`` at the counters of the samples' global indices -- ``sample_offsets[k]`` (what the script's loop counted) or k x n on
+    (an engine with ``seeded_masks``: the library's own counter-based draw, include/rcu.h rcu_dropout_masks; else from a torch generator seeded
+    with ``job_seed(seed, k, j)``), so they do not depend on the rank that runs the pass nor on the world size: every world size
     aggregates the same T samples (ranks that are all seeded alike, as the reference's ``do_seed`` does with
     ``config.seed``, would otherwise draw the same mask sequence on every rank and the T passes would hold only about T / world
     distinct samples).  ``seed=None`` draws from the device's default generator after seeding it per rank once.
@@ -200,10 +202,12 @@ class ShardedMcRunner:
         # How the weight-scaling probabilities reach the root: 'reduce' -- in the tail of the ONE reduce buffer (zeros on every rank
         # but their owner; one collective per volume, twice the bytes on every link) -- or 'p2p': the reduce carries the statistics
         # only and the owner of job 0 sends its tail to the root (nothing when the root owns it): half the bytes on the links the
-        # send does not use.
-        self.ws_transport = ws_transport or 'reduce'
-        if self.ws_transport not in ('reduce', 'p2p'):
+        # send does not use.  None (the default, round 6): 'p2p' where the backend has device send / recv -- RCCL ("nccl") -- so that the one
+        # collective of a volume carries the 63 MB of statistics and nothing else (SURVEY 8e budgets 31.5 MB of float32 sums; the exact float64
+        # sums are twice that; the tail would double it again, zeros from every rank but one); 'reduce' on gloo.  Resolved at the first exchange.
+        if ws_transport not in (None, 'reduce', 'p2p'):
             raise ValueError('ws_transport must be "reduce" or "p2p"')
+        self.ws_transport = ws_transport
         self.p2p_messages = 0          # send / recv pairs this rank took part in (0 whenever the root owns the weight-scaling pass)
         self._p2p_checked = False
         self.mc_steps = mc_steps
@@ -217,6 +221,7 @@ class ShardedMcRunner:
         self.group_samples = None
         self.lanes = max(1, int(lanes))
         self._generator = None
+        self.sample_offsets = {}       # step index -> global index of the batch's first sample (the sharded predict steps fill it in; else k x n)
         self.forwards_run = 0          # launches of this rank (a pass group counts its passes)
         self.reserve_plans = True      # (the ensemble runner: every launch is one member on n samples, nothing to make canonical)
 
@@ -225,7 +230,7 @@ class ShardedMcRunner:
         that samples on its own)."""
         seeded = getattr(self.engine, 'seeded_masks', None)
         if self.seed is not None and seeded is not None:
-            return seeded(x, [job_seed(self.seed, step_index, job)])
+            return seeded(x, [pass_seed(self.seed, job)], self.first_sample(x, step_index))
         sample = getattr(self.engine, 'sample_masks', None)
         if self.seed is None or sample is None:
             return None
@@ -233,6 +238,11 @@ class ShardedMcRunner:
             self._generator = torch.Generator(device=x.device)
         self._generator.manual_seed(job_seed(self.seed, step_index, job))
         return sample(x, self._generator)
+
+    def first_sample(self, x, step_index):
+        """Global index of the first sample of step ``step_index``'s batch x."""
+        offset = self.sample_offsets.get(step_index)
+        return int(step_index) * int(x.shape[0]) if offset is None else int(offset)
 
     def _ws_outputs(self, ws):
         hook = getattr(self.engine, 'ws_outputs', None)
@@ -284,7 +294,7 @@ class ShardedMcRunner:
                     if mask_sets is None:
                         seeded = getattr(self.engine, 'seeded_masks', None)
                         if self.seed is not None and seeded is not None:
-                            ms = seeded(x, [job_seed(self.seed, step_index, j) for j in group])
+                            ms = seeded(x, [pass_seed(self.seed, j) for j in group], self.first_sample(x, step_index))
                         else:
                             ms = [self.masks_of(x, step_index, j) for j in group]
                             ms = None if any(m is None for m in ms) else ms
@@ -308,6 +318,14 @@ class ShardedMcRunner:
             lanes.end(self.engine.merge)
         return flat, stats, ws
 
+    def exchange_bytes(self, flat, ws):
+        """Bytes of one volume's exchange as this runner sends it: (bytes in the sum-reduce, bytes point to point -- zero on the volumes
+        whose weight-scaling pass the root runs itself)."""
+        total = flat.numel() * flat.element_size()
+        tail = 0 if ws is None else ws.numel() * ws.element_size()
+        transport = self.ws_transport or ('p2p' if (dist.is_initialized() and dist.get_backend() == 'nccl') else 'reduce')
+        return (total, 0) if (ws is None or transport == 'reduce') else (total - tail, tail)
+
     def ws_owner(self, step_index):
         """Rank that runs the weight-scaling pass (job 0) of volume ``step_index``."""
         return (step_index * self.jobs_per_step) % self.world
@@ -316,6 +334,9 @@ class ShardedMcRunner:
         """The data exchange of one volume -> list of work handles (empty: everything completed).  'reduce': ONE sum-reduce of
         [statistics | ws].  'p2p': the sum-reduce covers the statistics (everything in front of the ws tail) and the owner of the
         weight-scaling pass sends the tail to the root."""
+        if self.ws_transport is None:      # the default: point to point where the backend can (RCCL), else inside the reduce
+            self.ws_transport = 'p2p' if (dist.get_backend() == 'nccl' or not flat.is_cuda) else 'reduce'
+            self._p2p_checked = True
         if ws is None or self.ws_transport == 'reduce':
             w = dist.reduce(flat, dst=self.root, op=dist.ReduceOp.SUM, async_op=async_op)
             return [w] if async_op else []
@@ -610,6 +631,10 @@ class _ShardedStepBase(steps_mod.BatchStep):
         """This rank's jobs of the batch + the exchange.  Root: the merged statistics go under ``multi_probabilities`` (the compute stream
         waits for the collective), the weight-scaling probabilities under ``ws_probabilities``; other ranks: ``None`` there
         (MultiPredictionSummary then has nothing to do) and the reduce stays in flight behind the next batch's passes."""
+        offsets = getattr(runner, 'sample_offsets', None)
+        if offsets is not None:       # the seeded masks are keyed by the samples' global indices, as the one-process step keys them
+            offsets[step_index] = steps_mod.first_sample_of(batch_context, x.shape[0])
+            offsets.pop(step_index - 64, None)
         stats, ws = runner.reduce_async(x, step_index, mask_sets)
         self._batches += 1
         batch_context.output['multi_probabilities'] = stats      # root: PendingStatistics (the summary finalises it on a side stream); else None
@@ -639,12 +664,17 @@ class ShardedMcPredictStep(_ShardedStepBase):
         n, _, h, w = images.shape
         group = steps_mod.pass_group_size(model, n, h, w, self.group_pixels)
         group = max(1, min(group, self.mc_steps))
-        key = (id(model), group)
+        key = id(model)
         if self._runner_key != key:
+            if self._runner is not None:      # another model: retire the old runner's collectives before it goes
+                self._runner.drain()
             self._runner = ShardedMcRunner(model, self.mc_steps, ws_pass=self.ws_pass, rank=self.rank, world=self.world, do_mi=self.do_mi,
                                            do_var=self.do_var, seed=self.seed, pass_group=group, lanes=self.lanes,
                                            ws_transport=self.ws_transport, exact=self.exact, engine=self._engine(model))
             self._runner_key = key
+        # the pass group follows the batch (a smaller last batch, a coalesced one): ONE runner keeps its collectives in flight, its counters
+        # and its side stream through the run
+        self._runner.pass_group = group
         self._hand_over(batch_context, self._runner, images, batch_context.batch_index, self.masks)
 
 

@@ -333,6 +333,15 @@ def _batch_pixels(batch, entry='images'):
     return int(v.shape[0]) * int(v.shape[-1]) * int(v.shape[-2])
 
 
+def _batch_samples(batch, entry='images'):
+    """Samples (slices / images) of a loader batch: the length of its image entry (channels-last or channels-first, tensor or array alike)."""
+    v = batch.get(entry) if isinstance(batch, dict) else None
+    try:
+        return int(v.shape[0])
+    except (AttributeError, IndexError, TypeError):
+        return 0
+
+
 def coalesced(iterable, max_pixels, entry='images', lazy=False):
     """Merge consecutive loader batches while the merged batch stays within ``max_pixels`` (samples x height x width of ``entry``)
     and the per-sample shapes agree.  The reference's ``batch_size`` is a loader setting: a forward pass is independent per sample
@@ -687,8 +696,10 @@ class Test:
 
         batches = prefetch(loader, depth=self.max_inflight if pipelined else 2, pin=pipelined, timing=self.loader_timing)
         try:
+            samples_seen = 0                  # the run's stream of slices / images: what the seeded Dropout2d masks are keyed by (steps.McPredictStep)
             for i, ((batch, release), last) in enumerate(_with_last_flag(batches)):
-                batch_context = BatchContext(batch, i)
+                batch_context = BatchContext(batch, i, sample_offset=samples_seen)
+                samples_seen += _batch_samples(batch)
                 batch_context.more['last_batch'] = last
                 hook.on_test_batch_start(batch_context, task_context, context)
                 if free_slots:

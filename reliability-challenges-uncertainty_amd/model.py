@@ -289,9 +289,10 @@ class UNet(nn.Module):
             return None
         return chunks[0] if len(chunks) == 1 else torch.cat(chunks)
 
-    def seeded_masks(self, n, device, seeds):
+    def seeded_masks(self, n, device, seeds, first_sample=0):
         """The Dropout2d factors of ``len(seeds)`` MC passes over n images, drawn on the device by ONE kernel (include/rcu.h,
-        rcu_dropout_masks) on the current stream: pass t from ``seeds[t]`` alone -- the same values whatever group, lane or rank the pass is
+        rcu_dropout_masks) on the current stream: the factors of image i in pass t from ``seeds[t]`` and the image's GLOBAL index
+        ``first_sample + i`` alone -- the same values whatever batch the image arrives in and whatever group, lane or rank the pass is
         launched in -- in the ``[site][passes * n][C_site]`` layout ``forward_accumulate(..., passes=len(seeds))`` reads (one pass: the layout
         of ``sample_masks``).  Sites whose Dropout2d is in eval mode get ones, p = 1 zeros, as ``sample_masks`` gives them."""
         sites = self.dropout_sites()
@@ -300,7 +301,7 @@ class UNet(nn.Module):
         g, count = len(seeds), len(sites)
         keeps = [(max(0.0, 1.0 - float(m.p)) if (m.training and m.p > 0) else -1.0) for m in self._site_modules]
         out = torch.empty(g * n * sum(c for _, c in sites), device=device, dtype=torch.float32)
-        _lib.check(_lib.load().rcu_dropout_masks((ctypes.c_uint64 * g)(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds]), g, n,
+        _lib.check(_lib.load().rcu_dropout_masks((ctypes.c_uint64 * g)(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds]), g, n, int(first_sample),
                                                  (ctypes.c_int32 * count)(*[c for _, c in sites]), (ctypes.c_float * count)(*keeps), count,
                                                  _lib.ptr(out), _lib.current_stream()))
         return out

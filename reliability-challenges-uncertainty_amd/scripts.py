@@ -129,6 +129,7 @@ class ConfusionOnDeviceStep(steps.BatchStep):
         self._pinned = [None] * self.RING      # (pinned uint8 tensor, event of the copy that read it last)
         self._next = 0
         self._volumes = {}         # subject index -> device uint8 [D, H, W]
+        self._side = None          # the root of a sharded run: the stream the counts are taken on (behind the batch's collective)
 
     def _upload(self, labels, device):
         """host uint8 array -> device tensor of its shape, asynchronously on the current stream."""
@@ -173,7 +174,25 @@ class ConfusionOnDeviceStep(steps.BatchStep):
         labels = None if volumes else batch.get('labels')
         if not volumes and not (torch.is_tensor(labels) and labels.numel() == probabilities.shape[0] * probabilities.shape[2] * probabilities.shape[3]):
             return            # (no labels of the batch's shape at hand: EvalSubjectStep evaluates the assembled subject itself)
-        steps.wait_for_outputs(batch_context)      # (the root of a sharded run: the summary's outputs come from a side stream)
+        # The root of a sharded run: the summary's outputs come from a side stream BEHIND the batch's collective.  Counting on the compute stream
+        # would put that stream -- and with it the next batch's passes -- behind every batch's reduce and finalize, on the one rank every reduce
+        # lands on; the counts are taken on a stream of their own that waits for the outputs, and the download waits for the counts instead.
+        ready = batch_context.more.get('outputs_ready')
+        if ready is None:
+            self._count(batch_context, task_context, probabilities, batch, dataset, volumes, labels)
+            return
+        if self._side is None or self._side.device != probabilities.device:
+            self._side = torch.cuda.Stream(device=probabilities.device)
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            if self._count(batch_context, task_context, probabilities, batch, dataset, volumes, labels):
+                probabilities.record_stream(self._side)
+                done = torch.cuda.Event()
+                done.record(self._side)
+                batch_context.more['outputs_ready'] = done      # (behind the old event by construction)
+
+    def _count(self, batch_context, task_context, probabilities, batch, dataset, volumes, labels):
+        """The arg-max map and the slice-wise confusion counts on the CURRENT stream -> whether they were taken."""
         prediction, _ = steps.prediction_and_foreground(probabilities)
         if volumes:
             subjects = [int(v) for v in batch['subject_index']]
@@ -185,7 +204,7 @@ class ConfusionOnDeviceStep(steps.BatchStep):
                     e += 1
                 volume = self._labels_of(subjects[b], dataset, prediction.device)
                 if volume is None:
-                    return
+                    return False
                 pieces.append(volume[slices[b]:slices[b] + (e - b)])
                 b = e
             target = pieces[0] if len(pieces) == 1 else torch.cat(pieces)
@@ -196,6 +215,7 @@ class ConfusionOnDeviceStep(steps.BatchStep):
             target = self._upload(np.ascontiguousarray(host).reshape(prediction.shape), prediction.device)
             batch_context.output['prediction'] = prediction.unsqueeze(1)      # (outputs carry the channel dim at 1: the loop moves it to the end)
         batch_context.output['confusion'] = ev.confusion_counts_on_device(prediction, target)
+        return True
 
 
 class CollectOnDeviceStep(steps.BatchStep):
@@ -318,7 +338,7 @@ def _other(context, key, default=None):
 
 
 def _mask_seed(context, world):
-    """Seed of the per-(batch, pass) Dropout2d masks: the YAML file's ``seed`` (the reference seeds torch with it,
+    """Seed of the per-(pass, slice) Dropout2d masks: the YAML file's ``seed`` (the reference seeds torch with it,
     common/trainloop/loops.py:183-185).  Without one a one-process run draws from the device generator; a sharded run agrees on a
     random seed (the masks of a pass must not depend on the rank that runs it)."""
     seed = context.config.seed
@@ -336,10 +356,17 @@ def _mask_seed(context, world):
 def _default_steps(context, world):
     if hasattr(context.config.others, 'mc'):
         lanes = _other(context, 'stream_lanes')
+        # ``others.group_pixels`` / ``others.exact`` (rcu_amd extensions): the memory / reproducibility trade of the MC step.  Every stream lane of every
+        # rank sizes its plan for n x min(group_pixels // (n H W), T) samples (canonical plans: 24 GB per lane for four passes of a 160-slice BraTS
+        # batch) and ``exact`` keeps the statistics as exact float64 sums; a smaller ``group_pixels`` (or ``stream_lanes: 1``) shrinks the workspace,
+        # ``exact: false`` halves the statistics and the reduce at the price of byte-identity across lanes, groups and world sizes.
+        group_pixels, exact = _other(context, 'group_pixels'), bool(_other(context, 'exact', True))
         if world.world > 1:     # the T + 1 passes of every batch sharded over the ranks, one sum-reduce per batch (rcu_amd.distributed)
-            return [rdist.ShardedMcPredictStep(context.config.others.mc, world, seed=_mask_seed(context, world), lanes=lanes),
+            return [rdist.ShardedMcPredictStep(context.config.others.mc, world, seed=_mask_seed(context, world), lanes=lanes,
+                                               group_pixels=group_pixels, exact=exact),
                     steps.MultiPredictionSummary()]
-        return [steps.McPredictStep(context.config.others.mc, seed=_mask_seed(context, world), lanes=lanes), steps.MultiPredictionSummary()]
+        return [steps.McPredictStep(context.config.others.mc, seed=_mask_seed(context, world), lanes=lanes, group_pixels=group_pixels, exact=exact),
+                steps.MultiPredictionSummary()]
     return [steps.SegmentationPredictStep(do_probs=True)]
 
 
@@ -366,11 +393,13 @@ def _load_additional_models(context):
 
 def _loop_options(context):
     """Test-loop options from the YAML file's ``others`` (rcu_amd extensions): ``coalesce_pixels`` -- merge loader batches up to that many
-    pixels per step (loops.Test: opt-in, changes what hooks see and which masks a seed draws; two BraTS volumes, 7864320, keep the
-    launches of an 8-GPU run at 640 samples) --, ``pipelined: false`` (the reference's callback order), ``max_inflight``,
-    ``loader_timing: true`` (the loader thread logs where its time went)."""
+    pixels per step (loops.Test; DEFAULT since round 6: ``loops.Test.COALESCE_PIXELS``, one benchmark-sized BraTS volume -- the shipped
+    ``batch_size: 32`` then runs as launches that fill the GPU, and, the seeded Dropout2d masks being keyed by the slice and not by the batch,
+    the same YAML file writes the same files for any ``batch_size``; ``0`` switches it off: steps and hooks then see the loader's batches, as in
+    the reference; two BraTS volumes, 7864320, keep the launches of an 8-GPU run at 640 samples) --, ``pipelined: false`` (the reference's
+    callback order), ``max_inflight``, ``loader_timing: true`` (the loader thread logs where its time went)."""
     value = _other(context, 'coalesce_pixels')
-    return dict(coalesce=None if value is None else int(value), pipelined=_other(context, 'pipelined'),
+    return dict(coalesce=loops.Test.COALESCE_PIXELS if value is None else int(value), pipelined=_other(context, 'pipelined'),
                 max_inflight=_other(context, 'max_inflight'), loader_timing=bool(_other(context, 'loader_timing', False)))
 
 
@@ -408,7 +437,7 @@ def _run(context, dataset, test_steps, write_hook, entries, world=None):
         test_steps = test_steps + [PrepareSubjectStep()]
     if not world.is_root:
         # a rank other than the root of a sharded run: the same loader and the same batch steps, nothing assembled, evaluated or written
-        # (the same coalescing: every rank must see the root's batches -- batch indices seed the masks, shapes size the collective)
+        # (the same coalescing: every rank must see the root's batches -- their shapes size the collective, their indices rotate the jobs)
         test = loops.Test(test_steps, [], None, entries=(), coalesce=options['coalesce'], pipelined=options['pipelined'],
                           max_inflight=options['max_inflight'])
         hook = loops.TestLoopHook()
@@ -422,15 +451,44 @@ def _run(context, dataset, test_steps, write_hook, entries, world=None):
         hook = _hooks(write_hook, extra_hooks)
     try:
         test(context, build, hook=hook)
-    finally:
+    except BaseException:
+        if world.world > 1 and sharded:
+            # A rank that failed must NOT issue the closing collectives: the other ranks are still in their per-batch reduces, a barrier from
+            # here would pair with one of those (mismatched collectives: RCCL hangs until its watchdog fires) and the traceback below would
+            # never be printed.  Log it, tear this rank's communicator down so that the peers' pending collectives fail instead of waiting, and
+            # let the exception end the process: a non-zero exit makes the launcher (torch.distributed.run) end the other ranks.
+            logging.exception('rank {} of {}: the test loop failed; leaving without the closing barrier'.format(world.rank, world.world))
+            _abandon_process_group()
+        raise
+    else:
         if world.world > 1 and sharded:      # (a run that is rank 0's alone has nobody to meet: the other ranks have left)
             import torch
             import torch.distributed as dist
             for s_ in sharded:
                 s_.finish()
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
             dist.barrier()           # no rank leaves (and frees what a collective still reads) before the root has the last batch
     return context
+
+
+def _abandon_process_group(timeout_s=10.0):
+    """Best effort, bounded in time: destroy this rank's process group from a helper thread (a communicator with collectives in flight may not
+    come down at once; the exception that brought us here must not wait for it)."""
+    import threading
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+
+    def destroy():
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001 - we are already failing; the original exception is the one to report
+            pass
+
+    t = threading.Thread(target=destroy, name='rcu-abandon-process-group', daemon=True)
+    t.start()
+    t.join(timeout_s)
 
 
 def test_default(dataset, config_file=None, config_id=None, device='cuda'):

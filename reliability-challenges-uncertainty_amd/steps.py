@@ -29,9 +29,12 @@ from . import model as model_mod
 
 
 class BatchContext:
-    def __init__(self, batch: dict, batch_index: int) -> None:
+    def __init__(self, batch: dict, batch_index: int, sample_offset: int = None) -> None:
         self.input = batch
         self.batch_index = batch_index
+        # global index of the batch's first sample in the run's stream of slices / images (the test loop counts them; None: batch_index x the
+        # batch's size): what the seeded Dropout2d masks of a stochastic step are keyed by -- a slice's MC sample must not depend on batch_size
+        self.sample_offset = sample_offset
         self.output = {}
         self.metrics = {}
         self.score = None
@@ -90,6 +93,18 @@ def job_seed(seed, step_index, job):
     """Seed of the dropout masks of MC pass ``job`` (1..T) of batch / volume ``step_index``: a function of (seed, batch, pass) only -- not
     of the pass groups, the stream lanes, the rank that runs the pass or the number of ranks."""
     return (int(seed) * 1000003 + int(step_index) * 10007 + int(job)) % (2 ** 63 - 1)
+
+
+def pass_seed(seed, job):
+    """Key of the library's counter-based mask draw (include/rcu.h, rcu_dropout_masks) for MC pass ``job`` (1..T): a function of (seed, pass) --
+    the draw's counter carries the sample's GLOBAL index, so a slice's masks do not depend on the batch it is loaded in either."""
+    return job_seed(seed, 0, job)
+
+
+def first_sample_of(batch_context, n):
+    """Global index of a batch's first sample: what the test loop counted (``BatchContext.sample_offset``), else batch_index x n."""
+    offset = getattr(batch_context, 'sample_offset', None)
+    return int(batch_context.batch_index) * int(n) if offset is None else int(offset)
 
 
 class McStatistics:
@@ -338,10 +353,12 @@ class SegmentationPredictStep(BatchStep):
 class McPredictStep(BatchStep):
     """T stochastic passes (plus the deterministic 'weight scaling' pass the reference always runs
     first, customsteps.py:22-25).
-    ``seed``: the Dropout2d masks of pass j of batch k are drawn from the seed ``job_seed(seed, k, j)`` (k = ``batch_context.batch_index``;
-    UNet.seeded_masks: one kernel per launch, include/rcu.h rcu_dropout_masks) instead of the device's default generator: the T samples of a batch are then a function of (seed,
-    batch, pass) alone -- the same whatever the pass groups and stream lanes, and the same when the passes are sharded over several GPUs
-    (rcu_amd.distributed.ShardedMcPredictStep).  The drop-in scripts pass the YAML file's ``seed``.
+    ``seed``: the Dropout2d factors of pass j for the slice with global index g (``batch_context.sample_offset`` + its position in the batch: the
+    test loop counts the slices it has handed out) are drawn under the key ``pass_seed(seed, j)`` at the counter of (g, site, channel)
+    (UNet.seeded_masks: one kernel per launch, include/rcu.h rcu_dropout_masks) instead of from the device's default generator: the T samples of a
+    SLICE are then a function of (seed, slice, pass) alone -- the same whatever ``batch_size`` the YAML file sets and however the loop coalesces
+    batches (round 6; rounds 1-5 keyed the draw by the batch), whatever the pass groups and stream lanes, and the same when the passes are
+    sharded over several GPUs (rcu_amd.distributed.ShardedMcPredictStep).  The drop-in scripts pass the YAML file's ``seed``.
     ``exact`` (default): the statistics are exact sums (McStatistics), so that ``MultiPredictionSummary``'s outputs do not depend on
     how the passes were grouped, laned or sharded either; ``exact=False`` keeps float32 sums (float64 with ``do_var``)."""
 
@@ -367,11 +384,12 @@ class McPredictStep(BatchStep):
         self.seed = seed
         self.exact = bool(exact) and mc_steps <= _lib.RCU_MC_EXACT_MAX_PASSES      # (beyond the exact form's 2,048 passes: plain float sums)
 
-    def _seeded_masks(self, model, images, batch_index, job):
-        """The mask tensor of MC pass ``job`` (1..T) of batch ``batch_index`` under ``self.seed`` (dropout mode is on)."""
-        return model.seeded_masks(images.shape[0], images.device, [job_seed(self.seed, batch_index, job)])
+    def _seeded_masks(self, model, images, first_sample, job):
+        """The mask tensor of MC pass ``job`` (1..T) of the batch whose first sample has global index ``first_sample`` under ``self.seed``
+        (dropout mode is on)."""
+        return model.seeded_masks(images.shape[0], images.device, [pass_seed(self.seed, job)], first_sample)
 
-    def _launch_masks(self, model, images, batch_index, first, count):
+    def _launch_masks(self, model, images, first_sample, first, count):
         """``masks`` argument of the launch that runs the passes first .. first + count - 1 (0-based): injected sets, seeded draws, or
         None = drawn inside the launch from the device's default generator."""
         if self.masks is not None:
@@ -379,13 +397,13 @@ class McPredictStep(BatchStep):
         if self.seed is None:
             return None
         # one kernel for the launch's passes, on the stream that reads them, already in the launch's layout (UNet.seeded_masks)
-        return model.seeded_masks(images.shape[0], images.device, [job_seed(self.seed, batch_index, j + 1) for j in range(first, first + count)])
+        return model.seeded_masks(images.shape[0], images.device, [pass_seed(self.seed, j + 1) for j in range(first, first + count)], first_sample)
 
     def __call__(self, batch_context, task_context, context) -> None:
         _check_context(context)
         images = _images_to_device(batch_context, context)
         model = context.model
-        k = batch_context.batch_index
+        k = first_sample_of(batch_context, images.shape[0])      # global index of the batch's first sample: what the seeded masks are keyed by
 
         if isinstance(model, model_mod.UNet):
             # The CANONICAL plan of the batch, on every lane, before the first forward: which kernel a layer gets depends on the batch its plan
@@ -418,7 +436,7 @@ class McPredictStep(BatchStep):
         finally:
             set_dropout_mode(model, is_train=False)   # reset to eval for the next batch (customsteps.py:39)
 
-    def _fused_passes(self, model, images, do_mi, do_var, batch_index=0, before=None):
+    def _fused_passes(self, model, images, do_mi, do_var, first_sample=0, before=None):
         """The T passes into per-voxel statistics (dropout mode is on).  The statistics carry a recipe that replays the passes
         -- same images, same masks (seeded: the same draws again; unseeded: the device generator is put back to where the sampling
         started) -- so that ``MultiPredictionSummary(do_mi / do_var)`` decides alone which outputs exist, as in the reference
@@ -443,7 +461,7 @@ class McPredictStep(BatchStep):
         for g in sizes:
             # the masks are drawn INSIDE the launch, i.e. on the lane's stream -- the stream that reads them (seeded: from the step's generator;
             # unseeded: by forward_accumulate from the device's, in launch order whatever the lane)
-            lanes.run(lambda st, lane, i=i, g=g: model.forward_accumulate(images, st, self._launch_masks(model, images, batch_index, i, g),
+            lanes.run(lambda st, lane, i=i, g=g: model.forward_accumulate(images, st, self._launch_masks(model, images, first_sample, i, g),
                                                                        passes=g, lane=lane))
             i += g
         lanes.end(merge_statistics)
@@ -455,12 +473,12 @@ class McPredictStep(BatchStep):
             set_dropout_mode(model, is_train=True)
             try:
                 if not materialize:
-                    return self._fused_passes(model, images, mi, var, batch_index)
+                    return self._fused_passes(model, images, mi, var, first_sample)
                 probs = []
                 t = 0
                 for g in sizes:                      # the same draws as the fused path makes: one per pass group
                     if not unseeded:
-                        sets = [self._launch_masks(model, images, batch_index, j, 1) for j in range(t, t + g)]
+                        sets = [self._launch_masks(model, images, first_sample, j, 1) for j in range(t, t + g)]
                     elif g == 1:
                         sets = [None]
                     else:                            # rows [site][pass * n + i]: split the group's draw into its passes

@@ -65,12 +65,12 @@ def test_argument_validation_without_gpu(lib):
     assert so.rcu_unet_set_fuse_head(None, 1) == -1
     # rcu_dropout_masks: null pointers, counts and the site table are checked before anything touches the GPU
     seeds, ch, keep = (ctypes.c_uint64 * 2)(1, 2), (ctypes.c_int32 * 2)(8, 8), (ctypes.c_float * 2)(0.9, 0.9)
-    assert so.rcu_dropout_masks(None, 2, 1, ch, keep, 2, ctypes.c_void_p(8), None) == -1
-    assert so.rcu_dropout_masks(seeds, 2, 1, ch, keep, 2, None, None) == -1
-    assert so.rcu_dropout_masks(seeds, 0, 1, ch, keep, 2, ctypes.c_void_p(8), None) == -1
-    assert so.rcu_dropout_masks(seeds, 2, 1, ch, keep, 41, ctypes.c_void_p(8), None) == -1 and b'n_sites' in so.rcu_last_error()
-    assert so.rcu_dropout_masks(seeds, 2, 1, ch, (ctypes.c_float * 2)(0.9, 1.5), 2, ctypes.c_void_p(8), None) == -1
-    assert so.rcu_dropout_masks(seeds, 2, 1 << 27, ch, keep, 2, ctypes.c_void_p(8), None) == -1 and b'2^31' in so.rcu_last_error()
+    assert so.rcu_dropout_masks(None, 2, 1, 0, ch, keep, 2, ctypes.c_void_p(8), None) == -1
+    assert so.rcu_dropout_masks(seeds, 2, 1, 0, ch, keep, 2, None, None) == -1
+    assert so.rcu_dropout_masks(seeds, 0, 1, 0, ch, keep, 2, ctypes.c_void_p(8), None) == -1
+    assert so.rcu_dropout_masks(seeds, 2, 1, 0, ch, keep, 41, ctypes.c_void_p(8), None) == -1 and b'n_sites' in so.rcu_last_error()
+    assert so.rcu_dropout_masks(seeds, 2, 1, 0, ch, (ctypes.c_float * 2)(0.9, 1.5), 2, ctypes.c_void_p(8), None) == -1
+    assert so.rcu_dropout_masks(seeds, 2, 1 << 27, 0, ch, keep, 2, ctypes.c_void_p(8), None) == -1 and b'2^31' in so.rcu_last_error()
     assert so.rcu_calib_set_blocks_per_workgroup(-1, 0) == -1 and so.rcu_calib_set_blocks_per_workgroup(0, 0) == 0
     with pytest.raises(lib.RcuError):
         lib.check(so.rcu_mc_finalize(None, 1, 1, 2, 1, 0, None, None, None, None, None))

@@ -371,8 +371,9 @@ def _w8_cases(rank, world):
     x = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(8))
     mk = lambda **kw: ShardedMcRunner(None, rank=rank, world=world, engine=TinyEngine(state), seed=3, lanes=2, **kw)  # noqa: E731
     return x, {
-        'mc20': mk(mc_steps=20, ws_pass=True, pass_group=2),
+        'mc20': mk(mc_steps=20, ws_pass=True, pass_group=2),      # the default transport (round 6): point to point where the backend can -- CPU tensors over gloo can
         'mc20_p2p': mk(mc_steps=20, ws_pass=True, pass_group=2, ws_transport='p2p'),
+        'mc20_reduce': mk(mc_steps=20, ws_pass=True, pass_group=2, ws_transport='reduce'),
         'mc50': mk(mc_steps=50, ws_pass=True, pass_group=2),
         'ens10': ShardedEnsembleRunner(members, rank=rank, world=world, engine=TinyEngine(state), lanes=2),
     }
@@ -384,12 +385,15 @@ def _w8_worker(rank, world, port, out_dir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(1)
     x, cases = _w8_cases(rank, world)
+    from rcu_amd.distributed import ShardedMcRunner
     counts = {}
     for name, runner in cases.items():
         pend = [runner.step_async(x, k) for k in range(W8_VOLUMES)]
         outs = [p.result() for p in pend]
         runner.drain()
         counts[name] = runner.forwards_run
+        if isinstance(runner, ShardedMcRunner) and world > 1:      # the default resolves to the point-to-point transport here; an explicit choice is kept
+            assert runner.ws_transport == ('reduce' if name.endswith('_reduce') else 'p2p'), (name, runner.ws_transport)
         if rank == 0:
             np.savez(os.path.join(out_dir, name + '.npz'),
                      **{'{}_{}'.format(key, k): v.numpy() for k, out in enumerate(outs) for key, v in out.items()})

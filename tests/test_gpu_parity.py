@@ -187,9 +187,19 @@ def test_seeded_masks_are_a_function_of_the_seed_alone(dev):
     # ... and they are the oracle's (oracle/mask_oracle.py: Philox4x32-10 pinned by the published known-answer vectors), bit for bit
     from oracle import mask_oracle as mo
     sites = m.dropout_sites()
-    for n, seeds in ((3, [11, 12, 13, 14]), (1, [2 ** 63 + 5]), (5, list(range(40, 75)))):
-        want = mo.group_masks(seeds, n, [c for _, c in sites], [0.7] * len(sites))
-        assert np.array_equal(m.seeded_masks(n, dev, seeds).cpu().numpy(), want), (n, len(seeds))
+    for n, seeds, first in ((3, [11, 12, 13, 14], 0), (1, [2 ** 63 + 5], 7), (5, list(range(40, 75)), 2 ** 35 + 3)):
+        want = mo.group_masks(seeds, n, [c for _, c in sites], [0.7] * len(sites), first_sample=first)
+        assert np.array_equal(m.seeded_masks(n, dev, seeds, first).cpu().numpy(), want), (n, len(seeds))
+    # a sample's factors are a function of its GLOBAL index, not of the batch it arrives in (round 6): eight samples at once = three, then five
+    whole = m.seeded_masks(8, dev, [21, 22], 100)
+    head, tail = m.seeded_masks(3, dev, [21, 22], 100), m.seeded_masks(5, dev, [21, 22], 103)
+    at_w = at_h = at_t = 0
+    for _, c in sites:
+        for t in range(2):
+            rows = whole[at_w + t * 8 * c:at_w + (t + 1) * 8 * c].view(8, c)
+            assert torch.equal(rows[:3], head[at_h + t * 3 * c:at_h + (t + 1) * 3 * c].view(3, c))
+            assert torch.equal(rows[3:], tail[at_t + t * 5 * c:at_t + (t + 1) * 5 * c].view(5, c))
+        at_w, at_h, at_t = at_w + 2 * 8 * c, at_h + 2 * 3 * c, at_t + 2 * 5 * c
     big = m.seeded_masks(64, dev, list(range(1000, 1040)))                 # 40 passes x 64 images x 72 channels
     values = torch.unique(big)
     keep = 1.0 - 0.3
@@ -1473,7 +1483,12 @@ def test_exact_statistics_do_not_depend_on_groups_lanes_or_the_materialised_stac
     for o in outs[1:]:
         for key in ('probabilities', 'entropy', 'mutual_info', 'variance', 'ws_probabilities'):
             assert torch.equal(outs[0][key], o[key]), key
-    # another batch index: other masks
+    # the loop's own count of the slices it has handed out wins over batch_index x n: the same offset, the same bits
+    bc = steps.BatchContext({'images': x}, 0, sample_offset=5 * n)
+    steps.McPredictStep(T, seed=20)(bc, None, ctx)
+    steps.MultiPredictionSummary()(bc, None, ctx)
+    assert torch.equal(bc.output['probabilities'], outs[0]['probabilities'])
+    # other slices (another batch index): other masks
     bc = steps.BatchContext({'images': x}, 6)
     steps.McPredictStep(T, seed=20)(bc, None, ctx)
     steps.MultiPredictionSummary()(bc, None, ctx)
@@ -1489,7 +1504,7 @@ def test_exact_statistics_do_not_depend_on_groups_lanes_or_the_materialised_stac
     from oracle import summary_oracle as so
     step = steps.McPredictStep(T, seed=20)
     steps.set_dropout_mode(model, True)
-    masks = [step._seeded_masks(model, x, 5, j) for j in range(1, T + 1)]
+    masks = [step._seeded_masks(model, x, 5 * n, j) for j in range(1, T + 1)]      # batch 5 of n slices: first global slice index 5 n
     steps.set_dropout_mode(model, False)
     sites = model.dropout_sites()
     mask_sets = [[m.cpu() for m in torch.split(ms, [n * c_ for _, c_ in sites])] for ms in masks]

@@ -378,6 +378,15 @@ def test_mask_oracle_against_the_published_philox_vectors():
     big = mo.pass_mask(7, 64, [256], [0.95])
     assert abs(float((big > 0).mean()) - 0.95) < 4 * (0.95 * 0.05 / big.size) ** 0.5
     assert not np.array_equal(mo.pass_mask(7, 4, [32], [0.5]), mo.pass_mask(7 + 2 ** 32, 4, [32], [0.5]))      # both key words count
+    # a sample's factors are a function of its GLOBAL index, not of the batch it arrives in: 8 samples at once = 3 + 5 samples, per site
+    whole, head, tail = mo.pass_mask(12345, 8, channels, keep), mo.pass_mask(12345, 3, channels, keep), mo.pass_mask(12345, 5, channels, keep, first_sample=3)
+    at_w = at_h = at_t = 0
+    for c in channels:
+        assert np.array_equal(whole[at_w:at_w + 8 * c], np.concatenate([head[at_h:at_h + 3 * c], tail[at_t:at_t + 5 * c]]))
+        at_w, at_h, at_t = at_w + 8 * c, at_h + 3 * c, at_t + 5 * c
+    assert np.array_equal(head, one)
+    far = mo.pass_mask(7, 2, [32], [0.5], first_sample=2 ** 40)          # the counter's second word counts
+    assert not np.array_equal(far, mo.pass_mask(7, 2, [32], [0.5], first_sample=2 ** 40 + 2 ** 36)) and not np.array_equal(far, mo.pass_mask(7, 2, [32], [0.5]))
     seeds = [3, 4, 5]
     grouped = mo.group_masks(seeds, 3, channels, keep)
     singles = [mo.pass_mask(s, 3, channels, keep) for s in seeds]
@@ -387,3 +396,21 @@ def test_mask_oracle_against_the_published_philox_vectors():
             assert np.array_equal(grouped[out:out + 3 * c], m[at:at + 3 * c])
             out += 3 * c
         at += 3 * c
+
+
+def test_uncertain_voxel_table_holds_under_the_local_numpy():
+    """ADVICE r05.  csrc/rcu_ue_table.inc (fixture g20) records for every float32 p whether the reference's ToEntropy([1 - p, p]) exceeds each of the
+    script's 11 thresholds -- as numpy's float32 ``log`` gave it in the container that built the fixture (``numpy_version`` / ``cpu_features`` are
+    stored with it).  A host whose numpy rounds ``log`` differently in the last ulp (another SIMD path) would disagree on the few values right at a
+    boundary; this re-evaluates every probe value of the fixture with the oracle's numpy restatement on THIS host.  (bench.py repeats the
+    check on the GPU box's host against the timed output: ``parity.ue_counts_equal``.)"""
+    from conftest import load_golden
+    from oracle import calib_oracle as co
+    g = load_golden('g20_ue_boundaries')
+    p = g['probe_bits'].view(np.float32)
+    u = co.normalised_entropy(np.stack([1 - p, p], -1))
+    member = np.stack([u > float(t) for t in g['thresholds']])
+    disagree = int(np.count_nonzero(member != g['probe_member'].astype(bool)))
+    assert disagree == 0, ('numpy {} on this CPU rounds log differently from the build that made the table (numpy {}, {}): {} probe values flip; '
+                           'rebuild the table (tests/golden/generate_ue_boundaries.py) or evaluate through rcu_normalised_entropy + rcu_unc_counts'
+                           .format(np.__version__, g['numpy_version'], g['cpu_features'], disagree))

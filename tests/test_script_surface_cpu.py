@@ -560,7 +560,8 @@ def test_round5_host_rules_seeds_worlds_and_loop_options(tmp_path, monkeypatch):
     built = scripts._default_steps(context, world)
     assert type(built[0]) is steps.McPredictStep and (built[0].seed, built[0].lanes, built[0].exact, built[0].mc_steps) == (20, 1, True, 20)
     context.config.others = cfg.OtherParameters().from_dict({})
-    assert scripts._loop_options(context) == dict(coalesce=None, pipelined=None, max_inflight=None, loader_timing=False)
+    # coalescing is the default (round 6: the seeded masks are keyed by the slice, not by the batch); ``coalesce_pixels: 0`` switches it off
+    assert scripts._loop_options(context) == dict(coalesce=loops.Test.COALESCE_PIXELS, pipelined=None, max_inflight=None, loader_timing=False)
     assert type(scripts._default_steps(context, world)[0]) is steps.SegmentationPredictStep
     test = loops.Test([], max_inflight=1, inflight_pixels=10, coalesce=5, pipelined=False, loader_timing=True)
     assert (test.max_inflight, test.inflight_pixels, test.coalesce, test.pipelined, test.loader_timing) == (1, 10, 5, False, True)

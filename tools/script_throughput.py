@@ -50,9 +50,9 @@ def main():
     # loader batches merged to one volume per step: opt-in (rcu_amd.loops.Test), through the YAML key the scripts pass on; argv[4] = 0 keeps
     # the reference's batches (one step per 32 slices)
     coalesce = int(sys.argv[4]) if len(sys.argv) > 4 else bench.SLICES * bench.HEIGHT * bench.WIDTH
-    if coalesce > 0:
-        text = text.replace('  others:\n', '  others:\n    coalesce_pixels: {}\n'.format(coalesce), 1)
-        assert 'coalesce_pixels' in text
+    # (0 = the loader's batches as they are: since round 6 coalescing is the scripts' default, so the key is written either way)
+    text = text.replace('  others:\n', '  others:\n    coalesce_pixels: {}\n'.format(coalesce), 1)
+    assert 'coalesce_pixels' in text
     if len(sys.argv) > 5 and sys.argv[5] == 'timing':
         text = text.replace('  others:\n', '  others:\n    loader_timing: true\n', 1)
     # RCU_SCRIPT_ENSEMBLE=K: bin-dl/brats_test_ensemble.py's surface instead -- K members (the first is the config's model_dir), no MC passes
