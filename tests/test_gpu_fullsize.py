@@ -462,3 +462,52 @@ def test_ensemble_members_share_one_activation_workspace(dev):
     fresh.forward_accumulate(xd, st2)
     torch.cuda.synchronize()
     assert torch.equal(st1.blob, st2.blob)
+
+
+@pytest.mark.timeout(1500)
+def test_native_brats_volume_mc20_on_padded_levels(dev):
+    """The reference's REAL BraTS volume -- 155 slices of 4 x 240 x 240 (scripts/create_brats18_dataset.py:53-72 never crops;
+    config/test_brats_baseline_mc.yaml:30-31 slices the volume) -- at the config's own T = 20, through ShardedMcRunner as
+    `bench.py --workload brats-native` runs it: one pass of 155 slices per launch (every tensor below 2 GB), two stream lanes, seeded masks,
+    exact statistics; every layer on a Winograd kernel over padded levels (csrc/rcu_api.hip choose_level_extents; rounds 1-5: >= 16 of 23
+    layers on the direct kernels).  Three slices against the oracle's 21 forwards under the runner's masks; two lanes == one lane and the
+    same seed gives the same bits (exact sums); a slice does not depend on the batch it runs in."""
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import distributed as rdist
+    from rcu_amd import steps
+    st = uo.synthetic_state(91, **PARAMS)
+    T, n, h, w = 20, 155, 240, 240
+    model = _model(PARAMS, st, dev)
+    g = torch.Generator().manual_seed(26)
+    x = torch.randn(n, 4, h, w, generator=g)
+    xd = x.to(dev)
+    sel = np.array([0, 77, 154])
+    group = steps.pass_group_size(model, n, h, w, steps.McPredictStep.GROUP_PIXELS)
+    assert group == 1
+    rows_ = model.layer_table(h, w, n)
+    assert sum('winograd' in r['kernel'] for r in rows_) == 22 and not any('igemm' in r['kernel'] for r in rows_)
+    runner = rdist.ShardedMcRunner(model, T, seed=13, lanes=2, pass_group=group)
+    out = runner.step(xd, 4)
+    assert runner.forwards_run == T + 1 and set(out) == {'probabilities', 'entropy', 'ws_probabilities'}
+    again = rdist.ShardedMcRunner(model, T, seed=13, lanes=2, pass_group=group).step(xd, 4)
+    one_lane = rdist.ShardedMcRunner(model, T, seed=13, lanes=1, pass_group=group).step(xd, 4)
+    for key in out:
+        assert torch.equal(out[key], again[key]) and torch.equal(out[key], one_lane[key]), key
+    rows = torch.as_tensor(sel)
+    mask_sets = [_split_masks(model, runner.masks_of(xd, 4, j), n, rows) for j in range(1, T + 1)]
+    small = rdist.ShardedMcRunner(model, T, lanes=1, pass_group=1).step(xd[sel], 4, mask_sets=mask_sets)
+    for key in out:
+        assert torch.equal(out[key][sel], small[key]), key
+    ws, multi = so.mc_probabilities(lambda xx, mk: uo.unet_forward(st, xx, mk, **PARAMS), x[sel], mask_sets)
+    ref = so.multi_prediction_summary(multi)
+    for key in ('probabilities', 'entropy'):
+        assert _maxdiff(out[key][sel].cpu().numpy(), ref[key].numpy()) < PROB_TOL, key
+    assert _maxdiff(out['ws_probabilities'][sel].cpu().numpy(), ws.numpy()) < PROB_TOL
+    # the step seam on a loader-sized batch of the same volume (64 slices: two batches of the shipped batch_size 32, coalesced)
+    bc = steps.BatchContext({'images': x[:64]}, 0, sample_offset=4 * n)
+    ctx = steps.TorchTestContext('cuda', model)
+    steps.McPredictStep(T, seed=13)(bc, None, ctx)
+    steps.MultiPredictionSummary()(bc, None, ctx)
+    # (the same slices, the same global indices, the same seed: the same MC samples -- through another plan, so to float32 summation order)
+    assert float((bc.output['probabilities'] - out['probabilities'][:64]).abs().max()) < 2e-6

@@ -153,13 +153,17 @@ def _launch_two_ranks(script, cfg, env, out_root=None, attempts=2, ranks=2):
     return last
 
 
-def _script_setup(tmp_path, seeds=(20,), mc=6):
-    """Two small BraTS-like subjects, model dir(s) + checkpoint(s), split and two YAML files that differ in their test_dir only."""
+def _script_setup(tmp_path, seeds=(20,), mc=6, coalesce=None):
+    """Two small BraTS-like subjects, model dir(s) + checkpoint(s), split and two YAML files that differ in their test_dir only.
+    ``coalesce``: ``others.coalesce_pixels`` (0: the loader's batches of 4 slices as they are; default: the scripts' -- everything in one step)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import test_gpu_scripts as tgs
     cfg, vols, _, _ = tgs._setup(tmp_path, mc=mc if len(seeds) == 1 else None, seeds=seeds)
     with open(cfg) as f:
         text = f.read()
+    if coalesce is not None:
+        assert '  others:\n' in text
+        text = text.replace('  others:\n', '  others:\n    coalesce_pixels: {}\n'.format(int(coalesce)), 1)
     cfgs = []
     for tag in ('one', 'two'):
         path = str(tmp_path / 'cfg_{}.yaml'.format(tag))
@@ -344,8 +348,9 @@ def test_full_size_script_run_is_the_same_bytes_on_two_ranks(tmp_path):
 def test_eight_ranks_write_the_one_process_files_too(tmp_path):
     """World size 8 (all eight ranks on the one GPU, gloo): T + 1 = 7 jobs per batch leave most ranks one job and one rank none per batch, the
     weight-scaling pass moves from rank to rank, eight partial sums meet in one reduce whose order is gloo's business -- and the files are
-    still the one-process run's, byte for byte: exact sums are associative."""
-    (cfg_one, cfg_two), vols = _script_setup(tmp_path, seeds=(20,))
+    still the one-process run's, byte for byte: exact sums are associative.  (``coalesce_pixels: 0``: the loader's four batches of 4 slices, so that
+    the jobs rotate over the ranks from batch to batch; the two-rank tests above run the scripts' default, one coalesced step.)"""
+    (cfg_one, cfg_two), vols = _script_setup(tmp_path, seeds=(20,), coalesce=0)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.pop('WORLD_SIZE', None)
     path = os.path.join(ROOT, 'bin-dl', 'brats_test_default.py')

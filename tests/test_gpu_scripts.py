@@ -249,6 +249,7 @@ def test_pipelined_coalesced_loop_writes_the_files_of_the_serial_loop(tmp_path, 
     assert 'batch_size: 4' in text
     with open(cfg_one, 'w') as f:
         f.write(text.replace('batch_size: 4', 'batch_size: 1'))
+    cfg_one = _with_others(cfg_one, 'uncoalesced', test_dir=str(tmp_path / 'one' / 'out'), coalesce_pixels=0)     # the loader's thirteen batches as they are
     inflight = []
     inner = loops.Test._finish_batch
 
