@@ -95,6 +95,7 @@ struct rcu_unet {
     int mask_floats = 0;
     int in_cp = 0, head_cp = 0, head_cph = 0;
     int t_input = -1, t_head = -1;
+    int t_features = -1;      // provide_features on a padded level 0: the compact [voxel][channel] copy rcu_unet_features hands out
     std::map<std::string, std::vector<float>> host_weights;
     float *w_cls = nullptr, *b_cls = nullptr, *w_sig = nullptr, *b_sig = nullptr;
     bool finalized = false;
@@ -364,6 +365,12 @@ static int build_plan_for(rcu_unet* h, bool* valid)
             }
         }
     }
+    h->t_features = -1;
+    if (d.provide_features && h->tensors[h->layers.back().t_src1].padded()) {
+        // rcu_unet_features hands the input of conv_cls.0 out as [voxel][channel]: on a padded level 0 a compact copy is made behind the forward
+        const Tensor& f = h->tensors[h->layers.back().t_src1];
+        h->t_features = new_tensor(h, -1, f.Hr, f.Wr, f.cp);
+    }
     h->site_offset.assign(h->sites.size() + 1, 0);
     for (size_t s = 0; s < h->sites.size(); ++s) h->site_offset[s + 1] = h->site_offset[s] + h->sites[s].second;
     h->mask_floats = h->site_offset.back();
@@ -431,7 +438,6 @@ static int choose_level_extents(rcu_unet* h)
     static const int kRound[] = {4, 8, 12, 16, 32};
     for (int sweep = 0; sweep < 2; ++sweep)
         for (int l = 0; l <= d.depth; ++l) {
-            if (l == 0 && d.provide_features) continue;   // rcu_unet_features hands the level-0 tensor out as [voxel][channel]
             const int Hl = d.height >> l, Wl = d.width >> l;
             std::pair<int, int> keep = h->level_ext[l];
             for (int rh : kRound)
@@ -1009,6 +1015,10 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
         if (rc) return rc;
         if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
     }
+    if (h->t_features >= 0) {   // (provide_features plans never fuse the head away from this point: the copy runs behind the last conv unit either way)
+        const Tensor& f = h->tensors[h->layers.back().t_src1];
+        RCU_HIP(launch_crop_nhwc(f.dev, h->tensors[h->t_features].dev, n, f.Hr, f.Wr, f.H, f.W, f.cp, stream));
+    }
     if (fuse) {
         if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
         return RCU_OK;
@@ -1101,10 +1111,10 @@ extern "C" int rcu_unet_features(const rcu_unet* h, const float** features_dev, 
     if (!h->finalized) return fail(RCU_ERR_STATE, "rcu_unet_features before rcu_unet_finalize_weights");
     for (const ConvLayer& L : h->layers)
         if (L.name == "conv_cls.0.conv2d_batch_relu.conv") {
-            if (h->tensors[L.t_src1].blocked)
+            if (h->tensors[L.t_src1].blocked || (h->tensors[L.t_src1].padded() && h->t_features < 0))
                 return fail(RCU_ERR_STATE, "rcu_unet_features: the handle was created without rcu_unet_desc.provide_features (the feature "
-                                           "tensor is held channel-blocked)");
-            *features_dev = h->tensors[L.t_src1].dev;
+                                           "tensor is held channel-blocked / on a padded level)");
+            *features_dev = h->t_features >= 0 ? h->tensors[h->t_features].dev : h->tensors[L.t_src1].dev;
             if (channels) *channels = L.cin1;
             if (channel_pitch) *channel_pitch = L.c1p;
             return RCU_OK;

@@ -170,6 +170,9 @@ hipError_t set_max_dynamic_lds(const void* kernel, int bytes);
 hipError_t launch_pack_input(const float* x_nchw, float* out_nhwc, int N, int C, int CP, int H, int W, int PH, int PW, int replicas,
                              hipStream_t stream);
 
+// the H x W real pixels of an NHWC tensor allocated PH x PW per image -> a compact [N][H][W][CP] tensor (rcu_unet_features on a padded level 0)
+hipError_t launch_crop_nhwc(const float* src, float* dst, int N, int H, int W, int PH, int PW, int CP, hipStream_t stream);
+
 // MC statistics blob: planes over the voxel index v = n*HW + hw.
 //   neither RCU_MC_VAR nor RCU_MC_EXACT : float planes  [sum_p[0..C-1]] [sum_H if MI]
 //   RCU_MC_VAR and / or RCU_MC_EXACT    : double planes [sum_p[0..C-1]] [sum_p^2[0..C-1] if VAR] [sum_H if MI]

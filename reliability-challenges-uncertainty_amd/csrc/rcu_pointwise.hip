@@ -48,6 +48,27 @@ hipError_t launch_pack_input(const float* x, float* out, int N, int C, int CP, i
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------- padded NHWC -> compact NHWC
+__global__ __launch_bounds__(PW_THREADS) void crop_nhwc_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t quads, int W, int HW, int PH,
+                                                                int PW, int CQ)
+{
+    const size_t i = (size_t)blockIdx.x * PW_THREADS + threadIdx.x;      // float4 of the compact tensor
+    if (i >= quads) return;
+    const size_t v = i / CQ;
+    const int q = (int)(i - v * CQ);
+    const size_t n = v / HW;
+    const int hw = (int)(v - n * HW), y = hw / W, x = hw - y * W;
+    dst[i] = src[((n * PH + y) * PW + x) * CQ + q];
+}
+
+hipError_t launch_crop_nhwc(const float* src, float* dst, int N, int H, int W, int PH, int PW, int CP, hipStream_t stream)
+{
+    const size_t quads = (size_t)N * H * W * (CP / 4);
+    hipLaunchKernelGGL(crop_nhwc_kernel, dim3(grid_for(quads)), dim3(PW_THREADS), 0, stream, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), quads, W, H * W, PH, PW, CP / 4);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------- fused head
 // act[v][0..CPh) -> logits (1x1 conv, unet.py:161); optional twin on act[v][CPh..2CPh) -> sigma
 // (unet.py:164); optional softmax + statistics update so that logits never reach HBM.

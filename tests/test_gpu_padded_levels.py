@@ -176,9 +176,11 @@ def test_padding_stays_zero_whatever_ran_before(dev):
 
 
 @pytest.mark.timeout(900)
-def test_feature_tap_keeps_level_0_real_and_pools_into_a_padded_level(dev):
-    """provide_features (common/model/unet.py:135-136, 178-179): the feature tensor is handed out as [voxel][channel], so level 0 keeps its real
-    extent and the direct kernels -- whose pooled output then lands in the PADDED level 1, and whose input is the up-convolution out of it."""
+def test_feature_tap_on_a_padded_level_and_direct_units_next_to_padded_levels(dev):
+    """provide_features (common/model/unet.py:135-136, 178-179): ``features`` is handed out as [voxel][channel] -- on a padded level 0 a compact
+    copy of the real pixels is made behind the forward (rcu_unet_features), so the auxiliary-network scripts run the Winograd kernels on the
+    reference's 240 x 240 slices too.  And the mixed plans: a level that keeps its real extent on the direct kernels (8 x 8 and 16 x 8 images:
+    padding a 32-channel level to the 32-pixel-wide tiles would multiply it) pools INTO a padded level and takes the up-convolution OUT of one."""
     from oracle import unet_oracle as uo
     params = dict(WIDE, provide_features=True)
     st = uo.synthetic_state(47, **WIDE)
@@ -189,9 +191,21 @@ def test_feature_tap_keeps_level_0_real_and_pools_into_a_padded_level(dev):
     masks = uo.sample_masks(sites, n, 0.3, g)
     m = _model(params, st, dev)
     rows = m.layer_table(h, w, n)
-    assert all((r['grid_height'], r['grid_width']) == (240, 240) for r in rows if r['height'] == 240 and not r['upsample'])
-    assert any((r['grid_height'], r['grid_width']) == (128, 128) for r in rows)
+    assert not any('igemm' in r['kernel'] for r in rows) and any((r['grid_height'], r['grid_width']) == (240, 256) for r in rows)
     ref_logits, ref_feat = uo.unet_forward(st, x, masks, return_features=True, **WIDE)
     out = m(x.to(dev), masks)
     assert _maxdiff(out.cpu().numpy(), ref_logits.numpy()) < LOGIT_TOL
+    assert tuple(m.features.shape) == tuple(ref_feat.shape)
     assert _maxdiff(m.features.cpu().numpy(), ref_feat.numpy()) < 2e-5 * float(ref_feat.abs().max())
+    shallow = dict(WIDE, depth=3)
+    st3 = uo.synthetic_state(48, **shallow)
+    m3 = _model(shallow, st3, dev)
+    _, sites3 = uo.unet_plan(**shallow)
+    for n, h, w in ((5, 8, 8), (9, 16, 8)):
+        rows = m3.layer_table(h, w, n)
+        direct_pooling = [r for r in rows if 'igemm' in r['kernel'] and r['pooled']]
+        assert direct_pooling and _padded_rows(rows), [(r['name'], r['kernel']) for r in rows]
+        x = torch.randn(n, 4, h, w, generator=g)
+        masks = uo.sample_masks(sites3, n, 0.3, g)
+        for mk in (None, masks):
+            assert _maxdiff(m3(x.to(dev), mk).cpu().numpy(), uo.unet_forward(st3, x, mk, **shallow).numpy()) < LOGIT_TOL

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end wall time of the drop-in brats_test_default script (YAML -> dataset -> Test loop -> NIfTI + metrics) on
 full-size synthetic subjects, with a cProfile breakdown of the host side:
-    python tools/script_throughput.py [subjects] [mc] [batch_size] [coalesce_pixels, 0 = off] [timing: the loader thread logs its time split]"""
+    python tools/script_throughput.py [subjects] [mc] [batch_size] [coalesce_pixels, 0 = off] [timing: the loader thread logs its time split]
+RCU_SCRIPT_NATIVE=1: subjects of the reference's real BraTS shape, 155 slices of 240 x 240 (bench.NATIVE_*), instead of the benchmark's 160 x 192 x 128."""
 import cProfile
 import json
 import os
@@ -28,7 +29,9 @@ def main():
     mc = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32
     tmp = tempfile.mkdtemp(prefix='rcu_e2e_')
-    x, mask, target = bench.make_volume(20)
+    if os.environ.get('RCU_SCRIPT_NATIVE') == '1':
+        bench.SLICES, bench.HEIGHT, bench.WIDTH = bench.NATIVE_SLICES, bench.NATIVE_HEIGHT, bench.NATIVE_WIDTH
+    x, mask, target = bench.make_volume(20, bench.SLICES, bench.HEIGHT, bench.WIDTH, bench.SLICES)
     names = []
     for i in range(n_subjects):
         name = 'Brats18_SYN_{:03d}_1'.format(i)
@@ -90,13 +93,16 @@ def main():
     if profile:
         prof.disable()
     dt = time.perf_counter() - t0
-    print('{} subjects, T={}, batch_size {}: {:.2f} s total, {:.2f} s per subject ({:.1f} MC-sample-volumes/s end to end, start-up and '
-          'the final join of the writers included)'.format(n_subjects, mc, batch, dt, dt / n_subjects, mc * n_subjects / dt))
+    unit = 'member' if members > 1 else 'MC-sample'
+    mc = members if members > 1 else (1 if aleatoric else mc)
+    print('{} subjects, T={}, batch_size {}: {:.2f} s total, {:.2f} s per subject ({:.1f} {}-volumes/s end to end, start-up and '
+          'the final join of the writers included; subjects of {} x {} x {})'.format(n_subjects, mc, batch, dt, dt / n_subjects, mc * n_subjects / dt, unit,
+                                                                                  bench.SLICES, bench.HEIGHT, bench.WIDTH))
     if len(stamps) > 2:
         # steady state: from the hand-over of the first subject to the writers to the end of the run (the last subject's files joined)
         steady = (t0 + dt - stamps[0]) / (len(stamps) - 1)
-        print('steady state (subjects 2..{}, incl. the final join): {:.3f} s per subject = {:.1f} MC-sample-volumes/s; start-up + first '
-              'subject {:.2f} s'.format(len(stamps), steady, mc / steady, stamps[0] - t0))
+        print('steady state (subjects 2..{}, incl. the final join): {:.3f} s per subject = {:.1f} {}-volumes/s; start-up + first '
+              'subject {:.2f} s'.format(len(stamps), steady, mc / steady, unit, stamps[0] - t0))
     if not profile:
         return
     st = pstats.Stats(prof)

@@ -30,8 +30,11 @@ def short(name):
     if m:
         kind, ts, th, tw, bn = m.groups()
         tile = ('S{}'.format(ts) if ts != '1' else '') + 'T{}x{}'.format(th, tw)
-        return '{}<{},N{},K8>{}'.format('conv3x3_winograd' if kind == 'conv' else 'upconv_winograd', tile, bn,
-                                        '+head' if ', true>' in name else '')
+        # template arguments behind the tile: conv <T, HEAD, PART>, upconv <T, PART> (PART: the padded-level store side, round 6)
+        flags = re.search(r'WinoTile<[^>]*>((?:, \w+)*)>', name)
+        flags = [f.strip() for f in flags.group(1).split(',') if f.strip()] if flags else []
+        head = kind == 'conv' and bool(flags) and flags[0] in ('true', '1')
+        return '{}<{},N{},K8>{}'.format('conv3x3_winograd' if kind == 'conv' else 'upconv_winograd', tile, bn, '+head' if head else '')
     m = re.search(r'conv_wino4_stream<rcu::Wino4Tile<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\w+))?(?:, (\w+))?>(?:, \d+)?(?:, (\w+))?', name)
     if m:   # block = SB slices x BR x BC tiles of 4x4 pixels, workgroup = WS x WR blocks; the tile's last flag: the folded 12x8 geometry;
             # the kernel's last flag (behind the ablation variant): the classifier head in the epilogue
@@ -83,6 +86,11 @@ def pmc(args):
         meta = dict(plan_fingerprint=line['roofline'].get('plan_fingerprint'), pass_group=line['config'].get('pass_group'),
                     bench_value=line.get('value'))
         args = args[:i] + args[i + 2:]
+    traffic_name = 'pmc_traffic.json'      # --traffic-name: the file bench.py reads for another workload (pmc_traffic_<workload>.json)
+    if '--traffic-name' in args:
+        i = args.index('--traffic-name')
+        traffic_name = args[i + 1]
+        args = args[:i] + args[i + 2:]
     out_path = args[-1]
     dirs = args[:-1]
     find = lambda d: [os.path.join(d, f) for f in os.listdir(d) if f.endswith('counter_collection.csv')][0]  # noqa: E731
@@ -111,7 +119,7 @@ def pmc(args):
         json.dump(result, f, indent=1, sort_keys=True)
     traffic = {k: v['hbm_bytes_per_launch'] for k, v in result.items() if k.startswith(('conv3x3', 'upconv'))}
     traffic['_meta'] = meta
-    with open(os.path.join(os.path.dirname(out_path), 'pmc_traffic.json'), 'w') as f:
+    with open(os.path.join(os.path.dirname(out_path), traffic_name), 'w') as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
 
 
