@@ -593,6 +593,7 @@ extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_op
     }
     h->ws = std::make_shared<Workspace>();
     h->ws->max_batch = d.max_batch;
+    bool zeroed = false;
     for (Tensor& t : h->tensors) {
         const size_t bytes = t.floats_per_slice * (size_t)d.max_batch * sizeof(float);
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&t.dev), bytes);
@@ -609,6 +610,16 @@ extern "C" int rcu_unet_create_with(const rcu_unet_desc* desc, const rcu_unet_op
                 rcu_unet_destroy(h);
                 return hip_fail(e, "hipMemset(centre-pad border / level padding)");
             }
+            zeroed = true;
+        }
+    }
+    if (zeroed) {
+        // a memset of device memory may return before it has run, and the forwards come on the caller's (non-blocking) streams, which the null
+        // stream does not order: the zeros are in place before the handle is handed out
+        hipError_t e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) {
+            rcu_unet_destroy(h);
+            return hip_fail(e, "hipStreamSynchronize(level padding)");
         }
     }
     *out = h;

@@ -637,6 +637,38 @@ def g15_unet_centre_pad():
     save('g15_unet_centre_pad', **out)
 
 
+def g21_unet_real_shapes():
+    """The shapes the reference's real data has, none of whose deeper levels is a whole number of the build's Winograd tiles (round 6: padded
+    levels): a BraTS slice is 240 x 240 (scripts/create_brats18_dataset.py:53-72 never crops; levels 240 / 120 / 60 / 30 / 15), an ISIC image
+    192 x 256 (scripts/prepare_isic_data.py:29-30; bottom level 12 x 16 -- here at depth 3 from 96 x 128, the same levels 24 x 32 and 12 x 16),
+    and a ragged 48 x 80 batch with MC-dropout masks."""
+    ref_th = __import__('common.utils.torchhelper', fromlist=['x'])
+    out = {}
+    params_a = dict(nb_classes=2, in_channels=4, depth=4, start_filters=4, dropout=0.3)
+    params_b = dict(nb_classes=2, in_channels=3, depth=3, start_filters=4, dropout=0.05)
+    model_a, model_b = make_unet(137, **params_a), make_unet(138, **params_b)
+    out.update({'params_a': np.array(repr(params_a)), 'params_b': np.array(repr(params_b))})
+    out.update(state_to_npz(model_a, 'sd_a::'))
+    out.update(state_to_npz(model_b, 'sd_b::'))
+    gen = torch.Generator().manual_seed(211)
+    for tag, model, shape in (('a', model_a, (1, 4, 240, 240)), ('b', model_b, (2, 3, 96, 128)), ('c', model_a, (3, 4, 48, 80))):
+        x = torch.randn(*shape, generator=gen)
+        with torch.no_grad():
+            y = model(x)
+        out.update({'x_' + tag: x.numpy(), 'logits_' + tag: y.numpy()})
+        if tag == 'c':       # the ragged batch under MC dropout (model a's weights), masks captured
+            with torch.no_grad():
+                torch.manual_seed(23)
+                ref_th.set_dropout_mode(model, True)
+                y_mc, recs = capture_masks(model, lambda: model(x))
+                ref_th.set_dropout_mode(model, False)
+            out['logits_mc_c'] = y_mc.numpy()
+            out['sites_c'] = np.array([n for n, _ in recs])
+            for s_, (_, mask) in enumerate(recs):
+                out['mask_c_{}'.format(s_)] = mask
+    save('g21_unet_real_shapes', **out)
+
+
 def g16_postnet_wide():
     """PostNet (postnet.py:6-18) on more than 32 feature channels (a U-Net with start_filters 48 / 64) and with MC-dropout inside
     (Conv2dBnRelu with a dropout rate, masks captured)."""
@@ -815,7 +847,7 @@ def main():
     torch.set_grad_enabled(False)
     for fn in (g1_unet_eval, g2_unet_mc, g3_unet_center, g4_unet_sigma, g5_unet_isic, g6_mc_summary,
                g7_mc_step_end2end, g8_ece, g9_uncertainty, g10_prep, g11_fullsize_digest, g12_eval_csv, g13_postnet, g14_unet_residual, g15_unet_centre_pad,
-               g16_postnet_wide, g17_unet_no_bn, g18_unet_stress, g19_confusion_third_party):
+               g16_postnet_wide, g17_unet_no_bn, g18_unet_stress, g19_confusion_third_party, g21_unet_real_shapes):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()

@@ -209,3 +209,26 @@ def test_feature_tap_on_a_padded_level_and_direct_units_next_to_padded_levels(de
         masks = uo.sample_masks(sites3, n, 0.3, g)
         for mk in (None, masks):
             assert _maxdiff(m3(x.to(dev), mk).cpu().numpy(), uo.unet_forward(st3, x, mk, **shallow).numpy()) < LOGIT_TOL
+
+
+@pytest.mark.timeout(900)
+def test_padded_levels_against_the_reference_itself_g21(golden, dev):
+    """Fixture g21 (tests/golden/generate_golden.py imports the reference): a 240 x 240 BraTS slice, ISIC's 24 x 32 / 12 x 16 levels, a ragged 48 x 80
+    batch under the reference's own captured Dropout2d masks -- logits of the GPU path on padded levels against the reference's."""
+    g = golden('g21_unet_real_shapes')
+
+    def tagged(tag):
+        params = eval(str(g['params_' + tag]), {'__builtins__': {}}, {'dict': dict})
+        return params, {k[len('sd_{}::'.format(tag)):]: v for k, v in g.items() if k.startswith('sd_{}::'.format(tag))}
+
+    pa, sta = tagged('a')
+    pb, stb = tagged('b')
+    ma, mb = _model(pa, sta, dev), _model(pb, stb, dev)
+    for m, tag in ((ma, 'a'), (mb, 'b'), (ma, 'c')):
+        x = torch.from_numpy(g['x_' + tag]).to(dev)
+        rows = m.layer_table(x.shape[2], x.shape[3], x.shape[0])
+        assert _padded_rows(rows), tag
+        assert _maxdiff(m(x).cpu().numpy(), g['logits_' + tag]) < LOGIT_TOL, tag
+    assert [s[0] for s in ma.dropout_sites()] == list(g['sites_c'])
+    masks = [g['mask_c_{}'.format(s)] for s in range(len(g['sites_c']))]
+    assert _maxdiff(ma(torch.from_numpy(g['x_c']).to(dev), masks).cpu().numpy(), g['logits_mc_c']) < LOGIT_TOL

@@ -414,3 +414,18 @@ def test_uncertain_voxel_table_holds_under_the_local_numpy():
     assert disagree == 0, ('numpy {} on this CPU rounds log differently from the build that made the table (numpy {}, {}): {} probe values flip; '
                            'rebuild the table (tests/golden/generate_ue_boundaries.py) or evaluate through rcu_normalised_entropy + rcu_unc_counts'
                            .format(np.__version__, g['numpy_version'], g['cpu_features'], disagree))
+
+
+def test_g21_real_data_shapes(golden):
+    """The shapes of the reference's real data -- a 240 x 240 BraTS slice (levels 240 / 120 / 60 / 30 / 15), ISIC's 24 x 32 and 12 x 16 levels, a ragged
+    48 x 80 batch under MC-dropout masks -- through the reference itself (tests/golden/generate_golden.py g21): what pins the oracle, and through
+    it the padded levels of the GPU path (tests/test_gpu_padded_levels.py), at shapes whose levels are not whole Winograd tiles."""
+    g = golden('g21_unet_real_shapes')
+    pa, sta = _tagged(g, 'a')
+    pb, stb = _tagged(g, 'b')
+    _close(uo.unet_forward(sta, g['x_a'], None, **pa).numpy(), g['logits_a'], 5e-6)
+    _close(uo.unet_forward(stb, g['x_b'], None, **pb).numpy(), g['logits_b'], 5e-6)
+    _close(uo.unet_forward(sta, g['x_c'], None, **pa).numpy(), g['logits_c'], 5e-6)
+    masks = [g['mask_c_{}'.format(s)] for s in range(len(g['sites_c']))]
+    assert any((m == 0).any() for m in masks)
+    _close(uo.unet_forward(sta, g['x_c'], masks, **pa).numpy(), g['logits_mc_c'], 5e-6)
