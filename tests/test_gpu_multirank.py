@@ -153,12 +153,12 @@ def _launch_two_ranks(script, cfg, env, out_root=None, attempts=2, ranks=2):
     return last
 
 
-def _script_setup(tmp_path, seeds=(20,), mc=6, coalesce=None):
+def _script_setup(tmp_path, seeds=(20,), mc=6, coalesce=None, shape=(32, 32)):
     """Two small BraTS-like subjects, model dir(s) + checkpoint(s), split and two YAML files that differ in their test_dir only.
     ``coalesce``: ``others.coalesce_pixels`` (0: the loader's batches of 4 slices as they are; default: the scripts' -- everything in one step)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import test_gpu_scripts as tgs
-    cfg, vols, _, _ = tgs._setup(tmp_path, mc=mc if len(seeds) == 1 else None, seeds=seeds)
+    cfg, vols, _, _ = tgs._setup(tmp_path, mc=mc if len(seeds) == 1 else None, seeds=seeds, shape=shape)
     with open(cfg) as f:
         text = f.read()
     if coalesce is not None:
@@ -365,3 +365,22 @@ def test_eight_ranks_write_the_one_process_files_too(tmp_path):
     import re
     shares = {int(m.group(1)): int(m.group(2)) for m in re.finditer(r'rank (\d) of 8: (\d+) forward passes in (\d+) batches', r8.stdout + r8.stderr)}
     assert sorted(shares) == list(range(8)) and sum(shares.values()) == 4 * 7 and max(shares.values()) - min(shares.values()) <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_two_ranks_on_the_references_real_slice_size_write_the_one_process_files(tmp_path):
+    """240 x 240 slices (padded levels) under the launcher: which kernel and which allocated extent a level gets is part of the plan,
+    and plans are canonical -- two ranks write the one-process run's bytes here too."""
+    (cfg_one, cfg_two), vols = _script_setup(tmp_path, seeds=(20,), mc=4, shape=(240, 240))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    path = os.path.join(ROOT, 'bin-dl', 'brats_test_default.py')
+    r1 = subprocess.run([sys.executable, path, '-config_file', cfg_one], capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    r2 = _launch_two_ranks(path, cfg_two, env, str(tmp_path / 'out_two'))
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    one, two = _written(str(tmp_path / 'out_one')), _written(str(tmp_path / 'out_two'))
+    assert sorted(one) == sorted(two) and len(one) == 2 * len(vols) + 1
+    for name in one:
+        assert one[name] == two[name], name

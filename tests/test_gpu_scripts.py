@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 PARAMS = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
 
 
-def _setup(tmp_path, mc=None, sigma=False, seeds=(20,)):
+def _setup(tmp_path, mc=None, sigma=False, seeds=(20,), shape=(32, 32)):
     from oracle import unet_oracle as uo
     from rcu_amd import data as data_mod
     from rcu_amd import management as mgt
@@ -25,9 +25,9 @@ def _setup(tmp_path, mc=None, sigma=False, seeds=(20,)):
     vols = {}
     for i in range(2):
         name = 'Brats18_T{}_1'.format(i)
-        images = rng.randn(6 + i, 32, 32, 4).astype(np.float32)
-        labels = (rng.rand(6 + i, 32, 32) < 0.3).astype(np.uint8)
-        props = nifti.ImageProperties((32, 32, 6 + i), (1.0, -2.0, 3.0), (1.0, 1.0, 2.5))
+        images = rng.randn(6 + i, shape[0], shape[1], 4).astype(np.float32)
+        labels = (rng.rand(6 + i, shape[0], shape[1]) < 0.3).astype(np.uint8)
+        props = nifti.ImageProperties((shape[1], shape[0], 6 + i), (1.0, -2.0, 3.0), (1.0, 1.0, 2.5))
         data_mod.write_volume(str(tmp_path / 'ds'), name, images, labels, props)
         vols[name] = (images, labels, props)
     states, dirs = [], []
@@ -707,3 +707,52 @@ def test_the_same_yaml_writes_the_same_files_for_any_batch_size(tmp_path):
         for other in (ctx_two, ctx_plain):
             got = nifti.read(os.path.join(other.test_dir, name + '_probabilities.nii.gz'))[0]
             assert float(np.max(np.abs(got - ref))) < 2e-6, name
+
+
+@pytest.mark.timeout(1200)
+def test_brats_scripts_on_the_references_real_slice_size(tmp_path):
+    """The drop-in scripts on slices of the reference's real size, 240 x 240 (scripts/create_brats18_dataset.py:53-72 never crops): the loader, the
+    coalesced steps, the MC step's pass groups and the writers on padded levels -- deterministic run and ensemble against the oracle,
+    MC run against the oracle's passes under the step's seeded masks (keyed by the slices' global indices), aleatoric run's sigma map."""
+    from oracle import summary_oracle as so
+    from oracle import unet_oracle as uo
+    from rcu_amd import nifti, scripts, steps
+    from rcu_amd.model import UNet
+    cfg_path, vols, states, params = _setup(tmp_path / 'det', shape=(240, 240))
+    ctx = scripts.test_default('brats', cfg_path, None)
+    outs = _outputs(ctx, vols)
+    for name, (images, labels, props) in vols.items():
+        x = torch.from_numpy(images).permute(0, 3, 1, 2)
+        ref = torch.softmax(uo.unet_forward(states[0], x, None, **params), 1)[:, 1].numpy()
+        p, pred, rprops = outs[name]
+        assert p.shape == ref.shape == labels.shape and rprops == props
+        assert np.max(np.abs(p - ref)) < 1e-4 and np.mean(pred == (ref > 0.5)) > 0.999
+    # MC-dropout: T = 3 passes under the masks the step draws for the run's 13 slices (global indices 0..12: subject 0 has slices 0..5)
+    cfg_mc, vols_mc, st_mc, _ = _setup(tmp_path / 'mc', mc=3, shape=(240, 240))
+    ctx_mc = scripts.test_default('brats', cfg_mc, None)
+    outs_mc = _outputs(ctx_mc, vols_mc)
+    model = UNet(**params)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in st_mc[0].items()})
+    model = model.cuda()
+    step = steps.McPredictStep(3, seed=20)
+    sites = model.dropout_sites()
+    offset = 0
+    for name in sorted(vols_mc):
+        images = vols_mc[name][0]
+        n = images.shape[0]
+        x = torch.from_numpy(images).permute(0, 3, 1, 2).contiguous()
+        steps.set_dropout_mode(model, True)
+        flat = [step._seeded_masks(model, x.cuda(), offset, j) for j in (1, 2, 3)]
+        steps.set_dropout_mode(model, False)
+        mask_sets = [[m.view(n, -1).cpu() for m in torch.split(f, [n * c for _, c in sites])] for f in flat]
+        _, multi = so.mc_probabilities(lambda xx, mk: uo.unet_forward(st_mc[0], xx, mk, **params), x, mask_sets)
+        ref = so.multi_prediction_summary(multi)['probabilities'][:, 1].numpy()
+        assert np.max(np.abs(outs_mc[name][0] - ref)) < 1e-4, name
+        offset += n
+    # ensemble of three members
+    cfg_ens, vols_ens, st_ens, _ = _setup(tmp_path / 'ens', seeds=(20, 21, 22), shape=(240, 240))
+    outs_ens = _outputs(scripts.test_ensemble('brats', cfg_ens), vols_ens)
+    for name, (images, _, _) in vols_ens.items():
+        x = torch.from_numpy(images).permute(0, 3, 1, 2)
+        multi = so.ensemble_probabilities([lambda xx, m, st=st: uo.unet_forward(st, xx, m, **params) for st in st_ens], x)
+        assert np.max(np.abs(outs_ens[name][0] - multi.mean(0)[:, 1].numpy())) < 1e-4
