@@ -318,14 +318,6 @@ class ShardedMcRunner:
             lanes.end(self.engine.merge)
         return flat, stats, ws
 
-    def exchange_bytes(self, flat, ws):
-        """Bytes of one volume's exchange as this runner sends it: (bytes in the sum-reduce, bytes point to point -- zero on the volumes
-        whose weight-scaling pass the root runs itself)."""
-        total = flat.numel() * flat.element_size()
-        tail = 0 if ws is None else ws.numel() * ws.element_size()
-        transport = self.ws_transport or ('p2p' if (dist.is_initialized() and dist.get_backend() == 'nccl') else 'reduce')
-        return (total, 0) if (ws is None or transport == 'reduce') else (total - tail, tail)
-
     def ws_owner(self, step_index):
         """Rank that runs the weight-scaling pass (job 0) of volume ``step_index``."""
         return (step_index * self.jobs_per_step) % self.world
