@@ -1024,6 +1024,9 @@ def main():
                                         T, '' if args.no_ws else ' + weight-scaling pass')),
                    'T': T, 'ws_pass': not (args.no_ws or args.ensemble), 'slices': n_slices, 'height': height, 'width': width,
                    'pass_group': g, 'lanes': args.lanes, 'volumes_per_step': v_step, 'samples_per_launch': samples_per_launch,
+                   # real extent -> allocated extent of every level (rcu_unet_options.pad_levels: a level that is not whole Winograd tiles is padded)
+                   'level_extents': sorted({'{}x{} -> {}x{}'.format(L['height'], L['width'], L['grid_height'], L['grid_width'])
+                                            for L in layers if not L['upsample']}, key=lambda t: -int(t.split('x')[0])),
                    'outputs': 'mean + entropy + mutual information + variance (float64 statistics)' if args.all_outputs else
                               'mean + entropy (MultiPredictionSummary() as every shipped script constructs it)',
                    'h2d': 'prefetched, inside timed region ({} MB per {} from pinned host memory on a copy stream, one event wait per '
