@@ -632,15 +632,16 @@ class Test:
     costs the host 100-190 ms (assembly, the metric seam, argmax, hand-over to the NIfTI writers; tools/loop_timeline.py) -- the GPU idled
     a third of the time; ten batches ahead keep it busy (0.185-0.192 -> 0.133-0.155 s per subject, tools/script_throughput.py 16 20 32 0;
     0.12 with coalescing, which also makes the launches volume-sized).
-    ``coalesce`` (OPT-IN: the constructor argument or the YAML key ``others.coalesce_pixels`` the scripts pass on;
-    default 0 = off, as the reference, whose loop never regroups batches): consecutive loader batches are merged up to
-    that many samples x height x width before the steps run -- ``COALESCE_PIXELS`` = one BraTS volume, 160 x 192 x 128, is what fills
-    the GPU (five batches of the shipped ``batch_size: 32`` become one step of 160 slices: the kernels' small levels run 1.3-2x faster
-    per slice).  What it changes, which is why it is not a default: the YAML batch_size no longer is the step's batch; steps and hooks see
-    the MERGED batch (fewer ``on_test_batch_*`` calls, renumbered ``batch_index``, fewer ``batch_metrics`` entries); the Dropout2d masks
-    of a stochastic step are drawn per step, so for a given seed MC / aleatoric outputs differ from the uncoalesced run's (another
-    sample of the same distribution; deterministic steps give the same files byte for byte); and the activation workspace grows to that
-    of the merged batch times the pass group (24 GB per lane for four passes of 160 slices)."""
+    ``coalesce`` (the constructor argument; the scripts pass the YAML key ``others.coalesce_pixels`` on and, since round 6, default to
+    ``COALESCE_PIXELS`` -- this class itself defaults to 0 = off, as the reference, whose loop never regroups batches): consecutive loader
+    batches are merged up to that many samples x height x width before the steps run -- ``COALESCE_PIXELS`` = one BraTS volume, 160 x 192 x 128,
+    is what fills the GPU (five batches of the shipped ``batch_size: 32`` become one step of 160 slices: the kernels' small levels run 1.3-2x
+    faster per slice).  What it changes: the YAML batch_size no longer is the step's batch; steps and hooks see the MERGED batch (fewer
+    ``on_test_batch_*`` calls, renumbered ``batch_index``, fewer ``batch_metrics`` entries); and the activation workspace grows to that of the
+    merged batch times the pass group (24 GB per lane for four passes of 160 slices).  What it does not change: the MC samples -- the seeded
+    Dropout2d masks of a stochastic step are keyed by a slice's GLOBAL index (``BatchContext.sample_offset``: this loop counts the slices it
+    hands out), not by the batch (rounds 1-5), so a run's files are the same for every ``batch_size`` and deterministic steps give the same
+    files byte for byte with or without coalescing."""
     __test__ = False
     COALESCE_PIXELS = 160 * 192 * 128
     INFLIGHT_PIXELS = 2 * 160 * 192 * 128
