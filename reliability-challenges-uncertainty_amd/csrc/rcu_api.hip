@@ -455,6 +455,24 @@ static int choose_level_extents(rcu_unet* h)
                 }
             h->level_ext[l] = keep;
         }
+#ifdef RCU_EXPERIMENTS
+    // Experiment builds only (make EXTRA=-DRCU_EXPERIMENTS; tools/layer_report.py under RCU_HIP_LIBRARY): RCU_FORCE_LEVEL_EXTENTS="256x256,128x128,..."
+    // overrides the chosen extents level by level (an entry that is smaller than the real extent, or a plan that is not valid, is ignored) --
+    // how the planner's choice is measured against its alternatives (HISTORY, round-6 log, item 3).
+    if (const char* force = getenv("RCU_FORCE_LEVEL_EXTENTS")) {
+        std::vector<std::pair<int, int>> keep = h->level_ext;
+        int l = 0;
+        for (const char* p = force; *p && l <= d.depth; ++l) {
+            int eh = 0, ew = 0, used = 0;
+            if (sscanf(p, "%dx%d%n", &eh, &ew, &used) != 2) break;
+            if (eh >= (d.height >> l) && ew >= (d.width >> l)) h->level_ext[l] = {eh, ew};
+            p += used;
+            if (*p == ',') ++p;
+        }
+        rc = build_plan_for(h, &valid);
+        if (rc != RCU_OK || !valid) h->level_ext = keep;
+    }
+#endif
     return build_plan_for(h, &valid);
 }
 
