@@ -607,3 +607,50 @@ def test_eval_subject_step_sums_the_counts_that_came_with_the_batches():
         plain = loops.SubjectContext(2, {'probabilities': probabilities, 'labels': np.zeros((5, 6, 4), np.uint8)})
         with pytest.raises(RuntimeError):
             scripts.EvalSubjectStep()(plain, None, None)
+
+
+def test_the_test_loop_counts_the_slices_it_hands_out_and_the_mask_key_follows():
+    """Round 6: the seeded Dropout2d masks of the MC step are keyed by a slice's GLOBAL index.  ``loops.Test`` numbers the run's stream of slices
+    (``BatchContext.sample_offset`` = slices handed out before the batch, whatever sizes the loader's batches have); ``steps.first_sample_of``
+    falls back to batch_index x n for a hand-built context; ``steps.pass_seed`` does not depend on the batch; the sharded runner takes the offset
+    the step hands it (``sample_offsets``) or step x n."""
+    import types
+    from rcu_amd import distributed as rdist
+    from rcu_amd import loops, steps
+
+    class Context(loops.TorchTestContext):
+        def __init__(self, batches):
+            super().__init__('cpu')
+            self.batches = batches
+
+        def setup_directory(self): pass
+        def setup_logging(self): pass
+        def get_seed(self): return None
+        def load_test_data(self, build_test): self.test_data = types.SimpleNamespace(loader=self.batches, nb_batches=len(self.batches), dataset=None)
+        def get_test_at(self): return 'best'
+        def load_from_checkpoint(self, epoch): self.model = None
+
+        def get_task_context(self):
+            tc = loops.TaskContext(0, self.test_data, None)
+            tc.history = loops.History()
+            return tc
+
+    seen = []
+
+    class Record(steps.BatchStep):
+        def __call__(self, batch_context, task_context, context):
+            n = batch_context.input['images'].shape[0]
+            seen.append((batch_context.batch_index, batch_context.sample_offset, steps.first_sample_of(batch_context, n)))
+
+    sizes = [4, 4, 3, 4, 1]
+    batches = [{'images': torch.zeros(n, 4, 8, 8)} for n in sizes]
+    loops.Test([Record()], pipelined=False)(Context(batches), None)
+    assert seen == [(0, 0, 0), (1, 4, 4), (2, 8, 8), (3, 11, 11), (4, 15, 15)]
+    assert steps.first_sample_of(steps.BatchContext({}, 3), 32) == 96 and steps.first_sample_of(steps.BatchContext({}, 3, sample_offset=7), 32) == 7
+    assert steps.pass_seed(20, 4) == steps.job_seed(20, 0, 4) == rdist.pass_seed(20, 4) != steps.pass_seed(20, 5)
+    runner = rdist.ShardedMcRunner(None, 4, engine=object(), seed=3)
+    x = torch.zeros(6, 4, 8, 8)
+    assert runner.first_sample(x, 5) == 30
+    runner.sample_offsets[5] = 17
+    assert runner.first_sample(x, 5) == 17 and runner.first_sample(x, 6) == 36
+    assert runner.ws_transport is None      # resolved at the first exchange: point to point on RCCL, inside the reduce on gloo with device tensors
