@@ -198,6 +198,9 @@ static int pick_config(const ConvLayer& L, int n_slices, const rcu_unet_options&
             if (gh % 32 == 0) return CONV_CFG_WINO4_T32x32_N32;
             if (gh % 16 == 0) return CONV_CFG_WINO4_S2T16x32_N32;
         }
+        // images exactly 32 wide whose height is a multiple of 8 but not of 16 (24x32: the fourth level of the reference's ISIC size 192x256): the
+        // full-width tile of four slices takes them as they are (round 6; padded to 32x32 the level would compute a third more)
+        if (w4_ok && gw == 32 && gh % 8 == 0) return CONV_CFG_WINO4_S4T8x32_N32;
         if (w4_ok && gw == 16 && gh % 8 == 0) return CONV_CFG_WINO4_S8T8x16_N32;
         // the 12x8 level (bottom_convs): F(4x4,3x3) with a slice's 6 tiles in the 8 tile slots of the S8 block -- 3 multiplications per output
         // pixel executed (2.25 x 4/3) against F(2x2,3x3)'s 4 (round 5; no pooled output in this geometry)

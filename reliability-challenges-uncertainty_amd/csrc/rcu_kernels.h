@@ -101,6 +101,7 @@ enum ConvConfig {
     CONV_CFG_WINO4_S8T8x16_N32,                  // 8x16 pixels of eight consecutive slices, images 16 pixels wide
     CONV_CFG_WINO4_S8T12x8_N32,                  // 12x8 pixels of eight consecutive slices (6 tiles per slice in the 8 tile slots of the S8 block), images 8 wide
     CONV_CFG_WINO4_T32x32_N32_HEAD,              // T32x32_N32 with the 1x1 head + softmax + statistics in the epilogue (run-time choice of forward_impl, never a plan entry)
+    CONV_CFG_WINO4_S4T8x32_N32,                  // 8x32 pixels of four consecutive slices, images 32 pixels wide (round 6: ISIC's 24x32 level without padding)
     CONV_CFG_END
 };
 

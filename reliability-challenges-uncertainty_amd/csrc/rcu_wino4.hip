@@ -894,13 +894,15 @@ using W4Cfg0 = Wino4Tile<1, 2, 8, 1, 4>;   // 32x32 pixels of one slice
 using W4Cfg1 = Wino4Tile<1, 2, 8, 2, 2>;   // 16x32 pixels of two consecutive slices (heights not divisible by 32)
 using W4Cfg2 = Wino4Tile<2, 2, 4, 4, 1, true>;   // 8x16 pixels of eight consecutive slices, full image width (the 24x16 level)
 using W4Cfg3 = Wino4Tile<2, 2, 4, 4, 1, true, true>;   // 12x8 pixels of eight consecutive slices, folded into the same block geometry (the 12x8 level)
+using W4Cfg4 = Wino4Tile<1, 2, 8, 4, 1, true>;   // 8x32 pixels of four consecutive slices, full image width (round 6: 24x32 levels -- the reference's ISIC size 192x256 -- without padding to 32x32)
 
-static const ConvConfigInfo kWino4Info[5] = {
+static const ConvConfigInfo kWino4Info[6] = {
     {W4Cfg0::TS, W4Cfg0::TH, W4Cfg0::TW, W4Cfg0::BN, 8, 36, "conv3x3_winograd4<T32x32,N32,K8>", 8, 0, 3},
     {W4Cfg1::TS, W4Cfg1::TH, W4Cfg1::TW, W4Cfg1::BN, 8, 36, "conv3x3_winograd4<S2T16x32,N32,K8>", 8, 0, 3},
     {W4Cfg2::TS, W4Cfg2::TH, W4Cfg2::TW, W4Cfg2::BN, 8, 36, "conv3x3_winograd4<S8T8x16,N32,K8>", 8, 0, 3},
     {W4Cfg3::TS, W4Cfg3::TH, W4Cfg3::TW, W4Cfg3::BN, 8, 36, "conv3x3_winograd4<S8T12x8,N32,K8>", 8, 0, 3},
     {W4Cfg0::TS, W4Cfg0::TH, W4Cfg0::TW, W4Cfg0::BN, 8, 36, "conv3x3_winograd4<T32x32,N32,K8>+head", 8, 0, 3},
+    {W4Cfg4::TS, W4Cfg4::TH, W4Cfg4::TW, W4Cfg4::BN, 8, 36, "conv3x3_winograd4<S4T8x32,N32,K8>", 8, 0, 3},
 };
 
 const ConvConfigInfo& wino4_config_info(int cfg) { return kWino4Info[cfg - CONV_CFG_WINO4_T32x32_N32]; }
@@ -975,6 +977,7 @@ hipError_t launch_conv_wino4(int cfg, const ConvArgs& a, hipStream_t stream)
         case CONV_CFG_WINO4_S8T8x16_N32: return launch_wino4_cfg<W4Cfg2>(a, stream);
         case CONV_CFG_WINO4_S8T12x8_N32: return launch_wino4_cfg<W4Cfg3>(a, stream);
         case CONV_CFG_WINO4_T32x32_N32_HEAD: return launch_wino4_cfg<W4Cfg0, true>(a, stream);
+        case CONV_CFG_WINO4_S4T8x32_N32: return launch_wino4_cfg<W4Cfg4>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -89,10 +89,11 @@ def test_unet_sigma_head_golden(golden, dev):
     assert _maxdiff(sp.cpu().numpy(), g['sigma_pred']) < 1e-6
 
 
-@pytest.mark.parametrize('shape', [(2, 192, 128), (3, 48, 32), (1, 32, 48), (1, 192, 128), (5, 96, 64), (8, 16, 16)])
+@pytest.mark.parametrize('shape', [(2, 192, 128), (3, 48, 32), (1, 32, 48), (1, 192, 128), (5, 96, 64), (8, 16, 16), (5, 128, 512)])
 def test_unet_full_width_vs_oracle(dev, shape):
     """start_filters=32 (the shipped width; no channel padding anywhere) incl. the BraTS slice size whose
-    bottom level (12x8) uses the two-slices-per-workgroup kernel; dropout masks sampled and injected."""
+    bottom level (12x8) uses the two-slices-per-workgroup kernel; dropout masks sampled and injected.  128 x 512: an 8 x 32 bottom level, the
+    full-width tile of four slices (conv3x3_winograd4<S4T8x32>, round 6) on a ragged batch of five."""
     from oracle import unet_oracle as uo
     n, h, w = shape
     params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05)
