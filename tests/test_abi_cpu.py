@@ -275,7 +275,9 @@ def test_planner_pads_the_levels_of_the_references_real_shapes():
     assert up[(30, 30)] == (16, 16) and up[(240, 240)] == (128, 128)
     isic = _plan_rows(192, 256, 32, cin=3)
     assert sum('winograd' in r[1] for r in isic) == 22
-    assert {(r[2], r[3]): (r[4], r[5]) for r in isic if 'upconv' not in r[0]}[(12, 16)] == (16, 16)
+    isic_grids = {(r[2], r[3]): (r[4], r[5], r[1]) for r in isic if 'upconv' not in r[0]}
+    assert isic_grids[(12, 16)][:2] == (16, 16)
+    assert isic_grids[(24, 32)] == (24, 32, 'conv3x3_winograd4<S4T8x32,N32,K8>')       # 32 wide, 8 | height: the full-width tile of four slices, unpadded
     assert all((r[2], r[3]) == (r[4], r[5]) for r in isic if r[2] >= 48 and 'upconv' not in r[0])       # the levels with whole tiles are left alone
     # the benchmark shapes: nothing is padded, the round-5 kernels
     bench = _plan_rows(192, 128, 640)
