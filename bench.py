@@ -776,7 +776,7 @@ def main():
     if args.lanes > 1:
         dom_ms, dom_layers = {}, {}
         for L, ms in zip(model.layer_table(height, width, n_slices * args.pass_group), slot_ms[1:]):
-            name = L['kernel'] + (L['head_suffix'] if model.fuse_head else '')
+            name = L['kernel'] + ('+head' if L['head_fusable'] and model.fuse_head else '')
             dom_ms[name] = dom_ms.get(name, 0.0) + ms
             dom_layers[name] = dom_layers.get(name, 0) + 1
         timed_region = dict(lanes=args.lanes, wall_ms_per_forward=elapsed * 1e3 / passes_run, profiled_forward_launches_lane0=launches,
@@ -817,7 +817,7 @@ def main():
     per_kernel = {}
     for L, ms in zip(layers, slot_ms[1:1 + len(layers)]):
         # (conv_cls.0 runs with the classifier head in its epilogue: another kernel than the plain form of the same tile, under its own name)
-        name = L['kernel'] + (L['head_suffix'] if model.fuse_head else '')
+        name = L['kernel'] + ('+head' if L['head_fusable'] and model.fuse_head else '')
         e = per_kernel.setdefault(name, dict(ms=0.0, flops=0.0, issued=0.0, launches=0))
         e['ms'] += ms
         e['flops'] += L['flops_per_slice'] * n_slices * passes_run

@@ -175,9 +175,7 @@ typedef struct rcu_layer_info {
                                         level), larger than the real one on a padded level (rcu_unet_options.pad_levels) */
     int32_t upsample, pooled, dual_source;
     int32_t head_fusable;         /* 1: forwards that want logits or statistics (no sigma) run this unit with the classifier head in the kernel's epilogue
-                                     while rcu_unet_options.fuse_head is on -- profilers see that kernel as `kernel` + "+head"; rcu_unet_run_layer runs the plain one.
-                                     2 (sigma_out models, round 6): the cls + sigma twin unit takes BOTH 1x1 heads into its epilogue for the forwards that want
-                                     (logits, sigma) or (statistics, sigma sums) -- `kernel` + "+twinhead" */
+                                     while rcu_unet_options.fuse_head is on -- profilers see that kernel as `kernel` + "+head"; rcu_unet_run_layer runs the plain one */
     double flops_per_slice;       /* algorithmic: 2*cin*cout*9*H*W of the layer as the reference computes it */
     double mfma_flops_per_slice;  /* what the kernel issues to the MFMA pipe (padded channels; 4 of 9 taps for the
                                      sub-pixel up-convolution; whole tiles) */

@@ -919,13 +919,6 @@ extern "C" int rcu_unet_finalize_weights(rcu_unet* h)
 // `head`: when set (conv_cls.0 on the 32-cout Winograd tile, two classes), the 1x1 classifier + softmax + statistics run in
 // the layer's epilogue and its output tensor is not written (rcu_wino.hip, wino_epilogue_head).
 // the plan's last unit can take the classifier into its epilogue: two classes, no sigma twin, one 32-cout Winograd tile of either family
-// ... and the cls + sigma twin unit both of its heads (round 6): two classes, the 64-cout unit on the 32x32-tile F(4x4,3x3) kernel -- one cout tile per head
-static bool twin_fusable(const rcu_unet* h)
-{
-    const ConvLayer& last = h->layers.back();
-    return last.cfg == CONV_CFG_WINO4_T32x32_N32 && h->d.nb_classes == 2 && !last.name2.empty() && h->head_cph == 32 && last.NT == 2;
-}
-
 static bool head_fusable(const rcu_unet* h)
 {
     const ConvLayer& last = h->layers.back();
@@ -938,11 +931,6 @@ struct FusedHead {
     void* stats;
     int flags;
     int passes;   // pass group: the batch holds `passes` x (n / passes) samples, all adding into the statistics of n / passes images
-    // the cls + sigma twin unit (twin_fusable): the sigma head's outputs
-    bool twin = false;
-    float* sigma = nullptr;
-    float* sigma_sum = nullptr;
-    int sigma_log = 0;
 };
 
 static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks, hipStream_t stream, const FusedHead* head = nullptr,
@@ -1014,12 +1002,7 @@ static int run_layer(rcu_unet* h, const ConvLayer& L, int n, const float* masks,
     a.wpack_bytes = (uint32_t)std::min<size_t>(L.wpack_floats * 4, 0xFFFFFFFFu);
     int cfg = L.cfg;
     if (head) {
-        cfg = head->twin ? CONV_CFG_WINO4_T32x32_N32_TWINHEAD
-                         : L.cfg == CONV_CFG_WINO4_T32x32_N32 ? CONV_CFG_WINO4_T32x32_N32_HEAD : CONV_CFG_WINO_T16x32_N32_HEAD;
-        if (head->twin) {
-            a.head_w2 = h->w_sig; a.head_b2 = h->b_sig;
-            a.head_sigma = head->sigma; a.head_sigma_sum = head->sigma_sum; a.head_sigma_log = head->sigma_log;
-        }
+        cfg = L.cfg == CONV_CFG_WINO4_T32x32_N32 ? CONV_CFG_WINO4_T32x32_N32_HEAD : CONV_CFG_WINO_T16x32_N32_HEAD;
         a.head_w = h->w_cls; a.head_b = h->b_cls;
         a.head_logits = head->logits; a.head_stats = head->stats; a.head_flags = head->flags;
         a.head_passes = head->passes;
@@ -1057,16 +1040,9 @@ static int forward_impl(rcu_unet* h, const float* x, int n, const float* masks, 
     // rcu_unet_set_fuse_head keep them apart): two classes, no sigma twin, 32-cout Winograd tile; the passes of a pass group run back to back on the
     // workgroup that owns the tile, so their read-modify-writes of the statistics are ordered (pass 0 first, as head_kernel adds them)
     const ConvLayer& last = h->layers.back();
-    bool fuse = head_fusable(h) && sigma == nullptr && (logits != nullptr || stats != nullptr) && h->opt.fuse_head != 0;
-    // the sigma-head model: both heads in the twin unit's epilogue -- the single pass that wants logits + raw sigma (AleatoricPredictStep,
-    // bin-dl/brats_test_aleatoric.py:63) or the MC pass(es) that feed the statistics and the sigma sums (the aleatoric + MC extension)
-    const bool twin = twin_fusable(h) && h->opt.fuse_head != 0 &&
-                      ((logits != nullptr && sigma != nullptr && stats == nullptr && sigma_sum == nullptr && passes == 1) ||
-                       (stats != nullptr && sigma_sum != nullptr && logits == nullptr && sigma == nullptr));
-    fuse = fuse || twin;
+    const bool fuse = head_fusable(h) && sigma == nullptr && (logits != nullptr || stats != nullptr) && h->opt.fuse_head != 0;
     for (const ConvLayer& L : h->layers) {
-        FusedHead fh{logits, stats, flags, passes};
-        fh.twin = twin; fh.sigma = sigma; fh.sigma_sum = sigma_sum; fh.sigma_log = sigma_log;
+        const FusedHead fh{logits, stats, flags, passes};
         int rc = run_layer(h, L, n, masks, stream, (fuse && &L == &last) ? &fh : nullptr, direct_input ? x : nullptr, n_one);
         if (rc) return rc;
         if (ev) RCU_HIP(hipEventRecord(*ev++, stream));
@@ -1340,7 +1316,7 @@ extern "C" int rcu_unet_layer_info(const rcu_unet* h, int layer, rcu_layer_info*
     out->height = L.H; out->width = L.W;
     out->grid_height = L.gh; out->grid_width = L.gw;
     out->upsample = L.upsample; out->pooled = L.t_pool >= 0; out->dual_source = L.t_src2 >= 0;
-    out->head_fusable = (layer + 1 == (int)h->layers.size()) ? (head_fusable(h) ? 1 : twin_fusable(h) ? 2 : 0) : 0;
+    out->head_fusable = (layer + 1 == (int)h->layers.size() && head_fusable(h)) ? 1 : 0;
     // an up-convolution works on the up-sampled grid, which a centre pad leaves smaller than the skip tensor it is padded to
     out->flops_per_slice = 2.0 * out->cin * out->cout * (L.is_1x1 ? 1.0 : 9.0) * (L.upsample ? 4.0 * (L.H / 2) * (L.W / 2) : (double)L.H * L.W);
     {

@@ -67,14 +67,6 @@ struct ConvArgs {
     size_t head_V;         // voxels of one pass = images * H * W
     int head_passes;       // MC passes in this launch: sample t * head_images + i is image i (pass groups); its statistics entry is i's
     int head_images;
-    // the cls + sigma twin unit with BOTH 1x1 heads in its epilogue (rcu_wino4.hip, CONV_CFG_WINO4_T32x32_N32_TWINHEAD; round 6): cout tile 0 is conv_cls.0
-    // and takes the classifier as above, cout tile 1 is conv_sigma.0 and takes head_w2 / head_b2 -> raw sigma out (NCHW) and / or the running sum of
-    // |sigma| (exp(sigma) with head_sigma_log) over the passes, added to in pass order as head_kernel adds it
-    const float* head_w2;
-    const float* head_b2;
-    float* head_sigma;       // NCHW [N][2][H*W] raw sigma, or null
-    float* head_sigma_sum;   // NCHW [images][2][H*W], or null
-    int head_sigma_log;
 };
 
 enum ConvConfig {
@@ -110,7 +102,6 @@ enum ConvConfig {
     CONV_CFG_WINO4_S8T12x8_N32,                  // 12x8 pixels of eight consecutive slices (6 tiles per slice in the 8 tile slots of the S8 block), images 8 wide
     CONV_CFG_WINO4_T32x32_N32_HEAD,              // T32x32_N32 with the 1x1 head + softmax + statistics in the epilogue (run-time choice of forward_impl, never a plan entry)
     CONV_CFG_WINO4_S4T8x32_N32,                  // 8x32 pixels of four consecutive slices, images 32 pixels wide (round 6: ISIC's 24x32 level without padding)
-    CONV_CFG_WINO4_T32x32_N32_TWINHEAD,          // the 64-cout cls + sigma unit on T32x32_N32 with both 1x1 heads in the epilogue (run-time choice of forward_impl, never a plan entry)
     CONV_CFG_END
 };
 

@@ -382,15 +382,12 @@ __device__ __forceinline__ void wino4_epilogue(const ConvArgs& a, const f32x4 (&
 // 64 weights + 2 biases are read from LDS (`wlds`: copied there once per kernel, WINO4_HEAD_LDS_BYTES behind the two chunk buffers; every lane
 // reads the same address: a broadcast) -- read through the kernel argument's pointer they became vector loads from global memory, four
 // dependent round trips per tile quarter on a wave that has nothing else to run meanwhile.
-constexpr int WINO4_HEAD_LDS_BYTES = 1024;   // [2][32] weights + [2] biases of the classifier, and of the sigma head behind them (twin unit)
+constexpr int WINO4_HEAD_LDS_BYTES = 512;
 // PART: the level is padded (ConvArgs::part) -- logits and statistics are the caller's arrays over the REAL Hr x Wr image; the lanes whose pixel lies
 // beyond it take part in the hand-over and touch no memory.
-// TWIN: the cls + sigma twin unit (ConvArgs::head_w2): cout tile 0 is the classifier as above; cout tile 1 (`sigma_tile`) is conv_sigma.0 -- its 1x1 head's
-// two raw sigmas are stored (NCHW) and / or |sigma| (exp(sigma)) is added to the running sum of the voxel, pass after pass on the tile's workgroup: the
-// order, and the bits, of head_kernel's sigma path.
-template <class T, bool PART = false, bool TWIN = false>
+template <class T, bool PART = false>
 __device__ __forceinline__ void wino4_epilogue_head(const ConvArgs& a, const f32x4 (&accv)[8], const WinoEpi& ep, int n0, int nstat, int y0, int x0,
-                                                    int wave, int lane, uint32_t area, uint32_t wlds, bool sigma_tile = false)
+                                                    int wave, int lane, uint32_t area, uint32_t wlds)
 {
     // the lane-constant parts of the addresses below are recomputed per tile: hoisted to the kernel's start they would be two more registers alive
     // through the chunk pipeline, which has none to spare (the build spilled them to scratch)
@@ -401,19 +398,8 @@ __device__ __forceinline__ void wino4_epilogue_head(const ConvArgs& a, const f32
     const int n16 = lane & 15, g = lane >> 4;
     // one batch of scalar loads
     const int H = PART ? a.Hr : a.H, W = PART ? a.Wr : a.W, flags = a.head_flags;
-    float* logits = a.head_logits;
-    void* stats = a.head_stats;
-    [[maybe_unused]] float* sigma_sum = nullptr;
-    [[maybe_unused]] int sigma_log = 0;
-    if constexpr (TWIN) {
-        if (sigma_tile) {      // wave-uniform: the sigma head's weights, its outputs in place of the classifier's
-            wlds += 66u * 4u;
-            logits = a.head_sigma;
-            stats = nullptr;
-            sigma_sum = a.head_sigma_sum;
-            sigma_log = a.head_sigma_log;
-        }
-    }
+    float* const logits = a.head_logits;
+    void* const stats = a.head_stats;
     const size_t V = a.head_V;
     const float relu_floor = a.relu ? 0.f : -__builtin_inff();
     int bs, by, sb, tr, tc;
@@ -479,14 +465,6 @@ __device__ __forceinline__ void wino4_epilogue_head(const ConvArgs& a, const f32
             st.add(flags, l);
             st.store(stats, (size_t)nstat * HW + hw, V, flags);
         }
-        if constexpr (TWIN) {
-            if (sigma_sum != nullptr && inside) {      // (only ever set on the sigma tile)
-                float* const s0 = sigma_sum + ((size_t)nstat * 2 + 0) * HW + hw;
-                float* const s1 = sigma_sum + ((size_t)nstat * 2 + 1) * HW + hw;
-                *s0 += sigma_log ? expf(l[0]) : fabsf(l[0]);
-                *s1 += sigma_log ? expf(l[1]) : fabsf(l[1]);
-            }
-        }
     });
 }
 
@@ -541,7 +519,7 @@ struct Wino4Trace<false> {
 // HEAD: the classifier head in the epilogue (wino4_epilogue_head).  total_items counts the tiles of ONE pass; the workgroup that owns a tile runs
 // the tile of every pass of the group back to back (sample n0 + pass * head_images), so the passes' read-modify-writes of a voxel's statistics
 // are ordered (pass 0 first, as head_kernel adds them) -- as rcu_wino.hip.
-template <class T, int VAR = 0, int HEAD = 0, bool PART = false>   // HEAD: 0 plain epilogue, 1 classifier head, 2 classifier + sigma heads of the twin unit
+template <class T, int VAR = 0, bool HEAD = false, bool PART = false>
 __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, const int total_items)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -590,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
     int item = wino_xcd_virtual_block(a.NT < 4 ? 4 : a.NT);
     [[maybe_unused]] int pass = 0;
     auto more_passes = [&]() {
-        if constexpr (HEAD != 0) return pass + 1 < wino_cold_args().head_passes;
+        if constexpr (HEAD) return pass + 1 < wino_cold_args().head_passes;
         return false;
     };
     bool has_next = more_passes() || item + (int)gridDim.x < total_items;
@@ -653,11 +631,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         const DmaJob job = dma_job(dp_wtile, 0, 0, true);
         wino_static_for<0, T::NW + T::NA>([&](auto i_c) { dma_piece(job, dp, i_c); });
     }
-    if constexpr (HEAD != 0) {   // the classifier: [2][32] weights, [2] biases (wino4_epilogue_head); twin unit: the sigma head's behind them
+    if constexpr (HEAD) {   // the classifier: [2][32] weights, [2] biases (wino4_epilogue_head)
         if (tid < 66) smem[2 * T::BUF_DW + tid] = tid < 64 ? a.head_w[tid] : a.head_b[tid - 64];
-        if constexpr (HEAD == 2) {
-            if (tid >= 128 && tid < 194) smem[2 * T::BUF_DW + 66 + (tid - 128)] = tid < 192 ? a.head_w2[tid - 128] : a.head_b2[tid - 192];
-        }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
@@ -891,10 +866,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_stream(const ConvArgs a, co
         }
         }
         WINO4_TRACE_MARK(1);
-        if constexpr (HEAD != 0)
-            wino4_epilogue_head<T, PART, HEAD == 2>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.n0, tile.n0 - pass * wino_cold_args().head_images, tile.y0, tile.x0,
-                                                    wave, lane, lds_base + (uint32_t)(T::BUF_DW + T::A_DW) * 4u, lds_base + (uint32_t)(2 * T::BUF_DW) * 4u,
-                                                    HEAD == 2 && tile.wtile != 0);
+        if constexpr (HEAD)
+            wino4_epilogue_head<T, PART>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.n0, tile.n0 - pass * wino_cold_args().head_images, tile.y0, tile.x0,
+                                         wave, lane, lds_base + (uint32_t)(T::BUF_DW + T::A_DW) * 4u, lds_base + (uint32_t)(2 * T::BUF_DW) * 4u);
         else if constexpr ((VAR & 2) == 0)
             wino4_epilogue<T, (VAR >> 8), PART>(wino_cold_args(), accv, wino_epilogue_fold(epr), tile.wtile, tile.n0, tile.y0, tile.x0, wave, lane, store_plan);
         WINO4_TRACE_MARK(2);
@@ -922,19 +896,18 @@ using W4Cfg2 = Wino4Tile<2, 2, 4, 4, 1, true>;   // 8x16 pixels of eight consecu
 using W4Cfg3 = Wino4Tile<2, 2, 4, 4, 1, true, true>;   // 12x8 pixels of eight consecutive slices, folded into the same block geometry (the 12x8 level)
 using W4Cfg4 = Wino4Tile<1, 2, 8, 4, 1, true>;   // 8x32 pixels of four consecutive slices, full image width (round 6: 24x32 levels -- the reference's ISIC size 192x256 -- without padding to 32x32)
 
-static const ConvConfigInfo kWino4Info[7] = {
+static const ConvConfigInfo kWino4Info[6] = {
     {W4Cfg0::TS, W4Cfg0::TH, W4Cfg0::TW, W4Cfg0::BN, 8, 36, "conv3x3_winograd4<T32x32,N32,K8>", 8, 0, 3},
     {W4Cfg1::TS, W4Cfg1::TH, W4Cfg1::TW, W4Cfg1::BN, 8, 36, "conv3x3_winograd4<S2T16x32,N32,K8>", 8, 0, 3},
     {W4Cfg2::TS, W4Cfg2::TH, W4Cfg2::TW, W4Cfg2::BN, 8, 36, "conv3x3_winograd4<S8T8x16,N32,K8>", 8, 0, 3},
     {W4Cfg3::TS, W4Cfg3::TH, W4Cfg3::TW, W4Cfg3::BN, 8, 36, "conv3x3_winograd4<S8T12x8,N32,K8>", 8, 0, 3},
     {W4Cfg0::TS, W4Cfg0::TH, W4Cfg0::TW, W4Cfg0::BN, 8, 36, "conv3x3_winograd4<T32x32,N32,K8>+head", 8, 0, 3},
     {W4Cfg4::TS, W4Cfg4::TH, W4Cfg4::TW, W4Cfg4::BN, 8, 36, "conv3x3_winograd4<S4T8x32,N32,K8>", 8, 0, 3},
-    {W4Cfg0::TS, W4Cfg0::TH, W4Cfg0::TW, W4Cfg0::BN, 8, 36, "conv3x3_winograd4<T32x32,N32,K8>+twinhead", 8, 0, 3},
 };
 
 const ConvConfigInfo& wino4_config_info(int cfg) { return kWino4Info[cfg - CONV_CFG_WINO4_T32x32_N32]; }
 
-template <class T, int VAR, int HEAD = 0, bool PART = false>
+template <class T, int VAR, bool HEAD = false, bool PART = false>
 static hipError_t launch_wino4_var(const ConvArgs& a, hipStream_t stream)
 {
     constexpr int lds_bytes = T::LDS_BYTES + (HEAD ? WINO4_HEAD_LDS_BYTES : 0);
@@ -948,18 +921,12 @@ static hipError_t launch_wino4_var(const ConvArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <class T, int HEAD = 0>
+template <class T, bool HEAD = false>
 static hipError_t launch_wino4_cfg(const ConvArgs& a, hipStream_t stream)
 {
-    if (HEAD == 1 && (a.head_w == nullptr || a.head_b == nullptr || a.NT != 1 || a.pooled != nullptr || a.mask2 != nullptr || a.head_passes < 1 ||
-                      a.head_images * a.head_passes != a.N || (a.head_passes > 1 && a.head_logits != nullptr) ||
-                      (a.head_logits == nullptr && a.head_stats == nullptr)))
-        return hipErrorInvalidValue;
-    // the twin unit: two cout tiles (classifier | sigma), either the single-pass outputs (logits + raw sigma) or the MC path (statistics + sigma sums)
-    if (HEAD == 2 && (a.head_w == nullptr || a.head_b == nullptr || a.head_w2 == nullptr || a.head_b2 == nullptr || a.NT != 2 || a.pooled != nullptr ||
-                      a.head_passes < 1 || a.head_images * a.head_passes != a.N ||
-                      (a.head_passes > 1 && (a.head_logits != nullptr || a.head_sigma != nullptr)) ||
-                      (a.head_logits == nullptr && a.head_stats == nullptr) || (a.head_sigma == nullptr && a.head_sigma_sum == nullptr)))
+    if (HEAD && (a.head_w == nullptr || a.head_b == nullptr || a.NT != 1 || a.pooled != nullptr || a.mask2 != nullptr || a.head_passes < 1 ||
+                 a.head_images * a.head_passes != a.N || (a.head_passes > 1 && a.head_logits != nullptr) ||
+                 (a.head_logits == nullptr && a.head_stats == nullptr)))
         return hipErrorInvalidValue;
     const int nchunks = (a.C1 + a.C2) / T::KC;
     if (nchunks < 4 || (nchunks & 1) != 0 || a.NTW_total != a.NT || a.src1_bytes == 0 || a.wpack_bytes == 0 ||
@@ -1009,8 +976,7 @@ hipError_t launch_conv_wino4(int cfg, const ConvArgs& a, hipStream_t stream)
         case CONV_CFG_WINO4_S2T16x32_N32: return launch_wino4_cfg<W4Cfg1>(a, stream);
         case CONV_CFG_WINO4_S8T8x16_N32: return launch_wino4_cfg<W4Cfg2>(a, stream);
         case CONV_CFG_WINO4_S8T12x8_N32: return launch_wino4_cfg<W4Cfg3>(a, stream);
-        case CONV_CFG_WINO4_T32x32_N32_HEAD: return launch_wino4_cfg<W4Cfg0, 1>(a, stream);
-        case CONV_CFG_WINO4_T32x32_N32_TWINHEAD: return launch_wino4_cfg<W4Cfg0, 2>(a, stream);
+        case CONV_CFG_WINO4_T32x32_N32_HEAD: return launch_wino4_cfg<W4Cfg0, true>(a, stream);
         case CONV_CFG_WINO4_S4T8x32_N32: return launch_wino4_cfg<W4Cfg4>(a, stream);
         default: return hipErrorInvalidValue;
     }

@@ -443,9 +443,6 @@ class UNet(nn.Module):
                              cout=info.cout, height=info.height, width=info.width, grid_height=info.grid_height, grid_width=info.grid_width,
                              upsample=bool(info.upsample),
                              pooled=bool(info.pooled), dual_source=bool(info.dual_source), head_fusable=bool(info.head_fusable),
-                             # what a profiler sees behind the kernel's name while the fused head is on: the classifier in the epilogue, or (sigma_out
-                             # models) both heads of the cls + sigma twin unit
-                             head_suffix={0: '', 1: '+head', 2: '+twinhead'}[int(info.head_fusable)],
                              flops_per_slice=info.flops_per_slice,
                              mfma_flops_per_slice=info.mfma_flops_per_slice))
         return rows

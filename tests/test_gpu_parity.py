@@ -1576,49 +1576,3 @@ def test_confusion_dice_accuracy_against_sklearn_g19(golden, dev):
         res = {}
         ev.ComposeEvaluation([ev.DiceNumpy(), ev.ConfusionMatrix()])({'prediction': pred, 'target': tgt}, res)
         assert [res[k] for k in ('tp', 'tn', 'fp', 'fn', 'n')] == list(g[name + '::counts_tp_tn_fp_fn_n'])
-
-
-@pytest.mark.timeout(900)
-def test_twin_head_matches_head_kernel_bitwise(dev):
-    """Round 6: the cls + sigma twin unit (sigma_out models: conv_cls.0 | conv_sigma.0 stacked on 64 output channels) takes BOTH 1x1 heads into the
-    epilogue of the 32x32-tile F(4x4,3x3) kernel (csrc/rcu_wino4.hip, CONV_CFG_WINO4_T32x32_N32_TWINHEAD) -- cout tile 0 the classifier, cout tile 1
-    the sigma head -- for the single pass that wants (logits, sigma) (AleatoricPredictStep, bin-dl/brats_test_aleatoric.py:63) and for the MC passes
-    that feed statistics + sigma sums (the aleatoric + MC extension).  Same bits as the plain epilogue + head_kernel (UNet.set_fuse_head(False)):
-    logits, raw sigma, exact statistics and the float32 sigma sums, single passes and pass groups, |sigma| and exp(sigma); and the oracle."""
-    from oracle import unet_oracle as uo
-    from rcu_amd import steps
-    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=32, dropout=0.05, sigma_out=True)
-    st = uo.synthetic_state(52, **params)
-    g = torch.Generator().manual_seed(90)
-    n, h, w, T = 3, 64, 96, 4
-    x = torch.randn(n, 4, h, w, generator=g)
-    _, sites = uo.unet_plan(**params)
-    mask_sets = [uo.sample_masks(sites, n, 0.3, g) for _ in range(T)]
-    fused, plain = _model(params, st, dev), _model(params, st, dev)
-    plain.set_fuse_head(False)
-    assert fused.layer_table(h, w, 2 * n)[-1]['head_suffix'] == '+twinhead'
-    xd = x.to(dev)
-    for mk in (None, mask_sets[0]):
-        lf, sf = fused(xd, mk)
-        lp, sp = plain(xd, mk)
-        assert torch.equal(lf, lp) and torch.equal(sf, sp)
-        ref_l, ref_s = uo.unet_forward(st, x, mk, **params)
-        assert _maxdiff(lf.cpu().numpy(), ref_l.numpy()) < LOGIT_TOL and _maxdiff(sf.cpu().numpy(), ref_s.numpy()) < LOGIT_TOL
-    for is_log in (False, True):
-        results = {}
-        for name, m, group in (('fused', fused, 1), ('plain', plain, 1), ('fused pairs', fused, 2), ('plain pairs', plain, 2)):
-            m.reserve(h, w, 2 * n)
-            stats = steps.McStatistics(n, 2, h, w, dev, do_mi=True, do_var=False, exact=True)
-            sigma_sum = torch.zeros(n, 2, h, w, device=dev)
-            for t in range(0, T, group):
-                if group == 1:
-                    m.forward_accumulate_sigma(xd, stats, sigma_sum, mask_sets[t], is_log_sigma=is_log)
-                else:
-                    m.forward_accumulate_sigma(xd, stats, sigma_sum, mask_sets[t:t + group], is_log_sigma=is_log, passes=group)
-            results[name] = dict(stats.finalize(True, False), sigma_sum=sigma_sum.clone())
-        for name in ('plain', 'fused pairs', 'plain pairs'):
-            for key in results['fused']:
-                assert torch.equal(results['fused'][key], results[name][key]), (is_log, name, key)
-        raw = torch.stack([uo.unet_forward(st, x, mk, **params)[1] for mk in mask_sets])
-        ref_sum = (raw.exp() if is_log else raw.abs()).sum(0)
-        assert _maxdiff(results['fused']['sigma_sum'].cpu().numpy(), ref_sum.numpy()) < 2e-5 * max(1.0, float(ref_sum.abs().max()))

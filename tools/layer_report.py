@@ -61,7 +61,7 @@ def main():
         issued = L['mfma_flops_per_slice'] * n
         tot_is += issued
         print('{:<52} {:>4}->{:<4} {:>3}x{:<3} {:>7} {:<34} {:>8.3f} {:>7.1f} {:>6.1f} {:>6.1f}'.format(
-            L['name'][:52], L['cin'], L['cout'], L['height'], L['width'], '{}x{}'.format(L['grid_height'], L['grid_width']), L['kernel'] + (L['head_suffix'] if model.fuse_head else ''), t, fl / t / 1e9, fl / t / 1e9 / 1.573,
+            L['name'][:52], L['cin'], L['cout'], L['height'], L['width'], '{}x{}'.format(L['grid_height'], L['grid_width']), L['kernel'] + ('+head' if L['head_fusable'] and model.fuse_head else ''), t, fl / t / 1e9, fl / t / 1e9 / 1.573,
             issued / t / 1e9 / 1.573))
     print('input re-layout {:.3f} ms, head {:.3f} ms'.format(ms[0] / cnt, ms[-1] / cnt))
     print('conv total {:.3f} ms  {:.1f} TF/s algorithmic ({:.1f}% of 157.3); MFMA pipe issue {:.1f}%'.format(

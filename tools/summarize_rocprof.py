@@ -42,7 +42,7 @@ def short(name):
         ts, th, tw = sb * ws, 4 * br * wr, 4 * bc
         if m.group(7) in ('true', '1'):
             th, tw = 12, 8
-        return 'conv3x3_winograd4<{}T{}x{},N32,K8>{}'.format('S{}'.format(ts) if ts != 1 else '', th, tw, '+head' if m.group(8) in ('true', '1') else '+twinhead' if m.group(8) == '2' else '')
+        return 'conv3x3_winograd4<{}T{}x{},N32,K8>{}'.format('S{}'.format(ts) if ts != 1 else '', th, tw, '+head' if m.group(8) in ('true', '1') else '')
     if 'conv3x3_first_kernel' in name:   # anonymous namespace of rcu_first.hip; one tile shape
         return 'conv3x3_first<T8x32,K36>'
     m = re.search(r'rcu::(\w+)', name)
