@@ -320,7 +320,12 @@ int rcu_unc_counts(const void* unc_dev, int unc_is_f64, const uint8_t* predictio
  * 8-byte-per-voxel entropy map is never made (6 bytes per voxel instead of 7 + 12 for making the map).
  * thr_host: strictly ascending, every value one of rcu_unc_from_p_threshold(0 .. rcu_unc_from_p_num_thresholds() - 1), else RCU_ERR_INVALID
  * (rcu_unc_from_p_supported tells beforehand; other thresholds take rcu_normalised_entropy + rcu_unc_counts).  The table (4.4 KB) is
- * copied to the workspace with every call, stream-ordered. */
+ * copied to the workspace with every call, stream-ordered.
+ * "The reference's sets" are those of the build that made the table: numpy 2.2.6's float32 log on a CPU with AVX512 (the fixture records
+ * numpy_version / cpu_features); a numpy that rounds log differently in the last ulp (another SIMD path) can disagree on the one to three
+ * float32 values right at a boundary.  tests/test_oracle_golden.py::test_uncertain_voxel_table_holds_under_the_local_numpy re-evaluates
+ * every probe value on the host it runs on, and bench.py re-checks the counts of its timed output on the GPU box's host (parity.ue_counts_equal);
+ * where they differ, rcu_normalised_entropy + rcu_unc_counts (the map-based path) is the reference-of-that-host's arithmetic. */
 int rcu_unc_from_p_num_thresholds(void);
 double rcu_unc_from_p_threshold(int i);
 int rcu_unc_from_p_supported(const double* thr_host, int n_thr);
