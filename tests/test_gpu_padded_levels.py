@@ -235,3 +235,28 @@ def test_padded_levels_against_the_reference_itself_g21(golden, dev):
     assert [s[0] for s in ma.dropout_sites()] == list(g['sites_c'])
     masks = [g['mask_c_{}'.format(s)] for s in range(len(g['sites_c']))]
     assert _maxdiff(ma(torch.from_numpy(g['x_c']).to(dev), masks).cpu().numpy(), g['logits_mc_c']) < LOGIT_TOL
+
+
+@pytest.mark.timeout(1200)
+def test_padded_levels_random_shapes_vs_oracle(dev):
+    """Fourteen more image sizes (multiples of 16 up to 272, drawn once with a fixed seed) and batch sizes 1..9 through whatever plan the planner
+    makes of them -- padded levels, real extents, direct kernels next to either -- against the oracle, eval mode and under masks: the planner
+    has a few hundred distinct (level extent, kernel) combinations; the hand-picked shapes above cover the ones the reference's data needs."""
+    from oracle import unet_oracle as uo
+    params = dict(nb_classes=2, in_channels=4, depth=4, start_filters=16, dropout=0.1)
+    st = uo.synthetic_state(49, **params)
+    m = _model(params, st, dev)
+    rng = np.random.RandomState(2026)
+    g = torch.Generator().manual_seed(82)
+    _, sites = uo.unet_plan(**params)
+    seen = set()
+    for _ in range(14):
+        n, h, w = int(rng.randint(1, 10)), 16 * int(rng.randint(1, 18)), 16 * int(rng.randint(1, 18))
+        x = torch.randn(n, 4, h, w, generator=g)
+        masks = uo.sample_masks(sites, n, 0.3, g)
+        rows = m.layer_table(h, w, n)
+        seen.update((r['kernel'], (r['grid_height'], r['grid_width']) != ((r['height'] // 2, r['width'] // 2) if r['upsample'] else (r['height'], r['width']))) for r in rows)
+        for mk in (None, masks):
+            ref = uo.unet_forward(st, x, mk, **params).numpy()
+            assert _maxdiff(m(x.to(dev), mk).cpu().numpy(), ref) < LOGIT_TOL, (n, h, w, mk is not None)
+    assert sum(1 for _, padded in seen if padded) >= 6 and sum(1 for k, _ in seen if 'igemm' in k) >= 1, sorted(seen)
